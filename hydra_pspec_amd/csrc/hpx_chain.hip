@@ -1,0 +1,840 @@
+// Plan management, iteration-invariant operators, and the per-iteration
+// kernels around the factor/solve: assembly of K'_aug, residual / chi^2 /
+// log-posterior reductions, and the inverse-gamma bandpower draw.
+#include <math.h>
+#include <stdarg.h>
+#include <string.h>
+#include "hpx_internal.h"
+
+// ---------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+void hpx_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+extern "C" const char* hpx_last_error(void) { return g_err; }
+extern "C" int hpx_version(void) { return HPX_VERSION; }
+extern "C" int hpx_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+extern "C" int hpx_set_device(int dev) {
+  HPX_HIP(hipSetDevice(dev));
+  return HPX_OK;
+}
+
+namespace {
+
+constexpr double SQRT2 = 1.4142135623730951;   // 2**0.5 (pspec.py:217)
+
+// deterministic block reductions (256 threads): fixed shuffle tree + fixed wave order
+__device__ __forceinline__ double block_sum(double v, double* red) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return (red[0] + red[1]) + (red[2] + red[3]);
+}
+__device__ __forceinline__ int block_sum_int(int v, int* red) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return red[0] + red[1] + red[2] + red[3];
+}
+__device__ __forceinline__ double block_min(double v, double* red) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmin(v, __shfl_down(v, o));
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return fmin(fmin(red[0], red[1]), fmin(red[2], red[3]));
+}
+__device__ __forceinline__ double block_max(double v, double* red) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_down(v, o));
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+}
+
+// ---- setup ------------------------------------------------------------------
+// Z[b][j][col]: col<TP: Ni (w d)_t + Ni^1/2 omega_b,t ; TP..: Ni F[:,m] ; TP+MP: Ni
+// D[b][j][t] = w_j d[t][j]
+__global__ void k_prep(const double* __restrict__ vis, const uint8_t* __restrict__ flags,
+                       const double* __restrict__ ninv, const double* __restrict__ fg,
+                       const int fg_shared, const double* __restrict__ omega,
+                       double* __restrict__ Zre, double* __restrict__ Zim,
+                       double* __restrict__ Dre, double* __restrict__ Dim,
+                       double* __restrict__ ni_out, const int T, const int N, const int M,
+                       const int NP, const int TP, const int MP, const int ncol) {
+  const int b = blockIdx.y;
+  const long tot = (long)NP * ncol;
+  const double* F = fg + (fg_shared ? 0 : (long)b * N * M * 2);
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < tot;
+       e += (long)gridDim.x * blockDim.x) {
+    const int j = (int)(e / ncol), col = (int)(e % ncol);
+    double zr = 0.0, zi = 0.0;
+    if (j < N) {
+      const double w = flags[(long)b * N + j] ? 1.0 : 0.0;
+      const double ni = ninv[(long)b * N + j] * w;
+      if (col < TP) {
+        const int t = col;
+        double dr = 0.0, di = 0.0;
+        if (t < T) {
+          const long o = (((long)b * T + t) * N + j) * 2;
+          dr = vis[o] * w;
+          di = vis[o + 1] * w;
+          zr = ni * dr;
+          zi = ni * di;
+          if (omega) {
+            const double nih = sqrt(ni);
+            zr += nih * (omega[((long)t * 4 + 2) * N + j] / SQRT2);
+            zi += nih * (omega[((long)t * 4 + 3) * N + j] / SQRT2);
+          }
+        }
+        Dre[((long)b * NP + j) * TP + t] = dr;
+        Dim[((long)b * NP + j) * TP + t] = di;
+      } else if (col < TP + MP) {
+        const int m = col - TP;
+        if (m < M) {
+          zr = ni * F[((long)j * M + m) * 2];
+          zi = ni * F[((long)j * M + m) * 2 + 1];
+        }
+      } else if (col == TP + MP) {
+        zr = ni;
+        ni_out[(long)b * N + j] = ni;
+      }
+    } else if (col < TP) {
+      Dre[((long)b * NP + j) * TP + col] = 0.0;
+      Dim[((long)b * NP + j) * TP + col] = 0.0;
+    }
+    Zre[(long)b * tot + e] = zr;
+    Zim[(long)b * tot + e] = zi;
+  }
+}
+
+// shared omega_a block: Z2[j][t] = (omi + i omj)/sqrt2
+__global__ void k_prep_omega(const double* __restrict__ omega, double* __restrict__ Zre,
+                             double* __restrict__ Zim, const int T, const int N, const int NP,
+                             const int TP) {
+  const long tot = (long)NP * TP;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < tot;
+       e += (long)gridDim.x * blockDim.x) {
+    const int j = (int)(e / TP), t = (int)(e % TP);
+    double zr = 0.0, zi = 0.0;
+    if (j < N && t < T) {
+      zr = omega[((long)t * 4 + 0) * N + j] / SQRT2;
+      zi = omega[((long)t * 4 + 1) * N + j] / SQRT2;
+    }
+    Zre[e] = zr;
+    Zim[e] = zi;
+  }
+}
+
+// circ[m] = R[(m + N/2) mod N][colC] / sqrt(N)
+__global__ void k_circ(const double* __restrict__ Rre, const double* __restrict__ Rim,
+                       double* __restrict__ Cre, double* __restrict__ Cim, const int N,
+                       const int NP, const int ncol, const int colC) {
+  const int b = blockIdx.y;
+  const double s = 1.0 / sqrt((double)N);
+  for (int m = blockIdx.x * blockDim.x + threadIdx.x; m < N; m += gridDim.x * blockDim.x) {
+    const int x = (m + N / 2) % N;
+    const long o = ((long)b * NP + x) * ncol + colC;
+    Cre[(long)b * N + m] = Rre[o] * s;
+    Cim[(long)b * N + m] = Rim[o] * s;
+  }
+}
+
+// H = F^H Ni F (M x M), P4 = F^H (Ni d + Ni^1/2 omega_b) (M x TP); Z holds the operands.
+__global__ void k_small(const double* __restrict__ fg, const int fg_shared,
+                        const double* __restrict__ Zre, const double* __restrict__ Zim,
+                        double* __restrict__ Hre, double* __restrict__ Him,
+                        double* __restrict__ P4re, double* __restrict__ P4im, const int N,
+                        const int M, const int NP, const int TP, const int MP, const int ncol) {
+  const int b = blockIdx.x;
+  const double* F = fg + (fg_shared ? 0 : (long)b * N * M * 2);
+  const double* zr = Zre + (long)b * NP * ncol;
+  const double* zi = Zim + (long)b * NP * ncol;
+  const int nh = M * M, np4 = M * TP;
+  for (int e = threadIdx.x; e < nh + np4; e += blockDim.x) {
+    int m, col;
+    if (e < nh) { m = e / M; col = TP + e % M; }
+    else { m = (e - nh) / TP; col = (e - nh) % TP; }
+    double sr = 0.0, si = 0.0;
+    for (int j = 0; j < N; ++j) {
+      const double fr = F[((long)j * M + m) * 2], fi = -F[((long)j * M + m) * 2 + 1];   // conj
+      const double ar = zr[(long)j * ncol + col], ai = zi[(long)j * ncol + col];
+      sr += fr * ar - fi * ai;
+      si += fr * ai + fi * ar;
+    }
+    if (e < nh) {
+      Hre[(long)b * nh + e] = sr;
+      Him[(long)b * nh + e] = si;
+    } else {
+      P4re[(long)b * np4 + (e - nh)] = sr;
+      P4im[(long)b * np4 + (e - nh)] = si;
+    }
+  }
+}
+
+__global__ void k_fg_planar(const double* __restrict__ fg, double* __restrict__ Fre,
+                            double* __restrict__ Fim, const long tot) {
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < tot;
+       e += (long)gridDim.x * blockDim.x) {
+    Fre[e] = fg[2 * e];
+    Fim[e] = fg[2 * e + 1];
+  }
+}
+
+__global__ void k_set_a(const double* __restrict__ ps, double* __restrict__ a,
+                        double* __restrict__ ps_cur, const long tot, const double invN) {
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < tot;
+       e += (long)gridDim.x * blockDim.x) {
+    const double v = ps[e];
+    ps_cur[e] = v;
+    a[e] = sqrt(v * invN);
+  }
+}
+
+// ---- K'_aug assembly ----------------------------------------------------------
+struct AsmArgs {
+  const double *a, *Cre, *Cim, *Rre, *Rim, *P2re, *P2im, *Hre, *Him, *P4re, *P4im;
+  double *Lre, *Lim;
+  int N, M, T, NP, TP, npad, ld, ncol, has_omega;
+};
+
+__global__ __launch_bounds__(256) void k_assemble(const AsmArgs A) {
+  const int b = blockIdx.y, cb = blockIdx.x;
+  const int N = A.N, M = A.M, TP = A.TP, npad = A.npad, ld = A.ld;
+  const double* a = A.a + (long)b * N;
+  const double* cre = A.Cre + (long)b * N;
+  const double* cim = A.Cim + (long)b * N;
+  const double* rre = A.Rre + (long)b * A.NP * A.ncol;
+  const double* rim = A.Rim + (long)b * A.NP * A.ncol;
+  double* Lre = A.Lre + (long)b * npad * ld;
+  double* Lim = A.Lim + (long)b * npad * ld;
+  const int rbeg = cb * 16, nrow = ld - rbeg;
+  for (int e = threadIdx.x; e < 16 * nrow; e += 256) {
+    const int c = rbeg + e / nrow, r = rbeg + e % nrow;
+    double vr = 0.0, vi = 0.0;
+    if (r >= c) {
+      if (c < N) {
+        const double ac = a[c];
+        if (r < N) {
+          const double s = a[r] * ac;
+          vr = s * cre[r - c] + (r == c ? 1.0 : 0.0);
+          vi = (r == c) ? 0.0 : s * cim[r - c];
+        } else if (r < N + M) {          // conj(G[c][m]) a_c
+          const long o = (long)c * A.ncol + TP + (r - N);
+          vr = rre[o] * ac;
+          vi = -rim[o] * ac;
+        } else if (r >= npad) {          // conj(a_c Q[c][t] + P2[c][t])
+          const int t = r - npad;
+          const long o = (long)c * A.ncol + t;
+          vr = ac * rre[o];
+          vi = ac * rim[o];
+          if (A.has_omega) {
+            vr += A.P2re[(long)c * TP + t];
+            vi += A.P2im[(long)c * TP + t];
+          }
+          vi = -vi;
+        }
+      } else if (c < N + M) {
+        const int mc = c - N;
+        if (r < N + M) {
+          vr = A.Hre[((long)b * M + (r - N)) * M + mc];
+          vi = (r == c) ? 0.0 : A.Him[((long)b * M + (r - N)) * M + mc];
+        } else if (r >= npad) {
+          const int t = r - npad;
+          vr = A.P4re[((long)b * M + mc) * TP + t];
+          vi = -A.P4im[((long)b * M + mc) * TP + t];
+        }
+      } else if (r == c) {
+        vr = 1.0;
+      }
+    }
+    Lre[(long)c * ld + r] = vr;
+    Lim[(long)c * ld + r] = vi;
+  }
+}
+
+__global__ void k_kaug_out(const double* __restrict__ Lre, const double* __restrict__ Lim,
+                           double* __restrict__ out, const int npad, const int ld) {
+  // (nbl, ld, npad) c128 row-major
+  const int b = blockIdx.y;
+  const long tot = (long)ld * npad;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < tot;
+       e += (long)gridDim.x * blockDim.x) {
+    const int r = (int)(e / npad), c = (int)(e % npad);
+    const long o = (long)b * npad * ld + (long)c * ld + r;
+    const bool keep = (r >= c);
+    out[((long)b * tot + e) * 2] = keep ? Lre[o] : 0.0;
+    out[((long)b * tot + e) * 2 + 1] = keep ? Lim[o] : 0.0;
+  }
+}
+
+// ---- residual, chi^2, first part of ln posterior, beta --------------------------
+struct ResArgs {
+  const double *Xre, *Xim, *Sre, *Sim, *Dre, *Dim, *Fre, *Fim, *ninv, *a;
+  const uint8_t* flags;
+  double *beta, *lnp1, *Gre, *Gim;      // G: masked signal (only if any_flags)
+  double *cr_out, *fg_out, *chisq_out;  // already offset to the slot; may be NULL
+  long cr_bstride, fg_bstride, chisq_bstride;
+  int N, M, T, NP, TP, npad, fg_shared, any_flags;
+};
+
+__global__ __launch_bounds__(256) void k_resid(const ResArgs A) {
+  __shared__ double red[4];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int N = A.N, M = A.M, T = A.T, TP = A.TP;
+  const double* xre = A.Xre + (long)b * A.npad * TP;
+  const double* xim = A.Xim + (long)b * A.npad * TP;
+  const double* sre = A.Sre + (long)b * A.NP * TP;
+  const double* sim = A.Sim + (long)b * A.NP * TP;
+  const double* dre = A.Dre + (long)b * A.NP * TP;
+  const double* dim_ = A.Dim + (long)b * A.NP * TP;
+  const double* fre = A.Fre + (A.fg_shared ? 0 : (long)b * N * M);
+  const double* fim = A.Fim + (A.fg_shared ? 0 : (long)b * N * M);
+  // beta_k = N a_k^2 sum_t |y'_kt|^2   ( |F s|^2 with s = U D^1/2 y' )
+  for (int k = tid; k < N; k += 256) {
+    double s = 0.0;
+    for (int t = 0; t < T; ++t) {
+      const double yr = xre[(long)k * TP + t], yi = xim[(long)k * TP + t];
+      s += yr * yr + yi * yi;
+    }
+    const double ak = A.a[(long)b * N + k];
+    A.beta[(long)b * N + k] = (double)N * (ak * ak) * s;
+  }
+  double acc = 0.0;
+  for (int e = tid; e < N * TP; e += 256) {
+    const int x = e / TP, t = e % TP;
+    if (t >= T) {
+      if (A.any_flags) { A.Gre[((long)b * A.NP + x) * TP + t] = 0.0; A.Gim[((long)b * A.NP + x) * TP + t] = 0.0; }
+      continue;
+    }
+    const double sr = sre[(long)x * TP + t], si = sim[(long)x * TP + t];
+    double mr = sr, mi = si;
+    for (int m = 0; m < M; ++m) {
+      const double fr = fre[(long)x * M + m], fi = fim[(long)x * M + m];
+      const double gr = xre[(long)(N + m) * TP + t], gi = xim[(long)(N + m) * TP + t];
+      mr += gr * fr - gi * fi;
+      mi += gr * fi + gi * fr;
+    }
+    const double rr = dre[(long)x * TP + t] - mr, ri = dim_[(long)x * TP + t] - mi;
+    const double w = A.flags[(long)b * N + x] ? 1.0 : 0.0;
+    const double c2 = (rr * rr + ri * ri) * A.ninv[(long)b * N + x];
+    acc += w * c2;
+    if (A.any_flags) {
+      A.Gre[((long)b * A.NP + x) * TP + t] = w * sr;
+      A.Gim[((long)b * A.NP + x) * TP + t] = w * si;
+    }
+    if (A.cr_out) {
+      double* o = A.cr_out + (long)b * A.cr_bstride + ((long)t * N + x) * 2;
+      o[0] = sr;
+      o[1] = si;
+    }
+    if (A.chisq_out) A.chisq_out[(long)b * A.chisq_bstride + (long)t * N + x] = c2;
+  }
+  if (A.fg_out) {
+    for (int e = tid; e < T * M; e += 256) {
+      const int t = e / M, m = e % M;
+      double* o = A.fg_out + (long)b * A.fg_bstride + (long)e * 2;
+      o[0] = xre[(long)(N + m) * TP + t];
+      o[1] = xim[(long)(N + m) * TP + t];
+    }
+  }
+  const double tot = block_sum(acc, red);
+  if (tid == 0) A.lnp1[b] = -tot;
+}
+
+// betam_k = sum_t |SK[k][t]|^2 (SK = F (w s), in the Z scratch with leading dim ncol)
+__global__ void k_betam(const double* __restrict__ Kre, const double* __restrict__ Kim,
+                        double* __restrict__ betam, const int N, const int T, const int NP,
+                        const int ncol) {
+  const int b = blockIdx.y;
+  for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < N; k += gridDim.x * blockDim.x) {
+    double s = 0.0;
+    const long o = ((long)b * NP + k) * ncol;
+    for (int t = 0; t < T; ++t) s += Kre[o + t] * Kre[o + t] + Kim[o + t] * Kim[o + t];
+    betam[(long)b * N + k] = s;
+  }
+}
+
+// ---- bandpower draw ---------------------------------------------------------------
+// Regularised upper incomplete gamma Q(a, z) for integer a >= 1:
+// Q = exp(-z) sum_{k<a} z^k / k!  (= scipy.special.gammaincc(a, z) = invgamma.cdf
+// of pspec.py:51 at x = beta/z).  Forward sum for z < a, scaled Horner form
+// around the leading term for z >= a (no overflow, all terms positive).
+__device__ double igamc_int(const int a, const double z, const double lgam_a) {
+  if (!(z > 0.0)) return 1.0;
+  if (z < (double)a) {
+    double t = 1.0, s = 1.0;
+    for (int k = 1; k < a; ++k) {
+      t *= z / (double)k;
+      s += t;
+    }
+    return exp(-z) * s;
+  }
+  const double rz = 1.0 / z;
+  double s = 1.0;
+  for (int m = 1; m < a; ++m) s = 1.0 + s * ((double)m * rz);
+  return exp(-z + (double)(a - 1) * log(z) - lgam_a) * s;
+}
+
+// One inversion draw by the whole block (256 threads); pspec.py:50-62.
+// cdfs: LDS array of ngrid doubles.  Returns the sample to every thread.
+__device__ double inversion_draw(const int alpha, const double lgam, const double beta,
+                                 const double u, const double* __restrict__ xg, const int ngrid,
+                                 double* cdfs, double* red, int* redi) {
+  const int tid = threadIdx.x;
+  double mn = INFINITY;
+  for (int i = tid; i < ngrid; i += 256) {
+    const double c = igamc_int(alpha, beta / xg[i], lgam);
+    cdfs[i] = c;
+    mn = fmin(mn, c);
+  }
+  mn = block_min(mn, red);
+  double mx = -INFINITY;
+  for (int i = tid; i < ngrid; i += 256) {
+    const double c = cdfs[i] - mn;      // cdf -= cdf.min()
+    cdfs[i] = c;
+    mx = fmax(mx, c);
+  }
+  mx = block_max(mx, red);
+  int cnt = 0;
+  for (int i = tid; i < ngrid; i += 256) {
+    const double c = cdfs[i] / mx;      // cdf /= cdf.max()
+    cdfs[i] = c;
+    cnt += (c < u) ? 1 : 0;
+  }
+  int hi = block_sum_int(cnt, redi);    // searchsorted(unique, u, 'left') in original indexing
+  __syncthreads();
+  // interp1d clips the bracket to [1, len-1] of the de-duplicated table
+  int lo;
+  if (hi >= ngrid) {                    // u above the table: last two distinct values
+    const double top = cdfs[ngrid - 1];
+    cnt = 0;
+    for (int i = tid; i < ngrid; i += 256) cnt += (cdfs[i] < top) ? 1 : 0;
+    hi = block_sum_int(cnt, redi);
+  }
+  if (hi == 0) {                        // u at/below the first value: first two distinct values
+    const double bot = cdfs[0];
+    cnt = 0;
+    for (int i = tid; i < ngrid; i += 256) cnt += (cdfs[i] <= bot) ? 1 : 0;
+    hi = block_sum_int(cnt, redi);
+    lo = 0;
+    if (hi >= ngrid) return xg[0];      // degenerate table (all equal): reference would give NaN
+  } else {
+    const double below = cdfs[hi - 1];  // previous distinct value; its first occurrence:
+    cnt = 0;
+    for (int i = tid; i < ngrid; i += 256) cnt += (cdfs[i] < below) ? 1 : 0;
+    lo = block_sum_int(cnt, redi);
+  }
+  const double clo = cdfs[lo], chi = cdfs[hi], xlo = xg[lo], xhi = xg[hi];
+  const double slope = (xhi - xlo) / (chi - clo);
+  return slope * (u - clo) + xlo;
+}
+
+struct DrawArgs {
+  const double *beta, *betam, *lnp1, *uni, *igy, *xgrid, *ps_forced;
+  const int32_t* pmap;
+  double *a, *ps_cur, *ps_out, *lnpost_out;
+  long ps_bstride, forced_bstride;   // strides between baselines in ps_out / ps_forced
+  int N, T, ngrid, prior_shared, any_flags;
+  double lgam_T;
+};
+
+__global__ __launch_bounds__(256) void k_draw(const DrawArgs A) {
+  extern __shared__ double dyn[];     // ngrid doubles
+  __shared__ double red[4];
+  __shared__ int redi[4];
+  const int b = blockIdx.x, tid = threadIdx.x, N = A.N;
+  const double* beta = A.beta + (long)b * N;
+  const double* bm = A.any_flags ? A.betam + (long)b * N : beta;
+  const int32_t* pmap = A.pmap + (A.prior_shared ? 0 : (long)b * N);
+  double* ps_out = A.ps_out + (long)b * A.ps_bstride;
+  // channels without a prior: x = beta * invgamma.ppf(U, a=T-1)   (pspec.py:125)
+  for (int k = tid; k < N; k += 256)
+    if (pmap[k] < 0) ps_out[k] = A.igy[k] * beta[k];
+  // channels with a prior: truncated draw with shape alpha+1 = T   (pspec.py:121-123)
+  for (int k = 0; k < N; ++k) {
+    const int row = pmap[k];
+    if (row < 0) continue;
+    const double v = inversion_draw(A.T, A.lgam_T, beta[k], A.uni[k], A.xgrid + (long)row * A.ngrid,
+                                    A.ngrid, dyn, red, redi);
+    if (tid == 0) ps_out[k] = v;
+    __syncthreads();
+  }
+  __syncthreads();
+  double acc = 0.0;
+  for (int k = tid; k < N; k += 256) {
+    const double pn = ps_out[k];
+    acc += bm[k] / pn;
+    const double nx = A.ps_forced ? A.ps_forced[(long)b * A.forced_bstride + k] : pn;
+    A.ps_cur[(long)b * N + k] = nx;
+    A.a[(long)b * N + k] = sqrt(nx / (double)N);
+  }
+  const double tot = block_sum(acc, red);
+  if (tid == 0) A.lnpost_out[b] = A.lnp1[b] - tot;
+}
+
+__global__ void k_inv_test(const int alpha, const double lgam, const double* __restrict__ beta,
+                           const double* __restrict__ u, const double* __restrict__ xgrid,
+                           const int ngrid, double* __restrict__ out) {
+  extern __shared__ double dyn[];
+  __shared__ double red[4];
+  __shared__ int redi[4];
+  const int i = blockIdx.x;
+  const double v = inversion_draw(alpha, lgam, beta[i], u[i], xgrid + (long)i * ngrid, ngrid, dyn,
+                                  red, redi);
+  if (threadIdx.x == 0) out[i] = v;
+}
+
+template <typename Tp>
+int dev_alloc(hpx_plan* p, Tp** ptr, size_t count) {
+  void* q = nullptr;
+  const size_t bytes = count * sizeof(Tp);
+  hipError_t e = hipMalloc(&q, bytes ? bytes : 8);
+  if (e != hipSuccess) {
+    hpx_set_error("hipMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(e));
+    return HPX_EHIP;
+  }
+  p->allocs.push_back(q);
+  p->bytes += (int64_t)bytes;
+  *ptr = (Tp*)q;
+  return HPX_OK;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------
+extern "C" int hpx_plan_create(hpx_plan** out, int nbl, int T, int N, int M) {
+  HPX_REQUIRE(out, "hpx_plan_create: null out");
+  HPX_REQUIRE(nbl > 0 && T > 1 && N > 0 && M >= 0, "hpx_plan_create: need nbl>0, T>1, N>0, M>=0");
+  hpx_plan* p = new hpx_plan();
+  p->nbl = nbl; p->T = T; p->N = N; p->M = M;
+  p->n = N + M;
+  p->npad = ceil16(p->n);
+  p->TP = ceil16(T);
+  p->ld = p->npad + p->TP;
+  p->NP = ceil16(N);
+  p->MP = ceil16(M > 0 ? M : 1);
+  p->ncolR = p->TP + p->MP + 16;
+  p->nblk = (p->npad + HPX_NB - 1) / HPX_NB;
+  p->lgam_T = lgamma((double)T);
+  p->ev_used = 0;
+  const size_t nb = nbl, lsz = (size_t)p->npad * p->ld, xsz = (size_t)p->npad * p->TP,
+               ssz = (size_t)p->NP * p->TP, rsz = (size_t)p->NP * p->ncolR;
+  int rc = HPX_OK;
+#define A_(ptr, cnt) if (rc == HPX_OK) rc = dev_alloc(p, &p->ptr, (cnt))
+  A_(Lre, nb * lsz); A_(Lim, nb * lsz);
+  A_(Wre, nb * p->nblk * 1024); A_(Wim, nb * p->nblk * 1024);
+  A_(Xre, nb * xsz); A_(Xim, nb * xsz);
+  A_(info, nb);
+  A_(a, nb * N); A_(ps_cur, nb * N); A_(beta, nb * N); A_(betam, nb * N); A_(lnp1, nb);
+  A_(Rre, nb * rsz); A_(Rim, nb * rsz); A_(Zre, nb * rsz); A_(Zim, nb * rsz);
+  A_(Cre, nb * N); A_(Cim, nb * N);
+  A_(P2re, ssz); A_(P2im, ssz);
+  A_(Hre, nb * M * M); A_(Him, nb * M * M);
+  A_(P4re, nb * M * p->TP); A_(P4im, nb * M * p->TP);
+  A_(Fopre, (size_t)p->NP * p->NP); A_(Fopim, (size_t)p->NP * p->NP);
+  A_(Dre, nb * ssz); A_(Dim, nb * ssz); A_(Sre, nb * ssz); A_(Sim, nb * ssz);
+  A_(Gre, nb * ssz); A_(Gim, nb * ssz);
+  A_(Fre, nb * N * (M > 0 ? M : 1)); A_(Fim, nb * N * (M > 0 ? M : 1));
+  A_(ninv, nb * N); A_(ni, nb * N);
+  A_(flags, nb * N);
+  A_(pmap, nb * N);
+#undef A_
+  if (rc != HPX_OK) { hpx_plan_destroy(p); return rc; }
+  hipError_t e = hipMemset(p->Xre, 0, nb * xsz * sizeof(double));
+  if (e == hipSuccess) e = hipMemset(p->Xim, 0, nb * xsz * sizeof(double));
+  if (e == hipSuccess) e = hipMemset(p->P2re, 0, ssz * sizeof(double));
+  if (e == hipSuccess) e = hipMemset(p->P2im, 0, ssz * sizeof(double));
+  if (e == hipSuccess) e = hipMemset(p->info, 0, nb * sizeof(int32_t));
+  if (e != hipSuccess) {
+    hpx_set_error("hpx_plan_create: memset failed: %s", hipGetErrorString(e));
+    hpx_plan_destroy(p);
+    return HPX_EHIP;
+  }
+  *out = p;
+  return HPX_OK;
+}
+
+extern "C" int hpx_plan_destroy(hpx_plan* p) {
+  if (!p) return HPX_OK;
+  for (void* q : p->allocs) hipFree(q);
+  for (hipEvent_t ev : p->events) hipEventDestroy(ev);
+  delete p;
+  return HPX_OK;
+}
+
+extern "C" int64_t hpx_plan_bytes(const hpx_plan* p) { return p ? p->bytes : 0; }
+
+extern "C" int hpx_plan_dims(const hpx_plan* p, int* npad, int* tpad, int* ld) {
+  HPX_REQUIRE(p, "hpx_plan_dims: null plan");
+  if (npad) *npad = p->npad;
+  if (tpad) *tpad = p->TP;
+  if (ld) *ld = p->ld;
+  return HPX_OK;
+}
+
+extern "C" int hpx_plan_set_static(hpx_plan* p, const double* vis, const uint8_t* flags,
+                                   const double* ninv, const double* fgmodes, int fg_shared,
+                                   const int32_t* prior_map, const double* xgrid, int nxrows,
+                                   int prior_shared, int ngrid, const double* omega,
+                                   const double* fop, int any_flags, void* stream) {
+  HPX_REQUIRE(p && vis && flags && ninv && fop && prior_map, "hpx_plan_set_static: null argument");
+  HPX_REQUIRE(p->M == 0 || fgmodes, "hpx_plan_set_static: fgmodes required when M > 0");
+  HPX_REQUIRE(nxrows == 0 || (xgrid && ngrid >= 2 && ngrid <= 8192),
+              "hpx_plan_set_static: bad prior grid");
+  hipStream_t st = (hipStream_t)stream;
+  const int nbl = p->nbl, N = p->N, M = p->M, T = p->T, NP = p->NP, TP = p->TP, MP = p->MP;
+  p->fg_shared = fg_shared ? 1 : 0;
+  p->prior_shared = prior_shared ? 1 : 0;
+  p->has_omega = omega ? 1 : 0;
+  p->any_flags = any_flags ? 1 : 0;
+  p->ngrid = ngrid;
+  p->nxrows = nxrows;
+  HPX_HIP(hipMemcpyAsync(p->flags, flags, (size_t)nbl * N, hipMemcpyDeviceToDevice, st));
+  HPX_HIP(hipMemcpyAsync(p->ninv, ninv, (size_t)nbl * N * sizeof(double), hipMemcpyDeviceToDevice, st));
+  HPX_HIP(hipMemcpyAsync(p->pmap, prior_map, (size_t)(prior_shared ? 1 : nbl) * N * sizeof(int32_t),
+                         hipMemcpyDeviceToDevice, st));
+  if (nxrows > 0) {
+    HPX_TRY(dev_alloc(p, &p->xgrid, (size_t)nxrows * ngrid));
+    HPX_HIP(hipMemcpyAsync(p->xgrid, xgrid, (size_t)nxrows * ngrid * sizeof(double),
+                           hipMemcpyDeviceToDevice, st));
+  }
+  HPX_TRY(hpx_fop_to_planar(fop, p->Fopre, p->Fopim, N, NP, st));
+  const double* fgp = fgmodes ? fgmodes : vis;   // never dereferenced when M == 0
+  if (M > 0) {
+    const long tot = (long)(fg_shared ? 1 : nbl) * N * M;
+    hipLaunchKernelGGL(k_fg_planar, dim3(256), dim3(256), 0, st, fgmodes, p->Fre, p->Fim, tot);
+    HPX_HIP(hipGetLastError());
+  }
+  hipLaunchKernelGGL(k_prep, dim3(128, nbl), dim3(256), 0, st, vis, flags, ninv, fgp, p->fg_shared,
+                     omega, p->Zre, p->Zim, p->Dre, p->Dim, p->ni, T, N, M, NP, TP, MP, p->ncolR);
+  HPX_HIP(hipGetLastError());
+  const double isn = 1.0 / sqrt((double)N);
+  // R = U^H Z = F Z / sqrt(N)
+  HPX_TRY(hpx_launch_dft(nbl, NP, p->ncolR, p->Fopre, p->Fopim, 0, p->Zre, p->Zim,
+                         (long)NP * p->ncolR, p->ncolR, nullptr, 0, p->Rre, p->Rim,
+                         (long)NP * p->ncolR, p->ncolR, isn, st));
+  hipLaunchKernelGGL(k_circ, dim3(4, nbl), dim3(256), 0, st, p->Rre, p->Rim, p->Cre, p->Cim, N, NP,
+                     p->ncolR, TP + MP);
+  HPX_HIP(hipGetLastError());
+  if (M > 0) {
+    hipLaunchKernelGGL(k_small, dim3(nbl), dim3(256), 0, st, fgp, p->fg_shared, p->Zre, p->Zim,
+                       p->Hre, p->Him, p->P4re, p->P4im, N, M, NP, TP, MP, p->ncolR);
+    HPX_HIP(hipGetLastError());
+  }
+  if (omega) {   // P2 = U^H omega_a (shared by all baselines): use G scratch of baseline 0
+    hipLaunchKernelGGL(k_prep_omega, dim3(64), dim3(256), 0, st, omega, p->Gre, p->Gim, T, N, NP, TP);
+    HPX_HIP(hipGetLastError());
+    HPX_TRY(hpx_launch_dft(1, NP, TP, p->Fopre, p->Fopim, 0, p->Gre, p->Gim, 0, TP, nullptr, 0,
+                           p->P2re, p->P2im, 0, TP, isn, st));
+  } else {
+    HPX_HIP(hipMemsetAsync(p->P2re, 0, (size_t)NP * TP * sizeof(double), st));
+    HPX_HIP(hipMemsetAsync(p->P2im, 0, (size_t)NP * TP * sizeof(double), st));
+  }
+  HPX_HIP(hipStreamSynchronize(st));
+  p->have_static = 1;
+  return HPX_OK;
+}
+
+extern "C" int hpx_plan_set_rng(hpx_plan* p, const double* uniforms, const double* igy, int niter) {
+  HPX_REQUIRE(p && uniforms && igy && niter > 0, "hpx_plan_set_rng: bad argument");
+  const size_t cnt = (size_t)niter * p->N;
+  HPX_TRY(dev_alloc(p, &p->uni, cnt));
+  HPX_TRY(dev_alloc(p, &p->igy, cnt));
+  HPX_HIP(hipMemcpy(p->uni, uniforms, cnt * sizeof(double), hipMemcpyDeviceToDevice));
+  HPX_HIP(hipMemcpy(p->igy, igy, cnt * sizeof(double), hipMemcpyDeviceToDevice));
+  p->niter_tab = niter;
+  return HPX_OK;
+}
+
+static int launch_assemble(hpx_plan* p, hipStream_t st) {
+  AsmArgs A;
+  A.a = p->a; A.Cre = p->Cre; A.Cim = p->Cim; A.Rre = p->Rre; A.Rim = p->Rim;
+  A.P2re = p->P2re; A.P2im = p->P2im; A.Hre = p->Hre; A.Him = p->Him;
+  A.P4re = p->P4re; A.P4im = p->P4im; A.Lre = p->Lre; A.Lim = p->Lim;
+  A.N = p->N; A.M = p->M; A.T = p->T; A.NP = p->NP; A.TP = p->TP; A.npad = p->npad;
+  A.ld = p->ld; A.ncol = p->ncolR; A.has_omega = p->has_omega;
+  hipLaunchKernelGGL(k_assemble, dim3(p->npad / 16, p->nbl), dim3(256), 0, st, A);
+  HPX_HIP(hipGetLastError());
+  return HPX_OK;
+}
+
+extern "C" int hpx_assemble_K(hpx_plan* p, const double* ps, double* k_out, void* stream) {
+  HPX_REQUIRE(p && p->have_static && ps, "hpx_assemble_K: plan not initialised or null ps");
+  hipStream_t st = (hipStream_t)stream;
+  const long tot = (long)p->nbl * p->N;
+  hipLaunchKernelGGL(k_set_a, dim3(256), dim3(256), 0, st, ps, p->a, p->ps_cur, tot, 1.0 / p->N);
+  HPX_HIP(hipGetLastError());
+  HPX_TRY(launch_assemble(p, st));
+  if (k_out) {
+    hipLaunchKernelGGL(k_kaug_out, dim3(128, p->nbl), dim3(256), 0, st, p->Lre, p->Lim, k_out,
+                       p->npad, p->ld);
+    HPX_HIP(hipGetLastError());
+  }
+  HPX_HIP(hipStreamSynchronize(st));
+  return HPX_OK;
+}
+
+extern "C" int hpx_plan_set_profiling(hpx_plan* p, int on) {
+  HPX_REQUIRE(p, "null plan");
+  p->profiling = on ? 1 : 0;
+  return HPX_OK;
+}
+
+extern "C" int hpx_plan_stage_ms(hpx_plan* p, float* ms_host) {
+  HPX_REQUIRE(p && ms_host, "null argument");
+  for (int i = 0; i < HPX_NSTAGE; ++i) ms_host[i] = p->stage_ms[i];
+  return HPX_OK;
+}
+
+extern "C" int hpx_plan_info(hpx_plan* p, int32_t* info_host) {
+  HPX_REQUIRE(p && info_host, "null argument");
+  HPX_HIP(hipMemcpy(info_host, p->info, (size_t)p->nbl * sizeof(int32_t), hipMemcpyDeviceToHost));
+  return HPX_OK;
+}
+
+static int mark(hpx_plan* p, hipStream_t st) {
+  if (!p->profiling) return HPX_OK;
+  if (p->ev_used == (int)p->events.size()) {
+    hipEvent_t ev;
+    HPX_HIP(hipEventCreate(&ev));
+    p->events.push_back(ev);
+  }
+  HPX_HIP(hipEventRecord(p->events[p->ev_used++], st));
+  return HPX_OK;
+}
+
+extern "C" int hpx_gibbs_run(hpx_plan* p, const double* ps0, int iter0, int niter,
+                             const double* ps_forced, double* ps_out, double* lnpost_out,
+                             double* cr_out, double* fg_out, double* chisq_out, int thin,
+                             double* ps_last, void* stream) {
+  HPX_REQUIRE(p && p->have_static, "hpx_gibbs_run: plan has no static inputs");
+  HPX_REQUIRE(ps_out && lnpost_out && niter > 0 && iter0 >= 0, "hpx_gibbs_run: bad argument");
+  HPX_REQUIRE(p->uni && iter0 + niter <= p->niter_tab, "hpx_gibbs_run: random tables too short");
+  if (thin < 1) thin = 1;
+  hipStream_t st = (hipStream_t)stream;
+  const int nbl = p->nbl, N = p->N, M = p->M, T = p->T, NP = p->NP, TP = p->TP;
+  const int nkeep = (niter + thin - 1) / thin;
+  const double isn = 1.0 / sqrt((double)N);
+  if (ps0) {
+    hipLaunchKernelGGL(k_set_a, dim3(256), dim3(256), 0, st, ps0, p->a, p->ps_cur, (long)nbl * N,
+                       1.0 / N);
+    HPX_HIP(hipGetLastError());
+  }
+  HPX_HIP(hipMemsetAsync(p->info, 0, (size_t)nbl * sizeof(int32_t), st));
+  p->ev_used = 0;
+  for (int it = 0; it < niter; ++it) {
+    HPX_TRY(mark(p, st));
+    HPX_TRY(launch_assemble(p, st));
+    HPX_TRY(mark(p, st));
+    HPX_TRY(hpx_launch_factor(nbl, p->npad, p->ld, p->Lre, p->Lim, p->Wre, p->Wim, p->info,
+                              iter0 + it + 1, st));
+    HPX_TRY(mark(p, st));
+    HPX_TRY(hpx_launch_backsolve(nbl, p->npad, TP, p->ld, p->Lre, p->Lim, p->Wre, p->Wim, p->Xre,
+                                 p->Xim, st));
+    HPX_TRY(mark(p, st));
+    // s = U D^1/2 y' = conj(F) (a . y') / sqrt(N)
+    HPX_TRY(hpx_launch_dft(nbl, NP, TP, p->Fopre, p->Fopim, 1, p->Xre, p->Xim, (long)p->npad * TP,
+                           TP, p->a, N, p->Sre, p->Sim, (long)NP * TP, TP, isn, st));
+    HPX_TRY(mark(p, st));
+    ResArgs R;
+    R.Xre = p->Xre; R.Xim = p->Xim; R.Sre = p->Sre; R.Sim = p->Sim; R.Dre = p->Dre; R.Dim = p->Dim;
+    R.Fre = p->Fre; R.Fim = p->Fim; R.ninv = p->ninv; R.a = p->a; R.flags = p->flags;
+    R.beta = p->beta; R.lnp1 = p->lnp1; R.Gre = p->Gre; R.Gim = p->Gim;
+    const bool keep = (it % thin) == 0;
+    const long slot = it / thin;
+    R.cr_bstride = (long)nkeep * T * N * 2;
+    R.fg_bstride = (long)nkeep * T * M * 2;
+    R.chisq_bstride = (long)nkeep * T * N;
+    R.cr_out = (cr_out && keep) ? cr_out + slot * T * N * 2 : nullptr;
+    R.fg_out = (fg_out && keep && M > 0) ? fg_out + slot * T * M * 2 : nullptr;
+    R.chisq_out = (chisq_out && keep) ? chisq_out + slot * T * N : nullptr;
+    R.N = N; R.M = M; R.T = T; R.NP = NP; R.TP = TP; R.npad = p->npad;
+    R.fg_shared = p->fg_shared; R.any_flags = p->any_flags;
+    hipLaunchKernelGGL(k_resid, dim3(nbl), dim3(256), 0, st, R);
+    HPX_HIP(hipGetLastError());
+    if (p->any_flags) {   // |F (w s)|^2 for the masked S^-1 quadratic form (pspec.py:479-483)
+      HPX_TRY(hpx_launch_dft(nbl, NP, TP, p->Fopre, p->Fopim, 0, p->Gre, p->Gim, (long)NP * TP, TP,
+                             nullptr, 0, p->Zre, p->Zim, (long)NP * p->ncolR, p->ncolR, 1.0, st));
+      hipLaunchKernelGGL(k_betam, dim3(4, nbl), dim3(256), 0, st, p->Zre, p->Zim, p->betam, N, T,
+                         NP, p->ncolR);
+      HPX_HIP(hipGetLastError());
+    }
+    HPX_TRY(mark(p, st));
+    DrawArgs D;
+    D.beta = p->beta; D.betam = p->betam; D.lnp1 = p->lnp1;
+    D.uni = p->uni + (long)(iter0 + it) * N; D.igy = p->igy + (long)(iter0 + it) * N;
+    D.xgrid = p->xgrid; D.pmap = p->pmap;
+    D.ps_forced = ps_forced ? ps_forced + (long)it * N : nullptr;
+    D.forced_bstride = (long)niter * N;
+    D.a = p->a; D.ps_cur = p->ps_cur;
+    D.ps_out = ps_out + (long)it * N; D.ps_bstride = (long)niter * N;
+    D.lnpost_out = nullptr;
+    D.N = N; D.T = T; D.ngrid = p->ngrid; D.prior_shared = p->prior_shared;
+    D.any_flags = p->any_flags; D.lgam_T = p->lgam_T;
+    // lnpost_out (nbl, niter): element [b][it]; the kernel writes lnpost_out[b] with a
+    // stride of one baseline, so stage through lnp1 and scatter below.
+    D.lnpost_out = p->lnp1;
+    hipLaunchKernelGGL(k_draw, dim3(nbl), dim3(256), (size_t)(p->ngrid > 0 ? p->ngrid : 1) * 8, st, D);
+    HPX_HIP(hipGetLastError());
+    HPX_HIP(hipMemcpy2DAsync(lnpost_out + it, (size_t)niter * sizeof(double), p->lnp1,
+                             sizeof(double), sizeof(double), nbl, hipMemcpyDeviceToDevice, st));
+    HPX_TRY(mark(p, st));
+  }
+  if (ps_last)
+    HPX_HIP(hipMemcpyAsync(ps_last, p->ps_cur, (size_t)nbl * N * sizeof(double),
+                           hipMemcpyDeviceToDevice, st));
+  HPX_HIP(hipStreamSynchronize(st));
+  if (p->profiling) {
+    for (int s = 0; s < HPX_NSTAGE; ++s) p->stage_ms[s] = 0.f;
+    const int per = HPX_NSTAGE + 1;
+    for (int it = 0; it < niter; ++it)
+      for (int s = 0; s < HPX_NSTAGE; ++s) {
+        float ms = 0.f;
+        HPX_HIP(hipEventElapsedTime(&ms, p->events[it * per + s], p->events[it * per + s + 1]));
+        p->stage_ms[s] += ms;
+      }
+  }
+  // report the first non-positive pivot, if any
+  std::vector<int32_t> info(nbl);
+  HPX_HIP(hipMemcpy(info.data(), p->info, (size_t)nbl * sizeof(int32_t), hipMemcpyDeviceToHost));
+  for (int b = 0; b < nbl; ++b)
+    if (info[b] != 0) {
+      hpx_set_error("non-positive pivot: baseline %d, iteration %d", b, info[b] - 1);
+      return HPX_ENOTPD;
+    }
+  return HPX_OK;
+}
+
+extern "C" int hpx_gibbs_step_general(hpx_plan* p, const double* shp, int iter0, double* ps_out,
+                                      double* lnpost_out, double* cr_out, double* fg_out,
+                                      double* chisq_out, double* ps_last, void* stream) {
+  (void)p; (void)shp; (void)iter0; (void)ps_out; (void)lnpost_out; (void)cr_out; (void)fg_out;
+  (void)chisq_out; (void)ps_last; (void)stream;
+  hpx_set_error("hpx_gibbs_step_general: not implemented in this build");
+  return HPX_EINVAL;
+}
+
+extern "C" int hpx_invgamma_inversion(int n, int alpha, const double* beta, const double* u,
+                                      const double* xgrid, int ngrid, double* out, void* stream) {
+  HPX_REQUIRE(n > 0 && alpha >= 1 && beta && u && xgrid && out && ngrid >= 2 && ngrid <= 8192,
+              "hpx_invgamma_inversion: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_inv_test, dim3(n), dim3(256), (size_t)ngrid * 8, st, alpha,
+                     lgamma((double)alpha), beta, u, xgrid, ngrid, out);
+  HPX_HIP(hipGetLastError());
+  HPX_HIP(hipStreamSynchronize(st));
+  return HPX_OK;
+}

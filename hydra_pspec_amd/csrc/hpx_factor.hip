@@ -1,0 +1,543 @@
+// Batched complex-Hermitian blocked Cholesky on FP64 MFMA, with the right-hand
+// sides carried as extra rows (forward substitution for free), and the
+// backward substitution.  One workgroup (4 waves) per baseline.
+//
+// Storage: planar (separate re / im planes), column-major, leading dimension
+// ld = npad + TP.  Column c, row r lives at [c*ld + r].  Rows npad..ld-1 of
+// the augmented matrix hold the conjugated right-hand sides, so that after the
+// factorisation they hold Z^H with Z = L^-1 R.
+//
+// Algorithm (left-looking by block columns of HPX_NB = 32):
+//   for each block column j:
+//     1. diagonal block  D = K[j,j] - sum_k L[j,k] L[j,k]^H   (MFMA, K split
+//        over the 4 waves, partials combined through LDS)
+//     2. D = Ljj Ljj^H and Ljj^-1 in LDS (fused right-looking elimination)
+//     3. every 16-row tile below:  X = (K[r,j] - sum_k L[r,k] L[j,k]^H) Ljj^-H
+//        computed TRANSPOSED so that the accumulator tile is directly the
+//        B operand of the multiplication by conj(Ljj^-1): no data movement.
+#include "hpx_internal.h"
+
+namespace {
+
+constexpr int WLD = HPX_WLD;
+
+struct FactorShared {
+  double slab[2][3][2][4][64];   // K-split partial sums of the diagonal tiles (24 KB)
+  double Dre[32 * WLD], Dim[32 * WLD];   // diagonal block (lower), row-major [r][c]
+  double Yre[32 * WLD], Yim[32 * WLD];   // running inverse; finally W = conj(Ljj^-1)
+};
+
+// One off-diagonal 16-row tile of block column (c0, CT*16 wide).
+template <int CT>
+__device__ __forceinline__ void offdiag_tile(double* __restrict__ Lre, double* __restrict__ Lim,
+                                             const int ld, const int c0, const int r0,
+                                             const double* Wre, const double* Wim,
+                                             const int lane) {
+  const int li = lane & 15, g = lane >> 4;
+  d4 ar[CT], ai[CT];
+#pragma unroll
+  for (int ci = 0; ci < CT; ++ci)
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const long off = (long)(c0 + 16 * ci + HPX_ACC_ROW(g, v)) * ld + r0 + li;
+      ar[ci][v] = Lre[off];
+      ai[ci][v] = Lim[off];
+    }
+  // acc^T[c][r] -= conj(L[c][k]) * L[r][k]
+  const int nks = c0 >> 2;
+  const double* pre = Lre + (long)g * ld;
+  const double* pim = Lim + (long)g * ld;
+  const long kstep = 4L * ld;
+#pragma unroll 4
+  for (int ks = 0; ks < nks; ++ks) {
+    const double br = pre[r0 + li], bi = pim[r0 + li];
+#pragma unroll
+    for (int ci = 0; ci < CT; ++ci) {
+      const double pr = pre[c0 + 16 * ci + li], pi = pim[c0 + 16 * ci + li];
+      ar[ci] = mfma64(-pr, br, ar[ci]);
+      ar[ci] = mfma64(-pi, bi, ar[ci]);
+      ai[ci] = mfma64(-pr, bi, ai[ci]);
+      ai[ci] = mfma64(pi, br, ai[ci]);
+    }
+    pre += kstep;
+    pim += kstep;
+  }
+  // X^T = W * acc^T,  W = conj(Ljj^-1) lower triangular (LDS), acc^T as B operand
+  d4 xr[CT], xi[CT];
+#pragma unroll
+  for (int ci = 0; ci < CT; ++ci) {
+    xr[ci] = (d4){0., 0., 0., 0.};
+    xi[ci] = (d4){0., 0., 0., 0.};
+#pragma unroll
+    for (int cj = 0; cj <= ci; ++cj)
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const int kq = 16 * cj + HPX_ACC_ROW(g, v);
+        const double wr = Wre[(16 * ci + li) * WLD + kq];
+        const double wi = Wim[(16 * ci + li) * WLD + kq];
+        xr[ci] = mfma64(wr, ar[cj][v], xr[ci]);
+        xr[ci] = mfma64(-wi, ai[cj][v], xr[ci]);
+        xi[ci] = mfma64(wr, ai[cj][v], xi[ci]);
+        xi[ci] = mfma64(wi, ar[cj][v], xi[ci]);
+      }
+  }
+#pragma unroll
+  for (int ci = 0; ci < CT; ++ci)
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const long off = (long)(c0 + 16 * ci + HPX_ACC_ROW(g, v)) * ld + r0 + li;
+      Lre[off] = xr[ci][v];
+      Lim[off] = xi[ci][v];
+    }
+}
+
+// K-split partial sums of the (up to) three lower tiles of the diagonal block.
+// tile 0 = (c-tile 0, r-tile 0), 1 = (0,1), 2 = (1,1); acc^T[c][r].
+template <int CT>
+__device__ __forceinline__ void diag_partial(const double* __restrict__ Lre,
+                                             const double* __restrict__ Lim, const int ld,
+                                             const int c0, const int wave, const int lane,
+                                             d4 (&ar)[3], d4 (&ai)[3]) {
+  const int li = lane & 15, g = lane >> 4;
+#pragma unroll
+  for (int t = 0; t < 3; ++t) {
+    ar[t] = (d4){0., 0., 0., 0.};
+    ai[t] = (d4){0., 0., 0., 0.};
+  }
+  const int nks = c0 >> 2;
+  for (int ks = wave; ks < nks; ks += 4) {
+    const long off = (long)(4 * ks + g) * ld + c0 + li;
+    const double v0r = Lre[off], v0i = Lim[off];
+    ar[0] = mfma64(-v0r, v0r, ar[0]);
+    ar[0] = mfma64(-v0i, v0i, ar[0]);
+    ai[0] = mfma64(-v0r, v0i, ai[0]);
+    ai[0] = mfma64(v0i, v0r, ai[0]);
+    if (CT == 2) {
+      const double v1r = Lre[off + 16], v1i = Lim[off + 16];
+      ar[1] = mfma64(-v0r, v1r, ar[1]);
+      ar[1] = mfma64(-v0i, v1i, ar[1]);
+      ai[1] = mfma64(-v0r, v1i, ai[1]);
+      ai[1] = mfma64(v0i, v1r, ai[1]);
+      ar[2] = mfma64(-v1r, v1r, ar[2]);
+      ar[2] = mfma64(-v1i, v1i, ar[2]);
+      ai[2] = mfma64(-v1r, v1i, ai[2]);
+      ai[2] = mfma64(v1i, v1r, ai[2]);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256, 2) void k_factor(double* __restrict__ Lre_all,
+                                                   double* __restrict__ Lim_all,
+                                                   double* __restrict__ Wre_all,
+                                                   double* __restrict__ Wim_all,
+                                                   int32_t* __restrict__ info, const int npad,
+                                                   const int ld, const int iter_tag) {
+  __shared__ FactorShared sh;
+  const int b = blockIdx.x;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int li = lane & 15, g = lane >> 4;
+  double* Lre = Lre_all + (long)b * npad * ld;
+  double* Lim = Lim_all + (long)b * npad * ld;
+  const int nblk = (npad + HPX_NB - 1) / HPX_NB;
+  double* Wgre = Wre_all + (long)b * nblk * 1024;
+  double* Wgim = Wim_all + (long)b * nblk * 1024;
+  const int nrt = ld >> 4;
+  bool bad = false;
+
+  for (int jb = 0; jb < nblk; ++jb) {
+    const int c0 = jb * HPX_NB;
+    const int wj = min(HPX_NB, npad - c0);
+    const int CT = wj >> 4;
+    // ---- 1. diagonal block: partial sums over this wave's share of k
+    d4 ar[3], ai[3];
+    if (CT == 2) diag_partial<2>(Lre, Lim, ld, c0, wave, lane, ar, ai);
+    else diag_partial<1>(Lre, Lim, ld, c0, wave, lane, ar, ai);
+    if (wave >= 2) {
+#pragma unroll
+      for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          sh.slab[wave - 2][t][0][v][lane] = ar[t][v];
+          sh.slab[wave - 2][t][1][v][lane] = ai[t][v];
+        }
+    }
+    __syncthreads();
+    if (wave < 2) {
+#pragma unroll
+      for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          sh.slab[wave][t][0][v][lane] += ar[t][v];
+          sh.slab[wave][t][1][v][lane] += ai[t][v];
+        }
+    }
+    // identity for the running inverse
+    for (int e = tid; e < 32 * 32; e += 256) {
+      const int i = e >> 5, q = e & 31;
+      sh.Yre[i * WLD + q] = (i == q) ? 1.0 : 0.0;
+      sh.Yim[i * WLD + q] = 0.0;
+    }
+    __syncthreads();
+    // combine: D[r][c] = K[r][c] + slab0 + slab1   (acc^T[c][r] layout in the slabs)
+    for (int e = tid; e < 3 * 4 * 64; e += 256) {
+      const int t = e >> 8, v = (e >> 6) & 3, l = e & 63;
+      if (CT == 1 && t > 0) continue;
+      const int ci = (t == 2) ? 1 : 0, ri = (t == 0) ? 0 : 1;
+      const int c = 16 * ci + HPX_ACC_ROW(l >> 4, v), r = 16 * ri + (l & 15);
+      const long off = (long)(c0 + c) * ld + c0 + r;
+      sh.Dre[r * WLD + c] = Lre[off] + sh.slab[0][t][0][v][l] + sh.slab[1][t][0][v][l];
+      sh.Dim[r * WLD + c] = Lim[off] + sh.slab[0][t][1][v][l] + sh.slab[1][t][1][v][l];
+    }
+    // ---- 2. fused Cholesky + inverse of the wj x wj block (unscaled columns;
+    //         column q of L is D[:,q]/sqrt(D[q][q]) and row i of L^-1 is Y[i,:]/sqrt(D[i][i]))
+    for (int k = 0; k < wj; ++k) {
+      __syncthreads();
+      const double dkk = sh.Dre[k * WLD + k];
+      if (!(dkk > 0.0)) bad = true;
+      const double rinv2 = 1.0 / dkk;
+      const int nel = (wj - k - 1) << 5;
+      for (int e = tid; e < nel; e += 256) {
+        const int i = k + 1 + (e >> 5), q = e & 31;
+        const double lr = sh.Dre[i * WLD + k] * rinv2, lim = sh.Dim[i * WLD + k] * rinv2;
+        if (q <= k) {
+          const double yr = sh.Yre[k * WLD + q], yi = sh.Yim[k * WLD + q];
+          sh.Yre[i * WLD + q] -= lr * yr - lim * yi;
+          sh.Yim[i * WLD + q] -= lr * yi + lim * yr;
+        } else if (q <= i) {
+          const double qr = sh.Dre[q * WLD + k], qi = sh.Dim[q * WLD + k];
+          sh.Dre[i * WLD + q] -= lr * qr + lim * qi;   // * conj(D[q][k])
+          sh.Dim[i * WLD + q] -= lim * qr - lr * qi;
+        }
+      }
+    }
+    __syncthreads();
+    // final scaling: L_jj to global, W = conj(Ljj^-1) to LDS, Ljj^-1 to the side buffer
+    for (int e = tid; e < 32 * 32; e += 256) {
+      const int i = e >> 5, q = e & 31;
+      double wr = 0.0, wi = 0.0;
+      if (i < wj && q <= i) {
+        const double sq = 1.0 / sqrt(sh.Dre[q * WLD + q]);
+        const long off = (long)(c0 + q) * ld + c0 + i;
+        Lre[off] = sh.Dre[i * WLD + q] * sq;
+        Lim[off] = (i == q) ? 0.0 : sh.Dim[i * WLD + q] * sq;
+        const double si = 1.0 / sqrt(sh.Dre[i * WLD + i]);
+        wr = sh.Yre[i * WLD + q] * si;
+        wi = sh.Yim[i * WLD + q] * si;
+      }
+      Wgre[jb * 1024 + e] = wr;
+      Wgim[jb * 1024 + e] = wi;
+      // LDS copy is conjugated, written after all reads of Y by this thread
+      sh.Yre[i * WLD + q] = wr;
+      sh.Yim[i * WLD + q] = -wi;
+    }
+    __syncthreads();
+    // ---- 3. tiles below the diagonal block (incl. the right-hand-side rows)
+    const int rt0 = (c0 + wj) >> 4;
+    for (int rt = rt0 + wave; rt < nrt; rt += 4) {
+      if (CT == 2) offdiag_tile<2>(Lre, Lim, ld, c0, rt << 4, sh.Yre, sh.Yim, lane);
+      else offdiag_tile<1>(Lre, Lim, ld, c0, rt << 4, sh.Yre, sh.Yim, lane);
+    }
+    __syncthreads();
+  }
+  if (bad && info) atomicCAS(&info[b], 0, iter_tag);
+  (void)li; (void)g;
+}
+
+// ---------------------------------------------------------------------------
+// Backward substitution  L^H X = Z.  Z^H sits in rows npad.. of the factor.
+// X[r][t] planar, row-major with leading dimension TP.  Wave w owns t-tile
+// (w % TT) and k-slice (w / TT) of a split of the rows below into NSL slices.
+struct BackShared {
+  double slab[4][2][2][4][64];   // partial Y tiles of the k-slices (32 KB)
+};
+
+template <int CT>
+__device__ __forceinline__ void back_block(const double* __restrict__ Lre,
+                                           const double* __restrict__ Lim,
+                                           const double* __restrict__ Wgre,
+                                           const double* __restrict__ Wgim,
+                                           double* __restrict__ Xre, double* __restrict__ Xim,
+                                           BackShared& sh, const int npad, const int TP,
+                                           const int ld, const int c0, const int tt,
+                                           const int ksl, const int nsl, const int wave,
+                                           const int lane) {
+  const int li = lane & 15, g = lane >> 4;
+  d4 yr[CT], yi[CT];
+#pragma unroll
+  for (int ci = 0; ci < CT; ++ci) {
+    yr[ci] = (d4){0., 0., 0., 0.};
+    yi[ci] = (d4){0., 0., 0., 0.};
+  }
+  if (tt >= 0) {
+    const int t0 = tt << 4;
+    if (ksl == 0) {   // Z[c][t] = conj(Laug[npad + t][c])
+#pragma unroll
+      for (int ci = 0; ci < CT; ++ci)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          const long off = (long)(c0 + 16 * ci + HPX_ACC_ROW(g, v)) * ld + npad + t0 + li;
+          yr[ci][v] = Lre[off];
+          yi[ci][v] = -Lim[off];
+        }
+    }
+    // Y[c][t] -= sum_r conj(L[r][c]) X[r][t] over this slice's 16-row chunks.
+    // lane (li, g) fetches rows rb+4g .. rb+4g+3 of column c (32 contiguous bytes)
+    // and uses row rb+4g+s in k-step s; the X operand follows the same order.
+    const int rbeg = c0 + 16 * CT, nch = (npad - rbeg) >> 4;
+    for (int ch = ksl; ch < nch; ch += nsl) {
+      const int rb = rbeg + (ch << 4);
+      double lr[CT][4], lm[CT][4];
+#pragma unroll
+      for (int ci = 0; ci < CT; ++ci) {
+        const long off = (long)(c0 + 16 * ci + li) * ld + rb + 4 * g;
+        const double2 a0 = *reinterpret_cast<const double2*>(Lre + off);
+        const double2 a1 = *reinterpret_cast<const double2*>(Lre + off + 2);
+        const double2 b0 = *reinterpret_cast<const double2*>(Lim + off);
+        const double2 b1 = *reinterpret_cast<const double2*>(Lim + off + 2);
+        lr[ci][0] = a0.x; lr[ci][1] = a0.y; lr[ci][2] = a1.x; lr[ci][3] = a1.y;
+        lm[ci][0] = b0.x; lm[ci][1] = b0.y; lm[ci][2] = b1.x; lm[ci][3] = b1.y;
+      }
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const long xo = (long)(rb + 4 * g + s) * TP + t0 + li;
+        const double xr = Xre[xo], xi = Xim[xo];
+#pragma unroll
+        for (int ci = 0; ci < CT; ++ci) {
+          yr[ci] = mfma64(-lr[ci][s], xr, yr[ci]);
+          yr[ci] = mfma64(-lm[ci][s], xi, yr[ci]);
+          yi[ci] = mfma64(-lr[ci][s], xi, yi[ci]);
+          yi[ci] = mfma64(lm[ci][s], xr, yi[ci]);
+        }
+      }
+    }
+    if (ksl > 0) {
+#pragma unroll
+      for (int ci = 0; ci < CT; ++ci)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          sh.slab[wave][ci][0][v][lane] = yr[ci][v];
+          sh.slab[wave][ci][1][v][lane] = yi[ci][v];
+        }
+    }
+  }
+  __syncthreads();
+  if (tt >= 0 && ksl == 0) {
+    const int TT = TP >> 4;
+    for (int s = 1; s < nsl; ++s) {
+      const int w2 = s * TT + tt;   // wave that owned (tt, slice s)
+#pragma unroll
+      for (int ci = 0; ci < CT; ++ci)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          yr[ci][v] += sh.slab[w2][ci][0][v][lane];
+          yi[ci][v] += sh.slab[w2][ci][1][v][lane];
+        }
+    }
+    // X[c][t] = sum_{c' >= c} conj(Linv[c'][c]) Y[c'][t]
+    d4 xr[CT], xi[CT];
+#pragma unroll
+    for (int ci = 0; ci < CT; ++ci) {
+      xr[ci] = (d4){0., 0., 0., 0.};
+      xi[ci] = (d4){0., 0., 0., 0.};
+#pragma unroll
+      for (int cj = ci; cj < CT; ++cj)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          const int kq = 16 * cj + HPX_ACC_ROW(g, v);
+          const double wr = Wgre[kq * 32 + 16 * ci + li], wi = Wgim[kq * 32 + 16 * ci + li];
+          xr[ci] = mfma64(wr, yr[cj][v], xr[ci]);
+          xr[ci] = mfma64(wi, yi[cj][v], xr[ci]);
+          xi[ci] = mfma64(wr, yi[cj][v], xi[ci]);
+          xi[ci] = mfma64(-wi, yr[cj][v], xi[ci]);
+        }
+    }
+    const int t0 = tt << 4;
+#pragma unroll
+    for (int ci = 0; ci < CT; ++ci)
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const long xo = (long)(c0 + 16 * ci + HPX_ACC_ROW(g, v)) * TP + t0 + li;
+        Xre[xo] = xr[ci][v];
+        Xim[xo] = xi[ci][v];
+      }
+  }
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(256, 2) void k_backsolve(const double* __restrict__ Lre_all,
+                                                      const double* __restrict__ Lim_all,
+                                                      const double* __restrict__ Wre_all,
+                                                      const double* __restrict__ Wim_all,
+                                                      double* __restrict__ Xre_all,
+                                                      double* __restrict__ Xim_all,
+                                                      const int npad, const int TP,
+                                                      const int ld) {
+  __shared__ BackShared sh;
+  const int b = blockIdx.x;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const double* Lre = Lre_all + (long)b * npad * ld;
+  const double* Lim = Lim_all + (long)b * npad * ld;
+  const int nblk = (npad + HPX_NB - 1) / HPX_NB;
+  const double* Wgre = Wre_all + (long)b * nblk * 1024;
+  const double* Wgim = Wim_all + (long)b * nblk * 1024;
+  double* Xre = Xre_all + (long)b * npad * TP;
+  double* Xim = Xim_all + (long)b * npad * TP;
+  const int TT = TP >> 4;
+  const int nsl = (TT >= 3) ? 1 : 4 / TT;     // k-slices per t-tile
+  for (int tg = 0; tg < TT; tg += 4) {        // groups of up to 4 t-tiles (one per wave)
+    int tt = -1, ksl = 0;
+    if (nsl == 1) { if (tg + wave < TT) tt = tg + wave; }
+    else { tt = wave % TT; ksl = wave / TT; }
+    for (int jb = nblk - 1; jb >= 0; --jb) {
+      const int c0 = jb * HPX_NB;
+      const int wj = min(HPX_NB, npad - c0);
+      if (wj == 32)
+        back_block<2>(Lre, Lim, Wgre + jb * 1024, Wgim + jb * 1024, Xre, Xim, sh, npad, TP, ld, c0,
+                      tt, ksl, nsl, wave, lane);
+      else
+        back_block<1>(Lre, Lim, Wgre + jb * 1024, Wgim + jb * 1024, Xre, Xim, sh, npad, TP, ld, c0,
+                      tt, ksl, nsl, wave, lane);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// stand-alone helpers: interleaved row-major <-> planar column-major
+__global__ void k_pack_herm(const double* __restrict__ a, const double* __restrict__ rhs,
+                            double* __restrict__ Lre, double* __restrict__ Lim, const int n,
+                            const int nrhs, const int npad, const int ld) {
+  // a (nb,n,n) c128 row-major; rhs (nb,n,nrhs) c128 row-major or NULL
+  const int b = blockIdx.y;
+  const long tot = (long)npad * ld;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < tot;
+       e += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(e / ld), r = (int)(e % ld);
+    double vr = 0.0, vi = 0.0;
+    if (r < npad) {
+      if (r >= c) {
+        if (r < n && c < n) {
+          const long o = ((long)b * n * n + (long)r * n + c) * 2;
+          vr = a[o];
+          vi = a[o + 1];
+        } else if (r == c) vr = 1.0;
+      }
+    } else if (rhs && c < n && (r - npad) < nrhs) {   // row npad+t, col c = conj(rhs[c][t])
+      const long o = ((long)b * n * nrhs + (long)c * nrhs + (r - npad)) * 2;
+      vr = rhs[o];
+      vi = -rhs[o + 1];
+    }
+    Lre[(long)b * tot + e] = vr;
+    Lim[(long)b * tot + e] = vi;
+  }
+}
+
+__global__ void k_unpack_lower(const double* __restrict__ Lre, const double* __restrict__ Lim,
+                               double* __restrict__ out, const int n, const int npad,
+                               const int ld) {
+  const int b = blockIdx.y;
+  const long tot = (long)n * n;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < tot;
+       e += (long)gridDim.x * blockDim.x) {
+    const int r = (int)(e / n), c = (int)(e % n);
+    double vr = 0.0, vi = 0.0;
+    if (r >= c) {
+      const long o = (long)b * npad * ld + (long)c * ld + r;
+      vr = Lre[o];
+      vi = Lim[o];
+    }
+    out[((long)b * tot + e) * 2] = vr;
+    out[((long)b * tot + e) * 2 + 1] = vi;
+  }
+}
+
+__global__ void k_unpack_x(const double* __restrict__ Xre, const double* __restrict__ Xim,
+                           double* __restrict__ out, const int n, const int nrhs, const int npad,
+                           const int TP) {
+  const int b = blockIdx.y;
+  const long tot = (long)n * nrhs;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < tot;
+       e += (long)gridDim.x * blockDim.x) {
+    const int r = (int)(e / nrhs), t = (int)(e % nrhs);
+    const long o = (long)b * npad * TP + (long)r * TP + t;
+    out[((long)b * tot + e) * 2] = Xre[o];
+    out[((long)b * tot + e) * 2 + 1] = Xim[o];
+  }
+}
+
+}  // namespace
+
+int hpx_launch_factor(int nbl, int npad, int ld, double* Lre, double* Lim, double* Wre,
+                      double* Wim, int32_t* info, int iter_tag, hipStream_t st) {
+  hipLaunchKernelGGL(k_factor, dim3(nbl), dim3(256), 0, st, Lre, Lim, Wre, Wim, info, npad, ld,
+                     iter_tag);
+  HPX_HIP(hipGetLastError());
+  return HPX_OK;
+}
+
+int hpx_launch_backsolve(int nbl, int npad, int TP, int ld, const double* Lre, const double* Lim,
+                         const double* Wre, const double* Wim, double* Xre, double* Xim,
+                         hipStream_t st) {
+  hipLaunchKernelGGL(k_backsolve, dim3(nbl), dim3(256), 0, st, Lre, Lim, Wre, Wim, Xre, Xim, npad,
+                     TP, ld);
+  HPX_HIP(hipGetLastError());
+  return HPX_OK;
+}
+
+// ---- stand-alone C-ABI entry points (tests, other callers) -----------------
+namespace {
+struct Scratch {
+  double *Lre = nullptr, *Lim = nullptr, *Wre = nullptr, *Wim = nullptr, *Xre = nullptr,
+         *Xim = nullptr;
+  ~Scratch() {
+    hipFree(Lre); hipFree(Lim); hipFree(Wre); hipFree(Wim); hipFree(Xre); hipFree(Xim);
+  }
+};
+}  // namespace
+
+static int potr_common(int nb, int n, int nrhs, const double* a, const double* rhs, double* l_out,
+                       double* x_out, int32_t* info, hipStream_t st) {
+  HPX_REQUIRE(nb > 0 && n > 0 && a, "hpx_zpotr*: bad dimensions or null matrix");
+  const int npad = ceil16(n), TP = nrhs > 0 ? ceil16(nrhs) : 0, ld = npad + TP;
+  const int nblk = (npad + HPX_NB - 1) / HPX_NB;
+  Scratch s;
+  const size_t lbytes = (size_t)nb * npad * ld * sizeof(double);
+  HPX_HIP(hipMalloc(&s.Lre, lbytes));
+  HPX_HIP(hipMalloc(&s.Lim, lbytes));
+  HPX_HIP(hipMalloc(&s.Wre, (size_t)nb * nblk * 1024 * sizeof(double)));
+  HPX_HIP(hipMalloc(&s.Wim, (size_t)nb * nblk * 1024 * sizeof(double)));
+  if (info) HPX_HIP(hipMemsetAsync(info, 0, (size_t)nb * sizeof(int32_t), st));
+  hipLaunchKernelGGL(k_pack_herm, dim3(64, nb), dim3(256), 0, st, a, rhs, s.Lre, s.Lim, n, nrhs,
+                     npad, ld);
+  HPX_HIP(hipGetLastError());
+  HPX_TRY(hpx_launch_factor(nb, npad, ld, s.Lre, s.Lim, s.Wre, s.Wim, info, 1, st));
+  if (l_out) {
+    hipLaunchKernelGGL(k_unpack_lower, dim3(64, nb), dim3(256), 0, st, s.Lre, s.Lim, l_out, n,
+                       npad, ld);
+    HPX_HIP(hipGetLastError());
+  }
+  if (x_out) {
+    const size_t xbytes = (size_t)nb * npad * TP * sizeof(double);
+    HPX_HIP(hipMalloc(&s.Xre, xbytes));
+    HPX_HIP(hipMalloc(&s.Xim, xbytes));
+    HPX_HIP(hipMemsetAsync(s.Xre, 0, xbytes, st));
+    HPX_HIP(hipMemsetAsync(s.Xim, 0, xbytes, st));
+    HPX_TRY(hpx_launch_backsolve(nb, npad, TP, ld, s.Lre, s.Lim, s.Wre, s.Wim, s.Xre, s.Xim, st));
+    hipLaunchKernelGGL(k_unpack_x, dim3(64, nb), dim3(256), 0, st, s.Xre, s.Xim, x_out, n, nrhs,
+                       npad, TP);
+    HPX_HIP(hipGetLastError());
+  }
+  HPX_HIP(hipStreamSynchronize(st));
+  return HPX_OK;
+}
+
+extern "C" int hpx_zpotrf_batched(int nb, int n, const double* a, double* l_out, int32_t* info,
+                                  void* stream) {
+  HPX_REQUIRE(l_out, "hpx_zpotrf_batched: null output");
+  return potr_common(nb, n, 0, a, nullptr, l_out, nullptr, info, (hipStream_t)stream);
+}
+
+extern "C" int hpx_zpotrs_batched(int nb, int n, int nrhs, const double* a, const double* b,
+                                  double* x_out, int32_t* info, void* stream) {
+  HPX_REQUIRE(nrhs > 0 && b && x_out, "hpx_zpotrs_batched: bad right-hand side");
+  return potr_common(nb, n, nrhs, a, b, nullptr, x_out, info, (hipStream_t)stream);
+}

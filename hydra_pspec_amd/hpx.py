@@ -1,0 +1,155 @@
+"""ctypes binding of libhpx.so (include/hpx.h) on torch ROCm tensors.
+
+torch is used for device memory and streams only; every number the sampler
+produces comes out of the HIP kernels behind this ABI.  There is no fallback:
+a missing library or a missing GPU raises.
+"""
+import ctypes as C
+import os
+from pathlib import Path
+
+import numpy as np
+
+_LIB = None
+_LIB_PATH = Path(__file__).resolve().parent / "libhpx.so"
+
+HPX_OK, HPX_EINVAL, HPX_EHIP, HPX_ENOTPD = 0, -1, -2, -3
+NSTAGE = 6
+STAGES = ("assemble", "factor", "backsolve", "transform", "residual", "draw")
+
+_vp, _i, _i64 = C.c_void_p, C.c_int, C.c_int64
+
+# name -> (restype, argtypes); must list every symbol declared in include/hpx.h
+SIGNATURES = {
+    "hpx_version": (_i, []),
+    "hpx_last_error": (C.c_char_p, []),
+    "hpx_device_count": (_i, []),
+    "hpx_set_device": (_i, [_i]),
+    "hpx_plan_create": (_i, [C.POINTER(_vp), _i, _i, _i, _i]),
+    "hpx_plan_destroy": (_i, [_vp]),
+    "hpx_plan_bytes": (_i64, [_vp]),
+    "hpx_plan_set_static": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _i, _vp]),
+    "hpx_plan_set_rng": (_i, [_vp, _vp, _vp, _i]),
+    "hpx_gibbs_run": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
+    "hpx_gibbs_step_general": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "hpx_plan_info": (_i, [_vp, _vp]),
+    "hpx_plan_set_profiling": (_i, [_vp, _i]),
+    "hpx_plan_stage_ms": (_i, [_vp, _vp]),
+    "hpx_assemble_K": (_i, [_vp, _vp, _vp, _vp]),
+    "hpx_plan_dims": (_i, [_vp, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),
+    "hpx_zpotrf_batched": (_i, [_i, _i, _vp, _vp, _vp, _vp]),
+    "hpx_zpotrs_batched": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "hpx_dft_batched": (_i, [_i, _i, _i, _vp, _vp, _vp, _i, _vp]),
+    "hpx_invgamma_inversion": (_i, [_i, _i, _vp, _vp, _vp, _i, _vp, _vp]),
+    "hpx_dpss_project": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "hpx_oqe_fisher": (_i, [_i, _i, _vp, _vp, _i, _vp]),
+    "hpx_oqe_qh": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp]),
+    "hpx_mfma_probe": (_i, [_vp, _vp, _vp]),
+}
+
+
+def lib():
+    """Load libhpx.so (built by ``__graft_entry__.build()`` / csrc/Makefile)."""
+    global _LIB
+    if _LIB is None:
+        if not _LIB_PATH.exists():
+            raise RuntimeError(
+                f"{_LIB_PATH} is missing: build the HIP extension first "
+                "(python -c 'import __graft_entry__ as g; g.build()' or make -C hydra_pspec_amd/csrc). "
+                "hydra_pspec_amd has no CPU fallback.")
+        L = C.CDLL(str(_LIB_PATH))
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)          # AttributeError if the symbol is not exported
+            fn.restype, fn.argtypes = res, args
+        _LIB = L
+    return _LIB
+
+
+def last_error():
+    return lib().hpx_last_error().decode(errors="replace")
+
+
+def check(rc, what=""):
+    if rc == HPX_OK:
+        return
+    msg = f"{what}: {last_error()}" if what else last_error()
+    if rc == HPX_EINVAL:
+        raise ValueError(msg)
+    if rc == HPX_ENOTPD:
+        raise FloatingPointError(msg)
+    raise RuntimeError(msg)
+
+
+def require_gpu():
+    import torch
+    if not torch.cuda.is_available():
+        raise RuntimeError("hydra_pspec_amd needs a ROCm GPU (MI355X); none is visible and there "
+                           "is no CPU fallback")
+    return torch
+
+
+def ptr(t):
+    """Device pointer of a contiguous torch tensor (None -> NULL)."""
+    if t is None:
+        return None
+    assert t.is_contiguous(), "tensor must be contiguous"
+    return C.c_void_p(t.data_ptr())
+
+
+def stream_ptr(torch):
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def to_dev(torch, x, dtype, device):
+    """numpy / torch (any device) -> contiguous torch tensor of `dtype` on `device`."""
+    if isinstance(x, np.ndarray):
+        x = torch.from_numpy(np.ascontiguousarray(x))
+    return x.to(device=device, dtype=dtype, non_blocking=False).contiguous()
+
+
+class Plan:
+    """RAII wrapper of hpx_plan (one batch of baselines on one GPU)."""
+
+    def __init__(self, nbl, T, N, M):
+        self._h = C.c_void_p()
+        check(lib().hpx_plan_create(C.byref(self._h), nbl, T, N, M), "hpx_plan_create")
+        self.nbl, self.T, self.N, self.M = nbl, T, N, M
+        self._keep = []
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            lib().hpx_plan_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    @property
+    def handle(self):
+        return self._h
+
+    def bytes(self):
+        return int(lib().hpx_plan_bytes(self._h))
+
+    def dims(self):
+        a, b, c = C.c_int(), C.c_int(), C.c_int()
+        check(lib().hpx_plan_dims(self._h, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
+
+    def stage_ms(self):
+        buf = (C.c_float * NSTAGE)()
+        check(lib().hpx_plan_stage_ms(self._h, buf))
+        return dict(zip(STAGES, [float(v) for v in buf]))
+
+    def set_profiling(self, on):
+        check(lib().hpx_plan_set_profiling(self._h, int(bool(on))))
+
+    def info(self):
+        out = np.zeros(self.nbl, dtype=np.int32)
+        check(lib().hpx_plan_info(self._h, out.ctypes.data_as(C.c_void_p)))
+        return out

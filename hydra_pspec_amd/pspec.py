@@ -1,0 +1,473 @@
+"""Gibbs sampler for the EoR bandpowers with a foreground-mode model: host side.
+
+Mirror of ``hydra_pspec.pspec`` (reference hydra_pspec/pspec.py) for the
+MI355X path: same function names, argument meaning, return shapes and error
+types.  The arithmetic is done by the HIP kernels in ``csrc/`` through the
+C-ABI of ``include/hpx.h``; this module only prepares inputs (including the
+reference's random-number streams, reproduced bit for bit with numpy's legacy
+MT19937) and lays out outputs.
+
+Formulation: with ``S = U diag(ps/N) U^H`` (``U = F^H/sqrt N``)
+and diagonal ``Ninv``, the reference's non-Hermitian system ``A x = b``
+(pspec.py:365-369) is solved as the Hermitian positive-definite system
+``K' [y'; f] = r'`` in the delay basis by a batched Cholesky factorisation;
+``s = U D^{1/2} y'``.  The accelerated entry point is
+:func:`gibbs_sample_with_fg_batched`; :func:`gibbs_sample_with_fg` is its
+``Nbl = 1`` drop-in special case.
+"""
+import ctypes as C
+import time
+
+import numpy as np
+import scipy.special
+
+from . import hpx, utils
+
+GCR_SEED0 = 912983          # reference pspec.py:153 (multiprocess_seed, never overridden)
+NGRID = 1000                # reference pspec.py:11 (ngrid default)
+FOURIER_FORM_TOL = 1e-9     # relative off-diagonal power allowed in F S F^H
+
+
+# --------------------------------------------------------------------------- RNG
+def omega_table(T, N):
+    """The reference's GCR noise draws: for time ``t`` the legacy stream seeded
+    with ``912983 + t`` yields ``omi, omj, omk, oml = randn(N,1) x 4`` in that
+    order (pspec.py:196-216).  Identical for every iteration and baseline.
+    Returns (T,4,N) float64."""
+    out = np.empty((T, 4, N))
+    for t in range(T):
+        out[t] = np.random.RandomState(GCR_SEED0 + t).randn(4, N)
+    return out
+
+
+def draw_tables(T, N, Niter, seed, reseed=True):
+    """Uniforms the chain's parent stream hands to the bandpower draw: exactly
+    one per channel per iteration, in channel order, for both branches of
+    ``sample_S`` (pspec.py:58, :125; scipy's ``invgamma.rvs`` is ``ppf(U)``).
+    Uses -- and advances -- numpy's GLOBAL legacy stream like the reference
+    (``np.random.seed(seed)`` at pspec.py:577, skipped for map_estimate).
+    Returns (uniforms, 1/gammainccinv(T-1, uniforms)), each (Niter,N)."""
+    if reseed:
+        np.random.seed(seed)
+    u = np.random.random_sample((Niter, N))
+    return u, 1.0 / scipy.special.gammainccinv(T - 1.0, u)
+
+
+# ------------------------------------------------------------------ input checks
+def _prior_tables(ps_prior, N):
+    """(.., 2, N) prior box -> (prior_map int32 (.., N), xgrid (nrows, NGRID)).
+    Raises the reference's ValueErrors (pspec.py:40-47) for bad bounds."""
+    pr = np.asarray(ps_prior, dtype=float)
+    assert pr.shape[-2:] == (2, N), "ps_prior must have shape (2, Nfreqs)"
+    has = np.any(pr > 0, axis=-2)
+    hi, lo = pr[..., 0, :], pr[..., 1, :]
+    if np.any(has):
+        if np.any(lo[has] <= 0):
+            raise ValueError("prior_min must be greater than zero")
+        if np.any(hi[has] <= 0):
+            raise ValueError("prior_max must be greater than zero")
+        if not np.all(np.isfinite(hi[has])):
+            raise ValueError("prior_max must be finite")
+        if np.any(hi[has] <= lo[has]):
+            raise ValueError("prior_max must be greater than prior_min")
+    pmap = np.full(has.shape, -1, dtype=np.int32)
+    rows, index = [], {}
+    for idx in zip(*np.nonzero(has)):
+        key = (lo[idx], hi[idx])
+        if key not in index:
+            index[key] = len(rows)
+            rows.append(np.logspace(np.log10(key[0]), np.log10(key[1]), NGRID))
+        pmap[idx] = index[key]
+    xgrid = np.array(rows) if rows else np.zeros((0, NGRID))
+    return pmap, xgrid
+
+
+def _ninv_diag(Ninv, nbl, T, N):
+    """Accept (N,), (nbl,N) diagonals or (N,N)/(nbl,N,N) dense matrices that are
+    diagonal; return (nbl,N).  Dense non-diagonal inverse covariances make the
+    reference's column-masked ``Ni`` non-Hermitian (pspec.py:361 FIXME) and are
+    not supported by the Cholesky formulation."""
+    Ninv = np.asarray(Ninv)
+    if Ninv.ndim == 3 and Ninv.shape[0] == T and Ninv.shape[0] != nbl:
+        raise NotImplementedError("time-dependent Ninv (Ntimes,Nfreqs,Nfreqs) is not supported "
+                                  "(the reference documents but does not implement it either)")
+    if Ninv.shape in ((N,), (nbl, N)):
+        return np.ascontiguousarray(np.broadcast_to(Ninv.real, (nbl, N)), dtype=float)
+    if Ninv.shape in ((N, N), (nbl, N, N)):
+        d = np.diagonal(Ninv, axis1=-2, axis2=-1)
+        off = Ninv - d[..., None] * np.eye(N)
+        if np.any(off != 0):
+            raise NotImplementedError("only diagonal inverse noise covariances are supported")
+        return np.ascontiguousarray(np.broadcast_to(d.real, (nbl, N)), dtype=float)
+    raise AssertionError("Ninv shape must be (Nfreqs, Nfreqs) or a diagonal (Nfreqs,)")
+
+
+def pspec_from_covariance(S, fourier_op=None):
+    """Inverse of :func:`covariance_from_pspec` for covariances of the form
+    ``F^H diag(ps/N^2) F``: returns (ps, relative off-diagonal residual)."""
+    S = np.asarray(S)
+    N = S.shape[-1]
+    F = utils.fourier_operator(N) if fourier_op is None else fourier_op
+    D = F @ S @ F.conj().T
+    ps = np.diagonal(D, axis1=-2, axis2=-1).real.copy()
+    off = D - np.eye(N) * np.diagonal(D, axis1=-2, axis2=-1)[..., None, :]
+    resid = np.linalg.norm(off, axis=(-2, -1)) / np.maximum(np.linalg.norm(D, axis=(-2, -1)), 1e-300)
+    return ps, resid
+
+
+# ------------------------------------------------------------------ batched core
+class GibbsBatch:
+    """A batch of independent baselines resident on one GPU.
+
+    Static inputs are uploaded and reduced to the iteration-invariant operators
+    once; :meth:`run` then advances all chains by ``niter`` iterations.
+    """
+
+    def __init__(self, vis, flags, fgmodes, ninv_diag, ps_prior, Niter, seed=None,
+                 map_estimate=False, device=None, tables=None):
+        torch = hpx.require_gpu()
+        self.torch = torch
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None \
+            else torch.device(device)
+        vis_shape = tuple(vis.shape)
+        assert len(vis_shape) == 3, "vis must have shape (Nbl, Ntimes, Nfreqs)"
+        nbl, T, N = vis_shape
+        fg_shape = tuple(fgmodes.shape)
+        assert fg_shape[-2] == N, "fgmodes must have shape (Nfreqs, Nmodes)"
+        M = fg_shape[-1]
+        assert tuple(flags.shape) == (nbl, N), "`flags` array must have shape (Nbl, Nfreqs)"
+        self.nbl, self.T, self.N, self.M = nbl, T, N, M
+        self.map_estimate = bool(map_estimate)
+        self.Niter = 1 if map_estimate else int(Niter)
+        with torch.cuda.device(self.device):
+            c128, f64 = torch.complex128, torch.float64
+            d_vis = hpx.to_dev(torch, vis, c128, self.device)
+            fl_np = flags if isinstance(flags, np.ndarray) else flags.detach().cpu().numpy()
+            d_flags = hpx.to_dev(torch, np.ascontiguousarray(fl_np).astype(np.uint8), torch.uint8,
+                                 self.device)
+            d_ninv = hpx.to_dev(torch, ninv_diag, f64, self.device)
+            assert tuple(d_ninv.shape) == (nbl, N)
+            fg_shared = len(fg_shape) == 2
+            d_fg = hpx.to_dev(torch, fgmodes, c128, self.device)
+            pmap, xgrid = _prior_tables(ps_prior if isinstance(ps_prior, np.ndarray)
+                                        else ps_prior.detach().cpu().numpy(), N)
+            prior_shared = pmap.ndim == 1
+            d_pmap = hpx.to_dev(torch, pmap, torch.int32, self.device)
+            d_xgrid = hpx.to_dev(torch, xgrid, f64, self.device) if len(xgrid) else None
+            if tables is None:
+                tables = draw_tables(T, N, self.Niter, seed, reseed=not map_estimate)
+            uni, igy = tables
+            assert uni.shape == (self.Niter, N) and igy.shape == (self.Niter, N)
+            d_omega = None if map_estimate else hpx.to_dev(torch, omega_table(T, N), f64, self.device)
+            d_fop = hpx.to_dev(torch, utils.fourier_operator(N), c128, self.device)
+            self.any_flags = bool((~fl_np.astype(bool)).any())
+            self.plan = hpx.Plan(nbl, T, N, M)
+            L = hpx.lib()
+            hpx.check(L.hpx_plan_set_static(
+                self.plan.handle, hpx.ptr(d_vis), hpx.ptr(d_flags), hpx.ptr(d_ninv),
+                hpx.ptr(d_fg) if M > 0 else None, int(fg_shared), hpx.ptr(d_pmap), hpx.ptr(d_xgrid),
+                int(len(xgrid)), int(prior_shared), NGRID, hpx.ptr(d_omega), hpx.ptr(d_fop),
+                int(self.any_flags), hpx.stream_ptr(torch)), "hpx_plan_set_static")
+            d_uni = hpx.to_dev(torch, uni, f64, self.device)
+            d_igy = hpx.to_dev(torch, igy, f64, self.device)
+            hpx.check(L.hpx_plan_set_rng(self.plan.handle, hpx.ptr(d_uni), hpx.ptr(d_igy),
+                                         self.Niter), "hpx_plan_set_rng")
+        self.iter_done = 0
+
+    def close(self):
+        self.plan.close()
+
+    def run(self, niter, ps0=None, ps_forced=None, keep=("ps", "ln_post"), thin=1):
+        """Advance every chain by ``niter`` iterations.
+
+        ps0 (nbl,N): bandpowers of the starting covariance (required on the
+        first call).  Returns a dict of device tensors: ``signal_ps``
+        (nbl,niter,N), ``ln_post`` (nbl,niter), ``ps_last`` (nbl,N) and, if named
+        in ``keep``, ``signal_cr`` (nbl,nkeep,T,N) c128, ``fg_amps``
+        (nbl,nkeep,T,M) c128, ``chisq`` (nbl,nkeep,T,N)."""
+        torch = self.torch
+        nbl, T, N, M = self.nbl, self.T, self.N, self.M
+        assert self.iter_done + niter <= self.Niter, "random tables exhausted"
+        assert ps0 is not None or self.iter_done > 0, "ps0 is required for the first run"
+        nkeep = (niter + thin - 1) // thin
+        with torch.cuda.device(self.device):
+            f64, c128 = torch.float64, torch.complex128
+            dev = self.device
+            d_ps0 = None if ps0 is None else hpx.to_dev(torch, ps0, f64, dev)
+            if d_ps0 is not None:
+                assert tuple(d_ps0.shape) == (nbl, N)
+            d_forced = None if ps_forced is None else hpx.to_dev(torch, ps_forced, f64, dev)
+            if d_forced is not None:
+                assert tuple(d_forced.shape) == (nbl, niter, N)
+            out = dict(signal_ps=torch.empty((nbl, niter, N), dtype=f64, device=dev),
+                       ln_post=torch.empty((nbl, niter), dtype=f64, device=dev),
+                       ps_last=torch.empty((nbl, N), dtype=f64, device=dev))
+            if "signal_cr" in keep:
+                out["signal_cr"] = torch.empty((nbl, nkeep, T, N), dtype=c128, device=dev)
+            if "fg_amps" in keep:
+                out["fg_amps"] = torch.zeros((nbl, nkeep, T, M), dtype=c128, device=dev)
+            if "chisq" in keep:
+                out["chisq"] = torch.empty((nbl, nkeep, T, N), dtype=f64, device=dev)
+            rc = hpx.lib().hpx_gibbs_run(
+                self.plan.handle, hpx.ptr(d_ps0), self.iter_done, niter, hpx.ptr(d_forced),
+                hpx.ptr(out["signal_ps"]), hpx.ptr(out["ln_post"]), hpx.ptr(out.get("signal_cr")),
+                hpx.ptr(out.get("fg_amps")), hpx.ptr(out.get("chisq")), thin,
+                hpx.ptr(out["ps_last"]), hpx.stream_ptr(torch))
+            hpx.check(rc, "hpx_gibbs_run")
+        self.iter_done += niter
+        return out
+
+
+def gibbs_sample_with_fg_batched(vis, flags, fgmodes, Ninv, ps_prior, S_initial=None,
+                                 ps_initial=None, Niter=100, seed=None, map_estimate=False,
+                                 keep=("ps", "ln_post"), thin=1, ps_forced=None, device=None,
+                                 as_numpy=True):
+    """Run the Gibbs chain of ``gibbs_sample_with_fg`` for ``Nbl`` baselines at once.
+
+    Parameters mirror the reference (pspec.py:493-571) with a leading baseline
+    axis: ``vis`` (Nbl,Ntimes,Nfreqs) complex, ``flags`` (Nbl,Nfreqs) bool
+    (True = use), ``fgmodes`` (Nfreqs,Nmodes) or (Nbl,Nfreqs,Nmodes), ``Ninv``
+    diagonal (Nbl,Nfreqs)/(Nfreqs,) or dense-but-diagonal matrices, ``ps_prior``
+    (2,Nfreqs) or (Nbl,2,Nfreqs) with rows [hi, lo].  The initial covariance is
+    given either as ``ps_initial`` (Nbl,Nfreqs)/(Nfreqs,) bandpowers
+    (``S = F^H diag(ps/N^2) F``) or as ``S_initial`` matrices of that form.
+    ``seed`` is shared by all baselines, as in the reference driver.
+
+    Returns a dict: ``signal_ps`` (Nbl,Niter,Nfreqs), ``ln_post`` (Nbl,Niter),
+    ``ps_last`` and the histories named in ``keep`` (``"signal_cr"``,
+    ``"fg_amps"``, ``"chisq"``; every ``thin``-th iteration)."""
+    nbl, T, N = tuple(vis.shape)
+    if ps_initial is None:
+        if S_initial is None:
+            raise ValueError("one of S_initial / ps_initial is required")
+        S0 = np.asarray(S_initial)
+        ps_initial, resid = pspec_from_covariance(S0)
+        if np.any(resid > FOURIER_FORM_TOL):
+            raise NotImplementedError("S_initial is not of the form F^H diag(ps/N^2) F "
+                                      f"(relative off-diagonal power {np.max(resid):.2e})")
+    ps0 = np.ascontiguousarray(np.broadcast_to(np.asarray(ps_initial, dtype=float), (nbl, N)))
+    ninv = _ninv_diag(Ninv, nbl, T, N)
+    gb = GibbsBatch(vis, flags, fgmodes, ninv, ps_prior, Niter, seed=seed,
+                    map_estimate=map_estimate, device=device)
+    try:
+        out = gb.run(gb.Niter, ps0=ps0, ps_forced=ps_forced, keep=keep, thin=thin)
+    finally:
+        gb.close()
+    if as_numpy:
+        out = {k: v.cpu().numpy() for k, v in out.items()}
+    return out
+
+
+# ------------------------------------------------------- reference call surface
+def covariance_from_pspec(ps, fourier_op):
+    """``fourier_op^H diag(ps) fourier_op`` (reference pspec.py:313-322), computed
+    with the batched DFT kernel: row j of ``(F * ps)`` is transformed by F^H."""
+    torch = hpx.require_gpu()
+    ps = np.asarray(ps, dtype=float)
+    N = ps.size
+    dev = torch.device("cuda", torch.cuda.current_device())
+    fop = hpx.to_dev(torch, np.asarray(fourier_op, dtype=complex), torch.complex128, dev)
+    rows = (fop * hpx.to_dev(torch, ps, torch.float64, dev)[None, :]).contiguous()   # F[j,k] ps[k]
+    # the operator is symmetric: F^T = F, so column j of diag(ps) F is row j of F diag(ps)
+    out = torch.empty((1, N, N), dtype=torch.complex128, device=dev)
+    hpx.check(hpx.lib().hpx_dft_batched(1, N, N, hpx.ptr(fop), hpx.ptr(rows), hpx.ptr(out), 1,
+                                        hpx.stream_ptr(torch)), "hpx_dft_batched")
+    return (out[0].T * N).cpu().numpy()
+
+
+def inversion_sample_invgamma(alpha, beta, prior_min, prior_max, ngrid=1000):
+    """Truncated inverse-gamma draw by inversion of the CDF sampled on a log grid
+    (reference pspec.py:11-64).  Consumes one ``np.random.uniform()``.  The HIP
+    kernel evaluates the CDF for integer ``alpha`` (the path always passes
+    ``alpha = Ntimes``)."""
+    if prior_min <= 0:
+        raise ValueError("prior_min must be greater than zero")
+    if prior_max <= 0:
+        raise ValueError("prior_max must be greater than zero")
+    if not np.isfinite(prior_max):
+        raise ValueError("prior_max must be finite")
+    if prior_max <= prior_min:
+        raise ValueError("prior_max must be greater than prior_min")
+    if float(alpha) != int(alpha) or alpha < 1:
+        raise NotImplementedError("the HIP inversion kernel needs a positive integer alpha")
+    torch = hpx.require_gpu()
+    dev = torch.device("cuda", torch.cuda.current_device())
+    x = np.logspace(np.log10(prior_min), np.log10(prior_max), ngrid)
+    u = np.random.uniform()
+    f64 = torch.float64
+    d_b = hpx.to_dev(torch, np.array([beta], dtype=float), f64, dev)
+    d_u = hpx.to_dev(torch, np.array([u]), f64, dev)
+    d_x = hpx.to_dev(torch, x[None, :], f64, dev)
+    d_o = torch.empty(1, dtype=f64, device=dev)
+    hpx.check(hpx.lib().hpx_invgamma_inversion(1, int(alpha), hpx.ptr(d_b), hpx.ptr(d_u),
+                                               hpx.ptr(d_x), ngrid, hpx.ptr(d_o),
+                                               hpx.stream_ptr(torch)), "hpx_invgamma_inversion")
+    return float(d_o.cpu()[0])
+
+
+def sample_S(s=None, sk=None, prior=None):
+    """Bandpower draw p(S|s) (reference pspec.py:67-127): one global uniform per
+    channel; ``x = beta * invgamma.ppf(U, Nobs-1)`` or the truncated draw with
+    shape ``Nobs`` inside the prior box."""
+    if s is None and sk is None:
+        raise ValueError("Must pass in s (real space) or sk (Fourier space) vector.")
+    torch = hpx.require_gpu()
+    dev = torch.device("cuda", torch.cuda.current_device())
+    c128, f64 = torch.complex128, torch.float64
+    if sk is None:
+        s = np.asarray(s, dtype=complex)
+        nobs, nfreq = s.shape
+        d_s = hpx.to_dev(torch, s[None], c128, dev)
+        d_sk = torch.empty_like(d_s)
+        d_fop = hpx.to_dev(torch, utils.fourier_operator(nfreq), c128, dev)
+        hpx.check(hpx.lib().hpx_dft_batched(1, nobs, nfreq, hpx.ptr(d_fop), hpx.ptr(d_s), hpx.ptr(d_sk),
+                                            0, hpx.stream_ptr(torch)), "hpx_dft_batched")
+        sk_t = d_sk[0]
+    else:
+        sk = np.asarray(sk, dtype=complex)
+        nobs, nfreq = sk.shape
+        sk_t = hpx.to_dev(torch, sk, c128, dev)
+    beta = (sk_t.real ** 2 + sk_t.imag ** 2).sum(dim=0).cpu().numpy()
+    if prior is None:
+        prior = np.zeros((2, nfreq))
+    pmap, xgrid = _prior_tables(prior, nfreq)
+    u = np.random.random_sample(nfreq)
+    x = beta / scipy.special.gammainccinv(nobs - 1.0, u)
+    sel = np.nonzero(pmap >= 0)[0]
+    if sel.size:
+        d_b = hpx.to_dev(torch, beta[sel], f64, dev)
+        d_u = hpx.to_dev(torch, u[sel], f64, dev)
+        d_x = hpx.to_dev(torch, xgrid[pmap[sel]], f64, dev)
+        d_o = torch.empty(sel.size, dtype=f64, device=dev)
+        hpx.check(hpx.lib().hpx_invgamma_inversion(int(sel.size), int(nobs), hpx.ptr(d_b), hpx.ptr(d_u),
+                                                   hpx.ptr(d_x), NGRID, hpx.ptr(d_o),
+                                                   hpx.stream_ptr(torch)), "hpx_invgamma_inversion")
+        x[sel] = d_o.cpu().numpy()
+    return x
+
+
+def sprior(signals, bins, factor):
+    """Prior box derived from data (reference pspec.py:130-148; unused by the
+    chain).  ``|fft(v)|^2`` is the centred transform's power, un-shifted."""
+    torch = hpx.require_gpu()
+    dev = torch.device("cuda", torch.cuda.current_device())
+    signals = np.asarray(signals, dtype=complex)
+    nobs, nfreq = signals.shape
+    c128 = torch.complex128
+    d_s = hpx.to_dev(torch, np.fft.fftshift(signals, axes=-1)[None], c128, dev)
+    d_sk = torch.empty_like(d_s)
+    d_fop = hpx.to_dev(torch, utils.fourier_operator(nfreq), c128, dev)
+    hpx.check(hpx.lib().hpx_dft_batched(1, nobs, nfreq, hpx.ptr(d_fop), hpx.ptr(d_s), hpx.ptr(d_sk), 0,
+                                        hpx.stream_ptr(torch)), "hpx_dft_batched")
+    ds = np.fft.ifftshift((d_sk[0].real ** 2 + d_sk[0].imag ** 2).sum(dim=0).cpu().numpy())
+    prior = np.zeros((2, nfreq))
+    prior[0] = ds * factor
+    prior[1] = ds / factor
+    prior[0, bins + 1:-bins] = 0
+    prior[1, bins + 1:-bins] = 0
+    return prior / (nobs / 2 - 1)
+
+
+def gibbs_step_fgmodes(vis, flags, signal_S, fgmodes, Ninv, ps_prior=None, f0=None, nproc=1,
+                       map_estimate=False, verbose=False):
+    """One Gibbs iteration (reference pspec.py:377-490).  Draws its N uniforms
+    from numpy's global stream without reseeding, like the reference.  ``f0`` and
+    ``nproc`` are accepted and ignored (a direct solve needs no initial guess)."""
+    vis = np.asarray(vis)
+    N = vis.shape[1]
+    assert flags.shape == (N,), "`flags` array must have shape (Nfreqs,)"
+    if ps_prior is None:
+        ps_prior = np.zeros((2, N))
+    ps0, resid = pspec_from_covariance(np.asarray(signal_S))
+    if resid > FOURIER_FORM_TOL:
+        raise NotImplementedError("signal_S is not of the form F^H diag(ps/N^2) F")
+    T = vis.shape[0]
+    gb = GibbsBatch(vis[None], np.asarray(flags)[None], fgmodes, _ninv_diag(Ninv, 1, T, N), ps_prior, 1,
+                    map_estimate=map_estimate, tables=draw_tables(T, N, 1, None, reseed=False))
+    try:
+        out = gb.run(1, ps0=ps0[None], keep=("signal_cr", "fg_amps", "chisq"))
+    finally:
+        gb.close()
+    ps_sample = out["signal_ps"][0, 0].cpu().numpy()
+    S_sample = covariance_from_pspec(ps_sample / N ** 2, utils.fourier_operator(N))
+    return (out["signal_cr"][0, 0].cpu().numpy(), S_sample, ps_sample,
+            out["fg_amps"][0, 0].cpu().numpy(), out["chisq"][0, 0].cpu().numpy(),
+            float(out["ln_post"][0, 0].cpu()))
+
+
+def gibbs_sample_with_fg(vis, flags, S_initial, fgmodes, Ninv, ps_prior, Niter=100, seed=None,
+                         verbose=True, nproc=1, write_Niter=100, out_dir=None, map_estimate=False):
+    """Drop-in for the reference chain driver (pspec.py:493-658).
+
+    Returns ``(signal_cr (Niter,Ntimes,Nfreqs) c128, signal_S (Nfreqs,Nfreqs)
+    c128 [last sample only, as in the reference], signal_ps (Niter,Nfreqs),
+    fg_amps (Niter,Ntimes,Nmodes) c128, chisq (Niter,Ntimes,Nfreqs), ln_post
+    (Niter,), write_time)``.  ``nproc`` is accepted and ignored: the reference's
+    results do not depend on it.  ``map_estimate=True`` forces ``Niter = 1`` and
+    does not reseed (pspec.py:572-577)."""
+    vis = np.asarray(vis)
+    flags = np.asarray(flags)
+    if map_estimate:
+        Niter = 1
+        write_Niter = 1
+    Ntimes, Nfreqs = vis.shape
+    Nmodes = fgmodes.shape[1]
+    assert flags.shape == (Nfreqs,), "`flags` array must have shape (Nfreqs,)"
+    assert fgmodes.shape[0] == Nfreqs, "fgmodes must have shape (Nfreqs, Nmodes)"
+    if len(np.shape(Ninv)) == 3:
+        assert np.shape(Ninv)[0] == Ntimes, \
+            "Ninv shape must be (Ntimes, Nfreqs, Nfreqs) or (Nfreqs, Nfreqs)"
+    ps0, resid = pspec_from_covariance(np.asarray(S_initial))
+    if resid > FOURIER_FORM_TOL:
+        raise NotImplementedError("S_initial is not of the form F^H diag(ps/N^2) F "
+                                  f"(relative off-diagonal power {resid:.2e})")
+    fop = utils.fourier_operator(Nfreqs)
+    gb = GibbsBatch(vis[None], flags[None], fgmodes, _ninv_diag(Ninv, 1, Ntimes, Nfreqs), ps_prior,
+                    Niter, seed=seed, map_estimate=map_estimate)
+    signal_cr = np.zeros((Niter, Ntimes, Nfreqs), dtype=complex)
+    signal_ps = np.zeros((Niter, Nfreqs))
+    fg_amps = np.zeros((Niter, Ntimes, Nmodes), dtype=complex)
+    chisq = np.zeros((Niter, Ntimes, Nfreqs))
+    ln_post = np.zeros(Niter)
+    signal_S = np.asarray(S_initial).copy()
+    if verbose:
+        print("Iter     Time [s]    Chisq    ln Post")
+        print("-----    --------    -----    -------")
+    write_time = 0
+    done = 0
+    chunk = max(1, int(write_Niter)) if out_dir is not None else Niter
+    try:
+        while done < Niter:
+            n = min(chunk - done % chunk, Niter - done)
+            t0 = time.perf_counter()
+            out = gb.run(n, ps0=ps0[None] if done == 0 else None,
+                         keep=("signal_cr", "fg_amps", "chisq"))
+            sl = slice(done, done + n)
+            signal_cr[sl] = out["signal_cr"][0].cpu().numpy()
+            signal_ps[sl] = out["signal_ps"][0].cpu().numpy()
+            fg_amps[sl] = out["fg_amps"][0].cpu().numpy()
+            chisq[sl] = out["chisq"][0].cpu().numpy()
+            ln_post[sl] = out["ln_post"][0].cpu().numpy()
+            done += n
+            signal_S = covariance_from_pspec(signal_ps[done - 1] / Nfreqs ** 2, fop)
+            if verbose:
+                dt = (time.perf_counter() - t0) / n
+                for i in range(done - n, done):
+                    cm = chisq[i][:, flags].mean()
+                    print(f"{i + 1:<9d}{dt:<12.3g}{cm:<9.3f}{ln_post[i]:<12.1f}")
+            if out_dir is not None and done % write_Niter == 0:
+                # periodic checkpoint: everything so far; cov-eor.npy gets rows [:done] of
+                # the CURRENT covariance, as in the reference (pspec.py:625-636)
+                tw = time.perf_counter()
+                utils.write_numpy_files(out_dir, signal_cr[:done], signal_S[:done], signal_ps[:done],
+                                        fg_amps[:done], chisq[:done], ln_post[:done])
+                write_time += time.perf_counter() - tw
+    finally:
+        gb.close()
+    if out_dir is not None and Niter % write_Niter > 0:
+        tw = time.perf_counter()
+        utils.write_numpy_files(out_dir, signal_cr, signal_S, signal_ps, fg_amps, chisq, ln_post)
+        write_time += time.perf_counter() - tw
+    if verbose:
+        print()
+    return signal_cr, signal_S, signal_ps, fg_amps, chisq, ln_post, write_time

@@ -1,0 +1,187 @@
+/* hpx.h -- C-ABI of the MI355X-native hydra-pspec Gibbs hot path (libhpx.so).
+ *
+ * The reference (HydraRadio/hydra-pspec) is pure Python and has no FFI of its
+ * own; this header is the boundary a binding for it would target (ctypes stub
+ * in INTEGRATION.md; the in-tree host side is hydra_pspec_amd/hpx.py).  Each
+ * entry point names the reference code it replaces (paths under the reference
+ * repo root).
+ *
+ * Conventions
+ *  - All array arguments are DEVICE pointers (HBM) unless marked "host".
+ *  - Complex arrays are interleaved (re,im) IEEE fp64 = numpy complex128,
+ *    C-contiguous, exactly the arrays the reference passes around.
+ *  - `stream` is a hipStream_t passed as void* (NULL = default stream).
+ *  - Return value: 0 = ok, HPX_EINVAL bad argument, HPX_EHIP HIP runtime
+ *    error, HPX_ENOTPD non-positive pivot in some baseline's factorisation
+ *    (reported after the run; see hpx_plan_info).  Nothing throws.
+ *    hpx_last_error() returns a thread-local message for the last failure.
+ *  - No global state besides the plan.  One host thread per plan.
+ */
+#ifndef HPX_H
+#define HPX_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HPX_OK      0
+#define HPX_EINVAL (-1)
+#define HPX_EHIP   (-2)
+#define HPX_ENOTPD (-3)
+
+#define HPX_VERSION 100
+
+typedef struct hpx_plan hpx_plan;
+
+int hpx_version(void);
+const char* hpx_last_error(void);
+
+/* Number of visible HIP devices / select one for the calling thread
+ * (one process per GPU: the launcher calls this once with LOCAL_RANK). */
+int hpx_device_count(void);
+int hpx_set_device(int dev);
+
+/* ---- plan: one batch of `nbl` independent baselines of shape (T,N), M fg modes.
+ * Replaces the per-baseline argument tuple of
+ * hydra_pspec/pspec.py:493-507 (gibbs_sample_with_fg).  Allocates every
+ * workspace up front; hpx_gibbs_run allocates nothing. */
+int hpx_plan_create(hpx_plan** out, int nbl, int T, int N, int M);
+int hpx_plan_destroy(hpx_plan* p);
+/* bytes of device memory held by the plan */
+int64_t hpx_plan_bytes(const hpx_plan* p);
+
+/* Static inputs (everything that does not change along the chain) and the
+ * iteration-invariant operators derived from them
+ * (C = U^H Ni U as its circulant generator, G = U^H Ni F, H = F^H Ni F, the
+ * data/noise parts of the right-hand side; pspec.py:359-369, :220-222).
+ *   vis      (nbl,T,N) c128   visibilities (NOT yet multiplied by flags; the
+ *                             library applies vis*flags as pspec.py:613 does)
+ *   flags    (nbl,N)   u8     1 = use channel, 0 = flagged (pspec.py:520-522)
+ *   ninv     (nbl,N)   f64    diagonal of the inverse noise covariance
+ *   fgmodes  (nbl|1,N,M) c128 foreground modes; fg_shared!=0 => one set for all
+ *   prior_map (nbl|1,N) i32   for each channel the row of `xgrid` holding its
+ *                             prior grid, or -1 for "no prior" (the reference's
+ *                             test any(prior[:,i] > 0), pspec.py:114)
+ *   xgrid    (nxrows,ngrid) f64 logspace(log10 lo, log10 hi, ngrid) per distinct
+ *                             prior box (pspec.py:50); ngrid is 1000 in the
+ *                             reference.  nxrows may be 0 (no priors).
+ *   omega    (T,4,N)   f64    the reference's per-time normal draws
+ *                             omi,omj,omk,oml (pspec.py:196-217), identical for
+ *                             every baseline and iteration; NULL = map estimate
+ *                             (pspec.py:210-212)
+ *   fop      (N,N)     c128   utils.fourier_operator(N) (utils.py:15-41)
+ *   any_flags                 0 if no baseline has a flagged channel (skips the
+ *                             masked transform of the log-posterior) */
+int hpx_plan_set_static(hpx_plan* p, const double* vis, const uint8_t* flags,
+                        const double* ninv, const double* fgmodes, int fg_shared,
+                        const int32_t* prior_map, const double* xgrid, int nxrows,
+                        int prior_shared, int ngrid, const double* omega,
+                        const double* fop, int any_flags, void* stream);
+
+/* Random tables of the bandpower draw (pspec.py:113-125): one uniform per
+ * channel per iteration from the chain's global stream.
+ *   uniforms (niter,N) f64   U
+ *   igy      (niter,N) f64   1/gammainccinv(T-1, U)  (= invgamma.ppf(U, a=T-1))
+ * Both shared by all baselines of the plan (the reference driver passes the same
+ * seed for every baseline, run-hydra-pspec.py:547). */
+int hpx_plan_set_rng(hpx_plan* p, const double* uniforms, const double* igy, int niter);
+
+/* Run `niter` Gibbs iterations for all baselines, starting at table row
+ * `iter0` (pspec.py:606-623; one iteration = pspec.py:377-490).
+ *   ps0       (nbl,N)       bandpowers defining the initial covariance
+ *                           S = F^H diag(ps0/N^2) F
+ *   ps_forced (nbl,niter,N) optional (NULL): teacher forcing -- iteration i+1
+ *                           uses ps_forced[:,i] instead of its own draw
+ *   ps_out    (nbl,niter,N) f64   always
+ *   lnpost_out(nbl,niter)   f64   always
+ *   cr_out    (nbl,nkeep,T,N) c128, fg_out (nbl,nkeep,T,M) c128,
+ *   chisq_out (nbl,nkeep,T,N) f64: optional (NULL); iteration i is stored at
+ *                           slot i/thin when i % thin == 0 (nkeep=ceil(niter/thin))
+ *   ps_last   (nbl,N)       optional: the state to resume from (= last draw or
+ *                           last forced value) */
+int hpx_gibbs_run(hpx_plan* p, const double* ps0, int iter0, int niter,
+                  const double* ps_forced, double* ps_out, double* lnpost_out,
+                  double* cr_out, double* fg_out, double* chisq_out, int thin,
+                  double* ps_last, void* stream);
+
+/* Iteration 0 for an initial covariance that is NOT of the form
+ * F^H diag(.) F (pspec.py:599 accepts any matrix): the caller supplies
+ * Sh' = U^H sqrtm(S_initial) U, (nbl,N,N) c128.  Runs exactly one iteration
+ * (table row iter0) with outputs as hpx_gibbs_run(niter=1). */
+int hpx_gibbs_step_general(hpx_plan* p, const double* shp, int iter0,
+                           double* ps_out, double* lnpost_out, double* cr_out,
+                           double* fg_out, double* chisq_out, double* ps_last,
+                           void* stream);
+
+/* per-baseline factorisation status of the last run: (nbl,) int32 host array,
+ * 0 = ok, k>0 = non-positive pivot first seen at iteration k-1+iter0. */
+int hpx_plan_info(hpx_plan* p, int32_t* info_host);
+
+/* time (ms) spent in each stage of the last hpx_gibbs_run, measured with HIP
+ * events on the run's stream; host array of HPX_NSTAGE floats
+ * [assemble, factor, backsolve, transform, residual, draw]; needs
+ * hpx_plan_set_profiling(p,1) before the run (adds event records only). */
+#define HPX_NSTAGE 6
+int hpx_plan_set_profiling(hpx_plan* p, int on);
+int hpx_plan_stage_ms(hpx_plan* p, float* ms_host);
+
+/* ---- unit-testable stages (same kernels the run uses) ------------------- */
+
+/* K'_aug for the current bandpowers `ps` (nbl,N): lower triangle of
+ * K' = [[I + D^1/2 C D^1/2, D^1/2 G],[G^H D^1/2, H]] plus the T right-hand-side
+ * rows, written to the plan's factor buffer and copied to `k_out`
+ * (nbl, npad+Tpad, npad) c128 row-major (upper triangle zero) if non-NULL.
+ * Replaces build_matrices + the RHS of gcr_fgmodes_1d (pspec.py:325-374,
+ * :220-222) in Hermitian form. */
+int hpx_assemble_K(hpx_plan* p, const double* ps, double* k_out, void* stream);
+int hpx_plan_dims(const hpx_plan* p, int* npad, int* tpad, int* ld);
+
+/* Batched complex Hermitian positive-definite factor / solve, stand-alone:
+ *   a (nb,n,n) c128 row-major, lower triangle referenced; l_out (nb,n,n) c128
+ *   lower-triangular L with A = L L^H (upper zero).  info (nb,) int32 device.
+ * hpx_zpotrs_batched: solves A X = B for b (nb,n,nrhs) c128 given the same A
+ * (factors internally).  Replaces the pinv-preconditioned CG of
+ * pspec.py:228 / :372. */
+int hpx_zpotrf_batched(int nb, int n, const double* a, double* l_out, int32_t* info,
+                       void* stream);
+int hpx_zpotrs_batched(int nb, int n, int nrhs, const double* a, const double* b,
+                       double* x_out, int32_t* info, void* stream);
+
+/* Batched centred DFT along the channel axis: out[b,t,:] = F in[b,t,:]
+ * (inverse!=0: F^H in / N), (nb,T,N) c128.  fop as in hpx_plan_set_static.
+ * Replaces sample_S's fftshift(fft(ifftshift())) (pspec.py:92-95) and
+ * fourier_operator products (pspec.py:321, :464). */
+int hpx_dft_batched(int nb, int T, int N, const double* fop, const double* in,
+                    double* out, int inverse, void* stream);
+
+/* Truncated inverse-gamma draw by CDF inversion (pspec.py:11-64) for `n`
+ * independent (alpha, beta, u, xgrid row) tuples; alpha must be a positive
+ * integer (the path always calls it with alpha = Ntimes). */
+int hpx_invgamma_inversion(int n, int alpha, const double* beta, const double* u,
+                           const double* xgrid, int ngrid, double* out, void* stream);
+
+/* DPSS weighted fit in closed form (hydra_pspec/dpss.py:7-94): for each of nb
+ * spectra d (nb,N) c128 with weights tw (nb,N) f64 (= taper*w), basis
+ * modes (nm,N) f64 and inverse covariance icov (N,N) c128 (Hermitian part is
+ * used), returns amps (nb, 2*nm) f64 interleaved (re,im). */
+int hpx_dpss_project(int nb, int N, int nm, const double* d, const double* tw,
+                     const double* modes, const double* icov, double* amps,
+                     void* stream);
+
+/* OQE (hydra_pspec/oqe.py): Fisher matrix F_ab = 1/2 tr(R* Q_a R Q_b)
+ * (oqe.py:43-50) and Ft (oqe.py:53-66) for nb weightings R (nb,s,s) c128,
+ * variant 0 = F, 1 = Ft; q_h (oqe.py:104-114) for V (nb,2P,s) -> (nb,P,s). */
+int hpx_oqe_fisher(int nb, int s, const double* R, double* F_out, int variant,
+                   void* stream);
+int hpx_oqe_qh(int nb, int npair, int s, const double* R, const double* V,
+               double* q_out, void* stream);
+
+/* Empirical lane map of v_mfma_f64_16x16x4_f64 (diagnostic used by the tests):
+ * computes D = A(16x4) * B(4x16) and writes, for lane l and register v, the
+ * value D holds; host (64*4) doubles. */
+int hpx_mfma_probe(const double* a_host, const double* b_host, double* d_host);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

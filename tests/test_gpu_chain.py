@@ -1,0 +1,183 @@
+"""Parity of the HIP Gibbs path with the reference chain (golden vectors made by
+running the real reference, tests/golden/make_golden.py).  GPU box only.
+
+Protocol: T1 = teacher-forced step parity on every channel of every
+iteration, rtol 1e-6 (the reference's own CG stops at 1e-8, so ~1e-8 is the
+floor); T2 = free-running chains gated on median / 99th percentile and on the
+first 50 iterations, reported next to the reference-vs-exact-solve control.
+"""
+import numpy as np
+import pytest
+
+from conftest import relerr
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-6          # stated fp64 tolerance on P(k) samples (BASELINE.json north_star)
+
+
+def _step_case(g, name):
+    return dict(vis=g[f"{name}_in_vis"], flags=g[f"{name}_in_flags"], S=g[f"{name}_in_S"],
+                F=g[f"{name}_in_fgmodes"], Ninv=g[f"{name}_in_Ninv"], prior=g[f"{name}_in_prior"])
+
+
+@pytest.mark.parametrize("name", list("abcdefgi"))
+def test_single_step_vs_reference(golden, name):
+    """gibbs_step_fgmodes (pspec.py:377-490): same global RNG state, same inputs."""
+    from hydra_pspec_amd import pspec
+    g = golden("steps")
+    c = _step_case(g, name)
+    np.random.seed(4242)
+    cr, S_s, ps, fg, chi, lp = pspec.gibbs_step_fgmodes(c["vis"] * c["flags"], c["flags"], c["S"], c["F"],
+                                                       c["Ninv"], c["prior"])
+    after = np.random.uniform()
+    np.random.seed(4242)
+    np.random.random_sample(c["vis"].shape[1])
+    assert after == np.random.uniform()            # consumed exactly N uniforms
+    assert np.max(np.abs(ps / g[f"{name}_ps"] - 1)) < RTOL
+    assert relerr(cr, g[f"{name}_cr"]) < RTOL
+    assert relerr(fg, g[f"{name}_fg"]) < RTOL
+    assert relerr(S_s, g[f"{name}_S"]) < RTOL
+    assert relerr(chi, g[f"{name}_chisq"]) < 1e-5   # |r|^2 of a residual known to ~1e-8
+    assert lp == pytest.approx(float(g[f"{name}_lnpost"]), rel=RTOL)
+
+
+def test_general_S_initial_rejected_loudly(golden):
+    from hydra_pspec_amd import pspec
+    c = _step_case(golden("steps"), "h")
+    with pytest.raises(NotImplementedError):
+        pspec.gibbs_step_fgmodes(c["vis"] * c["flags"], c["flags"], c["S"], c["F"], c["Ninv"], c["prior"])
+
+
+def test_map_estimate(golden):
+    from hydra_pspec_amd import pspec
+    g = golden("steps")
+    c = _step_case(g, "b")
+    np.random.seed(3)
+    res = pspec.gibbs_sample_with_fg(c["vis"], c["flags"], c["S"], c["F"], c["Ninv"], c["prior"], Niter=5,
+                                     seed=99, verbose=False, map_estimate=True)
+    assert res[0].shape[0] == 1
+    assert relerr(res[0], g["map_cr"]) < RTOL
+    assert np.max(np.abs(res[2] / g["map_ps"] - 1)) < RTOL
+    assert relerr(res[3], g["map_fg"]) < RTOL
+    assert relerr(res[1], g["map_S"]) < RTOL
+
+
+def _batched_synth(g, **kw):
+    from hydra_pspec_amd import pspec
+    vis = np.stack([g[f"b{b}_vis"] for b in range(3)])
+    flags = np.stack([g[f"b{b}_flags"] for b in range(3)])
+    return pspec.gibbs_sample_with_fg_batched(
+        vis, flags, g["fgmodes"], g["Ninv"], g["prior"], S_initial=g["S_initial"], Niter=200,
+        seed=int(g["seed"]), **kw)
+
+
+def test_chain_synth_teacher_forced(golden):
+    """T1 on 3 synthetic baselines x 200 iterations (one flagged), all channels."""
+    g = golden("chain_synth")
+    ref = np.stack([g[f"b{b}_ref_ps"] for b in range(3)])
+    out = _batched_synth(g, ps_forced=ref, keep=("signal_cr", "fg_amps", "chisq"))
+    dev = np.abs(out["signal_ps"] / ref - 1)
+    print("T1 synth: max", dev.max(), "median", np.median(dev))
+    assert dev.max() < RTOL
+    lp = np.stack([g[f"b{b}_ref_lnpost"] for b in range(3)])
+    assert np.max(np.abs(out["ln_post"] / lp - 1)) < RTOL
+    for b in range(3):
+        sel = g[f"b{b}_ref_sel"]
+        assert relerr(out["signal_cr"][b][sel], g[f"b{b}_ref_cr_sel"]) < RTOL
+        assert relerr(out["fg_amps"][b][sel], g[f"b{b}_ref_fg_sel"]) < RTOL
+        assert relerr(out["chisq"][b][sel], g[f"b{b}_ref_chisq_sel"]) < 1e-5
+
+
+def test_chain_synth_free_running(golden):
+    """T2: whole chains; gate median / p99 and the first 50 iterations; report the
+    reference-vs-exact-solver control next to it."""
+    g = golden("chain_synth")
+    out = _batched_synth(g)
+    for b in range(3):
+        ref, ctl = g[f"b{b}_ref_ps"], g[f"b{b}_exact_ps"]
+        dev = np.abs(out["signal_ps"][b] / ref - 1)
+        cdev = np.abs(ctl / ref - 1)
+        print(f"T2 synth b{b}: ours median {np.median(dev):.2e} p99 {np.percentile(dev, 99):.2e} "
+              f"max {dev.max():.2e} | control median {np.median(cdev):.2e} "
+              f"p99 {np.percentile(cdev, 99):.2e} max {cdev.max():.2e}")
+        assert np.median(dev) < RTOL
+        assert dev[:50].max() < 1e-5 if b == 2 else dev[:50].max() < RTOL
+        if b < 2:
+            assert np.percentile(dev, 99) < RTOL
+        # never worse than 20x the reference's own solver-noise control
+        assert np.percentile(dev, 99) < 20 * max(np.percentile(cdev, 99), 1e-9)
+
+
+def test_config1_testdata_chain(golden):
+    """BASELINE.json config 1: shipped test data (203 x 120, 12 modes), 200
+    iterations, through the drop-in single-baseline function."""
+    from hydra_pspec_amd import pspec
+    g = golden("chain_testdata")
+    Ninv = np.diag(g["ninv_diag"])
+    res = pspec.gibbs_sample_with_fg(g["vis"], g["flags"], g["S_initial"], g["fgmodes"], Ninv, g["prior"],
+                                     Niter=200, seed=int(g["seed"]), verbose=False)
+    cr, S_last, ps, fg, chi, lp, wt = res
+    ref, ctl = g["ref_ps"], g["exact_ps"]
+    dev, cdev = np.abs(ps / ref - 1), np.abs(ctl / ref - 1)
+    print(f"config1 free: ours median {np.median(dev):.2e} p99 {np.percentile(dev, 99):.2e} max {dev.max():.2e}"
+          f" | control median {np.median(cdev):.2e} p99 {np.percentile(cdev, 99):.2e} max {cdev.max():.2e}")
+    assert cr.shape == (200, 203, 120) and fg.shape == (200, 203, 12) and chi.shape == (200, 203, 120)
+    assert S_last.shape == (120, 120) and lp.shape == (200,)
+    assert np.median(dev) < RTOL and np.percentile(dev, 99) < RTOL
+    assert dev[:50].max() < RTOL
+    sel = g["ref_sel"][:2]                       # iterations 0, 1: before any divergence
+    assert relerr(cr[sel], g["ref_cr_sel"][:2]) < RTOL
+    assert relerr(fg[sel], g["ref_fg_sel"][:2]) < RTOL
+    # T3: posterior summaries agree with the reference chain (burn-in 50)
+    m_ours, m_ref = ps[50:].mean(0), ref[50:].mean(0)
+    assert np.max(np.abs(m_ours / m_ref - 1)) < 1e-3
+
+
+def test_config1_teacher_forced(golden):
+    from hydra_pspec_amd import pspec
+    g = golden("chain_testdata")
+    ref = g["ref_ps"]
+    out = pspec.gibbs_sample_with_fg_batched(
+        g["vis"][None], g["flags"][None], g["fgmodes"], g["ninv_diag"][None], g["prior"],
+        S_initial=g["S_initial"], Niter=200, seed=int(g["seed"]), ps_forced=ref[None])
+    dev = np.abs(out["signal_ps"][0] / ref - 1)
+    print("T1 config1: max", dev.max(), "median", np.median(dev))
+    assert dev.max() < RTOL
+    assert np.max(np.abs(out["ln_post"][0] / g["ref_lnpost"] - 1)) < RTOL
+
+
+def test_write_files_and_chunked_run(golden, tmp_path):
+    """write_Niter checkpoints (pspec.py:625-653): chunked runs equal one run, and
+    the six files have the reference's names/shapes (incl. the cov-eor row slice)."""
+    from hydra_pspec_amd import pspec
+    g = golden("steps")
+    c = _step_case(g, "a")
+    kw = dict(Niter=7, seed=5, verbose=False)
+    full = pspec.gibbs_sample_with_fg(c["vis"], c["flags"], c["S"], c["F"], c["Ninv"], c["prior"], **kw)
+    chunked = pspec.gibbs_sample_with_fg(c["vis"], c["flags"], c["S"], c["F"], c["Ninv"], c["prior"],
+                                         write_Niter=3, out_dir=tmp_path, **kw)
+    for a, b in zip(full[:6], chunked[:6]):
+        assert np.array_equal(a, b)
+    assert chunked[6] > 0
+    assert np.load(tmp_path / "dps-eor.npy").shape == (7, 32)
+    assert np.load(tmp_path / "gcr-eor.npy").shape == (7, 8, 32)
+    assert np.load(tmp_path / "cov-eor.npy").shape == (7, 32)
+    assert np.load(tmp_path / "fg-amps.npy").shape == (7, 8, 4)
+    assert np.load(tmp_path / "ln-post.npy").shape == (7,)
+    assert np.array_equal(np.load(tmp_path / "chisq.npy"), chunked[4])
+
+
+def test_shape_errors(golden):
+    from hydra_pspec_amd import pspec
+    c = _step_case(golden("steps"), "a")
+    with pytest.raises(AssertionError):
+        pspec.gibbs_sample_with_fg(c["vis"], c["flags"][:-1], c["S"], c["F"], c["Ninv"], c["prior"],
+                                   Niter=1, verbose=False)
+    with pytest.raises(AssertionError):
+        pspec.gibbs_sample_with_fg(c["vis"], c["flags"], c["S"], c["F"][:-1], c["Ninv"], c["prior"],
+                                   Niter=1, verbose=False)
+    bad = c["prior"].copy()
+    bad[1, 16] = 0.0
+    with pytest.raises(ValueError):
+        pspec.gibbs_sample_with_fg(c["vis"], c["flags"], c["S"], c["F"], c["Ninv"], bad, Niter=1,
+                                   verbose=False)

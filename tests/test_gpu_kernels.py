@@ -1,0 +1,188 @@
+"""Unit parity of the HIP stages against numpy, through the C-ABI (GPU box only)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from conftest import relerr
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def T():
+    import torch
+    from hydra_pspec_amd import hpx
+    hpx.require_gpu()
+    return torch
+
+
+def _dev(torch, x, dtype):
+    return torch.from_numpy(np.ascontiguousarray(x)).to("cuda", dtype=dtype).contiguous()
+
+
+def test_mfma_f64_lane_map():
+    """The accumulator lane map the kernels assume (HPX_ACC_ROW(g,v) = g + 4v)."""
+    from hydra_pspec_amd import hpx
+    rng = np.random.default_rng(0)
+    A = rng.integers(-9, 10, size=(16, 4)).astype(float)
+    B = rng.integers(-9, 10, size=(4, 16)).astype(float)       # asymmetric
+    D = np.zeros((64, 4))
+    hpx.check(hpx.lib().hpx_mfma_probe(A.ctypes.data_as(C.c_void_p), B.ctypes.data_as(C.c_void_p),
+                                       D.ctypes.data_as(C.c_void_p)))
+    ref = A @ B
+    for lane in range(64):
+        for v in range(4):
+            assert D[lane, v] == ref[(lane >> 4) + 4 * v, lane & 15], (lane, v)
+
+
+def _hpd(rng, nb, n, cond=1e3):
+    a = rng.standard_normal((nb, n, n)) + 1j * rng.standard_normal((nb, n, n))
+    q, _ = np.linalg.qr(a)
+    ev = np.logspace(0, np.log10(cond), n)
+    return (q * ev[None, None, :]) @ np.conj(np.swapaxes(q, 1, 2))
+
+
+@pytest.mark.parametrize("n", [5, 16, 35, 64, 132, 524])
+def test_zpotrf(T, n):
+    from hydra_pspec_amd import hpx
+    rng = np.random.default_rng(n)
+    nb = 3
+    A = _hpd(rng, nb, n)
+    A = 0.5 * (A + np.conj(np.swapaxes(A, 1, 2)))
+    dA = _dev(T, A, T.complex128)
+    dL = T.zeros_like(dA)
+    info = T.zeros(nb, dtype=T.int32, device="cuda")
+    hpx.check(hpx.lib().hpx_zpotrf_batched(nb, n, hpx.ptr(dA), hpx.ptr(dL), hpx.ptr(info), None))
+    L = dL.cpu().numpy()
+    assert not info.cpu().numpy().any()
+    ref = np.linalg.cholesky(A)
+    assert relerr(L, ref) < 1e-11
+    assert relerr(L @ np.conj(np.swapaxes(L, 1, 2)), A) < 1e-13
+
+
+def test_zpotrf_not_positive_definite(T):
+    from hydra_pspec_amd import hpx
+    A = np.eye(20, dtype=complex)[None].repeat(2, 0)
+    A[1, 7, 7] = -1.0
+    dA = _dev(T, A, T.complex128)
+    dL = T.zeros_like(dA)
+    info = T.zeros(2, dtype=T.int32, device="cuda")
+    hpx.check(hpx.lib().hpx_zpotrf_batched(2, 20, hpx.ptr(dA), hpx.ptr(dL), hpx.ptr(info), None))
+    assert info.cpu().numpy().tolist() == [0, 1]
+
+
+@pytest.mark.parametrize("n,nrhs", [(16, 16), (35, 3), (132, 203), (524, 32), (150, 48)])
+def test_zpotrs(T, n, nrhs):
+    from hydra_pspec_amd import hpx
+    rng = np.random.default_rng(n + nrhs)
+    nb = 2
+    A = _hpd(rng, nb, n)
+    A = 0.5 * (A + np.conj(np.swapaxes(A, 1, 2)))
+    B = rng.standard_normal((nb, n, nrhs)) + 1j * rng.standard_normal((nb, n, nrhs))
+    dA, dB = _dev(T, A, T.complex128), _dev(T, B, T.complex128)
+    dX = T.zeros_like(dB)
+    info = T.zeros(nb, dtype=T.int32, device="cuda")
+    hpx.check(hpx.lib().hpx_zpotrs_batched(nb, n, nrhs, hpx.ptr(dA), hpx.ptr(dB), hpx.ptr(dX),
+                                           hpx.ptr(info), None))
+    X = dX.cpu().numpy()
+    assert relerr(X, np.linalg.solve(A, B)) < 1e-10
+
+
+@pytest.mark.parametrize("N,Tn", [(8, 3), (30, 6), (120, 20), (512, 32)])
+def test_dft(T, N, Tn):
+    from hydra_pspec_amd import hpx, utils
+    rng = np.random.default_rng(N)
+    fop = utils.fourier_operator(N)
+    x = rng.standard_normal((2, Tn, N)) + 1j * rng.standard_normal((2, Tn, N))
+    dF, dx = _dev(T, fop, T.complex128), _dev(T, x, T.complex128)
+    dy = T.zeros_like(dx)
+    hpx.check(hpx.lib().hpx_dft_batched(2, Tn, N, hpx.ptr(dF), hpx.ptr(dx), hpx.ptr(dy), 0, None))
+    ref = np.fft.fftshift(np.fft.fft(np.fft.ifftshift(x, axes=-1), axis=-1), axes=-1)
+    assert relerr(dy.cpu().numpy(), ref) < 1e-13
+    hpx.check(hpx.lib().hpx_dft_batched(2, Tn, N, hpx.ptr(dF), hpx.ptr(dy), hpx.ptr(dx), 1, None))
+    assert relerr(dx.cpu().numpy(), x) < 1e-13
+
+
+def test_invgamma_inversion_golden(T, golden):
+    """pspec.py:11-64 against the reference's own draws (tests/golden small.npz F3)."""
+    from hydra_pspec_amd import hpx
+    cases = golden("small")["F3_cases"]
+    n = len(cases)
+    beta, u, xg, want = np.zeros(n), np.zeros(n), np.zeros((n, 1000)), np.zeros(n)
+    alphas = cases[:, 0].astype(int)
+    for i, (a, b, lo, hi, seed, v, _) in enumerate(cases):
+        np.random.seed(int(seed))
+        u[i] = np.random.uniform()
+        beta[i], want[i] = b, v
+        xg[i] = np.logspace(np.log10(lo), np.log10(hi), 1000)
+    for a in np.unique(alphas):
+        sel = np.nonzero(alphas == a)[0]
+        out = T.zeros(len(sel), dtype=T.float64, device="cuda")
+        hpx.check(hpx.lib().hpx_invgamma_inversion(
+            len(sel), int(a), hpx.ptr(_dev(T, beta[sel], T.float64)), hpx.ptr(_dev(T, u[sel], T.float64)),
+            hpx.ptr(_dev(T, xg[sel], T.float64)), 1000, hpx.ptr(out), None))
+        assert np.max(np.abs(out.cpu().numpy() / want[sel] - 1)) < 1e-10
+
+
+def test_inversion_sample_invgamma_api(T, golden):
+    from hydra_pspec_amd import pspec
+    for a, b, lo, hi, seed, v, u_after in golden("small")["F3_cases"][::5]:
+        np.random.seed(int(seed))
+        got = pspec.inversion_sample_invgamma(a, b, lo, hi)
+        assert got == pytest.approx(v, rel=1e-10)
+        assert np.random.uniform() == u_after
+    for bad in [(0.0, 1.0), (1.0, 0.0), (1.0, np.inf), (2.0, 1.0)]:
+        with pytest.raises(ValueError):
+            pspec.inversion_sample_invgamma(5, 5.0, *bad)
+
+
+def _reference_system(vis, flags, ninv, F, ps, omega):
+    """numpy construction of K' and r' from their definitions."""
+    from oracle import pspec_ref as R
+    Tn, N = vis.shape
+    fop = R.fourier_operator(N)
+    U = fop.conj().T / np.sqrt(N)
+    w = flags.astype(float)
+    ni = ninv * w
+    nih = np.sqrt(ni)
+    a = np.sqrt(ps / N)
+    Cm = U.conj().T @ (ni[:, None] * U)
+    G = U.conj().T @ (ni[:, None] * F)
+    H = F.conj().T @ (ni[:, None] * F)
+    d = vis * w
+    if omega is None:
+        oma = omb = np.zeros((Tn, N), dtype=complex)
+    else:
+        oma = (omega[:, 0] + 1j * omega[:, 1]) / 2 ** 0.5
+        omb = (omega[:, 2] + 1j * omega[:, 3]) / 2 ** 0.5
+    z = ni[:, None] * d.T + nih[:, None] * omb.T
+    rtop = a[:, None] * (U.conj().T @ z) + U.conj().T @ oma.T
+    rbot = F.conj().T @ z
+    K = np.block([[np.eye(N) + a[:, None] * Cm * a[None, :], a[:, None] * G],
+                  [G.conj().T * a[None, :], H]])
+    return K, np.vstack([rtop, rbot]), U, a
+
+
+@pytest.mark.parametrize("Tn,N,M,frac", [(8, 32, 4, 0.0), (6, 30, 5, 0.2), (20, 120, 12, 0.1)])
+def test_assemble_K(T, Tn, N, M, frac):
+    from hydra_pspec_amd import hpx, pspec, synthetic
+    d = synthetic.make_baselines(N, Tn, M, k0=7, nbl=2, flag_frac=frac)
+    F = d["fgmodes"] * (1 + 0.3j)          # exercise complex modes
+    gb = pspec.GibbsBatch(d["vis"], d["flags"], F, d["ninv_diag"], d["ps_prior"], 2, seed=1)
+    npad, tp, ld = gb.plan.dims()
+    ps = d["ps0"] * np.linspace(0.5, 1.5, N)
+    dps = _dev(T, np.stack([ps, ps[::-1]]), T.float64)
+    out = T.zeros((2, ld, npad), dtype=T.complex128, device="cuda")
+    hpx.check(hpx.lib().hpx_assemble_K(gb.plan.handle, hpx.ptr(dps), hpx.ptr(out), None))
+    Kd = out.cpu().numpy()
+    om = pspec.omega_table(Tn, N)
+    n = N + M
+    for b, psb in enumerate((ps, ps[::-1])):
+        K, r, _, _ = _reference_system(d["vis"][b], d["flags"][b], d["ninv_diag"][b], F, psb, om)
+        got = Kd[b]
+        assert relerr(np.tril(got[:n, :n]), np.tril(K)) < 1e-12
+        assert relerr(got[npad:npad + Tn, :n], r.conj().T) < 1e-12
+        pad = got[n:npad, :]
+        assert np.array_equal(pad[:, n:npad], np.eye(npad - n)) and not pad[:, :n].any()
+    gb.close()

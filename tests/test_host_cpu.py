@@ -1,0 +1,136 @@
+"""CPU-only checks: the C-ABI library loads and exports every declared symbol,
+and the host-side logic (random tables, prior tables, sharding) matches the
+reference's behaviour.  No compute entry point is called."""
+import ctypes as C
+import re
+from pathlib import Path
+
+import numpy as np
+import pytest
+import scipy.special
+
+from conftest import REPO, relerr
+
+
+def _declared_symbols():
+    text = (REPO / "include" / "hpx.h").read_text()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(hpx_[a-zA-Z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from hydra_pspec_amd import hpx
+    names = _declared_symbols()
+    assert len(names) >= 20
+    L = C.CDLL(str(REPO / "hydra_pspec_amd" / "libhpx.so"))
+    for n in names:
+        assert hasattr(L, n), f"libhpx.so does not export {n}"
+        assert n in hpx.SIGNATURES, f"hpx.py does not bind {n}"
+    assert set(hpx.SIGNATURES) == set(names)
+    assert hpx.lib().hpx_version() == 100
+
+
+def test_compute_entry_points_fail_loudly_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from hydra_pspec_amd import pspec
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        pspec.sample_S(s=np.ones((4, 8), dtype=complex))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        pspec.gibbs_sample_with_fg(np.ones((4, 8), dtype=complex), np.ones(8, bool), np.eye(8),
+                                   np.ones((8, 2)), np.eye(8), np.zeros((2, 8)), Niter=1, verbose=False)
+
+
+def test_product_never_imports_oracle():
+    for f in (REPO / "hydra_pspec_amd").rglob("*.py"):
+        assert "oracle" not in f.read_text(), f"{f} mentions the oracle"
+
+
+def test_fourier_operator_bits(golden):
+    from hydra_pspec_amd import utils
+    g = golden("small")
+    for n in (4, 5, 8):
+        assert np.array_equal(utils.fourier_operator(n), g[f"F1_fop_{n}"])
+
+
+def test_omega_table_matches_reference_stream(golden):
+    from hydra_pspec_amd import pspec
+    tab = pspec.omega_table(3, 6)
+    assert np.array_equal(tab[2], golden("small")["F7_omega_idx2_N6"])
+    np.random.seed(pspec.GCR_SEED0 + 1)
+    want = np.array([np.random.randn(6, 1)[:, 0] for _ in range(4)])
+    assert np.array_equal(tab[1], want)
+
+
+def test_draw_tables_reproduce_the_global_stream():
+    from hydra_pspec_amd import pspec
+    u, igy = pspec.draw_tables(8, 5, 3, seed=42)
+    after = np.random.uniform()
+    np.random.seed(42)
+    want = np.array([[np.random.uniform() for _ in range(5)] for _ in range(3)])
+    assert np.array_equal(u, want) and after == np.random.uniform()
+    assert np.array_equal(igy, 1.0 / scipy.special.gammainccinv(7.0, want))
+    # invgamma.rvs(a) is ppf(U) with one uniform from the global stream
+    from scipy.stats import invgamma
+    np.random.seed(42)
+    assert invgamma.rvs(a=7.0) == pytest.approx(igy[0, 0], rel=1e-15)
+    # no reseed (map_estimate, single steps): continues the caller's stream
+    np.random.seed(7)
+    first = np.random.uniform()
+    u2, _ = pspec.draw_tables(8, 2, 1, seed=123, reseed=False)
+    np.random.seed(7)
+    assert [np.random.uniform() for _ in range(3)] == [first, u2[0, 0], u2[0, 1]]
+
+
+def test_prior_tables():
+    from hydra_pspec_amd import pspec
+    pr = np.zeros((2, 10))
+    pr[0, 3:6], pr[1, 3:6] = 2.0, 0.1
+    pr[0, 8], pr[1, 8] = 5.0, 0.5
+    pmap, xg = pspec._prior_tables(pr, 10)
+    assert pmap.tolist() == [-1, -1, -1, 0, 0, 0, -1, -1, 1, -1]
+    assert np.array_equal(xg[0], np.logspace(np.log10(0.1), np.log10(2.0), 1000))
+    assert np.array_equal(xg[1], np.logspace(np.log10(0.5), np.log10(5.0), 1000))
+    pm3, _ = pspec._prior_tables(np.stack([pr, np.zeros((2, 10))]), 10)
+    assert pm3.shape == (2, 10) and (pm3[1] == -1).all()
+    for lo, hi in ((0.0, 1.0), (1.0, np.inf), (2.0, 1.0), (-1.0, 2.0)):
+        bad = np.zeros((2, 10))
+        bad[0, 4], bad[1, 4] = hi, lo
+        with pytest.raises(ValueError):
+            pspec._prior_tables(bad, 10)
+
+
+def test_pspec_from_covariance_roundtrip(golden):
+    from hydra_pspec_amd import pspec
+    g = golden("small")
+    ps, resid = pspec.pspec_from_covariance(g["F2_cov"])
+    assert relerr(ps, g["F2_ps"] * 64) < 1e-13 and resid < 1e-13   # S = F^H diag(ps/N^2) F
+    ps_eye, r_eye = pspec.pspec_from_covariance(np.eye(8))
+    assert np.allclose(ps_eye, 8.0) and r_eye < 1e-13
+    rng = np.random.default_rng(0)
+    a = rng.standard_normal((8, 8))
+    _, r_gen = pspec.pspec_from_covariance(a @ a.T)
+    assert r_gen > 1e-3
+
+
+def test_ninv_diag_validation():
+    from hydra_pspec_amd import pspec
+    d = pspec._ninv_diag(np.eye(6) * 3.0, 2, 4, 6)
+    assert d.shape == (2, 6) and (d == 3.0).all()
+    assert pspec._ninv_diag(np.arange(6.0), 2, 4, 6).shape == (2, 6)
+    with pytest.raises(NotImplementedError):
+        pspec._ninv_diag(np.eye(6) + 0.1, 1, 4, 6)
+    with pytest.raises(NotImplementedError):
+        pspec._ninv_diag(np.zeros((4, 6, 6)), 1, 4, 6)
+
+
+def test_synthetic_recipe_statistics():
+    from hydra_pspec_amd import synthetic, utils
+    d = synthetic.make_baselines(64, 16, 6, k0=0, nbl=4, flag_frac=0.25)
+    assert d["vis"].shape == (4, 16, 64) and d["flags"].sum(axis=1).tolist() == [48] * 4
+    ps, resid = __import__("hydra_pspec_amd.pspec", fromlist=["x"]).pspec_from_covariance(d["S_initial"])
+    assert relerr(ps, d["ps0"]) < 1e-12 and resid < 1e-12
+    assert d["ps_prior"][0, 29:36].tolist() == [2.0] * 7 and d["ps_prior"][1, 29:36].tolist() == [0.1] * 7
+    again = synthetic.make_baselines(64, 16, 6, k0=2, nbl=1, flag_frac=0.25)
+    assert np.array_equal(again["vis"][0], d["vis"][2]) and np.array_equal(again["flags"][0], d["flags"][2])

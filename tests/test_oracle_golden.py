@@ -1,0 +1,185 @@
+"""Pin the CPU oracle (oracle/) to vectors produced by the real reference
+(tests/golden/make_golden.py).  CPU only."""
+import numpy as np
+import pytest
+
+from oracle import pspec_ref as R, dpss_ref, oqe_ref
+from conftest import relerr
+
+TIGHT = 1e-12
+
+
+def test_fourier_operator_bits(golden):
+    g = golden("small")
+    for n in (4, 5, 8):
+        assert np.array_equal(R.fourier_operator(n), g[f"F1_fop_{n}"])
+
+
+def test_covariance_from_pspec(golden):
+    g = golden("small")
+    assert relerr(R.covariance_from_pspec(g["F2_ps"], R.fourier_operator(8)), g["F2_cov"]) < 1e-15
+
+
+def test_inversion_sample_invgamma(golden):
+    for a, beta, lo, hi, seed, v, u_after in golden("small")["F3_cases"]:
+        np.random.seed(int(seed))
+        got = float(R.inversion_sample_invgamma(a, beta, lo, hi))
+        assert got == pytest.approx(v, rel=1e-13)
+        assert np.random.uniform() == u_after      # exactly one uniform consumed
+
+
+@pytest.mark.parametrize("bad", [(0.0, 1.0), (1.0, 0.0), (1.0, np.inf), (2.0, 1.0), (-1.0, 2.0)])
+def test_inversion_sample_invgamma_errors(bad):
+    with pytest.raises(ValueError):
+        R.inversion_sample_invgamma(5.0, 5.0, bad[0], bad[1])
+
+
+def test_sample_S(golden):
+    g = golden("small")
+    np.random.seed(11)
+    assert relerr(R.sample_S(s=g["F4_s"]), g["F4_x_noprior"]) < TIGHT
+    np.random.seed(11)
+    assert relerr(R.sample_S(s=g["F4_s"], prior=g["F4_prior"]), g["F4_x_prior"]) < TIGHT
+    assert np.random.uniform() == g["F4_next_uniform"]
+    with pytest.raises(ValueError):
+        R.sample_S()
+
+
+def test_sprior(golden):
+    g = golden("small")
+    assert relerr(R.sprior(g["F4_s"], 2, 10.0), g["F5_prior"]) < 1e-15
+
+
+@pytest.mark.parametrize("tag", ["nf", "fl"])
+def test_build_matrices_and_gcr(golden, tag):
+    g = golden("small")
+    fl, S, Ninv, F = g[f"F6_{tag}_flags"], g[f"F6_{tag}_S_initial"], g[f"F6_{tag}_Ninv"], g[f"F6_{tag}_fgmodes"]
+    mats = R.build_matrices(19, fl, S, Ninv, F)
+    assert relerr(mats[0], g[f"F6_{tag}_ops"]) < TIGHT
+    assert relerr(mats[1][0], g[f"F6_{tag}_sys"][0]) < TIGHT
+    assert relerr(mats[1][1], g[f"F6_{tag}_sys"][1]) < 1e-9     # pinv: SVD-conditioned
+    vis = g[f"F6_{tag}_vis"] * fl
+    for row, idx in enumerate((0, 3)):
+        x, _, info = R.gcr_fgmodes_1d(idx, vis[idx], fl, mats, F)
+        assert info == 0
+        assert relerr(x, g[f"F7_{tag}_x"][row]) < 1e-10
+    x, _, _ = R.gcr_fgmodes_1d(1, vis[1], fl, mats, F, map_estimate=True)
+    assert relerr(x, g[f"F7_{tag}_xmap"]) < 1e-10
+
+
+def test_omega_stream(golden):
+    np.random.seed(R.GCR_SEED0 + 2)
+    got = np.array([np.random.randn(6, 1)[:, 0] for _ in range(4)])
+    assert np.array_equal(got, golden("small")["F7_omega_idx2_N6"])
+
+
+def test_gcr_loop_preserves_parent_stream(golden):
+    g = golden("small")
+    fl, S, Ninv, F = g["F6_nf_flags"], g["F6_nf_S_initial"], g["F6_nf_Ninv"], g["F6_nf_fgmodes"]
+    mats = R.build_matrices(19, fl, S, Ninv, F)
+    np.random.seed(5)
+    expect = np.random.uniform()
+    np.random.seed(5)
+    R.gcr_fgmodes(g["F6_nf_vis"], fl, mats, F)
+    assert np.random.uniform() == expect
+
+
+STEP_NAMES = list("abcdefghi")
+
+
+@pytest.mark.parametrize("name", STEP_NAMES)
+def test_gibbs_step(golden, name):
+    g = golden("steps")
+    vis, fl = g[f"{name}_in_vis"], g[f"{name}_in_flags"]
+    np.random.seed(4242)
+    cr, S_s, ps, fg, chi, lp = R.gibbs_step_fgmodes(
+        vis * fl, fl, g[f"{name}_in_S"], g[f"{name}_in_fgmodes"], g[f"{name}_in_Ninv"], g[f"{name}_in_prior"])
+    assert relerr(cr, g[f"{name}_cr"]) < 1e-9
+    assert relerr(fg, g[f"{name}_fg"]) < 1e-9
+    assert np.max(np.abs(ps / g[f"{name}_ps"] - 1)) < 1e-9
+    assert relerr(S_s, g[f"{name}_S"]) < 1e-9
+    assert relerr(chi, g[f"{name}_chisq"]) < 1e-8
+    assert lp == pytest.approx(float(g[f"{name}_lnpost"]), rel=1e-9)
+
+
+def test_map_estimate(golden):
+    g = golden("steps")
+    vis, fl = g["b_in_vis"], g["b_in_flags"]
+    np.random.seed(3)
+    res = R.gibbs_sample_with_fg(vis, fl, g["b_in_S"], g["b_in_fgmodes"], g["b_in_Ninv"], g["b_in_prior"],
+                                 Niter=5, seed=99, map_estimate=True)
+    assert res[0].shape[0] == 1                      # Niter forced to 1 (pspec.py:572-574)
+    assert relerr(res[0], g["map_cr"]) < 1e-9
+    assert np.max(np.abs(res[2] / g["map_ps"] - 1)) < 1e-9
+    assert relerr(res[3], g["map_fg"]) < 1e-9
+
+
+@pytest.mark.parametrize("b", [0, 2])
+def test_chain_synth_prefix(golden, b):
+    """First 12 iterations of the reference chain (same seed, same solver)."""
+    g = golden("chain_synth")
+    vis, fl = g[f"b{b}_vis"], g[f"b{b}_flags"]
+    res = R.gibbs_sample_with_fg(vis, fl, g["S_initial"], g["fgmodes"], g["Ninv"], g["prior"],
+                                 Niter=12, seed=int(g["seed"]))
+    assert np.max(np.abs(res[2] / g[f"b{b}_ref_ps"][:12] - 1)) < 1e-8
+    assert np.allclose(res[5], g[f"b{b}_ref_lnpost"][:12], rtol=1e-9)
+
+
+def test_chain_synth_teacher_forced_direct(golden):
+    """Exact-solve oracle, teacher-forced on the reference chain: every step
+    within the reference's own CG noise (T1 protocol on the CPU)."""
+    g = golden("chain_synth")
+    ref = g["b1_ref_ps"]
+    res = R.gibbs_sample_with_fg(g["b1_vis"], g["b1_flags"], g["S_initial"], g["fgmodes"], g["Ninv"],
+                                 g["prior"], Niter=40, seed=int(g["seed"]), solver="direct", ps_forced=ref)
+    assert np.max(np.abs(res[2] / ref[:40] - 1)) < 1e-6
+
+
+def _dpss_cost(p, modes, d, w, cov, taper):
+    """The reference objective, dpss.py:78-86."""
+    m = np.sum(p[0::2, None] * modes + 1j * p[1::2, None] * modes, axis=0)
+    x = (1.0 if taper is None else taper) * w * (d - m)
+    return (0.5 * np.dot(x.conj(), np.linalg.inv(cov) @ x)).real
+
+
+def test_dpss_fit(golden):
+    g = golden("small")
+    for i in range(3):
+        nm, al, has_t = g[f"F10_{i}_par"]
+        taper = g[f"F10_{i}_taper"] if has_t else None
+        args = (g[f"F10_{i}_d"], g[f"F10_{i}_w"], g[f"F10_{i}_freqs"], g[f"F10_{i}_cov"])
+        modes, amps = dpss_ref.dpss_fit_modes(*args, nmodes=int(nm), alpha=al, taper=taper)
+        assert np.array_equal(modes, g[f"F10_{i}_modes"])
+        scale = np.max(np.abs(g[f"F10_{i}_amps"]))
+        assert np.max(np.abs(amps - g[f"F10_{i}_amps"])) < 1e-9 * scale
+        _, amps_cf = dpss_ref.dpss_fit_closed_form(*args, nmodes=int(nm), alpha=al, taper=taper)
+        # The reference stops where L-BFGS-B (finite-difference gradients, default
+        # tolerances) stops; the closed form is the true minimiser of the same
+        # quadratic: it must not be worse, and it sits within the optimiser's slack.
+        assert np.max(np.abs(amps_cf - g[f"F10_{i}_amps"])) < 1e-3 * scale
+        assert _dpss_cost(amps_cf, modes, *args[:2], args[3], taper) <= \
+            _dpss_cost(g[f"F10_{i}_amps"], modes, *args[:2], args[3], taper) * (1 + 1e-12)
+
+
+@pytest.mark.parametrize("s", [8, 16])
+def test_oqe(golden, s):
+    g = golden("small")
+    Rm, Rg, V, Cn = g[f"F11_{s}_R"], g[f"F11_{s}_Rg"], g[f"F11_{s}_V"], g[f"F11_{s}_Cn"]
+    assert relerr(oqe_ref.Q(3, s), g[f"F11_{s}_Q3"]) < 1e-15
+    Fm = oqe_ref.F(s, Rm)
+    assert relerr(Fm, g[f"F11_{s}_F"]) < TIGHT
+    assert relerr(oqe_ref.Ft(s, Rm), g[f"F11_{s}_Ft"]) < TIGHT
+    assert relerr(oqe_ref.F(s, Rg), g[f"F11_{s}_Fg"]) < TIGHT
+    assert relerr(oqe_ref.Ft(s, Rg), g[f"F11_{s}_Ftg"]) < TIGHT
+    assert relerr(oqe_ref.M_opt(Fm), g[f"F11_{s}_Mopt"]) < TIGHT
+    assert relerr(oqe_ref.M_Finv(Fm), g[f"F11_{s}_MFinv"]) < 1e-10
+    assert relerr(oqe_ref.M_Fhalf(Fm), g[f"F11_{s}_MFhalf"]) < 1e-9
+    assert relerr(oqe_ref.q_h(V, s, Rm), g[f"F11_{s}_qh"]) < TIGHT
+    assert relerr(oqe_ref.q_h(V, s, Rg), g[f"F11_{s}_qhg"]) < TIGHT
+    b = np.array([oqe_ref.bias(t, s, Rm, Cn) for t in range(s)])
+    assert relerr(b, g[f"F11_{s}_bias"]) < TIGHT
+    with np.testing.suppress_warnings() as sup:
+        sup.filter(np.exceptions.ComplexWarning)
+        assert relerr(oqe_ref.q(V, s, Rm, b.real), g[f"F11_{s}_q"]) < TIGHT
+    assert relerr(oqe_ref.Sig_QEN(Rm, Cn, 0.37), g[f"F11_{s}_SigN"]) < TIGHT
+    assert relerr(oqe_ref.Sig_QESN(Rm, Cn, Rm, 0.37), g[f"F11_{s}_SigSN"]) < TIGHT
