@@ -1,0 +1,193 @@
+#!/usr/bin/env python3
+"""Benchmark of the MI355X Gibbs hot path on BASELINE.json's metric:
+baseline x Gibbs-iterations per second at Nfreq = 512.
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" = one Gibbs iteration of every baseline resident on the GPU
+(assemble -> Cholesky factor + forward solve -> back solve -> back transform ->
+residual / chi^2 / ln-posterior -> bandpower draw).  Workload (config C3 of
+BASELINE.json / SURVEY 8d): 1024 synthetic baselines per GPU of shape
+(Ntimes, Nfreq, Nfgmodes) = (32, 512, 12), DPSS foreground modes, 7-bin prior.
+N > 1 ranks each own a contiguous block of 1024 more baselines (C4 at N = 8):
+independent chains, no collective on the data path ("weak" scaling); rank 0
+reports (total baselines x K) / (max over ranks of the K-step wall time).
+Inputs are resident in HBM when the timed region starts.
+
+Extra objects on the JSON line: ``roofline`` for the dominant kernel (k_factor:
+FP64-MFMA bound; duration from HIP events recorded on the launch stream inside
+the timed region) and ``cpu_baseline`` (the numpy/scipy oracle = operation-by-
+operation port of the reference, timed on this host on a bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+REPO = Path(__file__).resolve().parent
+sys.path.insert(0, str(REPO))
+
+CONFIGS = {
+    # name: (baselines per GPU, Ntimes, Nfreq, Nmodes, flag fraction)
+    "C2": (64, 32, 256, 12, 0.0),
+    "C3": (1024, 32, 512, 12, 0.0),
+    "C5": (1024, 32, 1024, 12, 0.15),
+}
+FP64_MFMA_PEAK_TFLOPS = 78.6   # AMD spec (32 FLOP/clk/SIMD x 1024 SIMDs x 2.4 GHz); the local
+#                                microarch guide has no f64 row -- the measured issue peak is
+#                                reported next to it as roofline.peak_measured.
+HBM_PEAK_GBS = 8000.0
+
+
+def flops_factor(N, M, T):
+    """Algorithmic real flops of k_factor per unit (one baseline x one iteration):
+    complex Cholesky of the (N+M) system + forward substitution of T right-hand sides."""
+    n = N + M
+    return 4.0 / 3.0 * n ** 3 + 4.0 * n * n * T
+
+
+def flops_unit(N, M, T):
+    """SURVEY 8(d) F_alg per unit for the whole iteration."""
+    n = N + M
+    return 4.0 / 3.0 * n ** 3 + 8.0 * n * n * T + 2 * T * 5 * N * np.log2(N) + 8.0 * N * N
+
+
+def bytes_unit(N, M, T):
+    """SURVEY 8(d) B_alg per unit."""
+    n = N + M
+    return 16.0 * N * N + 2 * 16.0 * n * n + 3 * 16.0 * T * n + 8.0 * N
+
+
+def cpu_baseline(N, T, M, flag_frac, nbl=2, niter=3):
+    """Time the oracle (port of the reference's numpy/scipy path) on this host."""
+    from oracle import pspec_ref
+    from hydra_pspec_amd import synthetic
+    d = synthetic.make_baselines(N, T, M, k0=0, nbl=nbl, flag_frac=flag_frac)
+    chains = []
+    t0 = time.perf_counter()
+    for b in range(nbl):
+        r = pspec_ref.gibbs_sample_with_fg(d["vis"][b], d["flags"][b], d["S_initial"], d["fgmodes"],
+                                           d["Ninv"], d["ps_prior"], Niter=niter, seed=d["seed"])
+        chains.append(r[2])
+    dt = time.perf_counter() - t0
+    try:
+        from threadpoolctl import threadpool_info
+        cores = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
+    except Exception:
+        cores = os.cpu_count()
+    return dict(value=nbl * niter / dt, unit="baseline*iter/s", cores=int(cores), kind="port",
+                sample=f"{nbl} baselines x {niter} iterations of (Ntimes {T}, Nfreq {N}, Nmodes {M}), "
+                       f"one process, default BLAS threads, {dt:.1f} s"), np.array(chains), d
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--config", default="C3", choices=sorted(CONFIGS))
+    ap.add_argument("--nbl", type=int, default=None, help="baselines per GPU (default: config)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    import torch
+    assert torch.cuda.is_available(), "bench.py needs a GPU"
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from hydra_pspec_amd import hpx, pspec, synthetic
+    from hydra_pspec_amd.sharding import split_counts
+    nbl_gpu, T, N, M, frac = CONFIGS[args.config]
+    if args.nbl:
+        nbl_gpu = args.nbl
+    counts = split_counts(nbl_gpu * world, world)
+    k0 = sum(counts[:rank])
+    nbl = counts[rank]
+    K, W = args.steps, args.warmup
+
+    d = synthetic.make_baselines(N, T, M, k0=k0, nbl=nbl, flag_frac=frac, dense=False)
+    gb = pspec.GibbsBatch(d["vis"], d["flags"], d["fgmodes"], d["ninv_diag"], d["ps_prior"],
+                          W + K, seed=d["seed"])
+    ps0 = np.broadcast_to(d["ps0"], (nbl, N)).copy()
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    if W > 0:
+        first = gb.run(W, ps0=ps0)
+    barrier()
+    gb.plan.set_profiling(True)
+    t0 = time.perf_counter()
+    out = gb.run(K, ps0=ps0 if W == 0 else None)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    stage = gb.plan.stage_ms()
+    if dist is not None:
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+        dist.barrier()
+    torch.cuda.synchronize()
+
+    if rank == 0:
+        total_units = sum(counts) * K
+        value = total_units / dt
+        fac_ms = stage["factor"] / K                        # average k_factor launch (HIP events)
+        fac_tflops = nbl * flops_factor(N, M, T) / (fac_ms * 1e-3) / 1e12
+        peak_meas = np.zeros(1)
+        import ctypes
+        hpx.check(hpx.lib().hpx_mfma_f64_peak(20000, peak_meas.ctypes.data_as(ctypes.c_void_p)))
+        res = {
+            "metric": "baseline x Gibbs-iter/sec at Nfreq=512; P(k) rtol vs CPU ref",
+            "value": value, "unit": "baseline*iter/s", "n_gpus": world, "steps": K, "warmup": W,
+            "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"{args.config}: {nbl_gpu} synthetic baselines per GPU x "
+                                   f"(Ntimes {T}, Nfreq {N}, {M} DPSS fg modes), flag fraction {frac}, "
+                                   "7-bin prior, fp64",
+                       "baselines_total": int(sum(counts)), "sharding": "contiguous blocks by baseline index, "
+                       "no collective"},
+            "roofline": {"kernel": "k_factor (batched complex Cholesky + forward solve, FP64 MFMA)",
+                         "bound": "mfma", "achieved": fac_tflops, "peak": FP64_MFMA_PEAK_TFLOPS,
+                         "unit": "TFLOP/s", "frac": fac_tflops / FP64_MFMA_PEAK_TFLOPS, "traffic": None,
+                         "peak_measured": float(peak_meas[0]),
+                         "avg_launch_ms": fac_ms, "flops_per_unit": flops_factor(N, M, T),
+                         "units_per_launch": nbl,
+                         "whole_step": {"flops_per_unit": flops_unit(N, M, T),
+                                        "bytes_per_unit": bytes_unit(N, M, T),
+                                        "tflops": value / world * flops_unit(N, M, T) / 1e12,
+                                        "frac_mfma": value / world * flops_unit(N, M, T) / 1e12
+                                        / FP64_MFMA_PEAK_TFLOPS,
+                                        "frac_hbm": value / world * bytes_unit(N, M, T) / 1e9 / HBM_PEAK_GBS}},
+            "stage_ms_per_step": {k: v / K for k, v in stage.items()},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            cb, ref_ps, dd = cpu_baseline(N, T, M, frac)
+            res["cpu_baseline"] = cb
+            # P(k) deviation of the GPU chain from the CPU chain on the same baselines/seed
+            chk = pspec.gibbs_sample_with_fg_batched(dd["vis"], dd["flags"], dd["fgmodes"], dd["ninv_diag"],
+                                                     dd["ps_prior"], ps_initial=dd["ps0"],
+                                                     Niter=ref_ps.shape[1], seed=dd["seed"])
+            res["pk_max_rel_dev_vs_cpu"] = float(np.max(np.abs(chk["signal_ps"] / ref_ps - 1)))
+            res["speedup_vs_cpu_baseline"] = value / cb["value"]
+        print(json.dumps(res))
+    gb.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

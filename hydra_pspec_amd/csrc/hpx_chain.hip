@@ -569,8 +569,8 @@ extern "C" int hpx_plan_create(hpx_plan** out, int nbl, int T, int N, int M) {
 
 extern "C" int hpx_plan_destroy(hpx_plan* p) {
   if (!p) return HPX_OK;
-  for (void* q : p->allocs) hipFree(q);
-  for (hipEvent_t ev : p->events) hipEventDestroy(ev);
+  for (void* q : p->allocs) (void)hipFree(q);
+  for (hipEvent_t ev : p->events) (void)hipEventDestroy(ev);
   delete p;
   return HPX_OK;
 }

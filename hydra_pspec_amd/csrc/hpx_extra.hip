@@ -16,6 +16,20 @@ __global__ void k_probe(const double* __restrict__ a, const double* __restrict__
   for (int v = 0; v < 4; ++v) d[l * 4 + v] = c[v];
 }
 
+// back-to-back v_mfma_f64_16x16x4_f64 issue rate: 4 independent accumulators per wave
+__global__ __launch_bounds__(256) void k_mfma_peak(double* __restrict__ sink, const int iters) {
+  d4 c0 = {0., 0., 0., 0.}, c1 = c0, c2 = c0, c3 = c0;
+  const double a = 1.0 + 1e-9 * threadIdx.x, b = 1.0 - 1e-9 * threadIdx.x;
+  for (int i = 0; i < iters; ++i) {
+    c0 = mfma64(a, b, c0);
+    c1 = mfma64(b, a, c1);
+    c2 = mfma64(a, a, c2);
+    c3 = mfma64(b, b, c3);
+  }
+  const d4 s = c0 + c1 + c2 + c3;
+  if (s[0] == -1.0) sink[blockIdx.x * 256 + threadIdx.x] = s[0] + s[1] + s[2] + s[3];
+}
+
 // ---- DPSS ---------------------------------------------------------------------
 // in[b][j][col]: col < nm: tw_b[j] * modes[col][j];  col == nm: tw_b[j] * d_b[j]
 __global__ void k_dpss_in(const double* __restrict__ d, const double* __restrict__ tw,
@@ -258,7 +272,30 @@ extern "C" int hpx_mfma_probe(const double* a_host, const double* b_host, double
   hipLaunchKernelGGL(k_probe, dim3(1), dim3(64), 0, 0, a, b, d);
   HPX_HIP(hipGetLastError());
   HPX_HIP(hipMemcpy(d_host, d, 256 * 8, hipMemcpyDeviceToHost));
-  hipFree(a); hipFree(b); hipFree(d);
+  (void)hipFree(a); (void)hipFree(b); (void)hipFree(d);
+  return HPX_OK;
+}
+
+extern "C" int hpx_mfma_f64_peak(int iters, double* tflops_host) {
+  HPX_REQUIRE(iters > 0 && tflops_host, "hpx_mfma_f64_peak: bad argument");
+  int dev = 0, ncu = 0;
+  HPX_HIP(hipGetDevice(&dev));
+  HPX_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
+  const int nblk = ncu * 2;   // 2 workgroups of 4 waves per CU = 2 waves per SIMD
+  double* sink = nullptr;
+  HPX_HIP(hipMalloc(&sink, (size_t)nblk * 256 * 8));
+  hipEvent_t e0, e1;
+  HPX_HIP(hipEventCreate(&e0));
+  HPX_HIP(hipEventCreate(&e1));
+  hipLaunchKernelGGL(k_mfma_peak, dim3(nblk), dim3(256), 0, 0, sink, iters);   // warm-up
+  HPX_HIP(hipEventRecord(e0, 0));
+  hipLaunchKernelGGL(k_mfma_peak, dim3(nblk), dim3(256), 0, 0, sink, iters);
+  HPX_HIP(hipEventRecord(e1, 0));
+  HPX_HIP(hipEventSynchronize(e1));
+  float ms = 0.f;
+  HPX_HIP(hipEventElapsedTime(&ms, e0, e1));
+  *tflops_host = (double)nblk * 4.0 * iters * 4.0 * 2048.0 / (ms * 1e-3) / 1e12;
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipFree(sink);
   return HPX_OK;
 }
 
@@ -287,7 +324,7 @@ extern "C" int hpx_dpss_project(int nb, int N, int nm, const double* d, const do
     if (hipGetLastError() != hipSuccess) rc = HPX_EHIP;
   }
   hipError_t e = hipStreamSynchronize(st);
-  hipFree(wre); hipFree(wim); hipFree(buf);
+  (void)hipFree(wre); (void)hipFree(wim); (void)hipFree(buf);
   if (e != hipSuccess) { hpx_set_error("hpx_dpss_project: %s", hipGetErrorString(e)); return HPX_EHIP; }
   return rc;
 }
@@ -312,7 +349,7 @@ extern "C" int hpx_oqe_fisher(int nb, int s, const double* R, double* F_out, int
   hipLaunchKernelGGL(k_oqe_combine, grid, dim3(256), 0, st, X, Wm, F_out, s, variant);
   hipError_t e = hipGetLastError();
   if (e == hipSuccess) e = hipStreamSynchronize(st);
-  hipFree(buf);
+  (void)hipFree(buf);
   if (e != hipSuccess) { hpx_set_error("hpx_oqe_fisher: %s", hipGetErrorString(e)); return HPX_EHIP; }
   return HPX_OK;
 }
@@ -329,7 +366,7 @@ extern "C" int hpx_oqe_qh(int nb, int npair, int s, const double* R, const doubl
                      npair);
   hipError_t e = hipGetLastError();
   if (e == hipSuccess) e = hipStreamSynchronize(st);
-  hipFree(Y);
+  (void)hipFree(Y);
   if (e != hipSuccess) { hpx_set_error("hpx_oqe_qh: %s", hipGetErrorString(e)); return HPX_EHIP; }
   return HPX_OK;
 }

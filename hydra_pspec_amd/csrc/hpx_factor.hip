@@ -489,7 +489,7 @@ struct Scratch {
   double *Lre = nullptr, *Lim = nullptr, *Wre = nullptr, *Wim = nullptr, *Xre = nullptr,
          *Xim = nullptr;
   ~Scratch() {
-    hipFree(Lre); hipFree(Lim); hipFree(Wre); hipFree(Wim); hipFree(Xre); hipFree(Xim);
+    (void)hipFree(Lre); (void)hipFree(Lim); (void)hipFree(Wre); (void)hipFree(Wim); (void)hipFree(Xre); (void)hipFree(Xim);
   }
 };
 }  // namespace

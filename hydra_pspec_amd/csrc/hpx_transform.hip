@@ -175,7 +175,7 @@ extern "C" int hpx_dft_batched(int nb, int T, int N, const double* fop, const do
     if (hipGetLastError() != hipSuccess) rc = HPX_EHIP;
   }
   hipError_t e = hipStreamSynchronize(st);
-  hipFree(wre); hipFree(wim); hipFree(buf);
+  (void)hipFree(wre); (void)hipFree(wim); (void)hipFree(buf);
   if (e != hipSuccess) { hpx_set_error("hpx_dft_batched: %s", hipGetErrorString(e)); return HPX_EHIP; }
   return rc;
 }

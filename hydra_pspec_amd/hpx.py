@@ -45,6 +45,7 @@ SIGNATURES = {
     "hpx_oqe_fisher": (_i, [_i, _i, _vp, _vp, _i, _vp]),
     "hpx_oqe_qh": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp]),
     "hpx_mfma_probe": (_i, [_vp, _vp, _vp]),
+    "hpx_mfma_f64_peak": (_i, [_i, _vp]),
 }
 
 
@@ -57,6 +58,10 @@ def lib():
                 f"{_LIB_PATH} is missing: build the HIP extension first "
                 "(python -c 'import __graft_entry__ as g; g.build()' or make -C hydra_pspec_amd/csrc). "
                 "hydra_pspec_amd has no CPU fallback.")
+        # torch ships its own libamdhip64 (same soname as /opt/rocm's).  Import it first so
+        # that libhpx binds to the HIP runtime torch already loaded: one runtime per process,
+        # otherwise torch's streams and device pointers would belong to a different runtime.
+        import torch  # noqa: F401
         L = C.CDLL(str(_LIB_PATH))
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)          # AttributeError if the symbol is not exported

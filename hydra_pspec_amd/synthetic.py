@@ -51,7 +51,6 @@ def make_baselines(N, T, M, k0=0, nbl=1, flag_frac=0.0, prior=True, dense=True):
     initial bandpowers], S_initial (N,N) c128 (only if ``dense``), fgmodes (N,M)
     f64, ninv_diag (nbl,N) f64, Ninv (N,N) f64 (only if ``dense``; same for all
     baselines), ps_prior (2,N), seed."""
-    fop = fourier_operator(N)
     p = true_pspec(N)
     sig_e = np.sqrt(p.mean() / N)
     sig_n = sig_e / 10.0
@@ -59,10 +58,12 @@ def make_baselines(N, T, M, k0=0, nbl=1, flag_frac=0.0, prior=True, dense=True):
     fscale = 2000.0 * sig_e * np.sqrt(N) / (1.0 + np.arange(M)) ** 2
     vis = np.empty((nbl, T, N), dtype=complex)
     flags = np.ones((nbl, N), dtype=bool)
-    fh = fop.conj().T
+    sqp = np.sqrt(p)
     for i in range(nbl):
         rng = np.random.default_rng(1000 + k0 + i)
-        e = (np.sqrt(p)[None, :] * _cnormal(rng, (T, N))) @ fh.T / N
+        # e = F^H (sqrt(p) z) / N, evaluated as the centred inverse FFT
+        e = np.fft.fftshift(np.fft.ifft(np.fft.ifftshift(sqp[None, :] * _cnormal(rng, (T, N)), axes=1),
+                                        axis=1), axes=1)
         a = _cnormal(rng, (T, M)) * fscale[None, :]
         noise = sig_n * _cnormal(rng, (T, N))
         vis[i] = e + a @ F.T + noise
@@ -74,6 +75,7 @@ def make_baselines(N, T, M, k0=0, nbl=1, flag_frac=0.0, prior=True, dense=True):
                ps_prior=default_prior(N) if prior else np.zeros((2, N)),
                seed=CHAIN_SEED, sigma_n=sig_n)
     if dense:
-        out["S_initial"] = fh @ np.diag(p / N ** 2) @ fop
+        fop = fourier_operator(N)
+        out["S_initial"] = fop.conj().T @ np.diag(p / N ** 2) @ fop
         out["Ninv"] = np.eye(N) / sig_n ** 2
     return out

@@ -181,6 +181,11 @@ int hpx_oqe_qh(int nb, int npair, int s, const double* R, const double* V,
  * value D holds; host (64*4) doubles. */
 int hpx_mfma_probe(const double* a_host, const double* b_host, double* d_host);
 
+/* Measured FP64-MFMA issue peak of the current device: every CU runs `iters`
+ * x 4 back-to-back independent v_mfma_f64_16x16x4_f64 per wave (2 waves per
+ * SIMD); returns TFLOP/s (host double).  Used by bench.py for the roofline. */
+int hpx_mfma_f64_peak(int iters, double* tflops_host);
+
 #ifdef __cplusplus
 }
 #endif
