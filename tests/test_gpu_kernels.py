@@ -119,9 +119,9 @@ def test_invgamma_inversion_golden(T, golden):
     for a in np.unique(alphas):
         sel = np.nonzero(alphas == a)[0]
         out = T.zeros(len(sel), dtype=T.float64, device="cuda")
-        hpx.check(hpx.lib().hpx_invgamma_inversion(
-            len(sel), int(a), hpx.ptr(_dev(T, beta[sel], T.float64)), hpx.ptr(_dev(T, u[sel], T.float64)),
-            hpx.ptr(_dev(T, xg[sel], T.float64)), 1000, hpx.ptr(out), None))
+        db, du, dx = _dev(T, beta[sel], T.float64), _dev(T, u[sel], T.float64), _dev(T, xg[sel], T.float64)
+        hpx.check(hpx.lib().hpx_invgamma_inversion(len(sel), int(a), hpx.ptr(db), hpx.ptr(du), hpx.ptr(dx),
+                                                   1000, hpx.ptr(out), None))
         assert np.max(np.abs(out.cpu().numpy() / want[sel] - 1)) < 1e-10
 
 
