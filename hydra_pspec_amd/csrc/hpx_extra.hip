@@ -17,7 +17,7 @@ __global__ void k_probe(const double* __restrict__ a, const double* __restrict__
 }
 
 // back-to-back v_mfma_f64_16x16x4_f64 issue rate: 4 independent accumulators per wave
-__global__ __launch_bounds__(256) void k_mfma_peak(double* __restrict__ sink, const int iters) {
+__global__ __launch_bounds__(256, 2) void k_mfma_peak(double* __restrict__ sink, const int iters) {
   d4 c0 = {0., 0., 0., 0.}, c1 = c0, c2 = c0, c3 = c0;
   const double a = 1.0 + 1e-9 * threadIdx.x, b = 1.0 - 1e-9 * threadIdx.x;
   for (int i = 0; i < iters; ++i) {

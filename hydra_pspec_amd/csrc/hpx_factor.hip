@@ -17,6 +17,23 @@
 //        B operand of the multiplication by conj(Ljj^-1): no data movement.
 #include "hpx_internal.h"
 
+// Timing-only ablation builds (wrong results; never shipped): HPX_DIAG bit 0 = no B-operand
+// loads in the k-loop, bit 1 = no panel (A) loads, bit 2 = skip the in-LDS Cholesky steps,
+// bit 3 = skip the diagonal-block partial sums.
+#ifndef HPX_DIAG
+#define HPX_DIAG 0
+#endif
+#if HPX_DIAG & 1
+#define HPX_LD(base, off) (1e-3 * (double)((off) & 7))
+#else
+#define HPX_LD(base, off) (base)[off]
+#endif
+#if HPX_DIAG & 2
+#define HPX_LDA(base, off) (1e-3 * (double)((off) & 7))
+#else
+#define HPX_LDA(base, off) (base)[off]
+#endif
+
 namespace {
 
 constexpr int WLD = HPX_WLD;
@@ -27,68 +44,113 @@ struct FactorShared {
   double Yre[32 * WLD], Yim[32 * WLD];   // running inverse; finally W = conj(Ljj^-1)
 };
 
-// One off-diagonal 16-row tile of block column (c0, CT*16 wide).
-template <int CT>
-__device__ __forceinline__ void offdiag_tile(double* __restrict__ Lre, double* __restrict__ Lim,
-                                             const int ld, const int c0, const int r0,
-                                             const double* Wre, const double* Wim,
-                                             const int lane) {
+// RT off-diagonal 16-row tiles (rows r0 + i*rstride) of block column (c0, CT*16 wide),
+// processed together so that the panel operand conj(L[c][k]) is fetched once per k-step
+// for all of them (the panel rows are the re-read-heavy operand: without this reuse every
+// tile streams the whole 32 x c0 panel again and the kernel becomes HBM/L2 bound).
+template <int CT, int RT>
+__device__ __forceinline__ void offdiag_group(double* __restrict__ Lre, double* __restrict__ Lim,
+                                              const int ld, const int c0, const int r0,
+                                              const int rstride, const double* Wre,
+                                              const double* Wim, const int lane) {
   const int li = lane & 15, g = lane >> 4;
-  d4 ar[CT], ai[CT];
+  d4 ar[RT][CT], ai[RT][CT];
 #pragma unroll
-  for (int ci = 0; ci < CT; ++ci)
+  for (int t = 0; t < RT; ++t)
 #pragma unroll
-    for (int v = 0; v < 4; ++v) {
-      const long off = (long)(c0 + 16 * ci + HPX_ACC_ROW(g, v)) * ld + r0 + li;
-      ar[ci][v] = Lre[off];
-      ai[ci][v] = Lim[off];
-    }
-  // acc^T[c][r] -= conj(L[c][k]) * L[r][k]
-  const int nks = c0 >> 2;
+    for (int ci = 0; ci < CT; ++ci)
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const long off = (long)(c0 + 16 * ci + HPX_ACC_ROW(g, v)) * ld + r0 + t * rstride + li;
+        ar[t][ci][v] = Lre[off];
+        ai[t][ci][v] = Lim[off];
+      }
+  // acc^T[c][r] -= conj(L[c][k]) * L[r][k].  c0 is a multiple of 32, so the k range is a
+  // whole number of chunk pairs; operands of the next chunk are fetched into the other
+  // register buffer while the current one feeds the MFMAs (explicit double buffering:
+  // hipcc does not software-pipeline across loop iterations).
+  constexpr int KC = (RT >= 3) ? 1 : 2;     // k-steps per chunk
+  const int nch = (c0 >> 2) / KC;
   const double* pre = Lre + (long)g * ld;
   const double* pim = Lim + (long)g * ld;
   const long kstep = 4L * ld;
-#pragma unroll 4
-  for (int ks = 0; ks < nks; ++ks) {
-    const double br = pre[r0 + li], bi = pim[r0 + li];
+  double b0r[RT][KC], b0i[RT][KC], b1r[RT][KC], b1i[RT][KC];
+  double p0r[CT][KC], p0i[CT][KC], p1r[CT][KC], p1i[CT][KC];
+#define HPX_LOAD_CHUNK(br_, bi_, pr_, pi_, base_re, base_im)                     \
+  _Pragma("unroll") for (int s = 0; s < KC; ++s) {                               \
+    _Pragma("unroll") for (int t = 0; t < RT; ++t) {                             \
+      br_[t][s] = HPX_LD((base_re), s * kstep + r0 + t * rstride + li);          \
+      bi_[t][s] = HPX_LD((base_im), s * kstep + r0 + t * rstride + li);          \
+    }                                                                            \
+    _Pragma("unroll") for (int ci = 0; ci < CT; ++ci) {                          \
+      pr_[ci][s] = HPX_LDA((base_re), s * kstep + c0 + 16 * ci + li);            \
+      pi_[ci][s] = HPX_LDA((base_im), s * kstep + c0 + 16 * ci + li);            \
+    }                                                                            \
+  }
+#define HPX_MMA_CHUNK(br_, bi_, pr_, pi_)                                        \
+  _Pragma("unroll") for (int s = 0; s < KC; ++s)                                 \
+    _Pragma("unroll") for (int ci = 0; ci < CT; ++ci) {                          \
+      const double npr = -pr_[ci][s], npi = -pi_[ci][s];                         \
+      _Pragma("unroll") for (int t = 0; t < RT; ++t) {                           \
+        ar[t][ci] = mfma64(npr, br_[t][s], ar[t][ci]);                           \
+        ar[t][ci] = mfma64(npi, bi_[t][s], ar[t][ci]);                           \
+        ai[t][ci] = mfma64(npr, bi_[t][s], ai[t][ci]);                           \
+        ai[t][ci] = mfma64(pi_[ci][s], br_[t][s], ai[t][ci]);                    \
+      }                                                                          \
+    }
+  if (nch > 0) {
+    HPX_LOAD_CHUNK(b0r, b0i, p0r, p0i, pre, pim)
+    for (int ch = 0; ch < nch; ch += 2) {
+      const double* qre = pre + KC * kstep;
+      const double* qim = pim + KC * kstep;
+      HPX_LOAD_CHUNK(b1r, b1i, p1r, p1i, qre, qim)        // chunk ch+1 always exists (nch even)
+      HPX_MMA_CHUNK(b0r, b0i, p0r, p0i)
+      pre += 2 * KC * kstep;
+      pim += 2 * KC * kstep;
+      if (ch + 2 < nch) { HPX_LOAD_CHUNK(b0r, b0i, p0r, p0i, pre, pim) }
+      HPX_MMA_CHUNK(b1r, b1i, p1r, p1i)
+    }
+  }
+#undef HPX_LOAD_CHUNK
+#undef HPX_MMA_CHUNK
+  // X^T = W * acc^T,  W = conj(Ljj^-1) lower triangular (LDS), acc^T as B operand
+#pragma unroll
+  for (int t = 0; t < RT; ++t) {
+    d4 xr[CT], xi[CT];
 #pragma unroll
     for (int ci = 0; ci < CT; ++ci) {
-      const double pr = pre[c0 + 16 * ci + li], pi = pim[c0 + 16 * ci + li];
-      ar[ci] = mfma64(-pr, br, ar[ci]);
-      ar[ci] = mfma64(-pi, bi, ar[ci]);
-      ai[ci] = mfma64(-pr, bi, ai[ci]);
-      ai[ci] = mfma64(pi, br, ai[ci]);
+      xr[ci] = (d4){0., 0., 0., 0.};
+      xi[ci] = (d4){0., 0., 0., 0.};
+#pragma unroll
+      for (int cj = 0; cj <= ci; ++cj)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          const int kq = 16 * cj + HPX_ACC_ROW(g, v);
+          const double wr = Wre[(16 * ci + li) * WLD + kq];
+          const double wi = Wim[(16 * ci + li) * WLD + kq];
+          xr[ci] = mfma64(wr, ar[t][cj][v], xr[ci]);
+          xr[ci] = mfma64(-wi, ai[t][cj][v], xr[ci]);
+          xi[ci] = mfma64(wr, ai[t][cj][v], xi[ci]);
+          xi[ci] = mfma64(wi, ar[t][cj][v], xi[ci]);
+        }
     }
-    pre += kstep;
-    pim += kstep;
-  }
-  // X^T = W * acc^T,  W = conj(Ljj^-1) lower triangular (LDS), acc^T as B operand
-  d4 xr[CT], xi[CT];
 #pragma unroll
-  for (int ci = 0; ci < CT; ++ci) {
-    xr[ci] = (d4){0., 0., 0., 0.};
-    xi[ci] = (d4){0., 0., 0., 0.};
-#pragma unroll
-    for (int cj = 0; cj <= ci; ++cj)
+    for (int ci = 0; ci < CT; ++ci)
 #pragma unroll
       for (int v = 0; v < 4; ++v) {
-        const int kq = 16 * cj + HPX_ACC_ROW(g, v);
-        const double wr = Wre[(16 * ci + li) * WLD + kq];
-        const double wi = Wim[(16 * ci + li) * WLD + kq];
-        xr[ci] = mfma64(wr, ar[cj][v], xr[ci]);
-        xr[ci] = mfma64(-wi, ai[cj][v], xr[ci]);
-        xi[ci] = mfma64(wr, ai[cj][v], xi[ci]);
-        xi[ci] = mfma64(wi, ar[cj][v], xi[ci]);
+        const long off = (long)(c0 + 16 * ci + HPX_ACC_ROW(g, v)) * ld + r0 + t * rstride + li;
+        Lre[off] = xr[ci][v];
+        Lim[off] = xi[ci][v];
       }
   }
-#pragma unroll
-  for (int ci = 0; ci < CT; ++ci)
-#pragma unroll
-    for (int v = 0; v < 4; ++v) {
-      const long off = (long)(c0 + 16 * ci + HPX_ACC_ROW(g, v)) * ld + r0 + li;
-      Lre[off] = xr[ci][v];
-      Lim[off] = xi[ci][v];
-    }
+}
+
+// 16-wide last block column (npad % 32 == 16): rare, kept out of line so that it does not
+// add to the register pressure of the main path.
+__device__ __noinline__ void offdiag_narrow(double* Lre, double* Lim, const int ld, const int c0,
+                                            const int r0, const double* Wre, const double* Wim,
+                                            const int lane) {
+  offdiag_group<1, 1>(Lre, Lim, ld, c0, r0, 64, Wre, Wim, lane);
 }
 
 // K-split partial sums of the (up to) three lower tiles of the diagonal block.
@@ -104,7 +166,7 @@ __device__ __forceinline__ void diag_partial(const double* __restrict__ Lre,
     ar[t] = (d4){0., 0., 0., 0.};
     ai[t] = (d4){0., 0., 0., 0.};
   }
-  const int nks = c0 >> 2;
+  const int nks = (HPX_DIAG & 8) ? 0 : (c0 >> 2);
   for (int ks = wave; ks < nks; ks += 4) {
     const long off = (long)(4 * ks + g) * ld + c0 + li;
     const double v0r = Lre[off], v0i = Lim[off];
@@ -190,7 +252,7 @@ __global__ __launch_bounds__(256, 2) void k_factor(double* __restrict__ Lre_all,
     }
     // ---- 2. fused Cholesky + inverse of the wj x wj block (unscaled columns;
     //         column q of L is D[:,q]/sqrt(D[q][q]) and row i of L^-1 is Y[i,:]/sqrt(D[i][i]))
-    for (int k = 0; k < wj; ++k) {
+    for (int k = 0; k < ((HPX_DIAG & 4) ? 0 : wj); ++k) {
       __syncthreads();
       const double dkk = sh.Dre[k * WLD + k];
       if (!(dkk > 0.0)) bad = true;
@@ -231,15 +293,22 @@ __global__ __launch_bounds__(256, 2) void k_factor(double* __restrict__ Lre_all,
       sh.Yim[i * WLD + q] = -wi;
     }
     __syncthreads();
-    // ---- 3. tiles below the diagonal block (incl. the right-hand-side rows)
+    // ---- 3. tiles below the diagonal block (incl. the right-hand-side rows): wave w owns
+    //         tiles rt0 + w + 4 i and works through them in groups
     const int rt0 = (c0 + wj) >> 4;
-    for (int rt = rt0 + wave; rt < nrt; rt += 4) {
-      if (CT == 2) offdiag_tile<2>(Lre, Lim, ld, c0, rt << 4, sh.Yre, sh.Yim, lane);
-      else offdiag_tile<1>(Lre, Lim, ld, c0, rt << 4, sh.Yre, sh.Yim, lane);
+    int rt = rt0 + wave;
+    if (CT == 2) {
+#if HPX_RT3
+      for (; rt + 8 < nrt; rt += 12) offdiag_group<2, 3>(Lre, Lim, ld, c0, rt << 4, 64, sh.Yre, sh.Yim, lane);
+#endif
+      for (; rt + 4 < nrt; rt += 8) offdiag_group<2, 2>(Lre, Lim, ld, c0, rt << 4, 64, sh.Yre, sh.Yim, lane);
+      if (rt < nrt) offdiag_group<2, 1>(Lre, Lim, ld, c0, rt << 4, 64, sh.Yre, sh.Yim, lane);
+    } else {
+      for (; rt < nrt; rt += 4) offdiag_narrow(Lre, Lim, ld, c0, rt << 4, sh.Yre, sh.Yim, lane);
     }
     __syncthreads();
   }
-  if (bad && info) atomicCAS(&info[b], 0, iter_tag);
+  if (bad && info && !HPX_DIAG) atomicCAS(&info[b], 0, iter_tag);
   (void)li; (void)g;
 }
 

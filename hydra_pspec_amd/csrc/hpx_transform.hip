@@ -49,7 +49,7 @@ __device__ __forceinline__ void dft_tile(const double* __restrict__ Wre,
     }
 }
 
-__global__ __launch_bounds__(256) void k_dft(const double* __restrict__ Wre,
+__global__ __launch_bounds__(256, 2) void k_dft(const double* __restrict__ Wre,
                                              const double* __restrict__ Wim, const int conjW,
                                              const double* __restrict__ inre,
                                              const double* __restrict__ inim,
