@@ -204,79 +204,34 @@ __global__ void k_set_a(const double* __restrict__ ps, double* __restrict__ a,
 }
 
 // ---- K'_aug assembly ----------------------------------------------------------
-struct AsmArgs {
-  const double *a, *Cre, *Cim, *Rre, *Rim, *P2re, *P2im, *Hre, *Him, *P4re, *P4im;
-  double *Lre, *Lim;
-  int N, M, T, NP, TP, npad, ld, ncol, has_omega;
-};
-
-__global__ __launch_bounds__(256) void k_assemble(const AsmArgs A) {
+__global__ __launch_bounds__(256) void k_assemble(const hpx_gen_batch B, double* __restrict__ L_all,
+                                                  const int npad, const int ld) {
   const int b = blockIdx.y, cb = blockIdx.x;
-  const int N = A.N, M = A.M, TP = A.TP, npad = A.npad, ld = A.ld;
-  const double* a = A.a + (long)b * N;
-  const double* cre = A.Cre + (long)b * N;
-  const double* cim = A.Cim + (long)b * N;
-  const double* rre = A.Rre + (long)b * A.NP * A.ncol;
-  const double* rim = A.Rim + (long)b * A.NP * A.ncol;
-  double* Lre = A.Lre + (long)b * npad * ld;
-  double* Lim = A.Lim + (long)b * npad * ld;
+  const hpx_gen G = hpx_gen_for(B, b);
+  double* L = L_all + (long)b * npad * ld * 2;
   const int rbeg = cb * 16, nrow = ld - rbeg;
   for (int e = threadIdx.x; e < 16 * nrow; e += 256) {
     const int c = rbeg + e / nrow, r = rbeg + e % nrow;
-    double vr = 0.0, vi = 0.0;
-    if (r >= c) {
-      if (c < N) {
-        const double ac = a[c];
-        if (r < N) {
-          const double s = a[r] * ac;
-          vr = s * cre[r - c] + (r == c ? 1.0 : 0.0);
-          vi = (r == c) ? 0.0 : s * cim[r - c];
-        } else if (r < N + M) {          // conj(G[c][m]) a_c
-          const long o = (long)c * A.ncol + TP + (r - N);
-          vr = rre[o] * ac;
-          vi = -rim[o] * ac;
-        } else if (r >= npad) {          // conj(a_c Q[c][t] + P2[c][t])
-          const int t = r - npad;
-          const long o = (long)c * A.ncol + t;
-          vr = ac * rre[o];
-          vi = ac * rim[o];
-          if (A.has_omega) {
-            vr += A.P2re[(long)c * TP + t];
-            vi += A.P2im[(long)c * TP + t];
-          }
-          vi = -vi;
-        }
-      } else if (c < N + M) {
-        const int mc = c - N;
-        if (r < N + M) {
-          vr = A.Hre[((long)b * M + (r - N)) * M + mc];
-          vi = (r == c) ? 0.0 : A.Him[((long)b * M + (r - N)) * M + mc];
-        } else if (r >= npad) {
-          const int t = r - npad;
-          vr = A.P4re[((long)b * M + mc) * TP + t];
-          vi = -A.P4im[((long)b * M + mc) * TP + t];
-        }
-      } else if (r == c) {
-        vr = 1.0;
-      }
-    }
-    Lre[(long)c * ld + r] = vr;
-    Lim[(long)c * ld + r] = vi;
+    double vr, vi;
+    hpx_gen_entry(G, r, c, npad, vr, vi);
+    const long o = HPX_LIDX(r, c, npad);
+    L[o] = vr;
+    L[o + 16] = vi;
   }
 }
 
-__global__ void k_kaug_out(const double* __restrict__ Lre, const double* __restrict__ Lim,
-                           double* __restrict__ out, const int npad, const int ld) {
+__global__ void k_kaug_out(const double* __restrict__ L, double* __restrict__ out, const int npad,
+                           const int ld) {
   // (nbl, ld, npad) c128 row-major
   const int b = blockIdx.y;
   const long tot = (long)ld * npad;
   for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < tot;
        e += (long)gridDim.x * blockDim.x) {
     const int r = (int)(e / npad), c = (int)(e % npad);
-    const long o = (long)b * npad * ld + (long)c * ld + r;
+    const long o = (long)b * npad * ld * 2 + HPX_LIDX(r, c, npad);
     const bool keep = (r >= c);
-    out[((long)b * tot + e) * 2] = keep ? Lre[o] : 0.0;
-    out[((long)b * tot + e) * 2 + 1] = keep ? Lim[o] : 0.0;
+    out[((long)b * tot + e) * 2] = keep ? L[o] : 0.0;
+    out[((long)b * tot + e) * 2 + 1] = keep ? L[o + 16] : 0.0;
   }
 }
 
@@ -534,7 +489,7 @@ extern "C" int hpx_plan_create(hpx_plan** out, int nbl, int T, int N, int M) {
                ssz = (size_t)p->NP * p->TP, rsz = (size_t)p->NP * p->ncolR;
   int rc = HPX_OK;
 #define A_(ptr, cnt) if (rc == HPX_OK) rc = dev_alloc(p, &p->ptr, (cnt))
-  A_(Lre, nb * lsz); A_(Lim, nb * lsz);
+  A_(L, nb * lsz * 2);
   A_(Wre, nb * p->nblk * 1024); A_(Wim, nb * p->nblk * 1024);
   A_(Xre, nb * xsz); A_(Xim, nb * xsz);
   A_(info, nb);
@@ -659,14 +614,19 @@ extern "C" int hpx_plan_set_rng(hpx_plan* p, const double* uniforms, const doubl
   return HPX_OK;
 }
 
+static hpx_gen_batch gen_of(const hpx_plan* p) {
+  hpx_gen_batch B;
+  B.a = p->a; B.cre = p->Cre; B.cim = p->Cim; B.rre = p->Rre; B.rim = p->Rim;
+  B.p2re = p->P2re; B.p2im = p->P2im; B.hre = p->Hre; B.him = p->Him;
+  B.p4re = p->P4re; B.p4im = p->P4im;
+  B.N = p->N; B.M = p->M; B.NP = p->NP; B.TP = p->TP; B.ncol = p->ncolR;
+  B.has_omega = p->has_omega;
+  return B;
+}
+
 static int launch_assemble(hpx_plan* p, hipStream_t st) {
-  AsmArgs A;
-  A.a = p->a; A.Cre = p->Cre; A.Cim = p->Cim; A.Rre = p->Rre; A.Rim = p->Rim;
-  A.P2re = p->P2re; A.P2im = p->P2im; A.Hre = p->Hre; A.Him = p->Him;
-  A.P4re = p->P4re; A.P4im = p->P4im; A.Lre = p->Lre; A.Lim = p->Lim;
-  A.N = p->N; A.M = p->M; A.T = p->T; A.NP = p->NP; A.TP = p->TP; A.npad = p->npad;
-  A.ld = p->ld; A.ncol = p->ncolR; A.has_omega = p->has_omega;
-  hipLaunchKernelGGL(k_assemble, dim3(p->npad / 16, p->nbl), dim3(256), 0, st, A);
+  hipLaunchKernelGGL(k_assemble, dim3(p->npad / 16, p->nbl), dim3(256), 0, st, gen_of(p), p->L,
+                     p->npad, p->ld);
   HPX_HIP(hipGetLastError());
   return HPX_OK;
 }
@@ -679,8 +639,7 @@ extern "C" int hpx_assemble_K(hpx_plan* p, const double* ps, double* k_out, void
   HPX_HIP(hipGetLastError());
   HPX_TRY(launch_assemble(p, st));
   if (k_out) {
-    hipLaunchKernelGGL(k_kaug_out, dim3(128, p->nbl), dim3(256), 0, st, p->Lre, p->Lim, k_out,
-                       p->npad, p->ld);
+    hipLaunchKernelGGL(k_kaug_out, dim3(128, p->nbl), dim3(256), 0, st, p->L, k_out, p->npad, p->ld);
     HPX_HIP(hipGetLastError());
   }
   HPX_HIP(hipStreamSynchronize(st));
@@ -737,13 +696,13 @@ extern "C" int hpx_gibbs_run(hpx_plan* p, const double* ps0, int iter0, int nite
   p->ev_used = 0;
   for (int it = 0; it < niter; ++it) {
     HPX_TRY(mark(p, st));
-    HPX_TRY(launch_assemble(p, st));
+    // K'_aug is generated inside the factor kernel (no assembly pass, L is write-only)
     HPX_TRY(mark(p, st));
-    HPX_TRY(hpx_launch_factor(nbl, p->npad, p->ld, p->Lre, p->Lim, p->Wre, p->Wim, p->info,
-                              iter0 + it + 1, st));
+    const hpx_gen_batch gen = gen_of(p);
+    HPX_TRY(hpx_launch_factor(nbl, p->npad, p->ld, p->L, p->Wre, p->Wim, p->info, iter0 + it + 1,
+                              &gen, st));
     HPX_TRY(mark(p, st));
-    HPX_TRY(hpx_launch_backsolve(nbl, p->npad, TP, p->ld, p->Lre, p->Lim, p->Wre, p->Wim, p->Xre,
-                                 p->Xim, st));
+    HPX_TRY(hpx_launch_backsolve(nbl, p->npad, TP, p->ld, p->L, p->Wre, p->Wim, p->Xre, p->Xim, st));
     HPX_TRY(mark(p, st));
     // s = U D^1/2 y' = conj(F) (a . y') / sqrt(N)
     HPX_TRY(hpx_launch_dft(nbl, NP, TP, p->Fopre, p->Fopim, 1, p->Xre, p->Xim, (long)p->npad * TP,

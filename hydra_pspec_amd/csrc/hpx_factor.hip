@@ -2,10 +2,13 @@
 // sides carried as extra rows (forward substitution for free), and the
 // backward substitution.  One workgroup (4 waves) per baseline.
 //
-// Storage: planar (separate re / im planes), column-major, leading dimension
-// ld = npad + TP.  Column c, row r lives at [c*ld + r].  Rows npad..ld-1 of
-// the augmented matrix hold the conjugated right-hand sides, so that after the
-// factorisation they hold Z^H with Z = L^-1 R.
+// Storage ("16-row panel major"): the ld = npad + TP rows are cut into 16-row panels;
+// element (r, c) has its real part at HPX_LIDX(r, c, npad) and its imaginary part 16
+// doubles further, i.e. panel (r>>4) is a contiguous [npad columns][re 16 | im 16] strip.
+// A wave streaming the k range of one row tile therefore reads 256 contiguous bytes per
+// column (sequential DRAM pages), instead of 128-byte pieces 8*ld bytes apart as in a
+// column-major layout.  Rows npad..ld-1 hold the conjugated right-hand sides, so that
+// after the factorisation they hold Z^H with Z = L^-1 R.
 //
 // Algorithm (left-looking by block columns of HPX_NB = 32):
 //   for each block column j:
@@ -48,11 +51,12 @@ struct FactorShared {
 // processed together so that the panel operand conj(L[c][k]) is fetched once per k-step
 // for all of them (the panel rows are the re-read-heavy operand: without this reuse every
 // tile streams the whole 32 x c0 panel again and the kernel becomes HBM/L2 bound).
-template <int CT, int RT>
+template <int CT, int RT, bool GEN>
 __device__ __forceinline__ void offdiag_group(double* __restrict__ Lre, double* __restrict__ Lim,
-                                              const int ld, const int c0, const int r0,
+                                              const int npad, const int c0, const int r0,
                                               const int rstride, const double* Wre,
-                                              const double* Wim, const int lane) {
+                                              const double* Wim, const int lane,
+                                              const hpx_gen& G) {
   const int li = lane & 15, g = lane >> 4;
   d4 ar[RT][CT], ai[RT][CT];
 #pragma unroll
@@ -61,9 +65,16 @@ __device__ __forceinline__ void offdiag_group(double* __restrict__ Lre, double* 
     for (int ci = 0; ci < CT; ++ci)
 #pragma unroll
       for (int v = 0; v < 4; ++v) {
-        const long off = (long)(c0 + 16 * ci + HPX_ACC_ROW(g, v)) * ld + r0 + t * rstride + li;
-        ar[t][ci][v] = Lre[off];
-        ai[t][ci][v] = Lim[off];
+        if (GEN) {
+          double vr, vi;
+          hpx_gen_entry(G, r0 + t * rstride + li, c0 + 16 * ci + HPX_ACC_ROW(g, v), npad, vr, vi);
+          ar[t][ci][v] = vr;
+          ai[t][ci][v] = vi;
+        } else {
+          const long off = HPX_LIDX(r0 + t * rstride + li, c0 + 16 * ci + HPX_ACC_ROW(g, v), npad);
+          ar[t][ci][v] = Lre[off];
+          ai[t][ci][v] = Lim[off];
+        }
       }
   // acc^T[c][r] -= conj(L[c][k]) * L[r][k].  c0 is a multiple of 32, so the k range is a
   // whole number of chunk pairs; operands of the next chunk are fetched into the other
@@ -71,20 +82,23 @@ __device__ __forceinline__ void offdiag_group(double* __restrict__ Lre, double* 
   // hipcc does not software-pipeline across loop iterations).
   constexpr int KC = (RT >= 3) ? 1 : 2;     // k-steps per chunk
   const int nch = (c0 >> 2) / KC;
-  const double* pre = Lre + (long)g * ld;
-  const double* pim = Lim + (long)g * ld;
-  const long kstep = 4L * ld;
+  const double* pre = Lre + (long)g * 32;      // column k = 4 ks + g of every panel
+  const double* pim = Lim + (long)g * 32;
+  const long kstep = 128;                       // 4 columns x 32 doubles
+  const long ptile = (long)npad * 32;           // doubles per 16-row panel
+  const long boff = (long)(r0 >> 4) * ptile + li, bstr = (long)(rstride >> 4) * ptile;
+  const long aoff = (long)(c0 >> 4) * ptile + li;
   double b0r[RT][KC], b0i[RT][KC], b1r[RT][KC], b1i[RT][KC];
   double p0r[CT][KC], p0i[CT][KC], p1r[CT][KC], p1i[CT][KC];
 #define HPX_LOAD_CHUNK(br_, bi_, pr_, pi_, base_re, base_im)                     \
   _Pragma("unroll") for (int s = 0; s < KC; ++s) {                               \
     _Pragma("unroll") for (int t = 0; t < RT; ++t) {                             \
-      br_[t][s] = HPX_LD((base_re), s * kstep + r0 + t * rstride + li);          \
-      bi_[t][s] = HPX_LD((base_im), s * kstep + r0 + t * rstride + li);          \
+      br_[t][s] = HPX_LD((base_re), s * kstep + boff + t * bstr);                \
+      bi_[t][s] = HPX_LD((base_im), s * kstep + boff + t * bstr);                \
     }                                                                            \
     _Pragma("unroll") for (int ci = 0; ci < CT; ++ci) {                          \
-      pr_[ci][s] = HPX_LDA((base_re), s * kstep + c0 + 16 * ci + li);            \
-      pi_[ci][s] = HPX_LDA((base_im), s * kstep + c0 + 16 * ci + li);            \
+      pr_[ci][s] = HPX_LDA((base_re), s * kstep + aoff + ci * ptile);            \
+      pi_[ci][s] = HPX_LDA((base_im), s * kstep + aoff + ci * ptile);            \
     }                                                                            \
   }
 #define HPX_MMA_CHUNK(br_, bi_, pr_, pi_)                                        \
@@ -105,9 +119,13 @@ __device__ __forceinline__ void offdiag_group(double* __restrict__ Lre, double* 
       const double* qim = pim + KC * kstep;
       HPX_LOAD_CHUNK(b1r, b1i, p1r, p1i, qre, qim)        // chunk ch+1 always exists (nch even)
       HPX_MMA_CHUNK(b0r, b0i, p0r, p0i)
-      pre += 2 * KC * kstep;
-      pim += 2 * KC * kstep;
-      if (ch + 2 < nch) { HPX_LOAD_CHUNK(b0r, b0i, p0r, p0i, pre, pim) }
+      // Branch-free prefetch of chunk ch+2: on the last pair the current chunk is simply
+      // fetched again (in bounds, unused).  A conditional here gives the consuming block two
+      // predecessors and hipcc then waits with vmcnt(0), draining the prefetch as well.
+      const long adv = (ch + 2 < nch) ? 2 * KC * kstep : 0;
+      pre += adv;
+      pim += adv;
+      HPX_LOAD_CHUNK(b0r, b0i, p0r, p0i, pre, pim)
       HPX_MMA_CHUNK(b1r, b1i, p1r, p1i)
     }
   }
@@ -138,7 +156,7 @@ __device__ __forceinline__ void offdiag_group(double* __restrict__ Lre, double* 
     for (int ci = 0; ci < CT; ++ci)
 #pragma unroll
       for (int v = 0; v < 4; ++v) {
-        const long off = (long)(c0 + 16 * ci + HPX_ACC_ROW(g, v)) * ld + r0 + t * rstride + li;
+        const long off = HPX_LIDX(r0 + t * rstride + li, c0 + 16 * ci + HPX_ACC_ROW(g, v), npad);
         Lre[off] = xr[ci][v];
         Lim[off] = xi[ci][v];
       }
@@ -147,17 +165,18 @@ __device__ __forceinline__ void offdiag_group(double* __restrict__ Lre, double* 
 
 // 16-wide last block column (npad % 32 == 16): rare, kept out of line so that it does not
 // add to the register pressure of the main path.
-__device__ __noinline__ void offdiag_narrow(double* Lre, double* Lim, const int ld, const int c0,
+template <bool GEN>
+__device__ __noinline__ void offdiag_narrow(double* Lre, double* Lim, const int npad, const int c0,
                                             const int r0, const double* Wre, const double* Wim,
-                                            const int lane) {
-  offdiag_group<1, 1>(Lre, Lim, ld, c0, r0, 64, Wre, Wim, lane);
+                                            const int lane, const hpx_gen& G) {
+  offdiag_group<1, 1, GEN>(Lre, Lim, npad, c0, r0, 64, Wre, Wim, lane, G);
 }
 
 // K-split partial sums of the (up to) three lower tiles of the diagonal block.
 // tile 0 = (c-tile 0, r-tile 0), 1 = (0,1), 2 = (1,1); acc^T[c][r].
 template <int CT>
 __device__ __forceinline__ void diag_partial(const double* __restrict__ Lre,
-                                             const double* __restrict__ Lim, const int ld,
+                                             const double* __restrict__ Lim, const int npad,
                                              const int c0, const int wave, const int lane,
                                              d4 (&ar)[3], d4 (&ai)[3]) {
   const int li = lane & 15, g = lane >> 4;
@@ -168,14 +187,15 @@ __device__ __forceinline__ void diag_partial(const double* __restrict__ Lre,
   }
   const int nks = (HPX_DIAG & 8) ? 0 : (c0 >> 2);
   for (int ks = wave; ks < nks; ks += 4) {
-    const long off = (long)(4 * ks + g) * ld + c0 + li;
+    const long off = HPX_LIDX(c0 + li, 4 * ks + g, npad);
     const double v0r = Lre[off], v0i = Lim[off];
     ar[0] = mfma64(-v0r, v0r, ar[0]);
     ar[0] = mfma64(-v0i, v0i, ar[0]);
     ai[0] = mfma64(-v0r, v0i, ai[0]);
     ai[0] = mfma64(v0i, v0r, ai[0]);
     if (CT == 2) {
-      const double v1r = Lre[off + 16], v1i = Lim[off + 16];
+      const long off1 = off + (long)npad * 32;   // next 16-row panel
+      const double v1r = Lre[off1], v1i = Lim[off1];
       ar[1] = mfma64(-v0r, v1r, ar[1]);
       ar[1] = mfma64(-v0i, v1i, ar[1]);
       ai[1] = mfma64(-v0r, v1i, ai[1]);
@@ -188,23 +208,32 @@ __device__ __forceinline__ void diag_partial(const double* __restrict__ Lre,
   }
 }
 
-__global__ __launch_bounds__(256, 2) void k_factor(double* __restrict__ Lre_all,
-                                                   double* __restrict__ Lim_all,
+template <bool GEN>
+__global__ __launch_bounds__(256, 2) void k_factor(double* __restrict__ L_all,
                                                    double* __restrict__ Wre_all,
                                                    double* __restrict__ Wim_all,
                                                    int32_t* __restrict__ info, const int npad,
-                                                   const int ld, const int iter_tag) {
+                                                   const int ld, const int iter_tag,
+                                                   const hpx_gen_batch GB) {
   __shared__ FactorShared sh;
   const int b = blockIdx.x;
+  hpx_gen G;
+  if (GEN) G = hpx_gen_for(GB, b);
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int li = lane & 15, g = lane >> 4;
-  double* Lre = Lre_all + (long)b * npad * ld;
-  double* Lim = Lim_all + (long)b * npad * ld;
+  double* Lre = L_all + (long)b * npad * ld * 2;
+  double* Lim = Lre + 16;
   const int nblk = (npad + HPX_NB - 1) / HPX_NB;
   double* Wgre = Wre_all + (long)b * nblk * 1024;
   double* Wgim = Wim_all + (long)b * nblk * 1024;
   const int nrt = ld >> 4;
   bool bad = false;
+#if HPX_STAGGER
+  // Two workgroups share a CU and run the same program: started together they reach their
+  // MFMA-free phases (in-LDS Cholesky) together.  Delay every second one (speed only).
+  if ((blockIdx.x >> 8) & 1)
+    for (int i = 0; i < HPX_STAGGER; ++i) __builtin_amdgcn_s_sleep(127);
+#endif
 
   for (int jb = 0; jb < nblk; ++jb) {
     const int c0 = jb * HPX_NB;
@@ -212,8 +241,8 @@ __global__ __launch_bounds__(256, 2) void k_factor(double* __restrict__ Lre_all,
     const int CT = wj >> 4;
     // ---- 1. diagonal block: partial sums over this wave's share of k
     d4 ar[3], ai[3];
-    if (CT == 2) diag_partial<2>(Lre, Lim, ld, c0, wave, lane, ar, ai);
-    else diag_partial<1>(Lre, Lim, ld, c0, wave, lane, ar, ai);
+    if (CT == 2) diag_partial<2>(Lre, Lim, npad, c0, wave, lane, ar, ai);
+    else diag_partial<1>(Lre, Lim, npad, c0, wave, lane, ar, ai);
     if (wave >= 2) {
 #pragma unroll
       for (int t = 0; t < 3; ++t)
@@ -246,9 +275,16 @@ __global__ __launch_bounds__(256, 2) void k_factor(double* __restrict__ Lre_all,
       if (CT == 1 && t > 0) continue;
       const int ci = (t == 2) ? 1 : 0, ri = (t == 0) ? 0 : 1;
       const int c = 16 * ci + HPX_ACC_ROW(l >> 4, v), r = 16 * ri + (l & 15);
-      const long off = (long)(c0 + c) * ld + c0 + r;
-      sh.Dre[r * WLD + c] = Lre[off] + sh.slab[0][t][0][v][l] + sh.slab[1][t][0][v][l];
-      sh.Dim[r * WLD + c] = Lim[off] + sh.slab[0][t][1][v][l] + sh.slab[1][t][1][v][l];
+      double kr, ki;
+      if (GEN) {
+        hpx_gen_entry(G, c0 + r, c0 + c, npad, kr, ki);
+      } else {
+        const long off = HPX_LIDX(c0 + r, c0 + c, npad);
+        kr = Lre[off];
+        ki = Lim[off];
+      }
+      sh.Dre[r * WLD + c] = kr + sh.slab[0][t][0][v][l] + sh.slab[1][t][0][v][l];
+      sh.Dim[r * WLD + c] = ki + sh.slab[0][t][1][v][l] + sh.slab[1][t][1][v][l];
     }
     // ---- 2. fused Cholesky + inverse of the wj x wj block (unscaled columns;
     //         column q of L is D[:,q]/sqrt(D[q][q]) and row i of L^-1 is Y[i,:]/sqrt(D[i][i]))
@@ -279,7 +315,7 @@ __global__ __launch_bounds__(256, 2) void k_factor(double* __restrict__ Lre_all,
       double wr = 0.0, wi = 0.0;
       if (i < wj && q <= i) {
         const double sq = 1.0 / sqrt(sh.Dre[q * WLD + q]);
-        const long off = (long)(c0 + q) * ld + c0 + i;
+        const long off = HPX_LIDX(c0 + i, c0 + q, npad);
         Lre[off] = sh.Dre[i * WLD + q] * sq;
         Lim[off] = (i == q) ? 0.0 : sh.Dim[i * WLD + q] * sq;
         const double si = 1.0 / sqrt(sh.Dre[i * WLD + i]);
@@ -299,12 +335,12 @@ __global__ __launch_bounds__(256, 2) void k_factor(double* __restrict__ Lre_all,
     int rt = rt0 + wave;
     if (CT == 2) {
 #if HPX_RT3
-      for (; rt + 8 < nrt; rt += 12) offdiag_group<2, 3>(Lre, Lim, ld, c0, rt << 4, 64, sh.Yre, sh.Yim, lane);
+      for (; rt + 8 < nrt; rt += 12) offdiag_group<2, 3, GEN>(Lre, Lim, npad, c0, rt << 4, 64, sh.Yre, sh.Yim, lane, G);
 #endif
-      for (; rt + 4 < nrt; rt += 8) offdiag_group<2, 2>(Lre, Lim, ld, c0, rt << 4, 64, sh.Yre, sh.Yim, lane);
-      if (rt < nrt) offdiag_group<2, 1>(Lre, Lim, ld, c0, rt << 4, 64, sh.Yre, sh.Yim, lane);
+      for (; rt + 4 < nrt; rt += 8) offdiag_group<2, 2, GEN>(Lre, Lim, npad, c0, rt << 4, 64, sh.Yre, sh.Yim, lane, G);
+      if (rt < nrt) offdiag_group<2, 1, GEN>(Lre, Lim, npad, c0, rt << 4, 64, sh.Yre, sh.Yim, lane, G);
     } else {
-      for (; rt < nrt; rt += 4) offdiag_narrow(Lre, Lim, ld, c0, rt << 4, sh.Yre, sh.Yim, lane);
+      for (; rt < nrt; rt += 4) offdiag_narrow<GEN>(Lre, Lim, npad, c0, rt << 4, sh.Yre, sh.Yim, lane, G);
     }
     __syncthreads();
   }
@@ -344,7 +380,7 @@ __device__ __forceinline__ void back_block(const double* __restrict__ Lre,
       for (int ci = 0; ci < CT; ++ci)
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
-          const long off = (long)(c0 + 16 * ci + HPX_ACC_ROW(g, v)) * ld + npad + t0 + li;
+          const long off = HPX_LIDX(npad + t0 + li, c0 + 16 * ci + HPX_ACC_ROW(g, v), npad);
           yr[ci][v] = Lre[off];
           yi[ci][v] = -Lim[off];
         }
@@ -358,7 +394,7 @@ __device__ __forceinline__ void back_block(const double* __restrict__ Lre,
       double lr[CT][4], lm[CT][4];
 #pragma unroll
       for (int ci = 0; ci < CT; ++ci) {
-        const long off = (long)(c0 + 16 * ci + li) * ld + rb + 4 * g;
+        const long off = HPX_LIDX(rb + 4 * g, c0 + 16 * ci + li, npad);
         const double2 a0 = *reinterpret_cast<const double2*>(Lre + off);
         const double2 a1 = *reinterpret_cast<const double2*>(Lre + off + 2);
         const double2 b0 = *reinterpret_cast<const double2*>(Lim + off);
@@ -433,8 +469,7 @@ __device__ __forceinline__ void back_block(const double* __restrict__ Lre,
   __syncthreads();
 }
 
-__global__ __launch_bounds__(256, 2) void k_backsolve(const double* __restrict__ Lre_all,
-                                                      const double* __restrict__ Lim_all,
+__global__ __launch_bounds__(256, 2) void k_backsolve(const double* __restrict__ L_all,
                                                       const double* __restrict__ Wre_all,
                                                       const double* __restrict__ Wim_all,
                                                       double* __restrict__ Xre_all,
@@ -444,8 +479,8 @@ __global__ __launch_bounds__(256, 2) void k_backsolve(const double* __restrict__
   __shared__ BackShared sh;
   const int b = blockIdx.x;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const double* Lre = Lre_all + (long)b * npad * ld;
-  const double* Lim = Lim_all + (long)b * npad * ld;
+  const double* Lre = L_all + (long)b * npad * ld * 2;
+  const double* Lim = Lre + 16;
   const int nblk = (npad + HPX_NB - 1) / HPX_NB;
   const double* Wgre = Wre_all + (long)b * nblk * 1024;
   const double* Wgim = Wim_all + (long)b * nblk * 1024;
@@ -473,7 +508,7 @@ __global__ __launch_bounds__(256, 2) void k_backsolve(const double* __restrict__
 // ---------------------------------------------------------------------------
 // stand-alone helpers: interleaved row-major <-> planar column-major
 __global__ void k_pack_herm(const double* __restrict__ a, const double* __restrict__ rhs,
-                            double* __restrict__ Lre, double* __restrict__ Lim, const int n,
+                            double* __restrict__ L, const int n,
                             const int nrhs, const int npad, const int ld) {
   // a (nb,n,n) c128 row-major; rhs (nb,n,nrhs) c128 row-major or NULL
   const int b = blockIdx.y;
@@ -495,12 +530,13 @@ __global__ void k_pack_herm(const double* __restrict__ a, const double* __restri
       vr = rhs[o];
       vi = -rhs[o + 1];
     }
-    Lre[(long)b * tot + e] = vr;
-    Lim[(long)b * tot + e] = vi;
+    const long o = (long)b * tot * 2 + HPX_LIDX(r, c, npad);
+    L[o] = vr;
+    L[o + 16] = vi;
   }
 }
 
-__global__ void k_unpack_lower(const double* __restrict__ Lre, const double* __restrict__ Lim,
+__global__ void k_unpack_lower(const double* __restrict__ L,
                                double* __restrict__ out, const int n, const int npad,
                                const int ld) {
   const int b = blockIdx.y;
@@ -510,9 +546,9 @@ __global__ void k_unpack_lower(const double* __restrict__ Lre, const double* __r
     const int r = (int)(e / n), c = (int)(e % n);
     double vr = 0.0, vi = 0.0;
     if (r >= c) {
-      const long o = (long)b * npad * ld + (long)c * ld + r;
-      vr = Lre[o];
-      vi = Lim[o];
+      const long o = (long)b * npad * ld * 2 + HPX_LIDX(r, c, npad);
+      vr = L[o];
+      vi = L[o + 16];
     }
     out[((long)b * tot + e) * 2] = vr;
     out[((long)b * tot + e) * 2 + 1] = vi;
@@ -535,19 +571,23 @@ __global__ void k_unpack_x(const double* __restrict__ Xre, const double* __restr
 
 }  // namespace
 
-int hpx_launch_factor(int nbl, int npad, int ld, double* Lre, double* Lim, double* Wre,
-                      double* Wim, int32_t* info, int iter_tag, hipStream_t st) {
-  hipLaunchKernelGGL(k_factor, dim3(nbl), dim3(256), 0, st, Lre, Lim, Wre, Wim, info, npad, ld,
-                     iter_tag);
+int hpx_launch_factor(int nbl, int npad, int ld, double* L, double* Wre, double* Wim,
+                      int32_t* info, int iter_tag, const hpx_gen_batch* gen, hipStream_t st) {
+  if (gen) {
+    hipLaunchKernelGGL(k_factor<true>, dim3(nbl), dim3(256), 0, st, L, Wre, Wim, info, npad, ld,
+                       iter_tag, *gen);
+  } else {
+    hpx_gen_batch none = {};
+    hipLaunchKernelGGL(k_factor<false>, dim3(nbl), dim3(256), 0, st, L, Wre, Wim, info, npad, ld,
+                       iter_tag, none);
+  }
   HPX_HIP(hipGetLastError());
   return HPX_OK;
 }
 
-int hpx_launch_backsolve(int nbl, int npad, int TP, int ld, const double* Lre, const double* Lim,
-                         const double* Wre, const double* Wim, double* Xre, double* Xim,
-                         hipStream_t st) {
-  hipLaunchKernelGGL(k_backsolve, dim3(nbl), dim3(256), 0, st, Lre, Lim, Wre, Wim, Xre, Xim, npad,
-                     TP, ld);
+int hpx_launch_backsolve(int nbl, int npad, int TP, int ld, const double* L, const double* Wre,
+                         const double* Wim, double* Xre, double* Xim, hipStream_t st) {
+  hipLaunchKernelGGL(k_backsolve, dim3(nbl), dim3(256), 0, st, L, Wre, Wim, Xre, Xim, npad, TP, ld);
   HPX_HIP(hipGetLastError());
   return HPX_OK;
 }
@@ -555,10 +595,9 @@ int hpx_launch_backsolve(int nbl, int npad, int TP, int ld, const double* Lre, c
 // ---- stand-alone C-ABI entry points (tests, other callers) -----------------
 namespace {
 struct Scratch {
-  double *Lre = nullptr, *Lim = nullptr, *Wre = nullptr, *Wim = nullptr, *Xre = nullptr,
-         *Xim = nullptr;
+  double *L = nullptr, *Wre = nullptr, *Wim = nullptr, *Xre = nullptr, *Xim = nullptr;
   ~Scratch() {
-    (void)hipFree(Lre); (void)hipFree(Lim); (void)hipFree(Wre); (void)hipFree(Wim); (void)hipFree(Xre); (void)hipFree(Xim);
+    (void)hipFree(L); (void)hipFree(Wre); (void)hipFree(Wim); (void)hipFree(Xre); (void)hipFree(Xim);
   }
 };
 }  // namespace
@@ -570,18 +609,15 @@ static int potr_common(int nb, int n, int nrhs, const double* a, const double* r
   const int nblk = (npad + HPX_NB - 1) / HPX_NB;
   Scratch s;
   const size_t lbytes = (size_t)nb * npad * ld * sizeof(double);
-  HPX_HIP(hipMalloc(&s.Lre, lbytes));
-  HPX_HIP(hipMalloc(&s.Lim, lbytes));
+  HPX_HIP(hipMalloc(&s.L, 2 * lbytes));
   HPX_HIP(hipMalloc(&s.Wre, (size_t)nb * nblk * 1024 * sizeof(double)));
   HPX_HIP(hipMalloc(&s.Wim, (size_t)nb * nblk * 1024 * sizeof(double)));
   if (info) HPX_HIP(hipMemsetAsync(info, 0, (size_t)nb * sizeof(int32_t), st));
-  hipLaunchKernelGGL(k_pack_herm, dim3(64, nb), dim3(256), 0, st, a, rhs, s.Lre, s.Lim, n, nrhs,
-                     npad, ld);
+  hipLaunchKernelGGL(k_pack_herm, dim3(64, nb), dim3(256), 0, st, a, rhs, s.L, n, nrhs, npad, ld);
   HPX_HIP(hipGetLastError());
-  HPX_TRY(hpx_launch_factor(nb, npad, ld, s.Lre, s.Lim, s.Wre, s.Wim, info, 1, st));
+  HPX_TRY(hpx_launch_factor(nb, npad, ld, s.L, s.Wre, s.Wim, info, 1, nullptr, st));
   if (l_out) {
-    hipLaunchKernelGGL(k_unpack_lower, dim3(64, nb), dim3(256), 0, st, s.Lre, s.Lim, l_out, n,
-                       npad, ld);
+    hipLaunchKernelGGL(k_unpack_lower, dim3(64, nb), dim3(256), 0, st, s.L, l_out, n, npad, ld);
     HPX_HIP(hipGetLastError());
   }
   if (x_out) {
@@ -590,7 +626,7 @@ static int potr_common(int nb, int n, int nrhs, const double* a, const double* r
     HPX_HIP(hipMalloc(&s.Xim, xbytes));
     HPX_HIP(hipMemsetAsync(s.Xre, 0, xbytes, st));
     HPX_HIP(hipMemsetAsync(s.Xim, 0, xbytes, st));
-    HPX_TRY(hpx_launch_backsolve(nb, npad, TP, ld, s.Lre, s.Lim, s.Wre, s.Wim, s.Xre, s.Xim, st));
+    HPX_TRY(hpx_launch_backsolve(nb, npad, TP, ld, s.L, s.Wre, s.Wim, s.Xre, s.Xim, st));
     hipLaunchKernelGGL(k_unpack_x, dim3(64, nb), dim3(256), 0, st, s.Xre, s.Xim, x_out, n, nrhs,
                        npad, TP);
     HPX_HIP(hipGetLastError());

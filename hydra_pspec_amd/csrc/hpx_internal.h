@@ -36,6 +36,8 @@ __device__ __forceinline__ d4 mfma64(double a, double b, d4 c) {
   return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
 }
 
+// Factor storage: 16-row panels, each a contiguous [npad columns][re 16 | im 16] strip.
+#define HPX_LIDX(r, c, npad) ((((long)((r) >> 4) * (npad) + (c)) << 5) + ((r) & 15))
 #define HPX_NB 32          // block-column width of the factorisation
 #define HPX_WLD 34         // LDS leading dimension (doubles) of 32x32 blocks
 
@@ -54,7 +56,7 @@ struct hpx_plan {
   int fg_shared, prior_shared, has_omega, any_flags, have_static, profiling;
   int64_t bytes;
   // factor / solution
-  double *Lre, *Lim;       // [nbl][npad][ld] column-major planar
+  double *L;               // [nbl][ld/16 panels][npad][re16|im16]  (HPX_LIDX)
   double *Wre, *Wim;       // [nbl][nblk][32][32] inverse diagonal blocks
   double *Xre, *Xim;       // [nbl][npad][TP] solution [y' ; f]
   int32_t *info;           // [nbl]
@@ -89,12 +91,87 @@ struct hpx_plan {
   std::vector<void*> allocs;
 };
 
+// ---- K'_aug generator ---------------------------------------------------------
+// Entry (r, c), r >= c, of the augmented system of one baseline:
+//   r, c < N        : delta_rc + a_r a_c circ[r-c]            (I + D^1/2 C D^1/2)
+//   N <= r < N+M    : conj(G[c][m]) a_c  /  H[r-N][c-N]        (G^H D^1/2, H)
+//   N+M <= r < npad : identity padding
+//   r >= npad       : conj of right-hand side t = r - npad     (a_c Q[c][t] + P2[c][t] ; P4[c-N][t])
+// Pointers are per baseline (already offset), except P2 (shared).
+struct hpx_gen {
+  const double *a, *cre, *cim, *rre, *rim, *p2re, *p2im, *hre, *him, *p4re, *p4im;
+  int N, M, TP, ncol, has_omega;
+};
+__device__ __forceinline__ void hpx_gen_entry(const hpx_gen& G, const int r, const int c,
+                                              const int npad, double& vr, double& vi) {
+  vr = 0.0;
+  vi = 0.0;
+  const int N = G.N, M = G.M;
+  if (r < c) return;
+  if (c < N) {
+    const double ac = G.a[c];
+    if (r < N) {
+      const double s = G.a[r] * ac;
+      vr = s * G.cre[r - c] + (r == c ? 1.0 : 0.0);
+      vi = (r == c) ? 0.0 : s * G.cim[r - c];
+    } else if (r < N + M) {
+      const long o = (long)c * G.ncol + G.TP + (r - N);
+      vr = G.rre[o] * ac;
+      vi = -G.rim[o] * ac;
+    } else if (r >= npad) {
+      const int t = r - npad;
+      const long o = (long)c * G.ncol + t;
+      vr = ac * G.rre[o];
+      vi = ac * G.rim[o];
+      if (G.has_omega) {
+        vr += G.p2re[(long)c * G.TP + t];
+        vi += G.p2im[(long)c * G.TP + t];
+      }
+      vi = -vi;
+    }
+  } else if (c < N + M) {
+    const int mc = c - N;
+    if (r < N + M) {
+      vr = G.hre[(long)(r - N) * M + mc];
+      vi = (r == c) ? 0.0 : G.him[(long)(r - N) * M + mc];
+    } else if (r >= npad) {
+      const int t = r - npad;
+      vr = G.p4re[(long)mc * G.TP + t];
+      vi = -G.p4im[(long)mc * G.TP + t];
+    }
+  } else if (r == c) {
+    vr = 1.0;
+  }
+}
+// batch-level description: per-baseline strides are implied by the plan dimensions
+struct hpx_gen_batch {
+  const double *a, *cre, *cim, *rre, *rim, *p2re, *p2im, *hre, *him, *p4re, *p4im;
+  int N, M, NP, TP, ncol, has_omega;
+};
+__device__ __forceinline__ hpx_gen hpx_gen_for(const hpx_gen_batch& B, const int b) {
+  hpx_gen G;
+  G.a = B.a + (long)b * B.N;
+  G.cre = B.cre + (long)b * B.N;
+  G.cim = B.cim + (long)b * B.N;
+  G.rre = B.rre + (long)b * B.NP * B.ncol;
+  G.rim = B.rim + (long)b * B.NP * B.ncol;
+  G.p2re = B.p2re;
+  G.p2im = B.p2im;
+  G.hre = B.hre + (long)b * B.M * B.M;
+  G.him = B.him + (long)b * B.M * B.M;
+  G.p4re = B.p4re + (long)b * B.M * B.TP;
+  G.p4im = B.p4im + (long)b * B.M * B.TP;
+  G.N = B.N; G.M = B.M; G.TP = B.TP; G.ncol = B.ncol; G.has_omega = B.has_omega;
+  return G;
+}
+
 // ---- launchers (each returns HPX_OK / HPX_EHIP) -----------------------------
-int hpx_launch_factor(int nbl, int npad, int ld, double* Lre, double* Lim, double* Wre,
-                      double* Wim, int32_t* info, int iter_tag, hipStream_t st);
-int hpx_launch_backsolve(int nbl, int npad, int TP, int ld, const double* Lre,
-                         const double* Lim, const double* Wre, const double* Wim,
-                         double* Xre, double* Xim, hipStream_t st);
+// gen == nullptr: factor the matrix stored in L in place; otherwise K'_aug is generated on the
+// fly from *gen and L is write-only.
+int hpx_launch_factor(int nbl, int npad, int ld, double* L, double* Wre, double* Wim,
+                      int32_t* info, int iter_tag, const hpx_gen_batch* gen, hipStream_t st);
+int hpx_launch_backsolve(int nbl, int npad, int TP, int ld, const double* L, const double* Wre,
+                         const double* Wim, double* Xre, double* Xim, hipStream_t st);
 // out[b][x][c] = scale * sum_k W[x][k] in[b][k][c] (W = fop or conj(fop)), optional
 // row scaling of the input by rs[b][k]; ncol multiple of 16; matrices [NP][NP].
 int hpx_launch_dft(int nbl, int NP, int ncol, const double* Wre, const double* Wim,
