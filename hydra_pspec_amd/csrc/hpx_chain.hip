@@ -246,9 +246,13 @@ struct ResArgs {
 };
 
 __global__ __launch_bounds__(256) void k_resid(const ResArgs A) {
+  extern __shared__ double rl[];      // f_re[M][TP], f_im[M][TP], part[N][TP/16]
   __shared__ double red[4];
   const int b = blockIdx.x, tid = threadIdx.x;
-  const int N = A.N, M = A.M, T = A.T, TP = A.TP;
+  const int N = A.N, M = A.M, T = A.T, TP = A.TP, TG = TP >> 4;
+  double* lfr = rl;
+  double* lfi = rl + (long)M * TP;
+  double* part = rl + 2L * M * TP;
   const double* xre = A.Xre + (long)b * A.npad * TP;
   const double* xim = A.Xim + (long)b * A.npad * TP;
   const double* sre = A.Sre + (long)b * A.NP * TP;
@@ -257,56 +261,76 @@ __global__ __launch_bounds__(256) void k_resid(const ResArgs A) {
   const double* dim_ = A.Dim + (long)b * A.NP * TP;
   const double* fre = A.Fre + (A.fg_shared ? 0 : (long)b * N * M);
   const double* fim = A.Fim + (A.fg_shared ? 0 : (long)b * N * M);
-  // beta_k = N a_k^2 sum_t |y'_kt|^2   ( |F s|^2 with s = U D^1/2 y' )
-  for (int k = tid; k < N; k += 256) {
-    double s = 0.0;
-    for (int t = 0; t < T; ++t) {
-      const double yr = xre[(long)k * TP + t], yi = xim[(long)k * TP + t];
-      s += yr * yr + yi * yi;
-    }
-    const double ak = A.a[(long)b * N + k];
-    A.beta[(long)b * N + k] = (double)N * (ak * ak) * s;
+  const double* ninv = A.ninv + (long)b * N;
+  const uint8_t* fl = A.flags + (long)b * N;
+  for (int e = tid; e < M * TP; e += 256) {          // foreground amplitudes f[m][t]
+    lfr[e] = xre[(long)N * TP + e];
+    lfi[e] = xim[(long)N * TP + e];
   }
+  __syncthreads();
   double acc = 0.0;
-  for (int e = tid; e < N * TP; e += 256) {
-    const int x = e / TP, t = e % TP;
+  const int tot = N * TP;                            // multiple of 16; threads of a 16-lane group
+  for (int e0 = 0; e0 < tot; e0 += 256) {            // share x, so the shuffles stay in range
+    const int e = e0 + tid;
+    const bool in = e < tot;
+    const int x = in ? e / TP : 0, t = in ? e % TP : 0;
+    const long o = (long)x * TP + t;
+    // beta partial: |y'_xt|^2 summed over 16 consecutive times
+    double v = 0.0;
+    if (in) {
+      const double yr = xre[o], yi = xim[o];
+      v = yr * yr + yi * yi;
+    }
+    v += __shfl_xor(v, 8, 16);
+    v += __shfl_xor(v, 4, 16);
+    v += __shfl_xor(v, 2, 16);
+    v += __shfl_xor(v, 1, 16);
+    if (in && (t & 15) == 0) part[x * TG + (t >> 4)] = v;
+    if (!in) continue;
     if (t >= T) {
-      if (A.any_flags) { A.Gre[((long)b * A.NP + x) * TP + t] = 0.0; A.Gim[((long)b * A.NP + x) * TP + t] = 0.0; }
+      if (A.any_flags) { A.Gre[(long)b * A.NP * TP + o] = 0.0; A.Gim[(long)b * A.NP * TP + o] = 0.0; }
       continue;
     }
-    const double sr = sre[(long)x * TP + t], si = sim[(long)x * TP + t];
+    const double sr = sre[o], si = sim[o];
     double mr = sr, mi = si;
     for (int m = 0; m < M; ++m) {
       const double fr = fre[(long)x * M + m], fi = fim[(long)x * M + m];
-      const double gr = xre[(long)(N + m) * TP + t], gi = xim[(long)(N + m) * TP + t];
+      const double gr = lfr[m * TP + t], gi = lfi[m * TP + t];
       mr += gr * fr - gi * fi;
       mi += gr * fi + gi * fr;
     }
-    const double rr = dre[(long)x * TP + t] - mr, ri = dim_[(long)x * TP + t] - mi;
-    const double w = A.flags[(long)b * N + x] ? 1.0 : 0.0;
-    const double c2 = (rr * rr + ri * ri) * A.ninv[(long)b * N + x];
+    const double rr = dre[o] - mr, ri = dim_[o] - mi;
+    const double w = fl[x] ? 1.0 : 0.0;
+    const double c2 = (rr * rr + ri * ri) * ninv[x];
     acc += w * c2;
     if (A.any_flags) {
-      A.Gre[((long)b * A.NP + x) * TP + t] = w * sr;
-      A.Gim[((long)b * A.NP + x) * TP + t] = w * si;
+      A.Gre[(long)b * A.NP * TP + o] = w * sr;
+      A.Gim[(long)b * A.NP * TP + o] = w * si;
     }
     if (A.cr_out) {
-      double* o = A.cr_out + (long)b * A.cr_bstride + ((long)t * N + x) * 2;
-      o[0] = sr;
-      o[1] = si;
+      double* q = A.cr_out + (long)b * A.cr_bstride + ((long)t * N + x) * 2;
+      q[0] = sr;
+      q[1] = si;
     }
     if (A.chisq_out) A.chisq_out[(long)b * A.chisq_bstride + (long)t * N + x] = c2;
   }
   if (A.fg_out) {
     for (int e = tid; e < T * M; e += 256) {
       const int t = e / M, m = e % M;
-      double* o = A.fg_out + (long)b * A.fg_bstride + (long)e * 2;
-      o[0] = xre[(long)(N + m) * TP + t];
-      o[1] = xim[(long)(N + m) * TP + t];
+      double* q = A.fg_out + (long)b * A.fg_bstride + (long)e * 2;
+      q[0] = lfr[m * TP + t];
+      q[1] = lfi[m * TP + t];
     }
   }
-  const double tot = block_sum(acc, red);
-  if (tid == 0) A.lnp1[b] = -tot;
+  const double total = block_sum(acc, red);          // (barrier inside: part[] is complete)
+  if (tid == 0) A.lnp1[b] = -total;
+  // beta_k = N a_k^2 sum_t |y'_kt|^2   ( |F s|^2 with s = U D^1/2 y' )
+  for (int k = tid; k < N; k += 256) {
+    double sum = 0.0;
+    for (int j = 0; j < TG; ++j) sum += part[k * TG + j];
+    const double ak = A.a[(long)b * N + k];
+    A.beta[(long)b * N + k] = (double)N * (ak * ak) * sum;
+  }
 }
 
 // betam_k = sum_t |SK[k][t]|^2 (SK = F (w s), in the Z scratch with leading dim ncol)
@@ -580,7 +604,7 @@ extern "C" int hpx_plan_set_static(hpx_plan* p, const double* vis, const uint8_t
   // R = U^H Z = F Z / sqrt(N)
   HPX_TRY(hpx_launch_dft(nbl, NP, p->ncolR, p->Fopre, p->Fopim, 0, p->Zre, p->Zim,
                          (long)NP * p->ncolR, p->ncolR, nullptr, 0, p->Rre, p->Rim,
-                         (long)NP * p->ncolR, p->ncolR, isn, st));
+                         (long)NP * p->ncolR, p->ncolR, isn, st, N == NP));
   hipLaunchKernelGGL(k_circ, dim3(4, nbl), dim3(256), 0, st, p->Rre, p->Rim, p->Cre, p->Cim, N, NP,
                      p->ncolR, TP + MP);
   HPX_HIP(hipGetLastError());
@@ -593,7 +617,7 @@ extern "C" int hpx_plan_set_static(hpx_plan* p, const double* vis, const uint8_t
     hipLaunchKernelGGL(k_prep_omega, dim3(64), dim3(256), 0, st, omega, p->Gre, p->Gim, T, N, NP, TP);
     HPX_HIP(hipGetLastError());
     HPX_TRY(hpx_launch_dft(1, NP, TP, p->Fopre, p->Fopim, 0, p->Gre, p->Gim, 0, TP, nullptr, 0,
-                           p->P2re, p->P2im, 0, TP, isn, st));
+                           p->P2re, p->P2im, 0, TP, isn, st, N == NP));
   } else {
     HPX_HIP(hipMemsetAsync(p->P2re, 0, (size_t)NP * TP * sizeof(double), st));
     HPX_HIP(hipMemsetAsync(p->P2im, 0, (size_t)NP * TP * sizeof(double), st));
@@ -706,7 +730,7 @@ extern "C" int hpx_gibbs_run(hpx_plan* p, const double* ps0, int iter0, int nite
     HPX_TRY(mark(p, st));
     // s = U D^1/2 y' = conj(F) (a . y') / sqrt(N)
     HPX_TRY(hpx_launch_dft(nbl, NP, TP, p->Fopre, p->Fopim, 1, p->Xre, p->Xim, (long)p->npad * TP,
-                           TP, p->a, N, p->Sre, p->Sim, (long)NP * TP, TP, isn, st));
+                           TP, p->a, N, p->Sre, p->Sim, (long)NP * TP, TP, isn, st, N == NP));
     HPX_TRY(mark(p, st));
     ResArgs R;
     R.Xre = p->Xre; R.Xim = p->Xim; R.Sre = p->Sre; R.Sim = p->Sim; R.Dre = p->Dre; R.Dim = p->Dim;
@@ -722,11 +746,13 @@ extern "C" int hpx_gibbs_run(hpx_plan* p, const double* ps0, int iter0, int nite
     R.chisq_out = (chisq_out && keep) ? chisq_out + slot * T * N : nullptr;
     R.N = N; R.M = M; R.T = T; R.NP = NP; R.TP = TP; R.npad = p->npad;
     R.fg_shared = p->fg_shared; R.any_flags = p->any_flags;
-    hipLaunchKernelGGL(k_resid, dim3(nbl), dim3(256), 0, st, R);
+    hipLaunchKernelGGL(k_resid, dim3(nbl), dim3(256),
+                       (size_t)(2 * M * TP + N * (TP / 16)) * sizeof(double), st, R);
     HPX_HIP(hipGetLastError());
     if (p->any_flags) {   // |F (w s)|^2 for the masked S^-1 quadratic form (pspec.py:479-483)
       HPX_TRY(hpx_launch_dft(nbl, NP, TP, p->Fopre, p->Fopim, 0, p->Gre, p->Gim, (long)NP * TP, TP,
-                             nullptr, 0, p->Zre, p->Zim, (long)NP * p->ncolR, p->ncolR, 1.0, st));
+                             nullptr, 0, p->Zre, p->Zim, (long)NP * p->ncolR, p->ncolR, 1.0, st,
+                             N == NP));
       hipLaunchKernelGGL(k_betam, dim3(4, nbl), dim3(256), 0, st, p->Zre, p->Zim, p->betam, N, T,
                          NP, p->ncolR);
       HPX_HIP(hipGetLastError());

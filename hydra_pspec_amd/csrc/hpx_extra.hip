@@ -317,7 +317,7 @@ extern "C" int hpx_dpss_project(int nb, int N, int nm, const double* d, const do
                      ncol);
   // out = Ah * in: the stored planar matrix is Ah^T = conj(Ah), hence conjW = 1
   int rc = hpx_launch_dft(nb, NP, ncol, wre, wim, 1, ire, iim, (long)NP * ncol, ncol, nullptr, 0,
-                          ore, oim, (long)NP * ncol, ncol, 1.0, st);
+                          ore, oim, (long)NP * ncol, ncol, 1.0, st, 0);
   if (rc == HPX_OK) {
     hipLaunchKernelGGL(k_dpss_solve, dim3(nb), dim3(256), 0, st, tw, modes, ore, oim, amps, N, nm,
                        NP, ncol);

@@ -177,5 +177,6 @@ int hpx_launch_backsolve(int nbl, int npad, int TP, int ld, const double* L, con
 int hpx_launch_dft(int nbl, int NP, int ncol, const double* Wre, const double* Wim,
                    int conjW, const double* inre, const double* inim, long in_bstride,
                    int in_ld, const double* rs, int rs_n, double* outre, double* outim,
-                   long out_bstride, int out_ld, double scale, hipStream_t st);
+                   long out_bstride, int out_ld, double scale, hipStream_t st, int fft_ok = 1);
+extern int hpx_dft_use_fft;
 int hpx_fop_to_planar(const double* fop, double* re, double* im, int N, int NP, hipStream_t st);

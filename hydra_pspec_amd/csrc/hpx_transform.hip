@@ -78,6 +78,73 @@ __global__ __launch_bounds__(256, 2) void k_dft(const double* __restrict__ Wre,
                 lane);
 }
 
+// Power-of-two N: in-place radix-2 decimation-in-frequency FFT in LDS, TC columns per
+// workgroup (columns = time samples, contiguous in memory).  The centred transform is the
+// plain one with sign flips on both sides (N % 4 == 0):
+//   (F v)[k] = (-1)^k sum_x (-1)^x v[x] e^{-2 pi i k x / N},   F^H likewise with e^{+...}.
+// Twiddles e^{-2 pi i j / N} are row N/2+1 of the operator itself (numpy's exp on the host).
+template <int SIGN>
+__global__ __launch_bounds__(256) void k_fft(const double* __restrict__ Wre,
+                                             const double* __restrict__ Wim,
+                                             const double* __restrict__ inre,
+                                             const double* __restrict__ inim,
+                                             const long in_bstride, const int in_ld,
+                                             const double* __restrict__ rs, const int rs_n,
+                                             double* __restrict__ outre,
+                                             double* __restrict__ outim, const long out_bstride,
+                                             const int out_ld, const int N, const int logN,
+                                             const int ncol, const int TC, const double scale) {
+  extern __shared__ double fl[];
+  double* fre = fl;
+  double* fim = fl + (long)N * TC;
+  const int b = blockIdx.y, c0 = blockIdx.x * TC, tid = threadIdx.x;
+  const double* ir = inre + (long)b * in_bstride;
+  const double* ii = inim + (long)b * in_bstride;
+  const double* rsb = rs ? rs + (long)b * rs_n : nullptr;
+  const int h = N >> 1;
+  for (int e = tid; e < N * TC; e += 256) {
+    const int k = e / TC, tc = e % TC;
+    double vr = 0.0, vi = 0.0;
+    if (c0 + tc < ncol) {
+      double sc = (k & 1) ? -1.0 : 1.0;
+      if (rsb) sc = (k < rs_n) ? sc * rsb[k] : 0.0;
+      vr = ir[(long)k * in_ld + c0 + tc] * sc;
+      vi = ii[(long)k * in_ld + c0 + tc] * sc;
+    }
+    fre[e] = vr;
+    fim[e] = vi;
+  }
+  const double* twr = Wre + (long)(h + 1) * N + h;   // cos(2 pi j / N)
+  const double* twi = Wim + (long)(h + 1) * N + h;   // -sin(2 pi j / N)
+  for (int s = 0; s < logN; ++s) {
+    const int half = N >> (s + 1);
+    __syncthreads();
+    for (int idx = tid; idx < h * TC; idx += 256) {
+      const int tc = idx % TC, bf = idx / TC;
+      const int j = bf & (half - 1), blk = bf >> (logN - 1 - s);
+      const int i0 = (blk * 2 * half + j) * TC + tc, i1 = i0 + half * TC;
+      const double ar = fre[i0], ai = fim[i0], br = fre[i1], bi = fim[i1];
+      const double dr = ar - br, di = ai - bi;
+      const double wr = twr[j << s], wi = (SIGN > 0 ? -1.0 : 1.0) * twi[j << s];
+      fre[i0] = ar + br;
+      fim[i0] = ai + bi;
+      fre[i1] = dr * wr - di * wi;
+      fim[i1] = dr * wi + di * wr;
+    }
+  }
+  __syncthreads();
+  double* orr = outre + (long)b * out_bstride;
+  double* oi = outim + (long)b * out_bstride;
+  for (int e = tid; e < N * TC; e += 256) {
+    const int pidx = e / TC, tc = e % TC;
+    if (c0 + tc >= ncol) continue;
+    const int x = (int)(__brev((unsigned)pidx) >> (32 - logN));
+    const double sc = (x & 1) ? -scale : scale;
+    orr[(long)x * out_ld + c0 + tc] = fre[e] * sc;
+    oi[(long)x * out_ld + c0 + tc] = fim[e] * sc;
+  }
+}
+
 // interleaved (nb,T,N) c128  <->  planar [b][NP][TP] (channel major)
 __global__ void k_tn_to_planar(const double* __restrict__ in, double* __restrict__ ore,
                                double* __restrict__ oim, const int T, const int N, const int NP,
@@ -131,13 +198,33 @@ __global__ void k_fop_planar(const double* __restrict__ fop, double* __restrict_
 
 }  // namespace
 
+// The FFT path needs W to be the centred Fourier operator of order NP exactly (no padding):
+// callers that pass another matrix (DPSS inverse covariance) set fft_ok = 0.
+int hpx_dft_use_fft = 1;
+
 int hpx_launch_dft(int nbl, int NP, int ncol, const double* Wre, const double* Wim, int conjW,
                    const double* inre, const double* inim, long in_bstride, int in_ld,
                    const double* rs, int rs_n, double* outre, double* outim, long out_bstride,
-                   int out_ld, double scale, hipStream_t st) {
+                   int out_ld, double scale, hipStream_t st, int fft_ok) {
   if ((NP & 15) || (ncol & 15)) {
     hpx_set_error("hpx_launch_dft: NP and ncol must be multiples of 16");
     return HPX_EINVAL;
+  }
+  if (hpx_dft_use_fft && NP >= 16 && NP <= 4096 && (NP & (NP - 1)) == 0 && fft_ok) {
+    int logN = 0;
+    while ((1 << logN) < NP) ++logN;
+    int TC = 4096 / NP;                 // 64 KiB of LDS per workgroup
+    if (TC > 16) TC = 16;
+    const size_t lds = (size_t)NP * TC * 2 * sizeof(double);
+    dim3 grid((ncol + TC - 1) / TC, nbl);
+    if (conjW)
+      hipLaunchKernelGGL(k_fft<1>, grid, dim3(256), lds, st, Wre, Wim, inre, inim, in_bstride, in_ld,
+                         rs, rs_n, outre, outim, out_bstride, out_ld, NP, logN, ncol, TC, scale);
+    else
+      hipLaunchKernelGGL(k_fft<-1>, grid, dim3(256), lds, st, Wre, Wim, inre, inim, in_bstride, in_ld,
+                         rs, rs_n, outre, outim, out_bstride, out_ld, NP, logN, ncol, TC, scale);
+    HPX_HIP(hipGetLastError());
+    return HPX_OK;
   }
   dim3 grid((NP / 16 + 3) / 4, nbl);
   hipLaunchKernelGGL(k_dft, grid, dim3(256), 0, st, Wre, Wim, conjW, inre, inim, in_bstride,
@@ -168,7 +255,7 @@ extern "C" int hpx_dft_batched(int nb, int T, int N, const double* fop, const do
   if (rc == HPX_OK) {
     hipLaunchKernelGGL(k_tn_to_planar, dim3(64, nb), dim3(256), 0, st, in, ire, iim, T, N, NP, TP);
     rc = hpx_launch_dft(nb, NP, TP, wre, wim, inverse ? 1 : 0, ire, iim, (long)NP * TP, TP, nullptr,
-                        0, ore, oim, (long)NP * TP, TP, inverse ? 1.0 / N : 1.0, st);
+                        0, ore, oim, (long)NP * TP, TP, inverse ? 1.0 / N : 1.0, st, N == NP);
   }
   if (rc == HPX_OK) {
     hipLaunchKernelGGL(k_planar_to_tn, dim3(64, nb), dim3(256), 0, st, ore, oim, out, T, N, NP, TP);
