@@ -26,6 +26,29 @@
 #ifndef HPX_DIAG
 #define HPX_DIAG 0
 #endif
+#ifndef HPX_OUTER64
+#define HPX_OUTER64 0
+#endif
+#ifndef HPX_RT3
+#define HPX_RT3 1
+#endif
+#ifndef HPX_STAGGER
+#define HPX_STAGGER 0
+#endif
+#ifndef HPX_BULK_RT2
+#define HPX_BULK_RT2 0
+#endif
+#ifndef HPX_WGS
+#define HPX_WGS 2          // workgroups per CU the kernel is built for (register / LDS budget)
+#endif
+// With the 64-wide outer blocks everything inlined into one function makes hipcc spill
+// hundreds of registers (it keeps hoisted addresses of every inlined copy alive); out-of-line
+// pieces get their own allocation at the price of a small stack frame per call.
+#if HPX_OUTER64
+#define HPX_INL __noinline__
+#else
+#define HPX_INL __forceinline__
+#endif
 #if HPX_DIAG & 1
 #define HPX_LD(base, off) (1e-3 * (double)((off) & 7))
 #else
@@ -42,9 +65,12 @@ namespace {
 constexpr int WLD = HPX_WLD;
 
 struct FactorShared {
-  double slab[2][3][2][4][64];   // K-split partial sums of the diagonal tiles (24 KB)
+  double slab[3][2][4][64];      // K-split partial sums of the diagonal tiles (12 KB)
   double Dre[32 * WLD], Dim[32 * WLD];   // diagonal block (lower), row-major [r][c]
   double Yre[32 * WLD], Yim[32 * WLD];   // running inverse; finally W = conj(Ljj^-1)
+#if HPX_OUTER64
+  double Y2re[32 * WLD], Y2im[32 * WLD]; // same for the second panel of a 64-wide outer block
+#endif
 };
 
 // RT off-diagonal 16-row tiles (rows r0 + i*rstride) of block column (c0, CT*16 wide),
@@ -52,7 +78,7 @@ struct FactorShared {
 // for all of them (the panel rows are the re-read-heavy operand: without this reuse every
 // tile streams the whole 32 x c0 panel again and the kernel becomes HBM/L2 bound).
 template <int CT, int RT, bool GEN>
-__device__ __forceinline__ void offdiag_group(double* __restrict__ Lre, double* __restrict__ Lim,
+__device__ HPX_INL void offdiag_group(double* __restrict__ Lre, double* __restrict__ Lim,
                                               const int npad, const int c0, const int r0,
                                               const int rstride, const double* Wre,
                                               const double* Wim, const int lane,
@@ -118,7 +144,11 @@ __device__ __forceinline__ void offdiag_group(double* __restrict__ Lre, double* 
       const double* qre = pre + KC * kstep;
       const double* qim = pim + KC * kstep;
       HPX_LOAD_CHUNK(b1r, b1i, p1r, p1i, qre, qim)        // chunk ch+1 always exists (nch even)
+      // sched_barrier: without it hipcc hoists the second group of loads up here as well and
+      // then waits for loads issued in the SAME iteration (no prefetch distance left).
+      __builtin_amdgcn_sched_barrier(0);
       HPX_MMA_CHUNK(b0r, b0i, p0r, p0i)
+      __builtin_amdgcn_sched_barrier(0);
       // Branch-free prefetch of chunk ch+2: on the last pair the current chunk is simply
       // fetched again (in bounds, unused).  A conditional here gives the consuming block two
       // predecessors and hipcc then waits with vmcnt(0), draining the prefetch as well.
@@ -126,7 +156,9 @@ __device__ __forceinline__ void offdiag_group(double* __restrict__ Lre, double* 
       pre += adv;
       pim += adv;
       HPX_LOAD_CHUNK(b0r, b0i, p0r, p0i, pre, pim)
+      __builtin_amdgcn_sched_barrier(0);
       HPX_MMA_CHUNK(b1r, b1i, p1r, p1i)
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
 #undef HPX_LOAD_CHUNK
@@ -208,8 +240,258 @@ __device__ __forceinline__ void diag_partial(const double* __restrict__ Lre,
   }
 }
 
+// Bulk tile of a 64-wide outer block (inner block columns j0 at c0 and j1 at c0+32, both
+// already factored: W0/W1 = conj(L00^-1), conj(L11^-1) in LDS, L10 = L[j1 rows][j0 cols] in
+// global memory).  One k sweep over k < c0 accumulates all 64 columns, so every element of
+// the row operand L[r][k] read from HBM feeds 64 columns instead of 32; then
+//   X0 = acc0 L00^-H ;  acc1 -= X0 L10^H ;  X1 = acc1 L11^-H      (all transposed, see above).
+template <int RT, bool GEN>
+__device__ HPX_INL void bulk64(double* __restrict__ Lre, double* __restrict__ Lim,
+                                       const int npad, const int c0, const int r0,
+                                       const int rstride, const double* W0re, const double* W0im,
+                                       const double* W1re, const double* W1im, const int lane,
+                                       const hpx_gen& G) {
+  const int li = lane & 15, g = lane >> 4;
+  d4 ar[RT][4], ai[RT][4];
+#pragma unroll
+  for (int t = 0; t < RT; ++t)
+#pragma unroll
+    for (int ci = 0; ci < 4; ++ci)
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const int r = r0 + t * rstride + li, c = c0 + 16 * ci + HPX_ACC_ROW(g, v);
+        if (GEN) {
+          double vr, vi;
+          hpx_gen_entry(G, r, c, npad, vr, vi);
+          ar[t][ci][v] = vr;
+          ai[t][ci][v] = vi;
+        } else {
+          const long off = HPX_LIDX(r, c, npad);
+          ar[t][ci][v] = Lre[off];
+          ai[t][ci][v] = Lim[off];
+        }
+      }
+  const int nch = c0 >> 2;                      // one k-step per chunk; c0 % 64 == 0 => even
+  const double* pre = Lre + (long)g * 32;
+  const double* pim = Lim + (long)g * 32;
+  const long kstep = 128;
+  const long ptile = (long)npad * 32;
+  const long boff = (long)(r0 >> 4) * ptile + li, bstr = (long)(rstride >> 4) * ptile;
+  const long aoff = (long)(c0 >> 4) * ptile + li;
+  double b0r[RT], b0i[RT], b1r[RT], b1i[RT];
+  double p0r[4], p0i[4], p1r[4], p1i[4];
+#define HPX_LOAD64(br_, bi_, pr_, pi_, base_re, base_im)                          \
+  _Pragma("unroll") for (int t = 0; t < RT; ++t) {                                \
+    br_[t] = HPX_LD((base_re), boff + t * bstr);                                  \
+    bi_[t] = HPX_LD((base_im), boff + t * bstr);                                  \
+  }                                                                               \
+  _Pragma("unroll") for (int ci = 0; ci < 4; ++ci) {                              \
+    pr_[ci] = HPX_LDA((base_re), aoff + ci * ptile);                              \
+    pi_[ci] = HPX_LDA((base_im), aoff + ci * ptile);                              \
+  }
+#define HPX_MMA64(br_, bi_, pr_, pi_)                                             \
+  _Pragma("unroll") for (int ci = 0; ci < 4; ++ci) {                              \
+    const double npr = -pr_[ci], npi = -pi_[ci];                                  \
+    _Pragma("unroll") for (int t = 0; t < RT; ++t) {                              \
+      ar[t][ci] = mfma64(npr, br_[t], ar[t][ci]);                                 \
+      ar[t][ci] = mfma64(npi, bi_[t], ar[t][ci]);                                 \
+      ai[t][ci] = mfma64(npr, bi_[t], ai[t][ci]);                                 \
+      ai[t][ci] = mfma64(pi_[ci], br_[t], ai[t][ci]);                             \
+    }                                                                             \
+  }
+  if (nch > 0) {
+    HPX_LOAD64(b0r, b0i, p0r, p0i, pre, pim)
+    for (int ch = 0; ch < nch; ch += 2) {
+      const double* qre = pre + kstep;
+      const double* qim = pim + kstep;
+      HPX_LOAD64(b1r, b1i, p1r, p1i, qre, qim)
+      __builtin_amdgcn_sched_barrier(0);
+      HPX_MMA64(b0r, b0i, p0r, p0i)
+      __builtin_amdgcn_sched_barrier(0);
+      const long adv = (ch + 2 < nch) ? 2 * kstep : 0;     // branch-free prefetch (see above)
+      pre += adv;
+      pim += adv;
+      HPX_LOAD64(b0r, b0i, p0r, p0i, pre, pim)
+      __builtin_amdgcn_sched_barrier(0);
+      HPX_MMA64(b1r, b1i, p1r, p1i)
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+#undef HPX_LOAD64
+#undef HPX_MMA64
+#pragma unroll
+  for (int t = 0; t < RT; ++t) {
+    // X0^T = W0 acc0^T   (columns j0)
+    d4 xr[2], xi[2];
+#pragma unroll
+    for (int ci = 0; ci < 2; ++ci) {
+      xr[ci] = (d4){0., 0., 0., 0.};
+      xi[ci] = (d4){0., 0., 0., 0.};
+#pragma unroll
+      for (int cj = 0; cj <= ci; ++cj)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          const int kq = 16 * cj + HPX_ACC_ROW(g, v);
+          const double wr = W0re[(16 * ci + li) * WLD + kq], wi = W0im[(16 * ci + li) * WLD + kq];
+          xr[ci] = mfma64(wr, ar[t][cj][v], xr[ci]);
+          xr[ci] = mfma64(-wi, ai[t][cj][v], xr[ci]);
+          xi[ci] = mfma64(wr, ai[t][cj][v], xi[ci]);
+          xi[ci] = mfma64(wi, ar[t][cj][v], xi[ci]);
+        }
+    }
+#pragma unroll
+    for (int ci = 0; ci < 2; ++ci)
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const long off = HPX_LIDX(r0 + t * rstride + li, c0 + 16 * ci + HPX_ACC_ROW(g, v), npad);
+        Lre[off] = xr[ci][v];
+        Lim[off] = xi[ci][v];
+      }
+    // acc1^T[c1][r] -= conj(L10[c1][c0']) X0^T[c0'][r]
+#pragma unroll
+    for (int ci = 0; ci < 2; ++ci)
+#pragma unroll
+      for (int cj = 0; cj < 2; ++cj)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          const long off = HPX_LIDX(c0 + 32 + 16 * ci + li, c0 + 16 * cj + HPX_ACC_ROW(g, v), npad);
+          const double pr = Lre[off], pi = Lim[off];
+          ar[t][2 + ci] = mfma64(-pr, xr[cj][v], ar[t][2 + ci]);
+          ar[t][2 + ci] = mfma64(-pi, xi[cj][v], ar[t][2 + ci]);
+          ai[t][2 + ci] = mfma64(-pr, xi[cj][v], ai[t][2 + ci]);
+          ai[t][2 + ci] = mfma64(pi, xr[cj][v], ai[t][2 + ci]);
+        }
+    // X1^T = W1 acc1^T   (columns j1)
+#pragma unroll
+    for (int ci = 0; ci < 2; ++ci) {
+      xr[ci] = (d4){0., 0., 0., 0.};
+      xi[ci] = (d4){0., 0., 0., 0.};
+#pragma unroll
+      for (int cj = 0; cj <= ci; ++cj)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          const int kq = 16 * cj + HPX_ACC_ROW(g, v);
+          const double wr = W1re[(16 * ci + li) * WLD + kq], wi = W1im[(16 * ci + li) * WLD + kq];
+          xr[ci] = mfma64(wr, ar[t][2 + cj][v], xr[ci]);
+          xr[ci] = mfma64(-wi, ai[t][2 + cj][v], xr[ci]);
+          xi[ci] = mfma64(wr, ai[t][2 + cj][v], xi[ci]);
+          xi[ci] = mfma64(wi, ar[t][2 + cj][v], xi[ci]);
+        }
+    }
+#pragma unroll
+    for (int ci = 0; ci < 2; ++ci)
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const long off = HPX_LIDX(r0 + t * rstride + li, c0 + 32 + 16 * ci + HPX_ACC_ROW(g, v), npad);
+        Lre[off] = xr[ci][v];
+        Lim[off] = xi[ci][v];
+      }
+  }
+}
+
+// Diagonal block at c0 (width wj = 16 or 32): D = K[j,j] - sum_{k<c0} L[j,k] L[j,k]^H
+// (K-split over the waves), then D = Ljj Ljj^H and Ljj^-1 by the fused in-LDS elimination.
+// On return (after the trailing barrier) Yre/Yim hold W = conj(Ljj^-1); Ljj and Ljj^-1 are
+// in global memory.
 template <bool GEN>
-__global__ __launch_bounds__(256, 2) void k_factor(double* __restrict__ L_all,
+__device__ HPX_INL bool diag_panel(double* __restrict__ Lre, double* __restrict__ Lim,
+                                           double* __restrict__ Wgre, double* __restrict__ Wgim,
+                                           FactorShared& sh, double* Yre, double* Yim,
+                                           const int npad, const int c0, const int wj,
+                                           const int tid, const hpx_gen& G) {
+  const int wave = tid >> 6, lane = tid & 63;
+  const int CT = wj >> 4;
+  bool bad = false;
+  d4 ar[3], ai[3];
+  if (CT == 2) diag_partial<2>(Lre, Lim, npad, c0, wave, lane, ar, ai);
+  else diag_partial<1>(Lre, Lim, npad, c0, wave, lane, ar, ai);
+  for (int e = tid; e < 32 * 32; e += 256) {     // identity for the running inverse
+    const int i = e >> 5, q = e & 31;
+    Yre[i * WLD + q] = (i == q) ? 1.0 : 0.0;
+    Yim[i * WLD + q] = 0.0;
+  }
+  // fixed-order reduction of the four waves' partial tiles through one LDS slab
+  for (int w = 3; w >= 0; --w) {
+    if (wave == w) {
+#pragma unroll
+      for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          if (w == 3) {
+            sh.slab[t][0][v][lane] = ar[t][v];
+            sh.slab[t][1][v][lane] = ai[t][v];
+          } else {
+            sh.slab[t][0][v][lane] += ar[t][v];
+            sh.slab[t][1][v][lane] += ai[t][v];
+          }
+        }
+    }
+    __syncthreads();
+  }
+  // combine: D[r][c] = K[r][c] + slab   (acc^T[c][r] layout in the slab)
+  for (int e = tid; e < 3 * 4 * 64; e += 256) {
+    const int t = e >> 8, v = (e >> 6) & 3, l = e & 63;
+    if (CT == 1 && t > 0) continue;
+    const int ci = (t == 2) ? 1 : 0, ri = (t == 0) ? 0 : 1;
+    const int c = 16 * ci + HPX_ACC_ROW(l >> 4, v), r = 16 * ri + (l & 15);
+    double kr, ki;
+    if (GEN) {
+      hpx_gen_entry(G, c0 + r, c0 + c, npad, kr, ki);
+    } else {
+      const long off = HPX_LIDX(c0 + r, c0 + c, npad);
+      kr = Lre[off];
+      ki = Lim[off];
+    }
+    sh.Dre[r * WLD + c] = kr + sh.slab[t][0][v][l];
+    sh.Dim[r * WLD + c] = ki + sh.slab[t][1][v][l];
+  }
+  // fused Cholesky + inverse of the wj x wj block (unscaled columns; column q of L is
+  // D[:,q]/sqrt(D[q][q]) and row i of L^-1 is Y[i,:]/sqrt(D[i][i]))
+  for (int k = 0; k < ((HPX_DIAG & 4) ? 0 : wj); ++k) {
+    __syncthreads();
+    const double dkk = sh.Dre[k * WLD + k];
+    if (!(dkk > 0.0)) bad = true;
+    const double rinv2 = 1.0 / dkk;
+    const int nel = (wj - k - 1) << 5;
+    for (int e = tid; e < nel; e += 256) {
+      const int i = k + 1 + (e >> 5), q = e & 31;
+      const double lr = sh.Dre[i * WLD + k] * rinv2, lim = sh.Dim[i * WLD + k] * rinv2;
+      if (q <= k) {
+        const double yr = Yre[k * WLD + q], yi = Yim[k * WLD + q];
+        Yre[i * WLD + q] -= lr * yr - lim * yi;
+        Yim[i * WLD + q] -= lr * yi + lim * yr;
+      } else if (q <= i) {
+        const double qr = sh.Dre[q * WLD + k], qi = sh.Dim[q * WLD + k];
+        sh.Dre[i * WLD + q] -= lr * qr + lim * qi;   // * conj(D[q][k])
+        sh.Dim[i * WLD + q] -= lim * qr - lr * qi;
+      }
+    }
+  }
+  __syncthreads();
+  // final scaling: L_jj to global, W = conj(Ljj^-1) to LDS, Ljj^-1 to the side buffer
+  for (int e = tid; e < 32 * 32; e += 256) {
+    const int i = e >> 5, q = e & 31;
+    double wr = 0.0, wi = 0.0;
+    if (i < wj && q <= i) {
+      const double sq = 1.0 / sqrt(sh.Dre[q * WLD + q]);
+      const long off = HPX_LIDX(c0 + i, c0 + q, npad);
+      Lre[off] = sh.Dre[i * WLD + q] * sq;
+      Lim[off] = (i == q) ? 0.0 : sh.Dim[i * WLD + q] * sq;
+      const double si = 1.0 / sqrt(sh.Dre[i * WLD + i]);
+      wr = Yre[i * WLD + q] * si;
+      wi = Yim[i * WLD + q] * si;
+    }
+    Wgre[e] = wr;
+    Wgim[e] = wi;
+    Yre[i * WLD + q] = wr;        // LDS copy is conjugated
+    Yim[i * WLD + q] = -wi;
+  }
+  __syncthreads();
+  return bad;
+}
+
+template <bool GEN>
+__global__ __launch_bounds__(256, HPX_WGS) void k_factor(double* __restrict__ L_all,
                                                    double* __restrict__ Wre_all,
                                                    double* __restrict__ Wim_all,
                                                    int32_t* __restrict__ info, const int npad,
@@ -220,7 +502,6 @@ __global__ __launch_bounds__(256, 2) void k_factor(double* __restrict__ L_all,
   hpx_gen G;
   if (GEN) G = hpx_gen_for(GB, b);
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const int li = lane & 15, g = lane >> 4;
   double* Lre = L_all + (long)b * npad * ld * 2;
   double* Lim = Lre + 16;
   const int nblk = (npad + HPX_NB - 1) / HPX_NB;
@@ -228,124 +509,54 @@ __global__ __launch_bounds__(256, 2) void k_factor(double* __restrict__ L_all,
   double* Wgim = Wim_all + (long)b * nblk * 1024;
   const int nrt = ld >> 4;
   bool bad = false;
-#if HPX_STAGGER
-  // Two workgroups share a CU and run the same program: started together they reach their
-  // MFMA-free phases (in-LDS Cholesky) together.  Delay every second one (speed only).
-  if ((blockIdx.x >> 8) & 1)
-    for (int i = 0; i < HPX_STAGGER; ++i) __builtin_amdgcn_s_sleep(127);
-#endif
 
-  for (int jb = 0; jb < nblk; ++jb) {
-    const int c0 = jb * HPX_NB;
+  int c0 = 0;
+#if HPX_OUTER64
+  // ---- 64-wide outer blocks: two 32-wide panels, then one bulk sweep for both
+  for (; npad - c0 >= 64; c0 += 64) {
+    const int jb = c0 >> 5;
+    bad |= diag_panel<GEN>(Lre, Lim, Wgre + jb * 1024, Wgim + jb * 1024, sh, sh.Yre, sh.Yim, npad,
+                           c0, 32, tid, G);
+    // rows of the second panel against the columns of the first: L10 (two 16-row tiles)
+    if (wave < 2)
+      offdiag_group<2, 1, GEN>(Lre, Lim, npad, c0, c0 + 32 + 16 * wave, 64, sh.Yre, sh.Yim, lane, G);
+    __syncthreads();
+    bad |= diag_panel<GEN>(Lre, Lim, Wgre + (jb + 1) * 1024, Wgim + (jb + 1) * 1024, sh, sh.Y2re,
+                           sh.Y2im, npad, c0 + 32, 32, tid, G);
+    int rt = ((c0 + 64) >> 4) + wave;
+#if HPX_BULK_RT2
+    for (; rt + 4 < nrt; rt += 8)
+      bulk64<2, GEN>(Lre, Lim, npad, c0, rt << 4, 64, sh.Yre, sh.Yim, sh.Y2re, sh.Y2im, lane, G);
+#endif
+    for (; rt < nrt; rt += 4)
+      bulk64<1, GEN>(Lre, Lim, npad, c0, rt << 4, 64, sh.Yre, sh.Yim, sh.Y2re, sh.Y2im, lane, G);
+    __syncthreads();
+  }
+#endif
+  // ---- remaining (or all) 32-wide block columns
+  while (c0 < npad) {
     const int wj = min(HPX_NB, npad - c0);
-    const int CT = wj >> 4;
-    // ---- 1. diagonal block: partial sums over this wave's share of k
-    d4 ar[3], ai[3];
-    if (CT == 2) diag_partial<2>(Lre, Lim, npad, c0, wave, lane, ar, ai);
-    else diag_partial<1>(Lre, Lim, npad, c0, wave, lane, ar, ai);
-    if (wave >= 2) {
-#pragma unroll
-      for (int t = 0; t < 3; ++t)
-#pragma unroll
-        for (int v = 0; v < 4; ++v) {
-          sh.slab[wave - 2][t][0][v][lane] = ar[t][v];
-          sh.slab[wave - 2][t][1][v][lane] = ai[t][v];
-        }
-    }
-    __syncthreads();
-    if (wave < 2) {
-#pragma unroll
-      for (int t = 0; t < 3; ++t)
-#pragma unroll
-        for (int v = 0; v < 4; ++v) {
-          sh.slab[wave][t][0][v][lane] += ar[t][v];
-          sh.slab[wave][t][1][v][lane] += ai[t][v];
-        }
-    }
-    // identity for the running inverse
-    for (int e = tid; e < 32 * 32; e += 256) {
-      const int i = e >> 5, q = e & 31;
-      sh.Yre[i * WLD + q] = (i == q) ? 1.0 : 0.0;
-      sh.Yim[i * WLD + q] = 0.0;
-    }
-    __syncthreads();
-    // combine: D[r][c] = K[r][c] + slab0 + slab1   (acc^T[c][r] layout in the slabs)
-    for (int e = tid; e < 3 * 4 * 64; e += 256) {
-      const int t = e >> 8, v = (e >> 6) & 3, l = e & 63;
-      if (CT == 1 && t > 0) continue;
-      const int ci = (t == 2) ? 1 : 0, ri = (t == 0) ? 0 : 1;
-      const int c = 16 * ci + HPX_ACC_ROW(l >> 4, v), r = 16 * ri + (l & 15);
-      double kr, ki;
-      if (GEN) {
-        hpx_gen_entry(G, c0 + r, c0 + c, npad, kr, ki);
-      } else {
-        const long off = HPX_LIDX(c0 + r, c0 + c, npad);
-        kr = Lre[off];
-        ki = Lim[off];
-      }
-      sh.Dre[r * WLD + c] = kr + sh.slab[0][t][0][v][l] + sh.slab[1][t][0][v][l];
-      sh.Dim[r * WLD + c] = ki + sh.slab[0][t][1][v][l] + sh.slab[1][t][1][v][l];
-    }
-    // ---- 2. fused Cholesky + inverse of the wj x wj block (unscaled columns;
-    //         column q of L is D[:,q]/sqrt(D[q][q]) and row i of L^-1 is Y[i,:]/sqrt(D[i][i]))
-    for (int k = 0; k < ((HPX_DIAG & 4) ? 0 : wj); ++k) {
-      __syncthreads();
-      const double dkk = sh.Dre[k * WLD + k];
-      if (!(dkk > 0.0)) bad = true;
-      const double rinv2 = 1.0 / dkk;
-      const int nel = (wj - k - 1) << 5;
-      for (int e = tid; e < nel; e += 256) {
-        const int i = k + 1 + (e >> 5), q = e & 31;
-        const double lr = sh.Dre[i * WLD + k] * rinv2, lim = sh.Dim[i * WLD + k] * rinv2;
-        if (q <= k) {
-          const double yr = sh.Yre[k * WLD + q], yi = sh.Yim[k * WLD + q];
-          sh.Yre[i * WLD + q] -= lr * yr - lim * yi;
-          sh.Yim[i * WLD + q] -= lr * yi + lim * yr;
-        } else if (q <= i) {
-          const double qr = sh.Dre[q * WLD + k], qi = sh.Dim[q * WLD + k];
-          sh.Dre[i * WLD + q] -= lr * qr + lim * qi;   // * conj(D[q][k])
-          sh.Dim[i * WLD + q] -= lim * qr - lr * qi;
-        }
-      }
-    }
-    __syncthreads();
-    // final scaling: L_jj to global, W = conj(Ljj^-1) to LDS, Ljj^-1 to the side buffer
-    for (int e = tid; e < 32 * 32; e += 256) {
-      const int i = e >> 5, q = e & 31;
-      double wr = 0.0, wi = 0.0;
-      if (i < wj && q <= i) {
-        const double sq = 1.0 / sqrt(sh.Dre[q * WLD + q]);
-        const long off = HPX_LIDX(c0 + i, c0 + q, npad);
-        Lre[off] = sh.Dre[i * WLD + q] * sq;
-        Lim[off] = (i == q) ? 0.0 : sh.Dim[i * WLD + q] * sq;
-        const double si = 1.0 / sqrt(sh.Dre[i * WLD + i]);
-        wr = sh.Yre[i * WLD + q] * si;
-        wi = sh.Yim[i * WLD + q] * si;
-      }
-      Wgre[jb * 1024 + e] = wr;
-      Wgim[jb * 1024 + e] = wi;
-      // LDS copy is conjugated, written after all reads of Y by this thread
-      sh.Yre[i * WLD + q] = wr;
-      sh.Yim[i * WLD + q] = -wi;
-    }
-    __syncthreads();
-    // ---- 3. tiles below the diagonal block (incl. the right-hand-side rows): wave w owns
-    //         tiles rt0 + w + 4 i and works through them in groups
-    const int rt0 = (c0 + wj) >> 4;
-    int rt = rt0 + wave;
-    if (CT == 2) {
+    const int jb = c0 >> 5;
+    bad |= diag_panel<GEN>(Lre, Lim, Wgre + jb * 1024, Wgim + jb * 1024, sh, sh.Yre, sh.Yim, npad,
+                           c0, wj, tid, G);
+    // tiles below the diagonal block (incl. the right-hand-side rows): wave w owns tiles
+    // rt0 + w + 4 i and works through them in groups
+    int rt = ((c0 + wj) >> 4) + wave;
+    if (wj == 32) {
+#if !HPX_OUTER64 && HPX_WGS < 3
 #if HPX_RT3
       for (; rt + 8 < nrt; rt += 12) offdiag_group<2, 3, GEN>(Lre, Lim, npad, c0, rt << 4, 64, sh.Yre, sh.Yim, lane, G);
 #endif
       for (; rt + 4 < nrt; rt += 8) offdiag_group<2, 2, GEN>(Lre, Lim, npad, c0, rt << 4, 64, sh.Yre, sh.Yim, lane, G);
-      if (rt < nrt) offdiag_group<2, 1, GEN>(Lre, Lim, npad, c0, rt << 4, 64, sh.Yre, sh.Yim, lane, G);
+#endif
+      for (; rt < nrt; rt += 4) offdiag_group<2, 1, GEN>(Lre, Lim, npad, c0, rt << 4, 64, sh.Yre, sh.Yim, lane, G);
     } else {
       for (; rt < nrt; rt += 4) offdiag_narrow<GEN>(Lre, Lim, npad, c0, rt << 4, sh.Yre, sh.Yim, lane, G);
     }
     __syncthreads();
+    c0 += wj;
   }
   if (bad && info && !HPX_DIAG) atomicCAS(&info[b], 0, iter_tag);
-  (void)li; (void)g;
 }
 
 // ---------------------------------------------------------------------------
