@@ -204,14 +204,15 @@ __global__ void k_set_a(const double* __restrict__ ps, double* __restrict__ a,
 }
 
 // ---- K'_aug assembly ----------------------------------------------------------
+// rows >= rlo only (rlo = 0: the whole lower triangle + right-hand sides)
 __global__ __launch_bounds__(256) void k_assemble(const hpx_gen_batch B, double* __restrict__ L_all,
-                                                  const int npad, const int ld) {
+                                                  const int npad, const int ld, const int rlo) {
   const int b = blockIdx.y, cb = blockIdx.x;
   const hpx_gen G = hpx_gen_for(B, b);
   double* L = L_all + (long)b * npad * ld * 2;
-  const int rbeg = cb * 16, nrow = ld - rbeg;
+  const int rbeg = max(cb * 16, rlo), nrow = ld - rbeg;
   for (int e = threadIdx.x; e < 16 * nrow; e += 256) {
-    const int c = rbeg + e / nrow, r = rbeg + e % nrow;
+    const int c = cb * 16 + e / nrow, r = rbeg + e % nrow;
     double vr, vi;
     hpx_gen_entry(G, r, c, npad, vr, vi);
     const long o = HPX_LIDX(r, c, npad);
@@ -645,12 +646,13 @@ static hpx_gen_batch gen_of(const hpx_plan* p) {
   B.p4re = p->P4re; B.p4im = p->P4im;
   B.N = p->N; B.M = p->M; B.NP = p->NP; B.TP = p->TP; B.ncol = p->ncolR;
   B.has_omega = p->has_omega;
+  B.rmin = 32 * (p->N / 32);
   return B;
 }
 
-static int launch_assemble(hpx_plan* p, hipStream_t st) {
+static int launch_assemble(hpx_plan* p, hipStream_t st, int rlo) {
   hipLaunchKernelGGL(k_assemble, dim3(p->npad / 16, p->nbl), dim3(256), 0, st, gen_of(p), p->L,
-                     p->npad, p->ld);
+                     p->npad, p->ld, rlo);
   HPX_HIP(hipGetLastError());
   return HPX_OK;
 }
@@ -661,7 +663,7 @@ extern "C" int hpx_assemble_K(hpx_plan* p, const double* ps, double* k_out, void
   const long tot = (long)p->nbl * p->N;
   hipLaunchKernelGGL(k_set_a, dim3(256), dim3(256), 0, st, ps, p->a, p->ps_cur, tot, 1.0 / p->N);
   HPX_HIP(hipGetLastError());
-  HPX_TRY(launch_assemble(p, st));
+  HPX_TRY(launch_assemble(p, st, 0));
   if (k_out) {
     hipLaunchKernelGGL(k_kaug_out, dim3(128, p->nbl), dim3(256), 0, st, p->L, k_out, p->npad, p->ld);
     HPX_HIP(hipGetLastError());
@@ -720,9 +722,11 @@ extern "C" int hpx_gibbs_run(hpx_plan* p, const double* ps0, int iter0, int nite
   p->ev_used = 0;
   for (int it = 0; it < niter; ++it) {
     HPX_TRY(mark(p, st));
-    // K'_aug is generated inside the factor kernel (no assembly pass, L is write-only)
-    HPX_TRY(mark(p, st));
+    // Only the edge rows (foreground modes, padding, right-hand sides: rows >= rmin) are
+    // assembled; the signal x signal part of K' is generated inside the factor kernel.
     const hpx_gen_batch gen = gen_of(p);
+    HPX_TRY(launch_assemble(p, st, gen.rmin));
+    HPX_TRY(mark(p, st));
     HPX_TRY(hpx_launch_factor(nbl, p->npad, p->ld, p->L, p->Wre, p->Wim, p->info, iter0 + it + 1,
                               &gen, st));
     HPX_TRY(mark(p, st));

@@ -35,6 +35,9 @@
 #ifndef HPX_STAGGER
 #define HPX_STAGGER 0
 #endif
+#ifndef HPX_STAGGER_MODE
+#define HPX_STAGGER_MODE 0
+#endif
 #ifndef HPX_BULK_RT2
 #define HPX_BULK_RT2 0
 #endif
@@ -60,12 +63,33 @@
 #define HPX_LDA(base, off) (base)[off]
 #endif
 
+#ifndef HPX_STAMP
+#define HPX_STAMP 0
+#endif
+#if HPX_STAMP
+// Diagnostic build only: where does a wave of k_factor spend its cycles?  (never shipped;
+// the stamps go to a buffer nothing else reads)
+__device__ long long g_stamps[1 << 16];
+#define HPX_T0() long long t_last_ = __builtin_amdgcn_s_memtime()
+#define HPX_TICK(slot)                                        \
+  do {                                                        \
+    const long long t_now_ = __builtin_amdgcn_s_memtime();    \
+    st_[slot] += t_now_ - t_last_;                            \
+    t_last_ = t_now_;                                         \
+  } while (0)
+#else
+#define HPX_T0()
+#define HPX_TICK(slot)
+#endif
+
 namespace {
 
 constexpr int WLD = HPX_WLD;
 
 struct FactorShared {
   double slab[3][2][4][64];      // K-split partial sums of the diagonal tiles (12 KB)
+  double strip[2][4][16];        // published column / row of the 16x16 elimination
+  double piv[32];                // pivots d_k
   double Dre[32 * WLD], Dim[32 * WLD];   // diagonal block (lower), row-major [r][c]
   double Yre[32 * WLD], Yim[32 * WLD];   // running inverse; finally W = conj(Ljj^-1)
 #if HPX_OUTER64
@@ -82,30 +106,36 @@ __device__ HPX_INL void offdiag_group(double* __restrict__ Lre, double* __restri
                                               const int npad, const int c0, const int r0,
                                               const int rstride, const double* Wre,
                                               const double* Wim, const int lane,
-                                              const hpx_gen& G) {
+                                              const hpx_gen& G, long long* st_) {
   const int li = lane & 15, g = lane >> 4;
+  HPX_T0();
   d4 ar[RT][CT], ai[RT][CT];
 #pragma unroll
   for (int t = 0; t < RT; ++t)
 #pragma unroll
-    for (int ci = 0; ci < CT; ++ci)
+    for (int ci = 0; ci < CT; ++ci) {
+      if (GEN && r0 + t * rstride < G.rmin) {      // signal x signal tile: closed form
 #pragma unroll
-      for (int v = 0; v < 4; ++v) {
-        if (GEN) {
+        for (int v = 0; v < 4; ++v) {
           double vr, vi;
-          hpx_gen_entry(G, r0 + t * rstride + li, c0 + 16 * ci + HPX_ACC_ROW(g, v), npad, vr, vi);
+          hpx_gen_signal(G, r0 + t * rstride + li, c0 + 16 * ci + HPX_ACC_ROW(g, v), vr, vi);
           ar[t][ci][v] = vr;
           ai[t][ci][v] = vi;
-        } else {
+        }
+      } else {
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
           const long off = HPX_LIDX(r0 + t * rstride + li, c0 + 16 * ci + HPX_ACC_ROW(g, v), npad);
           ar[t][ci][v] = Lre[off];
           ai[t][ci][v] = Lim[off];
         }
       }
+    }
   // acc^T[c][r] -= conj(L[c][k]) * L[r][k].  c0 is a multiple of 32, so the k range is a
   // whole number of chunk pairs; operands of the next chunk are fetched into the other
   // register buffer while the current one feeds the MFMAs (explicit double buffering:
   // hipcc does not software-pipeline across loop iterations).
+  HPX_TICK(4);
   constexpr int KC = (RT >= 3) ? 1 : 2;     // k-steps per chunk
   const int nch = (c0 >> 2) / KC;
   const double* pre = Lre + (long)g * 32;      // column k = 4 ks + g of every panel
@@ -163,6 +193,7 @@ __device__ HPX_INL void offdiag_group(double* __restrict__ Lre, double* __restri
   }
 #undef HPX_LOAD_CHUNK
 #undef HPX_MMA_CHUNK
+  HPX_TICK(5);
   // X^T = W * acc^T,  W = conj(Ljj^-1) lower triangular (LDS), acc^T as B operand
 #pragma unroll
   for (int t = 0; t < RT; ++t) {
@@ -193,15 +224,14 @@ __device__ HPX_INL void offdiag_group(double* __restrict__ Lre, double* __restri
         Lim[off] = xi[ci][v];
       }
   }
+  HPX_TICK(6);
 }
 
-// 16-wide last block column (npad % 32 == 16): rare, kept out of line so that it does not
-// add to the register pressure of the main path.
 template <bool GEN>
 __device__ __noinline__ void offdiag_narrow(double* Lre, double* Lim, const int npad, const int c0,
                                             const int r0, const double* Wre, const double* Wim,
-                                            const int lane, const hpx_gen& G) {
-  offdiag_group<1, 1, GEN>(Lre, Lim, npad, c0, r0, 64, Wre, Wim, lane, G);
+                                            const int lane, const hpx_gen& G, long long* st_) {
+  offdiag_group<1, 1, GEN>(Lre, Lim, npad, c0, r0, 64, Wre, Wim, lane, G, st_);
 }
 
 // K-split partial sums of the (up to) three lower tiles of the diagonal block.
@@ -250,7 +280,7 @@ __device__ HPX_INL void bulk64(double* __restrict__ Lre, double* __restrict__ Li
                                        const int npad, const int c0, const int r0,
                                        const int rstride, const double* W0re, const double* W0im,
                                        const double* W1re, const double* W1im, const int lane,
-                                       const hpx_gen& G) {
+                                       const hpx_gen& G, long long* st_) {
   const int li = lane & 15, g = lane >> 4;
   d4 ar[RT][4], ai[RT][4];
 #pragma unroll
@@ -260,9 +290,9 @@ __device__ HPX_INL void bulk64(double* __restrict__ Lre, double* __restrict__ Li
 #pragma unroll
       for (int v = 0; v < 4; ++v) {
         const int r = r0 + t * rstride + li, c = c0 + 16 * ci + HPX_ACC_ROW(g, v);
-        if (GEN) {
+        if (GEN && r0 + t * rstride < G.rmin) {
           double vr, vi;
-          hpx_gen_entry(G, r, c, npad, vr, vi);
+          hpx_gen_signal(G, r, c, vr, vi);
           ar[t][ci][v] = vr;
           ai[t][ci][v] = vi;
         } else {
@@ -394,17 +424,19 @@ __device__ HPX_INL void bulk64(double* __restrict__ Lre, double* __restrict__ Li
 // On return (after the trailing barrier) Yre/Yim hold W = conj(Ljj^-1); Ljj and Ljj^-1 are
 // in global memory.
 template <bool GEN>
-__device__ HPX_INL bool diag_panel(double* __restrict__ Lre, double* __restrict__ Lim,
+__device__ __noinline__ bool diag_panel(double* __restrict__ Lre, double* __restrict__ Lim,
                                            double* __restrict__ Wgre, double* __restrict__ Wgim,
                                            FactorShared& sh, double* Yre, double* Yim,
                                            const int npad, const int c0, const int wj,
-                                           const int tid, const hpx_gen& G) {
+                                           const int tid, const hpx_gen& G, long long* st_) {
   const int wave = tid >> 6, lane = tid & 63;
   const int CT = wj >> 4;
   bool bad = false;
+  HPX_T0();
   d4 ar[3], ai[3];
   if (CT == 2) diag_partial<2>(Lre, Lim, npad, c0, wave, lane, ar, ai);
   else diag_partial<1>(Lre, Lim, npad, c0, wave, lane, ar, ai);
+  HPX_TICK(0);
   for (int e = tid; e < 32 * 32; e += 256) {     // identity for the running inverse
     const int i = e >> 5, q = e & 31;
     Yre[i * WLD + q] = (i == q) ? 1.0 : 0.0;
@@ -435,8 +467,9 @@ __device__ HPX_INL bool diag_panel(double* __restrict__ Lre, double* __restrict_
     const int ci = (t == 2) ? 1 : 0, ri = (t == 0) ? 0 : 1;
     const int c = 16 * ci + HPX_ACC_ROW(l >> 4, v), r = 16 * ri + (l & 15);
     double kr, ki;
-    if (GEN) {
-      hpx_gen_entry(G, c0 + r, c0 + c, npad, kr, ki);
+    if (GEN && c0 + 32 <= G.rmin) {
+      if (r > c) hpx_gen_signal(G, c0 + r, c0 + c, kr, ki);
+      else { const double ac = G.a[c0 + c]; kr = 1.0 + ac * ac * G.cre[0]; ki = 0.0; }
     } else {
       const long off = HPX_LIDX(c0 + r, c0 + c, npad);
       kr = Lre[off];
@@ -445,48 +478,165 @@ __device__ HPX_INL bool diag_panel(double* __restrict__ Lre, double* __restrict_
     sh.Dre[r * WLD + c] = kr + sh.slab[t][0][v][l];
     sh.Dim[r * WLD + c] = ki + sh.slab[t][1][v][l];
   }
+  HPX_TICK(1);
   // fused Cholesky + inverse of the wj x wj block (unscaled columns; column q of L is
   // D[:,q]/sqrt(D[q][q]) and row i of L^-1 is Y[i,:]/sqrt(D[i][i]))
-  for (int k = 0; k < ((HPX_DIAG & 4) ? 0 : wj); ++k) {
-    __syncthreads();
-    const double dkk = sh.Dre[k * WLD + k];
-    if (!(dkk > 0.0)) bad = true;
-    const double rinv2 = 1.0 / dkk;
-    const int nel = (wj - k - 1) << 5;
-    for (int e = tid; e < nel; e += 256) {
-      const int i = k + 1 + (e >> 5), q = e & 31;
-      const double lr = sh.Dre[i * WLD + k] * rinv2, lim = sh.Dim[i * WLD + k] * rinv2;
-      if (q <= k) {
-        const double yr = Yre[k * WLD + q], yi = Yim[k * WLD + q];
-        Yre[i * WLD + q] -= lr * yr - lim * yi;
-        Yim[i * WLD + q] -= lr * yi + lim * yr;
-      } else if (q <= i) {
-        const double qr = sh.Dre[q * WLD + k], qi = sh.Dim[q * WLD + k];
-        sh.Dre[i * WLD + q] -= lr * qr + lim * qi;   // * conj(D[q][k])
-        sh.Dim[i * WLD + q] -= lim * qr - lr * qi;
+  // Blocked elimination of the wj x wj block as 2 x 2 blocks of 16 (wj = 16: one block):
+  //   A. fused Cholesky + inverse of D00 on the vector ALU (16 steps, one D and one Y entry per
+  //      thread in registers; only column k of D and row k of Y go through LDS each step)
+  //   B. L10 = D10 L00^-H            C. D11 -= L10 L10^H          (MFMA, wave 0, operands in LDS)
+  //   D. as A for D11                E. W10 = -W11 L10 W00         (MFMA, wave 0)
+  // fp64 vector FMAs issue at ~10 cycles per wave: a 32-step scalar elimination of the whole
+  // 32 x 32 block costs ~1e5 cycles, this form ~2e4.
+  __syncthreads();                         // the combined block is complete
+  {
+    const int q = tid & 15, ib = tid >> 4;
+    const int lane_ = tid & 63, li = lane_ & 15, g = lane_ >> 4;
+    const int nhalf = wj >> 4;
+    for (int hb = 0; hb < nhalf; ++hb) {
+      const int o = 16 * hb;                // block offset inside the 32 x 32 block
+      if (hb == 1 && wave == 0) {
+        // ---- B: L10^T[c][r] = sum_c' conj(W00)[c][c'] D10[r][c']   (Y holds conj(W00))
+        d4 xr = {0., 0., 0., 0.}, xi = {0., 0., 0., 0.};
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+          const int kk = 4 * s4 + g;
+          const double wr = Yre[li * WLD + kk], wi = Yim[li * WLD + kk];
+          const double br = sh.Dre[(16 + li) * WLD + kk], bi = sh.Dim[(16 + li) * WLD + kk];
+          xr = mfma64(wr, br, xr);
+          xr = mfma64(-wi, bi, xr);
+          xi = mfma64(wr, bi, xi);
+          xi = mfma64(wi, br, xi);
+        }
+        // L10[r][c] -> LDS (over D10) and global
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          const int c = HPX_ACC_ROW(g, v);
+          sh.Dre[(16 + li) * WLD + c] = xr[v];
+          sh.Dim[(16 + li) * WLD + c] = xi[v];
+          const long off = HPX_LIDX(c0 + 16 + li, c0 + c, npad);
+          Lre[off] = xr[v];
+          Lim[off] = xi[v];
+        }
+        // ---- C: D11^T[c][r] -= sum_k conj(L10[c][k]) L10[r][k]  (B operand = L10^T accumulators)
+        d4 dr4, di4;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          dr4[v] = sh.Dre[(16 + li) * WLD + 16 + HPX_ACC_ROW(g, v)];
+          di4[v] = sh.Dim[(16 + li) * WLD + 16 + HPX_ACC_ROW(g, v)];
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): L10 stores above are visible to this wave
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          const int kk = HPX_ACC_ROW(g, v);
+          const double pr = sh.Dre[(16 + li) * WLD + kk], pi = sh.Dim[(16 + li) * WLD + kk];   // L10[c=li][k]
+          dr4 = mfma64(-pr, xr[v], dr4);
+          dr4 = mfma64(-pi, xi[v], dr4);
+          di4 = mfma64(-pr, xi[v], di4);
+          di4 = mfma64(pi, xr[v], di4);
+        }
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          sh.Dre[(16 + li) * WLD + 16 + HPX_ACC_ROW(g, v)] = dr4[v];
+          sh.Dim[(16 + li) * WLD + 16 + HPX_ACC_ROW(g, v)] = di4[v];
+        }
+      }
+      if (hb == 1) __syncthreads();
+      // ---- A / D: fused Cholesky + inverse of the 16 x 16 block at (o, o)
+      double dr = sh.Dre[(o + ib) * WLD + o + q], di = sh.Dim[(o + ib) * WLD + o + q];
+      double yr = (ib == q) ? 1.0 : 0.0, yi = 0.0;
+      const int nsteps = (HPX_DIAG & 4) ? 0 : 16;
+      for (int k = 0; k < nsteps; ++k) {
+        double* st = &sh.strip[k & 1][0][0];
+        if (q == k && ib >= k) { st[ib] = dr; st[16 + ib] = di; }          // column k of D
+        if (ib == k && q <= k) { st[32 + q] = yr; st[48 + q] = yi; }        // row k of Y
+        __syncthreads();
+        const double dkk = st[k];
+        const double cr = st[ib], cm = st[16 + ib];
+        const double a0 = st[32 + q], a1 = st[48 + q], b0 = st[q], b1 = st[16 + q];
+        if (!(dkk > 0.0)) bad = true;
+        if (tid == 0) sh.piv[o + k] = dkk;
+        const double rinv2 = 1.0 / dkk;
+        const bool isY = q <= k;
+        const double sr = isY ? a0 : b0, si = isY ? a1 : -b1;
+        const double lr = cr * rinv2, lm = cm * rinv2;
+        const double ur = lr * sr - lm * si, ui = lr * si + lm * sr;
+        const bool act = ib > k;
+        const bool toY = act && isY, toD = act && !isY && (q <= ib);
+        yr -= toY ? ur : 0.0;
+        yi -= toY ? ui : 0.0;
+        dr -= toD ? ur : 0.0;
+        di -= toD ? ui : 0.0;
+      }
+      __syncthreads();
+      // scaling: L block to global, W = conj(L^-1) block to LDS (Y), L^-1 block to the side buffer
+      {
+        double wr = 0.0, wi = 0.0;
+        if (q <= ib) {
+          const double sq = 1.0 / sqrt(sh.piv[o + q]);
+          const long off = HPX_LIDX(c0 + o + ib, c0 + o + q, npad);
+          Lre[off] = dr * sq;
+          Lim[off] = (ib == q) ? 0.0 : di * sq;
+          const double sv = 1.0 / sqrt(sh.piv[o + ib]);
+          wr = yr * sv;
+          wi = yi * sv;
+        }
+        Wgre[(o + ib) * 32 + o + q] = wr;
+        Wgim[(o + ib) * 32 + o + q] = wi;
+        Yre[(o + ib) * WLD + o + q] = wr;       // LDS copy is conjugated
+        Yim[(o + ib) * WLD + o + q] = -wi;
+        if (hb == 0) {                           // upper-right block of the inverse is zero
+          Wgre[ib * 32 + 16 + q] = 0.0;
+          Wgim[ib * 32 + 16 + q] = 0.0;
+          Yre[ib * WLD + 16 + q] = 0.0;
+          Yim[ib * WLD + 16 + q] = 0.0;
+          if (nhalf == 1) {                      // 16-wide block: nothing below either
+            Wgre[(16 + ib) * 32 + q] = 0.0; Wgim[(16 + ib) * 32 + q] = 0.0;
+            Wgre[(16 + ib) * 32 + 16 + q] = 0.0; Wgim[(16 + ib) * 32 + 16 + q] = 0.0;
+            Yre[(16 + ib) * WLD + q] = 0.0; Yim[(16 + ib) * WLD + q] = 0.0;
+            Yre[(16 + ib) * WLD + 16 + q] = 0.0; Yim[(16 + ib) * WLD + 16 + q] = 0.0;
+          }
+        }
+      }
+      __syncthreads();
+    }
+    HPX_TICK(2);
+    if (nhalf == 2 && wave == 0) {
+      // ---- E: W10 = -W11 (L10 W00).  T[r][c'] = sum_k L10[r][k] W00[k][c'], W00 = conj(Y00)
+      d4 tr = {0., 0., 0., 0.}, ti = {0., 0., 0., 0.};
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) {
+        const int kk = 4 * s4 + g;
+        const double pr = sh.Dre[(16 + li) * WLD + kk], pi = sh.Dim[(16 + li) * WLD + kk];      // L10[r=li][k]
+        const double wr = Yre[kk * WLD + li], wi = -Yim[kk * WLD + li];                        // W00[k][c'=li]
+        tr = mfma64(pr, wr, tr);
+        tr = mfma64(-pi, wi, tr);
+        ti = mfma64(pr, wi, ti);
+        ti = mfma64(pi, wr, ti);
+      }
+      // W10[i][c'] = -sum_r W11[i][r] T[r][c'],  W11 = conj(Y11); B operand = T accumulators
+      d4 zr = {0., 0., 0., 0.}, zi = {0., 0., 0., 0.};
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const int rr = HPX_ACC_ROW(g, v);
+        const double wr = Yre[(16 + li) * WLD + 16 + rr], wi = -Yim[(16 + li) * WLD + 16 + rr];   // W11[i=li][r]
+        zr = mfma64(-wr, tr[v], zr);
+        zr = mfma64(wi, ti[v], zr);
+        zi = mfma64(-wr, ti[v], zi);
+        zi = mfma64(-wi, tr[v], zi);
+      }
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const int i = HPX_ACC_ROW(g, v);
+        Wgre[(16 + i) * 32 + li] = zr[v];
+        Wgim[(16 + i) * 32 + li] = zi[v];
+        Yre[(16 + i) * WLD + li] = zr[v];
+        Yim[(16 + i) * WLD + li] = -zi[v];
       }
     }
   }
   __syncthreads();
-  // final scaling: L_jj to global, W = conj(Ljj^-1) to LDS, Ljj^-1 to the side buffer
-  for (int e = tid; e < 32 * 32; e += 256) {
-    const int i = e >> 5, q = e & 31;
-    double wr = 0.0, wi = 0.0;
-    if (i < wj && q <= i) {
-      const double sq = 1.0 / sqrt(sh.Dre[q * WLD + q]);
-      const long off = HPX_LIDX(c0 + i, c0 + q, npad);
-      Lre[off] = sh.Dre[i * WLD + q] * sq;
-      Lim[off] = (i == q) ? 0.0 : sh.Dim[i * WLD + q] * sq;
-      const double si = 1.0 / sqrt(sh.Dre[i * WLD + i]);
-      wr = Yre[i * WLD + q] * si;
-      wi = Yim[i * WLD + q] * si;
-    }
-    Wgre[e] = wr;
-    Wgim[e] = wi;
-    Yre[i * WLD + q] = wr;        // LDS copy is conjugated
-    Yim[i * WLD + q] = -wi;
-  }
-  __syncthreads();
+  HPX_TICK(3);
   return bad;
 }
 
@@ -509,27 +659,48 @@ __global__ __launch_bounds__(256, HPX_WGS) void k_factor(double* __restrict__ L_
   double* Wgim = Wim_all + (long)b * nblk * 1024;
   const int nrt = ld >> 4;
   bool bad = false;
+  long long st_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 
+#if HPX_STAGGER
+  // Two workgroups share a CU and run the same program: started together they reach their
+  // MFMA-free phases (in-LDS Cholesky) together.  Delay the one in the odd wave slot (speed
+  // only; HW_REG_HW_ID bits 3:0 = wave slot on the SIMD).
+  {
+    __shared__ int stag;
+    if (tid == 0) {
+#if HPX_STAGGER_MODE == 0
+      stag = __builtin_amdgcn_s_getreg((4) | (0 << 6) | (3 << 11)) & 1;
+#elif HPX_STAGGER_MODE == 1
+      stag = blockIdx.x & 1;
+#else
+      stag = (blockIdx.x >> 3) & 1;
+#endif
+    }
+    __syncthreads();
+    if (stag)
+      for (int i = 0; i < HPX_STAGGER; ++i) __builtin_amdgcn_s_sleep(127);
+  }
+#endif
   int c0 = 0;
 #if HPX_OUTER64
   // ---- 64-wide outer blocks: two 32-wide panels, then one bulk sweep for both
   for (; npad - c0 >= 64; c0 += 64) {
     const int jb = c0 >> 5;
     bad |= diag_panel<GEN>(Lre, Lim, Wgre + jb * 1024, Wgim + jb * 1024, sh, sh.Yre, sh.Yim, npad,
-                           c0, 32, tid, G);
+                           c0, 32, tid, G, st_);
     // rows of the second panel against the columns of the first: L10 (two 16-row tiles)
     if (wave < 2)
-      offdiag_group<2, 1, GEN>(Lre, Lim, npad, c0, c0 + 32 + 16 * wave, 64, sh.Yre, sh.Yim, lane, G);
+      offdiag_group<2, 1, GEN>(Lre, Lim, npad, c0, c0 + 32 + 16 * wave, 64, sh.Yre, sh.Yim, lane, G, st_);
     __syncthreads();
     bad |= diag_panel<GEN>(Lre, Lim, Wgre + (jb + 1) * 1024, Wgim + (jb + 1) * 1024, sh, sh.Y2re,
-                           sh.Y2im, npad, c0 + 32, 32, tid, G);
+                           sh.Y2im, npad, c0 + 32, 32, tid, G, st_);
     int rt = ((c0 + 64) >> 4) + wave;
 #if HPX_BULK_RT2
     for (; rt + 4 < nrt; rt += 8)
-      bulk64<2, GEN>(Lre, Lim, npad, c0, rt << 4, 64, sh.Yre, sh.Yim, sh.Y2re, sh.Y2im, lane, G);
+      bulk64<2, GEN>(Lre, Lim, npad, c0, rt << 4, 64, sh.Yre, sh.Yim, sh.Y2re, sh.Y2im, lane, G, st_);
 #endif
     for (; rt < nrt; rt += 4)
-      bulk64<1, GEN>(Lre, Lim, npad, c0, rt << 4, 64, sh.Yre, sh.Yim, sh.Y2re, sh.Y2im, lane, G);
+      bulk64<1, GEN>(Lre, Lim, npad, c0, rt << 4, 64, sh.Yre, sh.Yim, sh.Y2re, sh.Y2im, lane, G, st_);
     __syncthreads();
   }
 #endif
@@ -538,24 +709,33 @@ __global__ __launch_bounds__(256, HPX_WGS) void k_factor(double* __restrict__ L_
     const int wj = min(HPX_NB, npad - c0);
     const int jb = c0 >> 5;
     bad |= diag_panel<GEN>(Lre, Lim, Wgre + jb * 1024, Wgim + jb * 1024, sh, sh.Yre, sh.Yim, npad,
-                           c0, wj, tid, G);
+                           c0, wj, tid, G, st_);
     // tiles below the diagonal block (incl. the right-hand-side rows): wave w owns tiles
     // rt0 + w + 4 i and works through them in groups
     int rt = ((c0 + wj) >> 4) + wave;
     if (wj == 32) {
 #if !HPX_OUTER64 && HPX_WGS < 3
 #if HPX_RT3
-      for (; rt + 8 < nrt; rt += 12) offdiag_group<2, 3, GEN>(Lre, Lim, npad, c0, rt << 4, 64, sh.Yre, sh.Yim, lane, G);
+      for (; rt + 8 < nrt; rt += 12) offdiag_group<2, 3, GEN>(Lre, Lim, npad, c0, rt << 4, 64, sh.Yre, sh.Yim, lane, G, st_);
 #endif
-      for (; rt + 4 < nrt; rt += 8) offdiag_group<2, 2, GEN>(Lre, Lim, npad, c0, rt << 4, 64, sh.Yre, sh.Yim, lane, G);
+      for (; rt + 4 < nrt; rt += 8) offdiag_group<2, 2, GEN>(Lre, Lim, npad, c0, rt << 4, 64, sh.Yre, sh.Yim, lane, G, st_);
 #endif
-      for (; rt < nrt; rt += 4) offdiag_group<2, 1, GEN>(Lre, Lim, npad, c0, rt << 4, 64, sh.Yre, sh.Yim, lane, G);
+      for (; rt < nrt; rt += 4) offdiag_group<2, 1, GEN>(Lre, Lim, npad, c0, rt << 4, 64, sh.Yre, sh.Yim, lane, G, st_);
     } else {
-      for (; rt < nrt; rt += 4) offdiag_narrow<GEN>(Lre, Lim, npad, c0, rt << 4, sh.Yre, sh.Yim, lane, G);
+      for (; rt < nrt; rt += 4) offdiag_narrow<GEN>(Lre, Lim, npad, c0, rt << 4, sh.Yre, sh.Yim, lane, G, st_);
     }
+#if HPX_STAMP
+    { HPX_T0(); __syncthreads(); HPX_TICK(7); }
+#else
     __syncthreads();
+#endif
     c0 += wj;
   }
+#if HPX_STAMP
+  if (lane == 0 && b < 2048)
+    for (int i = 0; i < 8; ++i) g_stamps[(b * 4 + wave) * 8 + i] = st_[i];
+#endif
+  (void)st_;
   if (bad && info && !HPX_DIAG) atomicCAS(&info[b], 0, iter_tag);
 }
 
@@ -845,6 +1025,13 @@ static int potr_common(int nb, int n, int nrhs, const double* a, const double* r
   HPX_HIP(hipStreamSynchronize(st));
   return HPX_OK;
 }
+
+#if HPX_STAMP
+extern "C" int hpx_debug_stamps(long long* out_host, int n) {
+  HPX_HIP(hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_stamps), (size_t)n * sizeof(long long)));
+  return HPX_OK;
+}
+#endif
 
 extern "C" int hpx_zpotrf_batched(int nb, int n, const double* a, double* l_out, int32_t* info,
                                   void* stream) {

@@ -100,7 +100,7 @@ struct hpx_plan {
 // Pointers are per baseline (already offset), except P2 (shared).
 struct hpx_gen {
   const double *a, *cre, *cim, *rre, *rim, *p2re, *p2im, *hre, *him, *p4re, *p4im;
-  int N, M, TP, ncol, has_omega;
+  int N, M, TP, ncol, has_omega, rmin;
 };
 __device__ __forceinline__ void hpx_gen_entry(const hpx_gen& G, const int r, const int c,
                                               const int npad, double& vr, double& vi) {
@@ -143,10 +143,20 @@ __device__ __forceinline__ void hpx_gen_entry(const hpx_gen& G, const int r, con
     vr = 1.0;
   }
 }
+// Signal x signal entry strictly below the diagonal: a_r a_c circ[r-c] (no branches).  Used by
+// the factor kernel for all row tiles below `rmin` (= 32*floor(N/32)); rows >= rmin (foreground
+// modes, padding, right-hand sides) are written to the factor buffer by k_assemble beforehand.
+__device__ __forceinline__ void hpx_gen_signal(const hpx_gen& G, const int r, const int c,
+                                               double& vr, double& vi) {
+  const double s = G.a[r] * G.a[c];
+  vr = s * G.cre[r - c];
+  vi = s * G.cim[r - c];
+}
+
 // batch-level description: per-baseline strides are implied by the plan dimensions
 struct hpx_gen_batch {
   const double *a, *cre, *cim, *rre, *rim, *p2re, *p2im, *hre, *him, *p4re, *p4im;
-  int N, M, NP, TP, ncol, has_omega;
+  int N, M, NP, TP, ncol, has_omega, rmin;
 };
 __device__ __forceinline__ hpx_gen hpx_gen_for(const hpx_gen_batch& B, const int b) {
   hpx_gen G;
@@ -162,6 +172,7 @@ __device__ __forceinline__ hpx_gen hpx_gen_for(const hpx_gen_batch& B, const int
   G.p4re = B.p4re + (long)b * B.M * B.TP;
   G.p4im = B.p4im + (long)b * B.M * B.TP;
   G.N = B.N; G.M = B.M; G.TP = B.TP; G.ncol = B.ncol; G.has_omega = B.has_omega;
+  G.rmin = B.rmin;
   return G;
 }
 
