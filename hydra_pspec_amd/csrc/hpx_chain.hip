@@ -701,6 +701,87 @@ static int mark(hpx_plan* p, hipStream_t st) {
   return HPX_OK;
 }
 
+// Everything after the solve of one iteration: back transform, residual / chi^2 / first
+// ln-posterior term / beta, masked transform (flags), bandpower draw.  `rs` = row scaling of
+// y' in the back transform (a = sqrt(ps/N), or NULL when X already holds s' = Sh' y').
+struct IterOut {
+  const double* ps_forced;   // already offset to this iteration, or NULL
+  double *ps_out, *lnpost_out, *cr_out, *fg_out, *chisq_out;   // ps/lnpost offset to this iteration
+  long ps_bstride, forced_bstride, lnpost_pitch;
+  long cr_bstride, fg_bstride, chisq_bstride;
+};
+
+static int post_solve(hpx_plan* p, int it_abs, const double* rs, const IterOut& O, hipStream_t st) {
+  const int nbl = p->nbl, N = p->N, M = p->M, T = p->T, NP = p->NP, TP = p->TP;
+  const double isn = 1.0 / sqrt((double)N);
+  // s = U s' = conj(F) (rs . X) / sqrt(N)
+  HPX_TRY(hpx_launch_dft(nbl, NP, TP, p->Fopre, p->Fopim, 1, p->Xre, p->Xim, (long)p->npad * TP,
+                         TP, rs, N, p->Sre, p->Sim, (long)NP * TP, TP, isn, st, N == NP));
+  HPX_TRY(mark(p, st));
+  ResArgs R;
+  R.Xre = p->Xre; R.Xim = p->Xim; R.Sre = p->Sre; R.Sim = p->Sim; R.Dre = p->Dre; R.Dim = p->Dim;
+  R.Fre = p->Fre; R.Fim = p->Fim; R.ninv = p->ninv; R.a = p->a; R.flags = p->flags;
+  R.beta = p->beta; R.lnp1 = p->lnp1; R.Gre = p->Gre; R.Gim = p->Gim;
+  R.cr_bstride = O.cr_bstride; R.fg_bstride = O.fg_bstride; R.chisq_bstride = O.chisq_bstride;
+  R.cr_out = O.cr_out; R.fg_out = (M > 0) ? O.fg_out : nullptr; R.chisq_out = O.chisq_out;
+  R.N = N; R.M = M; R.T = T; R.NP = NP; R.TP = TP; R.npad = p->npad;
+  R.fg_shared = p->fg_shared; R.any_flags = p->any_flags;
+  hipLaunchKernelGGL(k_resid, dim3(nbl), dim3(256),
+                     (size_t)(2 * M * TP + N * (TP / 16)) * sizeof(double), st, R);
+  HPX_HIP(hipGetLastError());
+  if (p->any_flags) {   // |F (w s)|^2 for the masked S^-1 quadratic form (pspec.py:479-483)
+    HPX_TRY(hpx_launch_dft(nbl, NP, TP, p->Fopre, p->Fopim, 0, p->Gre, p->Gim, (long)NP * TP, TP,
+                           nullptr, 0, p->Zre, p->Zim, (long)NP * p->ncolR, p->ncolR, 1.0, st,
+                           N == NP));
+    hipLaunchKernelGGL(k_betam, dim3(4, nbl), dim3(256), 0, st, p->Zre, p->Zim, p->betam, N, T, NP,
+                       p->ncolR);
+    HPX_HIP(hipGetLastError());
+  }
+  HPX_TRY(mark(p, st));
+  DrawArgs D;
+  D.beta = p->beta; D.betam = p->betam; D.lnp1 = p->lnp1;
+  D.uni = p->uni + (long)it_abs * N; D.igy = p->igy + (long)it_abs * N;
+  D.xgrid = p->xgrid; D.pmap = p->pmap;
+  D.ps_forced = O.ps_forced; D.forced_bstride = O.forced_bstride;
+  D.a = p->a; D.ps_cur = p->ps_cur;
+  D.ps_out = O.ps_out; D.ps_bstride = O.ps_bstride;
+  D.N = N; D.T = T; D.ngrid = p->ngrid; D.prior_shared = p->prior_shared;
+  D.any_flags = p->any_flags; D.lgam_T = p->lgam_T;
+  D.lnpost_out = p->lnp1;   // staged per baseline, scattered to (nbl, niter) below
+  hipLaunchKernelGGL(k_draw, dim3(nbl), dim3(256), (size_t)(p->ngrid > 0 ? p->ngrid : 1) * 8, st, D);
+  HPX_HIP(hipGetLastError());
+  HPX_HIP(hipMemcpy2DAsync(O.lnpost_out, (size_t)O.lnpost_pitch * sizeof(double), p->lnp1,
+                           sizeof(double), sizeof(double), nbl, hipMemcpyDeviceToDevice, st));
+  HPX_TRY(mark(p, st));
+  return HPX_OK;
+}
+
+static int finish_run(hpx_plan* p, int niter, double* ps_last, hipStream_t st) {
+  const int nbl = p->nbl;
+  if (ps_last)
+    HPX_HIP(hipMemcpyAsync(ps_last, p->ps_cur, (size_t)nbl * p->N * sizeof(double),
+                           hipMemcpyDeviceToDevice, st));
+  HPX_HIP(hipStreamSynchronize(st));
+  if (p->profiling) {
+    for (int s = 0; s < HPX_NSTAGE; ++s) p->stage_ms[s] = 0.f;
+    const int per = HPX_NSTAGE + 1;
+    for (int it = 0; it < niter; ++it)
+      for (int s = 0; s < HPX_NSTAGE; ++s) {
+        float ms = 0.f;
+        HPX_HIP(hipEventElapsedTime(&ms, p->events[it * per + s], p->events[it * per + s + 1]));
+        p->stage_ms[s] += ms;
+      }
+  }
+  std::vector<int32_t> info(nbl);   // report the first non-positive pivot, if any
+  HPX_HIP(hipMemcpy(info.data(), p->info, (size_t)nbl * sizeof(int32_t), hipMemcpyDeviceToHost));
+  for (int b = 0; b < nbl; ++b)
+    if (info[b] != 0) {
+      hpx_set_error("non-positive pivot: baseline %d, iteration %d", b, info[b] - 1);
+      return HPX_ENOTPD;
+    }
+  return HPX_OK;
+}
+
 extern "C" int hpx_gibbs_run(hpx_plan* p, const double* ps0, int iter0, int niter,
                              const double* ps_forced, double* ps_out, double* lnpost_out,
                              double* cr_out, double* fg_out, double* chisq_out, int thin,
@@ -710,9 +791,8 @@ extern "C" int hpx_gibbs_run(hpx_plan* p, const double* ps0, int iter0, int nite
   HPX_REQUIRE(p->uni && iter0 + niter <= p->niter_tab, "hpx_gibbs_run: random tables too short");
   if (thin < 1) thin = 1;
   hipStream_t st = (hipStream_t)stream;
-  const int nbl = p->nbl, N = p->N, M = p->M, T = p->T, NP = p->NP, TP = p->TP;
+  const int nbl = p->nbl, N = p->N, M = p->M, T = p->T, TP = p->TP;
   const int nkeep = (niter + thin - 1) / thin;
-  const double isn = 1.0 / sqrt((double)N);
   if (ps0) {
     hipLaunchKernelGGL(k_set_a, dim3(256), dim3(256), 0, st, ps0, p->a, p->ps_cur, (long)nbl * N,
                        1.0 / N);
@@ -732,88 +812,172 @@ extern "C" int hpx_gibbs_run(hpx_plan* p, const double* ps0, int iter0, int nite
     HPX_TRY(mark(p, st));
     HPX_TRY(hpx_launch_backsolve(nbl, p->npad, TP, p->ld, p->L, p->Wre, p->Wim, p->Xre, p->Xim, st));
     HPX_TRY(mark(p, st));
-    // s = U D^1/2 y' = conj(F) (a . y') / sqrt(N)
-    HPX_TRY(hpx_launch_dft(nbl, NP, TP, p->Fopre, p->Fopim, 1, p->Xre, p->Xim, (long)p->npad * TP,
-                           TP, p->a, N, p->Sre, p->Sim, (long)NP * TP, TP, isn, st, N == NP));
-    HPX_TRY(mark(p, st));
-    ResArgs R;
-    R.Xre = p->Xre; R.Xim = p->Xim; R.Sre = p->Sre; R.Sim = p->Sim; R.Dre = p->Dre; R.Dim = p->Dim;
-    R.Fre = p->Fre; R.Fim = p->Fim; R.ninv = p->ninv; R.a = p->a; R.flags = p->flags;
-    R.beta = p->beta; R.lnp1 = p->lnp1; R.Gre = p->Gre; R.Gim = p->Gim;
     const bool keep = (it % thin) == 0;
     const long slot = it / thin;
-    R.cr_bstride = (long)nkeep * T * N * 2;
-    R.fg_bstride = (long)nkeep * T * M * 2;
-    R.chisq_bstride = (long)nkeep * T * N;
-    R.cr_out = (cr_out && keep) ? cr_out + slot * T * N * 2 : nullptr;
-    R.fg_out = (fg_out && keep && M > 0) ? fg_out + slot * T * M * 2 : nullptr;
-    R.chisq_out = (chisq_out && keep) ? chisq_out + slot * T * N : nullptr;
-    R.N = N; R.M = M; R.T = T; R.NP = NP; R.TP = TP; R.npad = p->npad;
-    R.fg_shared = p->fg_shared; R.any_flags = p->any_flags;
-    hipLaunchKernelGGL(k_resid, dim3(nbl), dim3(256),
-                       (size_t)(2 * M * TP + N * (TP / 16)) * sizeof(double), st, R);
-    HPX_HIP(hipGetLastError());
-    if (p->any_flags) {   // |F (w s)|^2 for the masked S^-1 quadratic form (pspec.py:479-483)
-      HPX_TRY(hpx_launch_dft(nbl, NP, TP, p->Fopre, p->Fopim, 0, p->Gre, p->Gim, (long)NP * TP, TP,
-                             nullptr, 0, p->Zre, p->Zim, (long)NP * p->ncolR, p->ncolR, 1.0, st,
-                             N == NP));
-      hipLaunchKernelGGL(k_betam, dim3(4, nbl), dim3(256), 0, st, p->Zre, p->Zim, p->betam, N, T,
-                         NP, p->ncolR);
-      HPX_HIP(hipGetLastError());
-    }
-    HPX_TRY(mark(p, st));
-    DrawArgs D;
-    D.beta = p->beta; D.betam = p->betam; D.lnp1 = p->lnp1;
-    D.uni = p->uni + (long)(iter0 + it) * N; D.igy = p->igy + (long)(iter0 + it) * N;
-    D.xgrid = p->xgrid; D.pmap = p->pmap;
-    D.ps_forced = ps_forced ? ps_forced + (long)it * N : nullptr;
-    D.forced_bstride = (long)niter * N;
-    D.a = p->a; D.ps_cur = p->ps_cur;
-    D.ps_out = ps_out + (long)it * N; D.ps_bstride = (long)niter * N;
-    D.lnpost_out = nullptr;
-    D.N = N; D.T = T; D.ngrid = p->ngrid; D.prior_shared = p->prior_shared;
-    D.any_flags = p->any_flags; D.lgam_T = p->lgam_T;
-    // lnpost_out (nbl, niter): element [b][it]; the kernel writes lnpost_out[b] with a
-    // stride of one baseline, so stage through lnp1 and scatter below.
-    D.lnpost_out = p->lnp1;
-    hipLaunchKernelGGL(k_draw, dim3(nbl), dim3(256), (size_t)(p->ngrid > 0 ? p->ngrid : 1) * 8, st, D);
-    HPX_HIP(hipGetLastError());
-    HPX_HIP(hipMemcpy2DAsync(lnpost_out + it, (size_t)niter * sizeof(double), p->lnp1,
-                             sizeof(double), sizeof(double), nbl, hipMemcpyDeviceToDevice, st));
-    HPX_TRY(mark(p, st));
+    IterOut O;
+    O.ps_forced = ps_forced ? ps_forced + (long)it * N : nullptr;
+    O.forced_bstride = (long)niter * N;
+    O.ps_out = ps_out + (long)it * N; O.ps_bstride = (long)niter * N;
+    O.lnpost_out = lnpost_out + it; O.lnpost_pitch = niter;
+    O.cr_bstride = (long)nkeep * T * N * 2;
+    O.fg_bstride = (long)nkeep * T * M * 2;
+    O.chisq_bstride = (long)nkeep * T * N;
+    O.cr_out = (cr_out && keep) ? cr_out + slot * T * N * 2 : nullptr;
+    O.fg_out = (fg_out && keep) ? fg_out + slot * T * M * 2 : nullptr;
+    O.chisq_out = (chisq_out && keep) ? chisq_out + slot * T * N : nullptr;
+    HPX_TRY(post_solve(p, iter0 + it, p->a, O, st));
   }
-  if (ps_last)
-    HPX_HIP(hipMemcpyAsync(ps_last, p->ps_cur, (size_t)nbl * N * sizeof(double),
-                           hipMemcpyDeviceToDevice, st));
-  HPX_HIP(hipStreamSynchronize(st));
-  if (p->profiling) {
-    for (int s = 0; s < HPX_NSTAGE; ++s) p->stage_ms[s] = 0.f;
-    const int per = HPX_NSTAGE + 1;
-    for (int it = 0; it < niter; ++it)
-      for (int s = 0; s < HPX_NSTAGE; ++s) {
-        float ms = 0.f;
-        HPX_HIP(hipEventElapsedTime(&ms, p->events[it * per + s], p->events[it * per + s + 1]));
-        p->stage_ms[s] += ms;
-      }
-  }
-  // report the first non-positive pivot, if any
-  std::vector<int32_t> info(nbl);
-  HPX_HIP(hipMemcpy(info.data(), p->info, (size_t)nbl * sizeof(int32_t), hipMemcpyDeviceToHost));
-  for (int b = 0; b < nbl; ++b)
-    if (info[b] != 0) {
-      hpx_set_error("non-positive pivot: baseline %d, iteration %d", b, info[b] - 1);
-      return HPX_ENOTPD;
-    }
-  return HPX_OK;
+  return finish_run(p, niter, ps_last, st);
 }
+
+// ---- general first iteration ---------------------------------------------------------------
+namespace {
+// (nbl,N,N) c128 row-major -> planar [b][NP][NP] (zero padded); entry [k][x] = M[k][x]
+__global__ void k_mat_planar(const double* __restrict__ m, double* __restrict__ re,
+                             double* __restrict__ im, const int N, const int NP) {
+  const int b = blockIdx.y;
+  const long tot = (long)NP * NP;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < tot;
+       e += (long)gridDim.x * blockDim.x) {
+    const int k = (int)(e / NP), x = (int)(e % NP);
+    double vr = 0.0, vi = 0.0;
+    if (k < N && x < N) {
+      vr = m[(((long)b * N + k) * N + x) * 2];
+      vi = m[(((long)b * N + k) * N + x) * 2 + 1];
+    }
+    re[(long)b * tot + e] = vr;
+    im[(long)b * tot + e] = vi;
+  }
+}
+// explicit circulant C[k][x] = circ[(k - x) mod N]
+__global__ void k_circ_matrix(const double* __restrict__ cre, const double* __restrict__ cim,
+                              double* __restrict__ re, double* __restrict__ im, const int N,
+                              const int NP) {
+  const int b = blockIdx.y;
+  const long tot = (long)NP * NP;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < tot;
+       e += (long)gridDim.x * blockDim.x) {
+    const int k = (int)(e / NP), x = (int)(e % NP);
+    double vr = 0.0, vi = 0.0;
+    if (k < N && x < N) {
+      const int m = (k - x + N) % N;
+      vr = cre[(long)b * N + m];
+      vi = cim[(long)b * N + m];
+    }
+    re[(long)b * tot + e] = vr;
+    im[(long)b * tot + e] = vi;
+  }
+}
+// K'_aug for a general Sh': top-left I + XT, fg rows conj(GS), right-hand sides conj(QS + P2)
+__global__ __launch_bounds__(256) void k_assemble_general(
+    const hpx_gen_batch B, const double* __restrict__ XTre, const double* __restrict__ XTim,
+    const double* __restrict__ RSre, const double* __restrict__ RSim, double* __restrict__ L_all,
+    const int npad, const int ld) {
+  const int b = blockIdx.y, cb = blockIdx.x;
+  const hpx_gen G = hpx_gen_for(B, b);
+  const int N = B.N, M = B.M, NP = B.NP, TP = B.TP;
+  double* L = L_all + (long)b * npad * ld * 2;
+  const double* xr = XTre + (long)b * NP * NP;
+  const double* xi = XTim + (long)b * NP * NP;
+  const double* rr = RSre + (long)b * NP * B.ncol;
+  const double* ri = RSim + (long)b * NP * B.ncol;
+  const int rbeg = cb * 16, nrow = ld - rbeg;
+  for (int e = threadIdx.x; e < 16 * nrow; e += 256) {
+    const int c = rbeg + e / nrow, r = rbeg + e % nrow;
+    double vr = 0.0, vi = 0.0;
+    if (r >= c && c < N && (r < N + M || r >= npad)) {
+      if (r < N) {                       // out[x=r][col=c] of the GEMM: stored [x][c]
+        vr = xr[(long)r * NP + c] + (r == c ? 1.0 : 0.0);
+        vi = (r == c) ? 0.0 : xi[(long)r * NP + c];
+      } else if (r < N + M) {            // conj((Sh' G)[c][m])
+        vr = rr[(long)c * B.ncol + TP + (r - N)];
+        vi = -ri[(long)c * B.ncol + TP + (r - N)];
+      } else {                           // conj((Sh' Q)[c][t] + P2[c][t])
+        const int t = r - npad;
+        vr = rr[(long)c * B.ncol + t];
+        vi = ri[(long)c * B.ncol + t];
+        if (B.has_omega) { vr += B.p2re[(long)c * TP + t]; vi += B.p2im[(long)c * TP + t]; }
+        vi = -vi;
+      }
+    } else {
+      hpx_gen_entry(G, r, c, npad, vr, vi);   // H, P4, padding: independent of S
+      if (c < N) { vr = 0.0; vi = 0.0; }      // (c < N cases are all handled above)
+    }
+    const long o = HPX_LIDX(r, c, npad);
+    L[o] = vr;
+    L[o + 16] = vi;
+  }
+}
+// X rows [0,N) <- s' (from scratch G), a <- 1
+__global__ void k_take_sprime(const double* __restrict__ Gre, const double* __restrict__ Gim,
+                              double* __restrict__ Xre, double* __restrict__ Xim,
+                              double* __restrict__ a, const int N, const int NP, const int TP,
+                              const int npad) {
+  const int b = blockIdx.y;
+  const long tot = (long)N * TP;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < tot;
+       e += (long)gridDim.x * blockDim.x) {
+    Xre[(long)b * npad * TP + e] = Gre[(long)b * NP * TP + e];
+    Xim[(long)b * npad * TP + e] = Gim[(long)b * NP * TP + e];
+    if (e < N) a[(long)b * N + e] = 1.0;
+  }
+}
+}  // namespace
 
 extern "C" int hpx_gibbs_step_general(hpx_plan* p, const double* shp, int iter0, double* ps_out,
                                       double* lnpost_out, double* cr_out, double* fg_out,
                                       double* chisq_out, double* ps_last, void* stream) {
-  (void)p; (void)shp; (void)iter0; (void)ps_out; (void)lnpost_out; (void)cr_out; (void)fg_out;
-  (void)chisq_out; (void)ps_last; (void)stream;
-  hpx_set_error("hpx_gibbs_step_general: not implemented in this build");
-  return HPX_EINVAL;
+  HPX_REQUIRE(p && p->have_static && shp && ps_out && lnpost_out, "hpx_gibbs_step_general: bad argument");
+  HPX_REQUIRE(p->uni && iter0 >= 0 && iter0 < p->niter_tab, "hpx_gibbs_step_general: random tables too short");
+  hipStream_t st = (hipStream_t)stream;
+  const int nbl = p->nbl, N = p->N, M = p->M, T = p->T, NP = p->NP, TP = p->TP;
+  const size_t msz = (size_t)nbl * NP * NP, rsz = (size_t)nbl * NP * p->ncolR;
+  if (!p->SHre) {
+    HPX_TRY(dev_alloc(p, &p->SHre, msz)); HPX_TRY(dev_alloc(p, &p->SHim, msz));
+    HPX_TRY(dev_alloc(p, &p->CMre, msz)); HPX_TRY(dev_alloc(p, &p->CMim, msz));
+    HPX_TRY(dev_alloc(p, &p->Y1re, msz)); HPX_TRY(dev_alloc(p, &p->Y1im, msz));
+    HPX_TRY(dev_alloc(p, &p->XTre, msz)); HPX_TRY(dev_alloc(p, &p->XTim, msz));
+    HPX_TRY(dev_alloc(p, &p->RSre, rsz)); HPX_TRY(dev_alloc(p, &p->RSim, rsz));
+  }
+  const long mstr = (long)NP * NP;
+  hipLaunchKernelGGL(k_mat_planar, dim3(64, nbl), dim3(256), 0, st, shp, p->SHre, p->SHim, N, NP);
+  hipLaunchKernelGGL(k_circ_matrix, dim3(64, nbl), dim3(256), 0, st, p->Cre, p->Cim, p->CMre, p->CMim,
+                     N, NP);
+  HPX_HIP(hipGetLastError());
+  // The dense kernel computes out = W in with W[x][k] read from the planar buffer at [k][x];
+  // both C and Sh' are Hermitian, so the stored row-major matrix is conj(W^T): conjW = 1.
+  HPX_TRY(hpx_launch_dft(nbl, NP, NP, p->CMre, p->CMim, 1, p->SHre, p->SHim, mstr, NP, nullptr, 0,
+                         p->Y1re, p->Y1im, mstr, NP, 1.0, st, 0, mstr));        // Y1 = C Sh'
+  HPX_TRY(hpx_launch_dft(nbl, NP, NP, p->SHre, p->SHim, 1, p->Y1re, p->Y1im, mstr, NP, nullptr, 0,
+                         p->XTre, p->XTim, mstr, NP, 1.0, st, 0, mstr));        // XT = Sh' C Sh'
+  HPX_TRY(hpx_launch_dft(nbl, NP, p->ncolR, p->SHre, p->SHim, 1, p->Rre, p->Rim,
+                         (long)NP * p->ncolR, p->ncolR, nullptr, 0, p->RSre, p->RSim,
+                         (long)NP * p->ncolR, p->ncolR, 1.0, st, 0, mstr));     // RS = Sh' [Q | G | .]
+  HPX_HIP(hipMemsetAsync(p->info, 0, (size_t)nbl * sizeof(int32_t), st));
+  p->ev_used = 0;
+  HPX_TRY(mark(p, st));
+  hipLaunchKernelGGL(k_assemble_general, dim3(p->npad / 16, nbl), dim3(256), 0, st, gen_of(p),
+                     p->XTre, p->XTim, p->RSre, p->RSim, p->L, p->npad, p->ld);
+  HPX_HIP(hipGetLastError());
+  HPX_TRY(mark(p, st));
+  HPX_TRY(hpx_launch_factor(nbl, p->npad, p->ld, p->L, p->Wre, p->Wim, p->info, iter0 + 1, nullptr, st));
+  HPX_TRY(mark(p, st));
+  HPX_TRY(hpx_launch_backsolve(nbl, p->npad, TP, p->ld, p->L, p->Wre, p->Wim, p->Xre, p->Xim, st));
+  HPX_TRY(mark(p, st));
+  // s' = Sh' y'  -> X rows [0,N);  a := 1 so that beta = N sum |s'|^2 and s = U s'
+  HPX_TRY(hpx_launch_dft(nbl, NP, TP, p->SHre, p->SHim, 1, p->Xre, p->Xim, (long)p->npad * TP, TP,
+                         nullptr, 0, p->Gre, p->Gim, (long)NP * TP, TP, 1.0, st, 0, mstr));
+  hipLaunchKernelGGL(k_take_sprime, dim3(32, nbl), dim3(256), 0, st, p->Gre, p->Gim, p->Xre, p->Xim,
+                     p->a, N, NP, TP, p->npad);
+  HPX_HIP(hipGetLastError());
+  IterOut O;
+  O.ps_forced = nullptr; O.forced_bstride = 0;
+  O.ps_out = ps_out; O.ps_bstride = N;
+  O.lnpost_out = lnpost_out; O.lnpost_pitch = 1;
+  O.cr_bstride = (long)T * N * 2; O.fg_bstride = (long)T * M * 2; O.chisq_bstride = (long)T * N;
+  O.cr_out = cr_out; O.fg_out = fg_out; O.chisq_out = chisq_out;
+  HPX_TRY(post_solve(p, iter0, nullptr, O, st));
+  return finish_run(p, 1, ps_last, st);
 }
 
 extern "C" int hpx_invgamma_inversion(int n, int alpha, const double* beta, const double* u,

@@ -83,7 +83,7 @@ struct hpx_plan {
   double *Gre, *Gim;       // [nbl][NP][TP] scratch (DFT input / masked DFT output)
   double *Zre, *Zim;       // [nbl][NP][ncolR] scratch for the invariant transform
   // general (non-Fourier S_initial) first step
-  double *SHre, *SHim;     // [nbl][N][N] (allocated on demand)
+  double *SHre, *SHim, *CMre, *CMim, *Y1re, *Y1im, *XTre, *XTim, *RSre, *RSim;   // general step (on demand)
   std::vector<hipEvent_t> events;   // profiling: (HPX_NSTAGE+1) per iteration
   int ev_used;
   float stage_ms[HPX_NSTAGE];
@@ -188,6 +188,7 @@ int hpx_launch_backsolve(int nbl, int npad, int TP, int ld, const double* L, con
 int hpx_launch_dft(int nbl, int NP, int ncol, const double* Wre, const double* Wim,
                    int conjW, const double* inre, const double* inim, long in_bstride,
                    int in_ld, const double* rs, int rs_n, double* outre, double* outim,
-                   long out_bstride, int out_ld, double scale, hipStream_t st, int fft_ok = 1);
+                   long out_bstride, int out_ld, double scale, hipStream_t st, int fft_ok = 1,
+                   long W_bstride = 0);
 extern int hpx_dft_use_fft;
 int hpx_fop_to_planar(const double* fop, double* re, double* im, int N, int NP, hipStream_t st);

@@ -49,8 +49,8 @@ __device__ __forceinline__ void dft_tile(const double* __restrict__ Wre,
     }
 }
 
-__global__ __launch_bounds__(256, 2) void k_dft(const double* __restrict__ Wre,
-                                             const double* __restrict__ Wim, const int conjW,
+__global__ __launch_bounds__(256, 2) void k_dft(const double* Wre, const double* Wim,
+                                                const int conjW,
                                              const double* __restrict__ inre,
                                              const double* __restrict__ inim,
                                              const long in_bstride, const int in_ld,
@@ -58,11 +58,13 @@ __global__ __launch_bounds__(256, 2) void k_dft(const double* __restrict__ Wre,
                                              double* __restrict__ outre,
                                              double* __restrict__ outim, const long out_bstride,
                                              const int out_ld, const int NP, const int ncol,
-                                             const double scale) {
+                                             const double scale, const long W_bstride) {
   const int b = blockIdx.y;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int xt = blockIdx.x * 4 + wave;
   if (xt * 16 >= NP) return;
+  Wre += (long)b * W_bstride;
+  Wim += (long)b * W_bstride;
   const double wsign = conjW ? -1.0 : 1.0;
   const double* ir = inre + (long)b * in_bstride;
   const double* ii = inim + (long)b * in_bstride;
@@ -205,12 +207,12 @@ int hpx_dft_use_fft = 1;
 int hpx_launch_dft(int nbl, int NP, int ncol, const double* Wre, const double* Wim, int conjW,
                    const double* inre, const double* inim, long in_bstride, int in_ld,
                    const double* rs, int rs_n, double* outre, double* outim, long out_bstride,
-                   int out_ld, double scale, hipStream_t st, int fft_ok) {
+                   int out_ld, double scale, hipStream_t st, int fft_ok, long W_bstride) {
   if ((NP & 15) || (ncol & 15)) {
     hpx_set_error("hpx_launch_dft: NP and ncol must be multiples of 16");
     return HPX_EINVAL;
   }
-  if (hpx_dft_use_fft && NP >= 16 && NP <= 4096 && (NP & (NP - 1)) == 0 && fft_ok) {
+  if (hpx_dft_use_fft && NP >= 16 && NP <= 4096 && (NP & (NP - 1)) == 0 && fft_ok && W_bstride == 0) {
     int logN = 0;
     while ((1 << logN) < NP) ++logN;
     int TC = 4096 / NP;                 // 64 KiB of LDS per workgroup
@@ -228,7 +230,7 @@ int hpx_launch_dft(int nbl, int NP, int ncol, const double* Wre, const double* W
   }
   dim3 grid((NP / 16 + 3) / 4, nbl);
   hipLaunchKernelGGL(k_dft, grid, dim3(256), 0, st, Wre, Wim, conjW, inre, inim, in_bstride,
-                     in_ld, rs, rs_n, outre, outim, out_bstride, out_ld, NP, ncol, scale);
+                     in_ld, rs, rs_n, outre, outim, out_bstride, out_ld, NP, ncol, scale, W_bstride);
   HPX_HIP(hipGetLastError());
   return HPX_OK;
 }

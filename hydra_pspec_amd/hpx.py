@@ -108,7 +108,10 @@ def stream_ptr(torch):
 def to_dev(torch, x, dtype, device):
     """numpy / torch (any device) -> contiguous torch tensor of `dtype` on `device`."""
     if isinstance(x, np.ndarray):
-        x = torch.from_numpy(np.ascontiguousarray(x))
+        x = np.ascontiguousarray(x)
+        if not x.flags.writeable:          # e.g. broadcast views, arrays out of an .npz
+            x = x.copy()
+        x = torch.from_numpy(x)
     return x.to(device=device, dtype=dtype, non_blocking=False).contiguous()
 
 

@@ -115,6 +115,21 @@ def pspec_from_covariance(S, fourier_op=None):
     return ps, resid
 
 
+def sqrt_cov_delay_basis(S, fourier_op=None):
+    """``Sh' = U^H sqrtm(S) U`` (``U = F^H / sqrt N``) for Hermitian positive semi-definite ``S``
+    (the principal square root the reference takes with ``scipy.linalg.sqrtm``,
+    pspec.py:359), via one Hermitian eigendecomposition on the host.  Used only for
+    the first iteration of a chain whose ``S_initial`` is not of the form
+    ``F^H diag(.) F``."""
+    S = np.asarray(S, dtype=complex)
+    N = S.shape[-1]
+    F = utils.fourier_operator(N) if fourier_op is None else fourier_op
+    Sh = 0.5 * (S + np.conj(np.swapaxes(S, -1, -2)))
+    lam, V = np.linalg.eigh(Sh)
+    root = (V * np.sqrt(np.clip(lam, 0.0, None))[..., None, :]) @ np.conj(np.swapaxes(V, -1, -2))
+    return F @ root @ F.conj().T / N
+
+
 # ------------------------------------------------------------------ batched core
 class GibbsBatch:
     """A batch of independent baselines resident on one GPU.
@@ -177,8 +192,12 @@ class GibbsBatch:
     def close(self):
         self.plan.close()
 
-    def run(self, niter, ps0=None, ps_forced=None, keep=("ps", "ln_post"), thin=1):
+    def run(self, niter, ps0=None, ps_forced=None, keep=("ps", "ln_post"), thin=1, shp0=None):
         """Advance every chain by ``niter`` iterations.
+
+        ``shp0`` (nbl,N,N) complex, first call only: general starting covariance given as
+        ``Sh' = U^H sqrtm(S_initial) U`` (:func:`sqrt_cov_delay_basis`) instead of ``ps0``; the
+        first iteration then runs through ``hpx_gibbs_step_general``.
 
         ps0 (nbl,N): bandpowers of the starting covariance (required on the
         first call).  Returns a dict of device tensors: ``signal_ps``
@@ -188,6 +207,8 @@ class GibbsBatch:
         torch = self.torch
         nbl, T, N, M = self.nbl, self.T, self.N, self.M
         assert self.iter_done + niter <= self.Niter, "random tables exhausted"
+        if shp0 is not None:
+            return self._run_general_first(niter, shp0, ps_forced, keep, thin)
         assert ps0 is not None or self.iter_done > 0, "ps0 is required for the first run"
         nkeep = (niter + thin - 1) // thin
         with torch.cuda.device(self.device):
@@ -217,6 +238,48 @@ class GibbsBatch:
         self.iter_done += niter
         return out
 
+    def _run_general_first(self, niter, shp0, ps_forced, keep, thin):
+        torch = self.torch
+        nbl, T, N, M = self.nbl, self.T, self.N, self.M
+        assert self.iter_done == 0, "a general starting covariance only makes sense for iteration 0"
+        with torch.cuda.device(self.device):
+            f64, c128, dev = torch.float64, torch.complex128, self.device
+            d_shp = hpx.to_dev(torch, shp0, c128, dev)
+            assert tuple(d_shp.shape) == (nbl, N, N)
+            first = dict(signal_ps=torch.empty((nbl, 1, N), dtype=f64, device=dev),
+                         ln_post=torch.empty((nbl, 1), dtype=f64, device=dev),
+                         ps_last=torch.empty((nbl, N), dtype=f64, device=dev))
+            if "signal_cr" in keep:
+                first["signal_cr"] = torch.empty((nbl, 1, T, N), dtype=c128, device=dev)
+            if "fg_amps" in keep:
+                first["fg_amps"] = torch.zeros((nbl, 1, T, M), dtype=c128, device=dev)
+            if "chisq" in keep:
+                first["chisq"] = torch.empty((nbl, 1, T, N), dtype=f64, device=dev)
+            rc = hpx.lib().hpx_gibbs_step_general(
+                self.plan.handle, hpx.ptr(d_shp), 0, hpx.ptr(first["signal_ps"]), hpx.ptr(first["ln_post"]),
+                hpx.ptr(first.get("signal_cr")), hpx.ptr(first.get("fg_amps")), hpx.ptr(first.get("chisq")),
+                hpx.ptr(first["ps_last"]), hpx.stream_ptr(torch))
+            hpx.check(rc, "hpx_gibbs_step_general")
+            self.iter_done = 1
+            if ps_forced is not None:     # teacher forcing: iteration 1 starts from the forced value
+                forced = hpx.to_dev(torch, ps_forced, f64, dev)
+                nxt_ps0 = forced[:, 0].contiguous()
+            else:
+                nxt_ps0 = None
+            if niter == 1:
+                return first
+            rest = self.run(niter - 1, ps0=nxt_ps0,
+                            ps_forced=None if ps_forced is None else forced[:, 1:].contiguous(),
+                            keep=keep, thin=1)
+            out = {}
+            for k in first:
+                out[k] = rest[k] if k == "ps_last" else torch.cat([first[k], rest[k]], dim=1)
+            if thin > 1:
+                for k in ("signal_cr", "fg_amps", "chisq"):
+                    if k in out:
+                        out[k] = out[k][:, ::thin].contiguous()
+            return out
+
 
 def gibbs_sample_with_fg_batched(vis, flags, fgmodes, Ninv, ps_prior, S_initial=None,
                                  ps_initial=None, Niter=100, seed=None, map_estimate=False,
@@ -237,20 +300,23 @@ def gibbs_sample_with_fg_batched(vis, flags, fgmodes, Ninv, ps_prior, S_initial=
     ``ps_last`` and the histories named in ``keep`` (``"signal_cr"``,
     ``"fg_amps"``, ``"chisq"``; every ``thin``-th iteration)."""
     nbl, T, N = tuple(vis.shape)
+    shp0 = None
     if ps_initial is None:
         if S_initial is None:
             raise ValueError("one of S_initial / ps_initial is required")
         S0 = np.asarray(S_initial)
         ps_initial, resid = pspec_from_covariance(S0)
-        if np.any(resid > FOURIER_FORM_TOL):
-            raise NotImplementedError("S_initial is not of the form F^H diag(ps/N^2) F "
-                                      f"(relative off-diagonal power {np.max(resid):.2e})")
-    ps0 = np.ascontiguousarray(np.broadcast_to(np.asarray(ps_initial, dtype=float), (nbl, N)))
+        if np.any(resid > FOURIER_FORM_TOL):     # general covariance: first iteration via Sh'
+            shp0 = np.ascontiguousarray(np.broadcast_to(sqrt_cov_delay_basis(S0), (nbl, N, N)))
     ninv = _ninv_diag(Ninv, nbl, T, N)
     gb = GibbsBatch(vis, flags, fgmodes, ninv, ps_prior, Niter, seed=seed,
                     map_estimate=map_estimate, device=device)
     try:
-        out = gb.run(gb.Niter, ps0=ps0, ps_forced=ps_forced, keep=keep, thin=thin)
+        if shp0 is not None:
+            out = gb.run(gb.Niter, shp0=shp0, ps_forced=ps_forced, keep=keep, thin=thin)
+        else:
+            ps0 = np.ascontiguousarray(np.broadcast_to(np.asarray(ps_initial, dtype=float), (nbl, N)))
+            out = gb.run(gb.Niter, ps0=ps0, ps_forced=ps_forced, keep=keep, thin=thin)
     finally:
         gb.close()
     if as_numpy:
@@ -379,13 +445,15 @@ def gibbs_step_fgmodes(vis, flags, signal_S, fgmodes, Ninv, ps_prior=None, f0=No
     if ps_prior is None:
         ps_prior = np.zeros((2, N))
     ps0, resid = pspec_from_covariance(np.asarray(signal_S))
-    if resid > FOURIER_FORM_TOL:
-        raise NotImplementedError("signal_S is not of the form F^H diag(ps/N^2) F")
     T = vis.shape[0]
     gb = GibbsBatch(vis[None], np.asarray(flags)[None], fgmodes, _ninv_diag(Ninv, 1, T, N), ps_prior, 1,
                     map_estimate=map_estimate, tables=draw_tables(T, N, 1, None, reseed=False))
     try:
-        out = gb.run(1, ps0=ps0[None], keep=("signal_cr", "fg_amps", "chisq"))
+        if resid > FOURIER_FORM_TOL:
+            out = gb.run(1, shp0=sqrt_cov_delay_basis(np.asarray(signal_S))[None],
+                         keep=("signal_cr", "fg_amps", "chisq"))
+        else:
+            out = gb.run(1, ps0=ps0[None], keep=("signal_cr", "fg_amps", "chisq"))
     finally:
         gb.close()
     ps_sample = out["signal_ps"][0, 0].cpu().numpy()
@@ -418,9 +486,7 @@ def gibbs_sample_with_fg(vis, flags, S_initial, fgmodes, Ninv, ps_prior, Niter=1
         assert np.shape(Ninv)[0] == Ntimes, \
             "Ninv shape must be (Ntimes, Nfreqs, Nfreqs) or (Nfreqs, Nfreqs)"
     ps0, resid = pspec_from_covariance(np.asarray(S_initial))
-    if resid > FOURIER_FORM_TOL:
-        raise NotImplementedError("S_initial is not of the form F^H diag(ps/N^2) F "
-                                  f"(relative off-diagonal power {resid:.2e})")
+    shp0 = sqrt_cov_delay_basis(np.asarray(S_initial))[None] if resid > FOURIER_FORM_TOL else None
     fop = utils.fourier_operator(Nfreqs)
     gb = GibbsBatch(vis[None], flags[None], fgmodes, _ninv_diag(Ninv, 1, Ntimes, Nfreqs), ps_prior,
                     Niter, seed=seed, map_estimate=map_estimate)
@@ -440,8 +506,11 @@ def gibbs_sample_with_fg(vis, flags, S_initial, fgmodes, Ninv, ps_prior, Niter=1
         while done < Niter:
             n = min(chunk - done % chunk, Niter - done)
             t0 = time.perf_counter()
-            out = gb.run(n, ps0=ps0[None] if done == 0 else None,
-                         keep=("signal_cr", "fg_amps", "chisq"))
+            if done == 0 and shp0 is not None:
+                out = gb.run(n, shp0=shp0, keep=("signal_cr", "fg_amps", "chisq"))
+            else:
+                out = gb.run(n, ps0=ps0[None] if done == 0 else None,
+                             keep=("signal_cr", "fg_amps", "chisq"))
             sl = slice(done, done + n)
             signal_cr[sl] = out["signal_cr"][0].cpu().numpy()
             signal_ps[sl] = out["signal_ps"][0].cpu().numpy()

@@ -1,0 +1,285 @@
+#!/usr/bin/env python3
+"""Driver for the MI355X Gibbs path with the reference driver's call surface.
+
+Counterpart of the reference's ``run-hydra-pspec.py`` for the hot path only
+(SURVEY 8b "driver counterpart"): same flag / YAML key names and defaults
+(reference run-hydra-pspec.py:39-239), same per-baseline prior construction
+(:509-517), ``w = ~flags`` and the any-time-flagged channel mask (:493, :531-535),
+same output tree ``<out_dir>/<dirname>/<ant1>-<ant2>/{gcr-eor,cov-eor,dps-eor,
+fg-amps,chisq,ln-post}.npy`` (:498-502, utils.py:307-312) and ``timings.json`` keys
+(:570-581).  What differs, on purpose:
+
+* no MPI: one process per GPU (``torchrun`` / RANK, WORLD_SIZE, LOCAL_RANK); baselines
+  are split over ranks with the reference's block rule (:268-287) and every rank reads
+  only its own block -- no scatter/gather;
+* all baselines of a rank run as ONE batch on the GPU;
+* inputs: ``.npy``/``.npz`` visibility cubes (``--file_paths cube.npy`` with shape
+  (Nbl,Ntimes,Nfreqs), optional ``antpairs.npy``), or ``--synthetic Nbl,Ntimes,Nfreqs``;
+  UVH5 files are read directly with h5py when it is installed (no pyuvdata).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+from resource import RUSAGE_SELF, getrusage
+
+import numpy as np
+import yaml
+
+REPO = Path(__file__).resolve().parent
+sys.path.insert(0, str(REPO))
+
+
+def build_parser():
+    p = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
+    p.add_argument("--config", type=str, help="YAML file whose keys are the flag names below")
+    p.add_argument("--file_paths", type=str, nargs="+", help=".npy/.npz cube(s) or UVH5 file(s)")
+    p.add_argument("--synthetic", type=str, help="Nbl,Ntimes,Nfreqs: synthetic inputs (SURVEY 8d recipe)")
+    p.add_argument("--ant_str", type=str, default="cross")
+    p.add_argument("--sigcov0", type=str)
+    p.add_argument("--sigcov0_file", type=str)
+    p.add_argument("--Nfgmodes", type=int, default=8)
+    p.add_argument("--fgmodes", type=str)
+    p.add_argument("--fgmodes_file", type=str)
+    p.add_argument("--freq_range", type=str)
+    p.add_argument("--flags", type=str)
+    p.add_argument("--flags_file", type=str)
+    p.add_argument("--noise", type=str)
+    p.add_argument("--noise_file", type=str)
+    p.add_argument("--noise_cov", type=str)
+    p.add_argument("--noise_cov_file", type=str)
+    p.add_argument("--nsamples", type=str)
+    p.add_argument("--nsamples_file", type=str)
+    p.add_argument("--n_ps_prior_bins", type=int, default=3)
+    p.add_argument("--ps_prior_lo", type=float, default=0.0)
+    p.add_argument("--ps_prior_hi", type=float, default=0.0)
+    p.add_argument("--map_estimate", action="store_true")
+    p.add_argument("--Niter", type=int, default=100)
+    p.add_argument("--seed", type=int, default=None)
+    p.add_argument("-v", "--verbose", action="store_true")
+    p.add_argument("--Nproc", type=int, default=1, help="accepted and ignored")
+    p.add_argument("--out_dir", type=str, default="./")
+    p.add_argument("--dirname", type=str, default=None)
+    p.add_argument("--clobber", action="store_true")
+    p.add_argument("--write_Niter", type=int, default=100)
+    p.add_argument("--outputs", type=str, default="all",
+                   help="'all' (the six reference files) or 'ps' (dps-eor.npy and ln-post.npy only)")
+    return p
+
+
+def parse_args(argv=None):
+    parser = build_parser()
+    args = parser.parse_args(argv)
+    if args.config:
+        with open(args.config) as f:
+            cfg = yaml.safe_load(f) or {}
+        known = {a.dest for a in parser._actions}
+        for k, v in cfg.items():
+            if k == "Nproc":
+                k = "Nproc"
+            if k not in known:
+                raise SystemExit(f"unknown config key: {k}")
+            if getattr(args, k) == parser.get_default(k):
+                setattr(args, k, v)
+    return args
+
+
+def make_ps_prior(Nfreqs, n_bins, lo, hi):
+    """(2,Nfreqs) rows [hi, lo] on Nfreqs//2 +- n_bins (run-hydra-pspec.py:509-517)."""
+    pr = np.zeros((2, Nfreqs))
+    if lo != 0 or hi != 0:
+        sl = slice(Nfreqs // 2 - n_bins, Nfreqs // 2 + n_bins + 1)
+        pr[0, sl] = hi
+        pr[1, sl] = lo
+    return pr
+
+
+def any_time_unflagged(w):
+    """Channel mask: True where NO time sample is flagged (run-hydra-pspec.py:531-535);
+    ``w`` (Ntimes,Nfreqs) bool, True = good."""
+    return np.all(w, axis=0)
+
+
+def load_aux(path, file_name, bl_str):
+    """'file or directory' convention of the reference (:248-266): a directory means
+    ``<dir>/<ant1>-<ant2>/<file_name>``."""
+    fp = Path(path)
+    if fp.is_dir():
+        return np.load(fp / bl_str / file_name)
+    return np.load(fp)
+
+
+def read_uvh5_block(paths, lo, hi):
+    """Minimal UVH5 reader (h5py): pseudo-Stokes I = XX + YY per baseline
+    (utils.py:105-132), baselines in file order.  Returns (antpairs, vis (nbl,T,N), flags)."""
+    import h5py
+    assert len(paths) == 1, "one UVH5 file at a time"
+    with h5py.File(paths[0], "r") as f:
+        a1, a2 = f["Header/ant_1_array"][:], f["Header/ant_2_array"][:]
+        pol = list(f["Header/polarization_array"][:])
+        pairs = sorted(set(zip(a1.tolist(), a2.tolist())))
+        out_v, out_f, out_p = [], [], []
+        for (i, j) in pairs[lo:hi]:
+            sel = np.nonzero((a1 == i) & (a2 == j))[0]
+            v = f["Data/visdata"][sel]
+            fl = f["Data/flags"][sel]
+            out_v.append(v[:, :, pol.index(-5)] + v[:, :, pol.index(-6)])
+            out_f.append(fl[:, :, pol.index(-5)])
+            out_p.append((i, j))
+    return out_p, np.array(out_v), np.array(out_f), len(pairs)
+
+
+def main(argv=None):
+    args = parse_args(argv)
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    t_start = time.perf_counter()
+
+    from hydra_pspec_amd import pspec, synthetic, utils
+    from hydra_pspec_amd.sharding import block_range
+
+    # ---- inputs of this rank's block --------------------------------------------------
+    if args.synthetic:
+        nbl_all, T, N = (int(v) for v in args.synthetic.split(","))
+        lo, hi = block_range(nbl_all, world, rank)
+        d = synthetic.make_baselines(N, T, args.Nfgmodes, k0=lo, nbl=hi - lo, dense=False)
+        vis, flags_td = d["vis"], np.broadcast_to(~d["flags"][:, None, :], d["vis"].shape)
+        antpairs = [(0, k + 1) for k in range(lo, hi)]
+        default_fg, default_ps0, default_ninv = d["fgmodes"], d["ps0"], d["ninv_diag"]
+    else:
+        if not args.file_paths:
+            raise SystemExit("Must pass file(s) to analyze via --file_paths.  Exiting.")
+        fp = Path(args.file_paths[0])
+        if fp.suffix in (".npy", ".npz"):
+            cube = np.load(fp)
+            if fp.suffix == ".npz":
+                vis_all = cube["vis"]
+                pairs_all = [tuple(p) for p in cube["antpairs"]] if "antpairs" in cube else None
+                flags_all = cube["flags"] if "flags" in cube else None
+            else:
+                vis_all, pairs_all, flags_all = cube, None, None
+            nbl_all = vis_all.shape[0]
+            lo, hi = block_range(nbl_all, world, rank)
+            vis = np.array(vis_all[lo:hi], dtype=complex)
+            flags_td = np.zeros(vis.shape, bool) if flags_all is None else np.array(flags_all[lo:hi], bool)
+            antpairs = pairs_all[lo:hi] if pairs_all else [(0, k + 1) for k in range(lo, hi)]
+        else:
+            _, _, _, nbl_all = read_uvh5_block([str(fp)], 0, 0)
+            lo, hi = block_range(nbl_all, world, rank)
+            antpairs, vis, flags_td, _ = read_uvh5_block([str(fp)], lo, hi)
+        T, N = vis.shape[1:]
+        default_fg = default_ps0 = default_ninv = None
+    nbl = vis.shape[0]
+    t_load = time.perf_counter() - t_start
+
+    # ---- per-baseline auxiliary inputs (reference :379-460) ----------------------------
+    ps0 = np.empty((nbl, N))
+    S_general = None
+    ninv = np.empty((nbl, N))
+    fg = None
+    flags_any = np.empty((nbl, N), bool)
+    for b, ap in enumerate(antpairs):
+        bl = f"{ap[0]}-{ap[1]}"
+        if args.flags:
+            fl = load_aux(args.flags, args.flags_file, bl).astype(bool)
+            assert fl.shape == vis[b].shape, "flags array does not match the per-baseline data"
+        else:
+            fl = flags_td[b]
+        flags_any[b] = any_time_unflagged(~fl)
+        if args.noise:
+            noise = load_aux(args.noise, args.noise_file, bl)
+            if args.nsamples:
+                noise = noise / np.sqrt(load_aux(args.nsamples, args.nsamples_file, bl))
+            vis[b] = vis[b] + noise                                   # :415
+        if args.sigcov0:
+            S0 = load_aux(args.sigcov0, args.sigcov0_file, bl)
+            p0, resid = pspec.pspec_from_covariance(S0)
+            if resid > pspec.FOURIER_FORM_TOL:
+                if S_general is None:
+                    S_general = np.zeros((nbl, N, N), dtype=complex)
+                S_general[b] = S0
+            ps0[b] = p0
+        else:
+            ps0[b] = default_ps0 if default_ps0 is not None else float(N)   # sigcov0 = eye(N) (:425)
+        if args.noise_cov:
+            ninv[b] = np.diag(np.linalg.inv(load_aux(args.noise_cov, args.noise_cov_file, bl))).real
+        else:
+            ninv[b] = default_ninv[b] if default_ninv is not None else 1.0 / 10.0 ** 2   # :438
+        if args.fgmodes:
+            f_b = load_aux(args.fgmodes, args.fgmodes_file or "fgmodes.npy", bl)[:, :args.Nfgmodes]
+        elif default_fg is not None:
+            f_b = default_fg
+        else:   # Legendre polynomials (:456-460)
+            import scipy.special
+            f_b = np.array([scipy.special.legendre(i)(np.linspace(-1., 1., N))
+                            for i in range(args.Nfgmodes)]).T
+        if fg is None:
+            fg = np.empty((nbl,) + f_b.shape, dtype=complex)
+        fg[b] = f_b
+    ps_prior = make_ps_prior(N, args.n_ps_prior_bins, args.ps_prior_lo, args.ps_prior_hi)
+
+    # ---- output tree ---------------------------------------------------------------------
+    out_dir = Path(args.out_dir)
+    dirname = args.dirname or f"results-seed-{args.seed}-Niter-{args.Niter}"
+    results = out_dir / dirname
+    if rank == 0:
+        results.mkdir(parents=True, exist_ok=True)
+        with open(results / "args.json", "w") as f:
+            json.dump(vars(args), f, indent=2)
+
+    # ---- sampling -----------------------------------------------------------------------
+    import torch
+    torch.cuda.set_device(local_rank)
+    keep = ("signal_cr", "fg_amps", "chisq") if args.outputs == "all" else ()
+    t0 = time.perf_counter()
+    if S_general is not None and np.any(np.abs(S_general).sum(axis=(1, 2)) == 0):
+        raise SystemExit("mixing Fourier-form and general sigcov0 across baselines is not supported")
+    out = pspec.gibbs_sample_with_fg_batched(
+        vis, flags_any, fg, ninv, ps_prior,
+        S_initial=S_general, ps_initial=None if S_general is not None else ps0,
+        Niter=args.Niter, seed=args.seed, map_estimate=args.map_estimate, keep=keep)
+    t_process = time.perf_counter() - t0
+
+    write_times, ant_strs = [], []
+    fop = utils.fourier_operator(N)
+    for b, ap in enumerate(antpairs):
+        bdir = results / f"{ap[0]}-{ap[1]}"
+        bdir.mkdir(parents=True, exist_ok=True)
+        tw = time.perf_counter()
+        np.save(bdir / "dps-eor.npy", out["signal_ps"][b])
+        np.save(bdir / "ln-post.npy", out["ln_post"][b])
+        if args.outputs == "all":
+            S_last = pspec.covariance_from_pspec(out["signal_ps"][b, -1] / N ** 2, fop)
+            niter = out["signal_ps"].shape[1]
+            # the reference writes rows [:Niter] of the current (N,N) covariance when the last
+            # write is a periodic one, the full matrix otherwise (pspec.py:625-651)
+            cov = S_last[:niter] if niter % args.write_Niter == 0 else S_last
+            np.save(bdir / "gcr-eor.npy", out["signal_cr"][b])
+            np.save(bdir / "cov-eor.npy", cov)
+            np.save(bdir / "fg-amps.npy", out["fg_amps"][b])
+            np.save(bdir / "chisq.npy", out["chisq"][b])
+        write_times.append(time.perf_counter() - tw)
+        ant_strs.append(f"{ap[0]}_{ap[1]}")
+
+    if rank == 0:
+        total = time.perf_counter() - t_start
+        timings = {"num_ranks": world, "num_baselines": int(nbl_all),
+                   "rank_0_timers": {"load_data": t_load, "scatter": 0.0, "process": t_process,
+                                     "barrier": 0.0, "total": total},
+                   "write_data": [{"rank": rank, "ant_pairs": ant_strs, "write_times": write_times}]}
+        with open(results / "timings.json", "w") as f:
+            json.dump(timings, f, indent=2)
+        ru = getrusage(RUSAGE_SELF)
+        with open(results / "resources.json", "w") as f:
+            json.dump({"ru_maxrss": ru.ru_maxrss, "ru_utime": ru.ru_utime, "ru_stime": ru.ru_stime}, f, indent=2)
+        if args.verbose:
+            print(f"{nbl_all} baselines x {args.Niter} iterations: process {t_process:.2f} s "
+                  f"({nbl * args.Niter / t_process:.1f} baseline*iter/s on this rank)")
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

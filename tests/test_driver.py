@@ -1,0 +1,97 @@
+"""run-hydra-pspec.py counterpart: argument surface / host logic on CPU, end-to-end on the GPU."""
+import importlib.util
+import json
+from pathlib import Path
+
+import numpy as np
+import pytest
+import yaml
+
+from conftest import REPO
+
+
+def _driver():
+    spec = importlib.util.spec_from_file_location("run_hydra_pspec", REPO / "run-hydra-pspec.py")
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_flag_names_and_defaults_match_reference():
+    drv = _driver()
+    a = drv.parse_args(["--file_paths", "x.npy"])
+    # reference defaults: run-hydra-pspec.py:40-234
+    assert (a.ant_str, a.Nfgmodes, a.n_ps_prior_bins, a.ps_prior_lo, a.ps_prior_hi) == ("cross", 8, 3, 0.0, 0.0)
+    assert (a.Niter, a.seed, a.Nproc, a.out_dir, a.write_Niter, a.clobber, a.map_estimate) == \
+        (100, None, 1, "./", 100, False, False)
+    for k in ("sigcov0", "sigcov0_file", "fgmodes", "fgmodes_file", "freq_range", "flags", "flags_file", "noise",
+              "noise_file", "noise_cov", "noise_cov_file", "nsamples", "nsamples_file", "dirname", "verbose"):
+        assert hasattr(a, k)
+
+
+def test_config_file_keys(tmp_path):
+    drv = _driver()
+    cfg = dict(ant_str="0_1", seed=7123689, Niter=1000, Nproc=2, verbose=True, ps_prior_lo=0.1, ps_prior_hi=2,
+               n_ps_prior_bins=3, dirname="results-x", clobber=False, sigcov0="./eor-cov.npy", Nfgmodes=12,
+               fgmodes="./fgmodes.npy", noise="./noise.npy", noise_cov="./noise-cov.npy",
+               file_paths=["./vis.npy"])          # the keys of test_data/config.yaml
+    (tmp_path / "c.yaml").write_text(yaml.safe_dump(cfg))
+    a = drv.parse_args(["--config", str(tmp_path / "c.yaml"), "--Niter", "200"])
+    assert a.Niter == 200 and a.seed == 7123689 and a.Nfgmodes == 12 and a.ps_prior_hi == 2
+    assert a.file_paths == ["./vis.npy"]
+    (tmp_path / "bad.yaml").write_text("not_a_key: 1\n")
+    with pytest.raises(SystemExit):
+        drv.parse_args(["--config", str(tmp_path / "bad.yaml")])
+
+
+def test_prior_and_flag_reduction():
+    drv = _driver()
+    pr = drv.make_ps_prior(120, 3, 0.1, 2.0)
+    assert pr[0, 57:64].tolist() == [2.0] * 7 and pr[1, 57:64].tolist() == [0.1] * 7 and pr[:, :57].sum() == 0
+    assert drv.make_ps_prior(120, 3, 0.0, 0.0).sum() == 0
+    w = np.ones((5, 6), bool)
+    w[2, 4] = False
+    assert drv.any_time_unflagged(w).tolist() == [True, True, True, True, False, True]
+
+
+@pytest.mark.gpu
+def test_driver_end_to_end_config1(golden, tmp_path):
+    """test_data-like directory layout through the driver: same chain as the reference."""
+    drv = _driver()
+    g = golden("chain_testdata")
+    aux = tmp_path / "aux" / "0-1"
+    aux.mkdir(parents=True)
+    np.save(aux / "eor-cov.npy", g["S_initial"])
+    np.save(aux / "fgmodes.npy", np.pad(g["fgmodes"], ((0, 0), (0, 3))))      # extra modes are cut (:453)
+    np.save(aux / "noise-cov.npy", np.diag(1.0 / g["ninv_diag"]))
+    np.savez(tmp_path / "vis.npz", vis=g["vis"][None], antpairs=np.array([[0, 1]]))
+    rc = drv.main(["--file_paths", str(tmp_path / "vis.npz"), "--sigcov0", str(tmp_path / "aux"),
+                   "--sigcov0_file", "eor-cov.npy", "--fgmodes", str(tmp_path / "aux"), "--fgmodes_file",
+                   "fgmodes.npy", "--Nfgmodes", "12", "--noise_cov", str(tmp_path / "aux"), "--noise_cov_file",
+                   "noise-cov.npy", "--ps_prior_lo", "0.1", "--ps_prior_hi", "2", "--seed", "7123689",
+                   "--Niter", "20", "--out_dir", str(tmp_path), "--dirname", "res"])
+    assert rc == 0
+    bdir = tmp_path / "res" / "0-1"
+    ps = np.load(bdir / "dps-eor.npy")
+    assert ps.shape == (20, 120)
+    assert np.max(np.abs(ps / g["ref_ps"][:20] - 1)) < 1e-6
+    assert np.load(bdir / "gcr-eor.npy").shape == (20, 203, 120)
+    assert np.load(bdir / "fg-amps.npy").shape == (20, 203, 12)
+    assert np.load(bdir / "chisq.npy").shape == (20, 203, 120)
+    assert np.load(bdir / "ln-post.npy").shape == (20,)
+    assert np.load(bdir / "cov-eor.npy").shape == (120, 120)
+    t = json.loads((tmp_path / "res" / "timings.json").read_text())
+    assert set(t) == {"num_ranks", "num_baselines", "rank_0_timers", "write_data"}
+    assert set(t["rank_0_timers"]) == {"load_data", "scatter", "process", "barrier", "total"}
+    assert (tmp_path / "res" / "args.json").exists()
+
+
+@pytest.mark.gpu
+def test_driver_synthetic_batch(tmp_path):
+    drv = _driver()
+    rc = drv.main(["--synthetic", "3,8,32", "--Nfgmodes", "4", "--ps_prior_lo", "0.1", "--ps_prior_hi", "2",
+                   "--seed", "5", "--Niter", "4", "--out_dir", str(tmp_path), "--dirname", "r", "--outputs", "ps"])
+    assert rc == 0
+    for k in (1, 2, 3):
+        assert np.load(tmp_path / "r" / f"0-{k}" / "dps-eor.npy").shape == (4, 32)
+        assert not (tmp_path / "r" / f"0-{k}" / "gcr-eor.npy").exists()

@@ -20,7 +20,7 @@ def _step_case(g, name):
                 F=g[f"{name}_in_fgmodes"], Ninv=g[f"{name}_in_Ninv"], prior=g[f"{name}_in_prior"])
 
 
-@pytest.mark.parametrize("name", list("abcdefgi"))
+@pytest.mark.parametrize("name", list("abcdefghi"))
 def test_single_step_vs_reference(golden, name):
     """gibbs_step_fgmodes (pspec.py:377-490): same global RNG state, same inputs."""
     from hydra_pspec_amd import pspec
@@ -52,11 +52,20 @@ def test_single_step_vs_reference(golden, name):
     assert np.max(np.abs(ps / o[2] - 1)) < 1e-7 and relerr(cr, o[0]) < 1e-7
 
 
-def test_general_S_initial_rejected_loudly(golden):
+def test_general_S_initial_chain(golden):
+    """S_initial that is NOT F^H diag F (case h): the first iteration goes through
+    hpx_gibbs_step_general, the rest through the spectral path; compare a short chain with
+    the exact-solve oracle (same seed)."""
     from hydra_pspec_amd import pspec
+    from oracle import pspec_ref
     c = _step_case(golden("steps"), "h")
-    with pytest.raises(NotImplementedError):
-        pspec.gibbs_step_fgmodes(c["vis"] * c["flags"], c["flags"], c["S"], c["F"], c["Ninv"], c["prior"])
+    res = pspec.gibbs_sample_with_fg(c["vis"], c["flags"], c["S"], c["F"], c["Ninv"], c["prior"], Niter=4,
+                                     seed=11, verbose=False)
+    ref = pspec_ref.gibbs_sample_with_fg(c["vis"], c["flags"], c["S"], c["F"], c["Ninv"], c["prior"], Niter=4,
+                                         seed=11, solver="direct")
+    assert np.max(np.abs(res[2] / ref[2] - 1)) < RTOL
+    assert relerr(res[0], ref[0]) < RTOL and relerr(res[3], ref[3]) < RTOL
+    assert np.allclose(res[5], ref[5], rtol=2e-5)
 
 
 def test_map_estimate(golden):

@@ -1,0 +1,62 @@
+"""Checks at the BASELINE.json shapes (N = 512 / 1024, T = 32, M = 12) through properties that do
+not need a full-size reference chain, plus one short oracle comparison per shape."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(nbl, N, T=32, M=12, frac=0.0, niter=3, k0=0, **kw):
+    from hydra_pspec_amd import pspec, synthetic
+    d = synthetic.make_baselines(N, T, M, k0=k0, nbl=nbl, flag_frac=frac, dense=False)
+    out = pspec.gibbs_sample_with_fg_batched(d["vis"], d["flags"], d["fgmodes"], d["ninv_diag"], d["ps_prior"],
+                                             ps_initial=d["ps0"], Niter=niter, seed=d["seed"], **kw)
+    return d, out
+
+
+@pytest.mark.parametrize("N,frac", [(512, 0.0), (1024, 0.15)])
+def test_batch_independence_and_determinism(N, frac):
+    """A baseline's chain does not depend on what else is in the batch, nor on the run:
+    bit-identical P(k) alone, inside a batch, and across two runs."""
+    d, big = _run(24, N, frac=frac, niter=3)
+    _, again = _run(24, N, frac=frac, niter=3)
+    assert np.array_equal(big["signal_ps"], again["signal_ps"])
+    assert np.array_equal(big["ln_post"], again["ln_post"])
+    _, one = _run(1, N, frac=frac, niter=3, k0=17)
+    assert np.array_equal(one["signal_ps"][0], big["signal_ps"][17])
+
+
+@pytest.mark.parametrize("N,frac", [(256, 0.0), (512, 0.0), (1024, 0.15)])
+def test_short_chain_vs_oracle(N, frac):
+    """2 iterations of one baseline at full channel count against the exact-solve oracle."""
+    from hydra_pspec_amd import synthetic
+    from oracle import pspec_ref
+    d, out = _run(2, N, frac=frac, niter=2, keep=("signal_cr", "fg_amps"))
+    dd = synthetic.make_baselines(N, 32, 12, k0=1, nbl=1, flag_frac=frac, dense=True)
+    assert np.array_equal(dd["vis"][0], d["vis"][1])
+    ref = pspec_ref.gibbs_sample_with_fg(dd["vis"][0], dd["flags"][0], dd["S_initial"], dd["fgmodes"], dd["Ninv"],
+                                         dd["ps_prior"], Niter=2, seed=dd["seed"], solver="direct")
+    dev = np.abs(out["signal_ps"][1] / ref[2] - 1)
+    print(f"N={N} flags={frac}: P(k) max rel dev vs exact-solve oracle {dev.max():.2e}")
+    assert dev.max() < 1e-6
+    assert np.max(np.abs(out["signal_cr"][1] - ref[0])) < 1e-6 * np.max(np.abs(ref[0]))
+    assert np.max(np.abs(out["fg_amps"][1] - ref[3])) < 1e-6 * np.max(np.abs(ref[3]))
+    assert np.allclose(out["ln_post"][1], ref[5], rtol=1e-6)
+
+
+def test_statistical_recovery_c2_shape():
+    """T3 at config C2's shape (Nfreq 256): after burn-in chi^2 ~ 1 and the posterior mean of
+    P(k) recovers the injected spectrum (mirrors test_data/plot-test-data-results.py:57-76)."""
+    from hydra_pspec_amd import synthetic
+    d, out = _run(16, 256, niter=120, keep=("chisq",), thin=10)
+    chi = out["chisq"][:, 3:]                     # kept iterations 30, 40, ...
+    assert abs(chi.mean() - 1.0) < 0.02
+    ps = out["signal_ps"][:, 30:]                 # (nbl, it, N)
+    ratio = np.median(ps, axis=1) / synthetic.true_pspec(256)[None, :]
+    # outside the foreground wedge (|k - N/2| > 12) the bandpowers are noise-free estimates with
+    # T - 1 = 31 degrees of freedom per baseline: the median over 16 baselines is within ~15 %
+    k = np.arange(256)
+    clean = np.abs(k - 128) > 12
+    med = np.median(ratio[:, clean], axis=0)
+    assert 0.8 < np.median(med) < 1.25
+    assert np.all(np.isfinite(out["ln_post"]))
