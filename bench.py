@@ -99,11 +99,18 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     import torch
     assert torch.cuda.is_available(), "bench.py needs a GPU"
-    torch.cuda.set_device(local_rank)
+    # rehearsal knobs (one-GPU box): HPX_BENCH_DEVICE pins every rank to one device and
+    # HPX_BENCH_BACKEND=gloo replaces RCCL for the timing barrier / max-reduction
+    dev_index = int(os.environ.get("HPX_BENCH_DEVICE", local_rank))
+    backend = os.environ.get("HPX_BENCH_BACKEND", "nccl")
+    torch.cuda.set_device(dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend)
 
     from hydra_pspec_amd import hpx, pspec, synthetic
     from hydra_pspec_amd.sharding import split_counts
@@ -136,7 +143,7 @@ def main():
     dt = time.perf_counter() - t0
     stage = gb.plan.stage_ms()
     if dist is not None:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
         dist.barrier()
@@ -147,6 +154,12 @@ def main():
         value = total_units / dt
         fac_ms = stage["factor"] / K                        # average k_factor launch (HIP events)
         fac_tflops = nbl * flops_factor(N, M, T) / (fac_ms * 1e-3) / 1e12
+        traffic = None
+        try:   # HBM bytes per k_factor launch from the committed PMC passes (profiles/), same workload
+            pm = json.load(open(REPO / "profiles" / "pmc_traffic.json"))[args.config]["k_factor<true>"]
+            traffic = pm["bytes_per_launch"] * nbl / pm["baselines"]
+        except Exception:
+            pass
         peak_meas = np.zeros(1)
         import ctypes
         hpx.check(hpx.lib().hpx_mfma_f64_peak(20000, peak_meas.ctypes.data_as(ctypes.c_void_p)))
@@ -162,7 +175,9 @@ def main():
                        "no collective"},
             "roofline": {"kernel": "k_factor (batched complex Cholesky + forward solve, FP64 MFMA)",
                          "bound": "mfma", "achieved": fac_tflops, "peak": FP64_MFMA_PEAK_TFLOPS,
-                         "unit": "TFLOP/s", "frac": fac_tflops / FP64_MFMA_PEAK_TFLOPS, "traffic": None,
+                         "unit": "TFLOP/s", "frac": fac_tflops / FP64_MFMA_PEAK_TFLOPS, "traffic": traffic,
+                         "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, (2*FETCH+WRITE)*1024 "
+                                           "(profiles/r01_pmc_c3.txt)" if traffic else None,
                          "peak_measured": float(peak_meas[0]),
                          "avg_launch_ms": fac_ms, "flops_per_unit": flops_factor(N, M, T),
                          "units_per_launch": nbl,
