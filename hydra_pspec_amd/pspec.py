@@ -284,7 +284,7 @@ class GibbsBatch:
 def gibbs_sample_with_fg_batched(vis, flags, fgmodes, Ninv, ps_prior, S_initial=None,
                                  ps_initial=None, Niter=100, seed=None, map_estimate=False,
                                  keep=("ps", "ln_post"), thin=1, ps_forced=None, device=None,
-                                 as_numpy=True):
+                                 as_numpy=True, iter0=0):
     """Run the Gibbs chain of ``gibbs_sample_with_fg`` for ``Nbl`` baselines at once.
 
     Parameters mirror the reference (pspec.py:493-571) with a leading baseline
@@ -298,7 +298,12 @@ def gibbs_sample_with_fg_batched(vis, flags, fgmodes, Ninv, ps_prior, S_initial=
 
     Returns a dict: ``signal_ps`` (Nbl,Niter,Nfreqs), ``ln_post`` (Nbl,Niter),
     ``ps_last`` and the histories named in ``keep`` (``"signal_cr"``,
-    ``"fg_amps"``, ``"chisq"``; every ``thin``-th iteration)."""
+    ``"fg_amps"``, ``"chisq"``; every ``thin``-th iteration).
+
+    ``iter0 > 0`` continues interrupted chains: ``ps_initial`` must then be the bandpowers of
+    iteration ``iter0 - 1`` and only iterations ``iter0 .. Niter-1`` are run and returned (the
+    random tables are generated for all ``Niter`` iterations, so the samples are those of an
+    uninterrupted run)."""
     nbl, T, N = tuple(vis.shape)
     shp0 = None
     if ps_initial is None:
@@ -313,10 +318,13 @@ def gibbs_sample_with_fg_batched(vis, flags, fgmodes, Ninv, ps_prior, S_initial=
                     map_estimate=map_estimate, device=device)
     try:
         if shp0 is not None:
+            assert iter0 == 0, "a general S_initial cannot be combined with iter0 > 0"
             out = gb.run(gb.Niter, shp0=shp0, ps_forced=ps_forced, keep=keep, thin=thin)
         else:
             ps0 = np.ascontiguousarray(np.broadcast_to(np.asarray(ps_initial, dtype=float), (nbl, N)))
-            out = gb.run(gb.Niter, ps0=ps0, ps_forced=ps_forced, keep=keep, thin=thin)
+            assert 0 <= iter0 < gb.Niter
+            gb.iter_done = iter0
+            out = gb.run(gb.Niter - iter0, ps0=ps0, ps_forced=ps_forced, keep=keep, thin=thin)
     finally:
         gb.close()
     if as_numpy:
@@ -464,7 +472,8 @@ def gibbs_step_fgmodes(vis, flags, signal_S, fgmodes, Ninv, ps_prior=None, f0=No
 
 
 def gibbs_sample_with_fg(vis, flags, S_initial, fgmodes, Ninv, ps_prior, Niter=100, seed=None,
-                         verbose=True, nproc=1, write_Niter=100, out_dir=None, map_estimate=False):
+                         verbose=True, nproc=1, write_Niter=100, out_dir=None, map_estimate=False,
+                         resume=False):
     """Drop-in for the reference chain driver (pspec.py:493-658).
 
     Returns ``(signal_cr (Niter,Ntimes,Nfreqs) c128, signal_S (Nfreqs,Nfreqs)
@@ -472,7 +481,12 @@ def gibbs_sample_with_fg(vis, flags, S_initial, fgmodes, Ninv, ps_prior, Niter=1
     fg_amps (Niter,Ntimes,Nmodes) c128, chisq (Niter,Ntimes,Nfreqs), ln_post
     (Niter,), write_time)``.  ``nproc`` is accepted and ignored: the reference's
     results do not depend on it.  ``map_estimate=True`` forces ``Niter = 1`` and
-    does not reseed (pspec.py:572-577)."""
+    does not reseed (pspec.py:572-577).
+
+    ``resume=True`` (extension; the reference writes checkpoints but cannot read them back,
+    pspec.py:625-636): if ``out_dir`` holds the six sample files of an interrupted run of
+    the SAME inputs and seed with ``k < Niter`` iterations, the chain continues from
+    iteration ``k`` and produces exactly the samples an uninterrupted run would have."""
     vis = np.asarray(vis)
     flags = np.asarray(flags)
     if map_estimate:
@@ -502,6 +516,18 @@ def gibbs_sample_with_fg(vis, flags, S_initial, fgmodes, Ninv, ps_prior, Niter=1
     write_time = 0
     done = 0
     chunk = max(1, int(write_Niter)) if out_dir is not None else Niter
+    if resume and out_dir is not None and not map_estimate:
+        from pathlib import Path
+        od = Path(out_dir)
+        if all((od / f).exists() for f in utils.SAMPLE_FILES):
+            prev = [np.load(od / f) for f in utils.SAMPLE_FILES]
+            k = prev[2].shape[0]
+            if 0 < k < Niter and prev[0].shape == (k, Ntimes, Nfreqs) and prev[3].shape == (k, Ntimes, Nmodes):
+                signal_cr[:k], signal_ps[:k], fg_amps[:k], chisq[:k], ln_post[:k] = \
+                    prev[0], prev[2], prev[3], prev[4], prev[5]
+                gb.iter_done = done = k
+                ps0, shp0 = signal_ps[k - 1].copy(), None
+    resumed_at = done
     try:
         while done < Niter:
             n = min(chunk - done % chunk, Niter - done)
@@ -509,7 +535,7 @@ def gibbs_sample_with_fg(vis, flags, S_initial, fgmodes, Ninv, ps_prior, Niter=1
             if done == 0 and shp0 is not None:
                 out = gb.run(n, shp0=shp0, keep=("signal_cr", "fg_amps", "chisq"))
             else:
-                out = gb.run(n, ps0=ps0[None] if done == 0 else None,
+                out = gb.run(n, ps0=ps0[None] if done == resumed_at else None,
                              keep=("signal_cr", "fg_amps", "chisq"))
             sl = slice(done, done + n)
             signal_cr[sl] = out["signal_cr"][0].cpu().numpy()

@@ -64,6 +64,8 @@ def build_parser():
     p.add_argument("--dirname", type=str, default=None)
     p.add_argument("--clobber", action="store_true")
     p.add_argument("--write_Niter", type=int, default=100)
+    p.add_argument("--resume", action="store_true",
+                   help="continue interrupted chains from the dps-eor.npy found in the output tree")
     p.add_argument("--outputs", type=str, default="all",
                    help="'all' (the six reference files) or 'ps' (dps-eor.npy and ln-post.npy only)")
     return p
@@ -77,8 +79,6 @@ def parse_args(argv=None):
             cfg = yaml.safe_load(f) or {}
         known = {a.dest for a in parser._actions}
         for k, v in cfg.items():
-            if k == "Nproc":
-                k = "Nproc"
             if k not in known:
                 raise SystemExit(f"unknown config key: {k}")
             if getattr(args, k) == parser.get_default(k):
@@ -237,10 +237,36 @@ def main(argv=None):
     t0 = time.perf_counter()
     if S_general is not None and np.any(np.abs(S_general).sum(axis=(1, 2)) == 0):
         raise SystemExit("mixing Fourier-form and general sigcov0 across baselines is not supported")
+    # --resume: continue from the checkpoints in the output tree (all baselines of the rank must
+    # have been interrupted at the same iteration)
+    iter0, previous = 0, None
+    if args.resume:
+        previous = []
+        for ap in antpairs:
+            bdir = results / f"{ap[0]}-{ap[1]}"
+            names = ("dps-eor.npy", "ln-post.npy") + (("gcr-eor.npy", "fg-amps.npy", "chisq.npy")
+                                                       if args.outputs == "all" else ())
+            if not all((bdir / n).exists() for n in names):
+                previous = None
+                break
+            previous.append({n: np.load(bdir / n) for n in names})
+        if previous:
+            ks = {len(pv["dps-eor.npy"]) for pv in previous}
+            if len(ks) == 1 and 0 < next(iter(ks)) < args.Niter and S_general is None:
+                iter0 = next(iter(ks))
+                ps0 = np.stack([pv["dps-eor.npy"][-1] for pv in previous])
+            else:
+                previous = None
     out = pspec.gibbs_sample_with_fg_batched(
         vis, flags_any, fg, ninv, ps_prior,
         S_initial=S_general, ps_initial=None if S_general is not None else ps0,
-        Niter=args.Niter, seed=args.seed, map_estimate=args.map_estimate, keep=keep)
+        Niter=args.Niter, seed=args.seed, map_estimate=args.map_estimate, keep=keep, iter0=iter0)
+    if iter0:
+        key = {"signal_ps": "dps-eor.npy", "ln_post": "ln-post.npy", "signal_cr": "gcr-eor.npy",
+               "fg_amps": "fg-amps.npy", "chisq": "chisq.npy"}
+        for name, fn in key.items():
+            if name in out:
+                out[name] = np.concatenate([np.stack([pv[fn] for pv in previous]), out[name]], axis=1)
     t_process = time.perf_counter() - t0
 
     write_times, ant_strs = [], []

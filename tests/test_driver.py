@@ -95,3 +95,16 @@ def test_driver_synthetic_batch(tmp_path):
     for k in (1, 2, 3):
         assert np.load(tmp_path / "r" / f"0-{k}" / "dps-eor.npy").shape == (4, 32)
         assert not (tmp_path / "r" / f"0-{k}" / "gcr-eor.npy").exists()
+
+
+@pytest.mark.gpu
+def test_driver_resume(tmp_path):
+    drv = _driver()
+    common = ["--synthetic", "2,8,32", "--Nfgmodes", "4", "--ps_prior_lo", "0.1", "--ps_prior_hi", "2", "--seed", "5",
+              "--out_dir", str(tmp_path)]
+    assert drv.main(common + ["--Niter", "6", "--dirname", "full"]) == 0
+    assert drv.main(common + ["--Niter", "3", "--dirname", "part"]) == 0
+    assert drv.main(common + ["--Niter", "6", "--dirname", "part", "--resume"]) == 0
+    for k in (1, 2):
+        for f in ("dps-eor.npy", "gcr-eor.npy", "ln-post.npy", "chisq.npy", "fg-amps.npy"):
+            assert np.array_equal(np.load(tmp_path / "part" / f"0-{k}" / f), np.load(tmp_path / "full" / f"0-{k}" / f))
