@@ -125,7 +125,7 @@ class Plan:
         self._keep = []
 
     def close(self):
-        if getattr(self, "_h", None) is not None and self._h:
+        if getattr(self, "_h", None) is not None and self._h and lib is not None:
             lib().hpx_plan_destroy(self._h)
             self._h = None
 

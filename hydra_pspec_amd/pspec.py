@@ -29,14 +29,16 @@ FOURIER_FORM_TOL = 1e-9     # relative off-diagonal power allowed in F S F^H
 
 
 # --------------------------------------------------------------------------- RNG
-def omega_table(T, N):
+def omega_table(T, N, idx=None, seed0=GCR_SEED0):
     """The reference's GCR noise draws: for time ``t`` the legacy stream seeded
     with ``912983 + t`` yields ``omi, omj, omk, oml = randn(N,1) x 4`` in that
     order (pspec.py:196-216).  Identical for every iteration and baseline.
+    ``idx`` selects explicit time indices (default ``range(T)``).
     Returns (T,4,N) float64."""
-    out = np.empty((T, 4, N))
-    for t in range(T):
-        out[t] = np.random.RandomState(GCR_SEED0 + t).randn(4, N)
+    idx = range(T) if idx is None else idx
+    out = np.empty((len(idx), 4, N))
+    for i, t in enumerate(idx):
+        out[i] = np.random.RandomState(seed0 + int(t)).randn(4, N)
     return out
 
 
@@ -139,7 +141,7 @@ class GibbsBatch:
     """
 
     def __init__(self, vis, flags, fgmodes, ninv_diag, ps_prior, Niter, seed=None,
-                 map_estimate=False, device=None, tables=None):
+                 map_estimate=False, device=None, tables=None, omega=None):
         torch = hpx.require_gpu()
         self.torch = torch
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None \
@@ -173,7 +175,10 @@ class GibbsBatch:
                 tables = draw_tables(T, N, self.Niter, seed, reseed=not map_estimate)
             uni, igy = tables
             assert uni.shape == (self.Niter, N) and igy.shape == (self.Niter, N)
-            d_omega = None if map_estimate else hpx.to_dev(torch, omega_table(T, N), f64, self.device)
+            if omega is None:
+                omega = omega_table(T, N)
+            assert tuple(omega.shape) == (T, 4, N)
+            d_omega = None if map_estimate else hpx.to_dev(torch, omega, f64, self.device)
             d_fop = hpx.to_dev(torch, utils.fourier_operator(N), c128, self.device)
             self.any_flags = bool((~fl_np.astype(bool)).any())
             self.plan = hpx.Plan(nbl, T, N, M)
@@ -333,6 +338,146 @@ def gibbs_sample_with_fg_batched(vis, flags, fgmodes, Ninv, ps_prior, S_initial=
 
 
 # ------------------------------------------------------- reference call surface
+class GcrMatrices(list):
+    """Return type of :func:`build_matrices`: indexes like the reference's two-element list
+    (``m[0]`` = (4,N,N) ``Sh, S, Ni, Nih``; ``m[1]`` = (2,n,n) ``A, Ai``) and also carries the
+    inputs the device solver works from."""
+    flags = None
+    signal_S = None
+    ninv_diag = None
+    fgmodes = None
+
+
+def _gpu_herm_solve(K, B):
+    """X = K^-1 B for Hermitian positive definite K (n,n) and B (n,m), on the GPU
+    (batched Cholesky + triangular solves of hpx_factor.hip)."""
+    torch = hpx.require_gpu()
+    n, m = K.shape[0], B.shape[1]
+    dev = torch.device("cuda", torch.cuda.current_device())
+    dK = hpx.to_dev(torch, np.asarray(K, dtype=complex)[None], torch.complex128, dev)
+    dB = hpx.to_dev(torch, np.asarray(B, dtype=complex)[None], torch.complex128, dev)
+    dX = torch.empty((1, n, m), dtype=torch.complex128, device=dev)
+    info = torch.zeros(1, dtype=torch.int32, device=dev)
+    hpx.check(hpx.lib().hpx_zpotrs_batched(1, n, m, hpx.ptr(dK), hpx.ptr(dB), hpx.ptr(dX), hpx.ptr(info),
+                                           hpx.stream_ptr(torch)), "hpx_zpotrs_batched")
+    if int(info.item()) != 0:
+        raise np.linalg.LinAlgError("GCR system is not positive definite")
+    return dX[0].cpu().numpy()
+
+
+def build_matrices(Nparams, flags, signal_S, Ninv, fgmodes):
+    """The operators of the GCR system in the reference's layout (pspec.py:325-374):
+    ``[ (4,N,N) = Sh, S, Ni, Nih ; (2,Nparams,Nparams) = A, Ai ]``.
+
+    The sampler itself never forms these (it factorises the equivalent Hermitian system,
+    DESIGN.md section 2); this function exists for callers that inspect or reuse them.  ``Sh``
+    is the principal square root via a Hermitian eigendecomposition, ``Ni = Ninv * flags``
+    (column mask, as the reference) and ``Nih`` its element-wise root for the diagonal ``Ninv``
+    the path supports.  ``Ai`` -- the reference's ``pinv(A)`` preconditioner -- is the exact
+    inverse ``P K'^-1 P^-1`` with ``P = diag(Sh, I)`` and ``K'`` the Hermitian positive-definite
+    matrix the device factorises; it therefore needs a positive-definite ``signal_S``."""
+    S = np.asarray(signal_S, dtype=complex)
+    N = S.shape[0]
+    fl = np.asarray(flags)
+    F = np.asarray(fgmodes, dtype=complex)
+    M = F.shape[1]
+    assert Nparams == N + M, "Nparams must equal Nfreqs + Nmodes"
+    ninv = _ninv_diag(Ninv, 1, 1, N)[0]
+    ops = np.zeros((4, N, N), dtype=complex)
+    lam, V = np.linalg.eigh(0.5 * (S + S.conj().T))
+    if lam.min() <= 1e-14 * lam.max():
+        raise np.linalg.LinAlgError("build_matrices needs a positive-definite signal_S")
+    ops[0] = (V * np.sqrt(lam)) @ V.conj().T
+    ops[1] = S
+    ni = ninv * fl
+    ops[2] = np.diag(ni)
+    ops[3] = np.diag(np.sqrt(ni))
+    sys_ = np.zeros((2, Nparams, Nparams), dtype=complex)
+    A = sys_[0]
+    A[:N, :N] = np.eye(N) + S * ni[None, :]
+    A[:N, N:] = (S * ni[None, :]) @ F
+    A[N:, :N] = F.conj().T * ni[None, :]
+    A[N:, N:] = (F.conj().T * ni[None, :]) @ F
+    # Ai = P K'^-1 P^-1,  K' = [[I + Sh Ni Sh, Sh Ni F], [F^H Ni Sh, F^H Ni F]]
+    Sh = ops[0]
+    Kp = np.empty_like(A)
+    Kp[:N, :N] = np.eye(N) + (Sh * ni[None, :]) @ Sh
+    Kp[:N, N:] = (Sh * ni[None, :]) @ F
+    Kp[N:, :N] = Kp[:N, N:].conj().T
+    Kp[N:, N:] = A[N:, N:]
+    Pinv = np.eye(Nparams, dtype=complex)
+    Pinv[:N, :N] = (V / np.sqrt(lam)) @ V.conj().T
+    X = _gpu_herm_solve(Kp, Pinv)
+    X[:N] = Sh @ X[:N]
+    sys_[1] = X
+    out = GcrMatrices([ops, sys_])
+    out.flags, out.signal_S, out.ninv_diag, out.fgmodes = fl, S, ninv, F
+    return out
+
+
+def _gcr_solve(vis2d, w, matrices, fgmodes, map_estimate, idx):
+    """Constrained realisations [s_t ; f_t] for the rows of ``vis2d`` on the GPU, with the
+    reference's per-time noise streams for time indices ``idx``."""
+    vis2d = np.asarray(vis2d, dtype=complex)
+    if vis2d.shape[0] == 1:      # a plan holds at least two times (the draw's shape is Ntimes - 1)
+        idx = [0] if idx is None else idx
+        return _gcr_solve(np.repeat(vis2d, 2, axis=0), w, matrices, fgmodes, map_estimate,
+                          [idx[0], idx[0]])[:1]
+    T, N = vis2d.shape
+    F = np.asarray(fgmodes, dtype=complex)
+    M = F.shape[1]
+    S = np.asarray(matrices[0][1])
+    ni = np.real(np.diagonal(np.asarray(matrices[0][2])))          # already column-masked
+    if np.abs(np.asarray(matrices[0][2]) - np.diag(np.diagonal(matrices[0][2]))).max() > 0:
+        raise NotImplementedError("only diagonal inverse noise covariances are supported")
+    fl = np.asarray(w).reshape(-1).astype(bool)
+    ps0, resid = pspec_from_covariance(S)
+    tables = (np.full((1, N), 0.5), np.ones((1, N)))     # the bandpower draw's output is discarded
+    gb = GibbsBatch(vis2d[None], fl[None], F, np.ascontiguousarray(ni)[None], np.zeros((2, N)), 1,
+                    map_estimate=map_estimate, tables=tables, omega=omega_table(T, N, idx=idx))
+    try:
+        if resid > FOURIER_FORM_TOL:
+            out = gb.run(1, shp0=sqrt_cov_delay_basis(S)[None], keep=("signal_cr", "fg_amps"))
+        else:
+            out = gb.run(1, ps0=ps0[None], keep=("signal_cr", "fg_amps"))
+    finally:
+        gb.close()
+    return np.concatenate([out["signal_cr"][0, 0].cpu().numpy(), out["fg_amps"][0, 0].cpu().numpy()], axis=1)
+
+
+def gcr_fgmodes_1d(idx, vis, w, matrices, fgmodes, f0=None, map_estimate=False, verbose=False,
+                   multiprocess_seed=GCR_SEED0):
+    """GCR step for one time sample (reference pspec.py:151-235): returns
+    ``(xsoln (Nfreqs+Nmodes,), residual, info)``.  The noise realisation is the reference's
+    (stream seeded with ``multiprocess_seed + idx``); the system is solved directly on the GPU,
+    so ``f0`` is accepted and ignored and ``info`` is always 0.  ``residual`` (verbose only) is
+    the mean absolute residual of the reference's own system ``A x = b``."""
+    F = np.asarray(fgmodes)
+    N = F.shape[0]
+    d = np.asarray(vis).reshape(1, N)
+    if multiprocess_seed != GCR_SEED0:
+        raise NotImplementedError("the reference never overrides multiprocess_seed (pspec.py:289-298)")
+    x = _gcr_solve(d, w, matrices, fgmodes, map_estimate, [idx])[0]
+    residual = None
+    if verbose:
+        Sh, S, Ni, Nih, A = matrices[0][0], matrices[0][1], matrices[0][2], matrices[0][3], matrices[1][0]
+        o = np.zeros((4, N)) if map_estimate else omega_table(1, N, idx=[idx])[0]
+        oma, omb = (o[0] + 1j * o[1]) / 2 ** 0.5, (o[2] + 1j * o[3]) / 2 ** 0.5
+        wd = (np.asarray(w).reshape(-1) * d[0])
+        b = np.concatenate([S @ (Ni @ wd) + Sh @ oma + S @ (Nih @ omb),
+                            F.conj().T @ (Ni @ wd + Nih @ omb)])
+        residual = np.abs(A @ x - b).mean()
+    return x, residual, 0
+
+
+def gcr_fgmodes(vis, w, matrices, fgmodes, f0=None, nproc=1, map_estimate=False, verbose=False):
+    """GCR step for all time samples of one baseline (reference pspec.py:238-310): returns
+    samples of shape ``(Ntimes, Nfreqs + Nmodes)`` = rows ``[s_t ; f_t]``.  All times are
+    solved in one batched GPU call; ``nproc`` and ``f0`` are accepted and ignored."""
+    vis = np.asarray(vis)
+    return _gcr_solve(vis, w, matrices, fgmodes, map_estimate, None)
+
+
 def covariance_from_pspec(ps, fourier_op):
     """``fourier_op^H diag(ps) fourier_op`` (reference pspec.py:313-322), computed
     with the batched DFT kernel: row j of ``(F * ps)`` is transformed by F^H."""

@@ -232,3 +232,35 @@ def test_resume_from_checkpoint(golden, tmp_path):
     for a, b in zip(res[:6], full[:6]):
         assert np.array_equal(a, b)
     assert np.load(tmp_path / "dps-eor.npy").shape == (9, 64)
+
+
+@pytest.mark.parametrize("tag", ["nf", "fl"])
+def test_build_matrices_and_gcr_vs_reference(golden, tag):
+    """build_matrices (pspec.py:325-374), gcr_fgmodes_1d (:151-235), gcr_fgmodes (:238-310):
+    fixtures F6/F7, N=16, M=3, with and without flags."""
+    from hydra_pspec_amd import pspec
+    g = golden("small")
+    vis, fl = g[f"F6_{tag}_vis"], g[f"F6_{tag}_flags"]
+    S, Ninv, F = g[f"F6_{tag}_S_initial"], g[f"F6_{tag}_Ninv"], g[f"F6_{tag}_fgmodes"]
+    mats = pspec.build_matrices(19, fl, S, Ninv, F)
+    ops, sys_ = g[f"F6_{tag}_ops"], g[f"F6_{tag}_sys"]
+    assert mats[0].shape == ops.shape and mats[1].shape == sys_.shape
+    for k in range(4):
+        assert relerr(mats[0][k], ops[k]) < 1e-9
+    assert relerr(mats[1][0], sys_[0]) < 1e-12
+    # the reference's Ai is pinv(A) through an SVD; ours is the exact inverse via the Cholesky path
+    assert relerr(mats[1][1], sys_[1]) < 1e-7
+    assert relerr(mats[1][1] @ mats[1][0], np.eye(19)) < 1e-9
+    xs = g[f"F7_{tag}_x"]
+    for j, idx in enumerate((0, 3)):
+        x, res, info = pspec.gcr_fgmodes_1d(idx, (vis * fl)[idx], fl, mats, F, verbose=True)
+        assert info == 0 and x.shape == (19,)
+        assert relerr(x, xs[j]) < RTOL
+        assert res < 1e-8 * np.abs(x).max() * np.abs(sys_[0]).max()
+    x, res, _ = pspec.gcr_fgmodes_1d(1, (vis * fl)[1], fl, mats, F, map_estimate=True)
+    assert res is None
+    assert relerr(x, g[f"F7_{tag}_xmap"]) < RTOL
+    # all times at once; a plain list in the reference's layout works as well
+    smp = pspec.gcr_fgmodes(vis * fl, fl, [ops, sys_], F, nproc=3)
+    assert smp.shape == (vis.shape[0], 19)
+    assert relerr(smp[0], xs[0]) < RTOL and relerr(smp[3], xs[1]) < RTOL

@@ -134,3 +134,31 @@ def test_synthetic_recipe_statistics():
     assert d["ps_prior"][0, 29:36].tolist() == [2.0] * 7 and d["ps_prior"][1, 29:36].tolist() == [0.1] * 7
     again = synthetic.make_baselines(64, 16, 6, k0=2, nbl=1, flag_frac=0.25)
     assert np.array_equal(again["vis"][0], d["vis"][2]) and np.array_equal(again["flags"][0], d["flags"][2])
+
+
+def test_reference_call_surface_is_importable():
+    """the reference's public names on the path exist under the same module names."""
+    import inspect
+    from hydra_pspec_amd import pspec, utils, dpss, oqe
+    sigs = {
+        "gibbs_sample_with_fg": ["vis", "flags", "S_initial", "fgmodes", "Ninv", "ps_prior", "Niter", "seed",
+                                 "verbose", "nproc", "write_Niter", "out_dir", "map_estimate"],
+        "gibbs_step_fgmodes": ["vis", "flags", "signal_S", "fgmodes", "Ninv", "ps_prior", "f0", "nproc",
+                               "map_estimate", "verbose"],
+        "build_matrices": ["Nparams", "flags", "signal_S", "Ninv", "fgmodes"],
+        "gcr_fgmodes": ["vis", "w", "matrices", "fgmodes", "f0", "nproc", "map_estimate", "verbose"],
+        "gcr_fgmodes_1d": ["idx", "vis", "w", "matrices", "fgmodes", "f0", "map_estimate", "verbose",
+                           "multiprocess_seed"],
+        "covariance_from_pspec": ["ps", "fourier_op"],
+        "sample_S": ["s", "sk", "prior"],
+        "inversion_sample_invgamma": ["alpha", "beta", "prior_min", "prior_max", "ngrid"],
+        "sprior": ["signals", "bins", "factor"],
+    }
+    for name, args in sigs.items():
+        got = list(inspect.signature(getattr(pspec, name)).parameters)
+        assert got[:len(args)] == args, (name, got)
+    for mod, names in ((utils, ["fourier_operator", "write_numpy_files"]), (dpss, ["dpss_fit_modes"]),
+                       (oqe, ["m", "Q", "F", "Ft", "M_opt", "M_Finv", "M_Fhalf", "qhat_h", "q_h", "bias",
+                              "qhat", "q", "p", "Sig_QEN", "Sig_QESN", "matc", "getqs"])):
+        for n in names:
+            assert callable(getattr(mod, n)), (mod.__name__, n)
