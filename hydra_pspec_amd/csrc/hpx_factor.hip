@@ -12,8 +12,8 @@
 //
 // Algorithm (left-looking by block columns of HPX_NB = 32):
 //   for each block column j:
-//     1. diagonal block  D = K[j,j] - sum_k L[j,k] L[j,k]^H   (MFMA, K split
-//        over the 4 waves, partials combined through LDS)
+//     1. diagonal block  D = K[j,j] - sum_k L[j,k] L[j,k]^H   (MFMA, one of its
+//        three lower 16x16 tiles per wave, written straight to LDS)
 //     2. D = Ljj Ljj^H and Ljj^-1 in LDS (fused right-looking elimination)
 //     3. every 16-row tile below:  X = (K[r,j] - sum_k L[r,k] L[j,k]^H) Ljj^-H
 //        computed TRANSPOSED so that the accumulator tile is directly the
@@ -30,6 +30,16 @@
 #define HPX_RT3 1
 #endif
 #define HPX_INL __forceinline__
+#ifndef HPX_WGS
+#define HPX_WGS 2          // workgroups per CU the register budget is set for
+#endif
+// Out-of-line functions get the full 256-VGPR budget whatever the kernel's launch bounds say
+// (the occupancy attribute is kernel-only), so a 3-workgroup build has to inline them.
+#if HPX_WGS > 2
+#define HPX_OUTLINE __forceinline__
+#else
+#define HPX_OUTLINE __noinline__
+#endif
 #if HPX_DIAG & 1
 #define HPX_LD(base, off) (1e-3 * (double)((off) & 7))
 #else
@@ -65,11 +75,22 @@ namespace {
 constexpr int WLD = HPX_WLD;
 
 struct FactorShared {
-  double slab[3][2][4][64];      // K-split partial sums of the diagonal tiles (12 KB)
   double strip[2][4][16];        // published column / row of the 16x16 elimination
   double piv[32];                // pivots d_k
   double Dre[32 * WLD], Dim[32 * WLD];   // diagonal block (lower), row-major [r][c]
   double Yre[32 * WLD], Yim[32 * WLD];   // running inverse; finally W = conj(Ljj^-1)
+};
+
+// Pointers handed to the out-of-line functions carry their address space: a plain `double*`
+// argument is a generic pointer there, and hipcc then emits FLAT loads/stores for the LDS
+// traffic of the elimination (several hundred cycles per round trip instead of ~64, and every
+// wait becomes vmcnt(0)+lgkmcnt(0)).
+typedef __attribute__((address_space(3))) FactorShared lds_FactorShared;
+typedef __attribute__((address_space(3))) double lds_f64;
+typedef __attribute__((address_space(1))) double glb_f64;
+struct gen_signal {             // the part of hpx_gen the diagonal block needs (by value)
+  const glb_f64 *a, *cre, *cim;
+  int rmin;
 };
 
 // RT off-diagonal 16-row tiles (rows r0 + i*rstride) of block column (c0, CT*16 wide),
@@ -203,7 +224,7 @@ __device__ HPX_INL void offdiag_group(double* __restrict__ Lre, double* __restri
 }
 
 template <bool GEN>
-__device__ __noinline__ void offdiag_narrow(double* Lre, double* Lim, const int npad, const int c0,
+__device__ HPX_OUTLINE void offdiag_narrow(double* Lre, double* Lim, const int npad, const int c0,
                                             const int r0, const double* Wre, const double* Wim,
                                             const int lane, const hpx_gen& G, long long* st_) {
   offdiag_group<1, 1, GEN>(Lre, Lim, npad, c0, r0, 64, Wre, Wim, lane, G, st_);
@@ -211,118 +232,125 @@ __device__ __noinline__ void offdiag_narrow(double* Lre, double* Lim, const int 
 
 // K-split partial sums of the (up to) three lower tiles of the diagonal block.
 // tile 0 = (c-tile 0, r-tile 0), 1 = (0,1), 2 = (1,1); acc^T[c][r].
-#ifndef HPX_TOKEN
-#define HPX_TOKEN 0
+#ifndef HPX_PRIO
+#define HPX_PRIO 2
 #endif
-#if HPX_TOKEN
-__device__ int g_cu_token[4096];   // one slot per (XCC, SE, SH, CU); self-clearing
+#ifndef HPX_ROT
+#define HPX_ROT 1
+#endif
+#ifndef HPX_PAIR_MIN
+#define HPX_PAIR_MIN (1 << 30)   // batch size from which two baselines share a 512-thread workgroup (off)
 #endif
 
-template <int CT>
-__device__ __forceinline__ void diag_partial(const double* __restrict__ Lre,
-                                             const double* __restrict__ Lim, const int npad,
-                                             const int c0, const int wave, const int lane,
-                                             d4 (&ar)[3], d4 (&ai)[3]) {
+// One 16 x 16 tile of the diagonal block's update, acc^T[c][r] = -sum_{k<c0} conj(L[c][k]) L[r][k],
+// over the whole k range on one wave (tile 0 = (c-tile 0, r-tile 0), 1 = (0,1), 2 = (1,1)).
+// The three tiles of a 32-wide block go to three waves: nothing to reduce afterwards.  Operands
+// are fetched four k-steps at a time into two register sets (the next chunk is in flight while
+// the current one is multiplied); c0 is a multiple of 32, so the chunk count is even.
+template <int TILE>
+__device__ __forceinline__ void diag_tile(const glb_f64* __restrict__ Lre,
+                                          const glb_f64* __restrict__ Lim, const int npad,
+                                          const int c0, const int lane, d4& ar, d4& ai) {
   const int li = lane & 15, g = lane >> 4;
-#pragma unroll
-  for (int t = 0; t < 3; ++t) {
-    ar[t] = (d4){0., 0., 0., 0.};
-    ai[t] = (d4){0., 0., 0., 0.};
+  ar = (d4){0., 0., 0., 0.};
+  ai = (d4){0., 0., 0., 0.};
+  const int nch = (HPX_DIAG & 8) ? 0 : (c0 >> 4);          // chunks of 4 k-steps (16 columns)
+  if (nch == 0) return;
+  const glb_f64* pAr = Lre + HPX_LIDX(c0 + (TILE == 2 ? 16 : 0) + li, g, npad);
+  const glb_f64* pAi = Lim + HPX_LIDX(c0 + (TILE == 2 ? 16 : 0) + li, g, npad);
+  const glb_f64* pBr = Lre + HPX_LIDX(c0 + 16 + li, g, npad);
+  const glb_f64* pBi = Lim + HPX_LIDX(c0 + 16 + li, g, npad);
+  double xr[2][4], xi[2][4], yr[2][4], yi[2][4];
+#define HPX_DT_LOAD(buf, ch)                                   \
+  _Pragma("unroll") for (int u = 0; u < 4; ++u) {              \
+    const int o_ = ((ch) * 16 + 4 * u) << 5;                   \
+    xr[buf][u] = pAr[o_];                                      \
+    xi[buf][u] = pAi[o_];                                      \
+    if (TILE == 1) {                                           \
+      yr[buf][u] = pBr[o_];                                    \
+      yi[buf][u] = pBi[o_];                                    \
+    }                                                          \
   }
-  const int nks = (HPX_DIAG & 8) ? 0 : (c0 >> 2);
-  for (int ks = wave; ks < nks; ks += 4) {
-    const long off = HPX_LIDX(c0 + li, 4 * ks + g, npad);
-    const double v0r = Lre[off], v0i = Lim[off];
-    ar[0] = mfma64(-v0r, v0r, ar[0]);
-    ar[0] = mfma64(-v0i, v0i, ar[0]);
-    ai[0] = mfma64(-v0r, v0i, ai[0]);
-    ai[0] = mfma64(v0i, v0r, ai[0]);
-    if (CT == 2) {
-      const long off1 = off + (long)npad * 32;   // next 16-row panel
-      const double v1r = Lre[off1], v1i = Lim[off1];
-      ar[1] = mfma64(-v0r, v1r, ar[1]);
-      ar[1] = mfma64(-v0i, v1i, ar[1]);
-      ai[1] = mfma64(-v0r, v1i, ai[1]);
-      ai[1] = mfma64(v0i, v1r, ai[1]);
-      ar[2] = mfma64(-v1r, v1r, ar[2]);
-      ar[2] = mfma64(-v1i, v1i, ar[2]);
-      ai[2] = mfma64(-v1r, v1i, ai[2]);
-      ai[2] = mfma64(v1i, v1r, ai[2]);
-    }
+#define HPX_DT_MUL(buf)                                        \
+  _Pragma("unroll") for (int u = 0; u < 4; ++u) {              \
+    const double cr_ = xr[buf][u], ci_ = xi[buf][u];           \
+    const double rr_ = (TILE == 1) ? yr[buf][u] : cr_;         \
+    const double ri_ = (TILE == 1) ? yi[buf][u] : ci_;         \
+    ar = mfma64(-cr_, rr_, ar);                                \
+    ar = mfma64(-ci_, ri_, ar);                                \
+    ai = mfma64(-cr_, ri_, ai);                                \
+    ai = mfma64(ci_, rr_, ai);                                 \
   }
+  HPX_DT_LOAD(0, 0);
+  for (int ch = 0; ch < nch; ch += 2) {
+    HPX_DT_LOAD(1, ch + 1);
+    __builtin_amdgcn_sched_barrier(0);
+    HPX_DT_MUL(0);
+    __builtin_amdgcn_sched_barrier(0);
+    const int nx = (ch + 2 < nch) ? ch + 2 : ch;              // branch-free tail: harmless re-read
+    HPX_DT_LOAD(0, nx);
+    __builtin_amdgcn_sched_barrier(0);
+    HPX_DT_MUL(1);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+#undef HPX_DT_LOAD
+#undef HPX_DT_MUL
 }
 
 // Diagonal block at c0 (width wj = 16 or 32): D = K[j,j] - sum_{k<c0} L[j,k] L[j,k]^H
-// (K-split over the waves), then D = Ljj Ljj^H and Ljj^-1 by the fused in-LDS elimination.
+// (one 16 x 16 tile per wave), then D = Ljj Ljj^H and Ljj^-1 by the fused in-LDS elimination.
 // On return (after the trailing barrier) Yre/Yim hold W = conj(Ljj^-1); Ljj and Ljj^-1 are
 // in global memory.
 template <bool GEN>
-__device__ __noinline__ bool diag_panel(double* __restrict__ Lre, double* __restrict__ Lim,
-                                           double* __restrict__ Wgre, double* __restrict__ Wgim,
-                                           FactorShared& sh, double* Yre, double* Yim,
+__device__ HPX_OUTLINE bool diag_panel(glb_f64* __restrict__ Lre, glb_f64* __restrict__ Lim,
+                                           glb_f64* __restrict__ Wgre, glb_f64* __restrict__ Wgim,
+                                           lds_FactorShared* __restrict__ shp,
                                            const int npad, const int c0, const int wj,
-                                           const int tid, const hpx_gen& G, long long* st_) {
+                                           const int tid, const gen_signal G, long long* st_) {
+  lds_FactorShared& sh = *shp;
+  lds_f64* const Yre = sh.Yre;
+  lds_f64* const Yim = sh.Yim;
   const int wave = tid >> 6, lane = tid & 63;
   const int CT = wj >> 4;
   bool bad = false;
   HPX_T0();
-  d4 ar[3], ai[3];
-  if (CT == 2) diag_partial<2>(Lre, Lim, npad, c0, wave, lane, ar, ai);
-  else diag_partial<1>(Lre, Lim, npad, c0, wave, lane, ar, ai);
+  d4 ar, ai;
+  if (wave == 0) diag_tile<0>(Lre, Lim, npad, c0, lane, ar, ai);
+  else if (CT == 2 && wave == 1) diag_tile<1>(Lre, Lim, npad, c0, lane, ar, ai);
+  else if (CT == 2 && wave == 2) diag_tile<2>(Lre, Lim, npad, c0, lane, ar, ai);
   HPX_TICK(0);
-  // Experiment (HPX_TOKEN=1, off): a per-CU token that serialises this latency-bound section
-  // between the two workgroups resident on a CU, forcing one workgroup's elimination to overlap
-  // the other's MFMA work.  Measured neutral: fp64 vector ops and f64 MFMAs
-  // share the DP pipe, so the elimination slows down by what the k-loop gains.
-#if HPX_TOKEN
-  int* tok = nullptr;
-  if (tid == 0) {
-    const unsigned cu = __builtin_amdgcn_s_getreg((7 << 11) | (8 << 6) | 4);    // HW_ID[15:8]: cu, sh, se
-    const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20);             // XCC_ID[3:0]
-    tok = &g_cu_token[(xcc << 8) | cu];
-    for (int spin = 0; spin < 8192 && atomicCAS(tok, 0, 1) != 0; ++spin) __builtin_amdgcn_s_sleep(4);
-  }
+#if HPX_PRIO
+  // the elimination is a chain of dependent fp64 vector ops that queue behind the co-resident
+  // workgroup's 64-cycle MFMAs on the shared DP pipe: let them go first
+  __builtin_amdgcn_s_setprio(HPX_PRIO);
 #endif
   for (int e = tid; e < 32 * 32; e += 256) {     // identity for the running inverse
     const int i = e >> 5, q = e & 31;
     Yre[i * WLD + q] = (i == q) ? 1.0 : 0.0;
     Yim[i * WLD + q] = 0.0;
   }
-  // fixed-order reduction of the four waves' partial tiles through one LDS slab
-  for (int w = 3; w >= 0; --w) {
-    if (wave == w) {
+  // D[r][c] = K[r][c] + acc^T[c][r], written by the wave that owns the tile
+  if (wave < (CT == 2 ? 3 : 1)) {
+    const int ci = (wave == 2) ? 1 : 0, ri = (wave == 0) ? 0 : 1;
+    const int r = 16 * ri + (lane & 15);
 #pragma unroll
-      for (int t = 0; t < 3; ++t)
-#pragma unroll
-        for (int v = 0; v < 4; ++v) {
-          if (w == 3) {
-            sh.slab[t][0][v][lane] = ar[t][v];
-            sh.slab[t][1][v][lane] = ai[t][v];
-          } else {
-            sh.slab[t][0][v][lane] += ar[t][v];
-            sh.slab[t][1][v][lane] += ai[t][v];
-          }
-        }
+    for (int v = 0; v < 4; ++v) {
+      const int c = 16 * ci + HPX_ACC_ROW(lane >> 4, v);
+      double kr, ki;
+      if (GEN && c0 + 32 <= G.rmin) {
+        if (r > c) {
+          const double sc = G.a[c0 + r] * G.a[c0 + c];
+          kr = sc * G.cre[r - c];
+          ki = sc * G.cim[r - c];
+        } else { const double ac = G.a[c0 + c]; kr = 1.0 + ac * ac * G.cre[0]; ki = 0.0; }
+      } else {
+        const long off = HPX_LIDX(c0 + r, c0 + c, npad);
+        kr = Lre[off];
+        ki = Lim[off];
+      }
+      sh.Dre[r * WLD + c] = kr + ar[v];
+      sh.Dim[r * WLD + c] = ki + ai[v];
     }
-    __syncthreads();
-  }
-  // combine: D[r][c] = K[r][c] + slab   (acc^T[c][r] layout in the slab)
-  for (int e = tid; e < 3 * 4 * 64; e += 256) {
-    const int t = e >> 8, v = (e >> 6) & 3, l = e & 63;
-    if (CT == 1 && t > 0) continue;
-    const int ci = (t == 2) ? 1 : 0, ri = (t == 0) ? 0 : 1;
-    const int c = 16 * ci + HPX_ACC_ROW(l >> 4, v), r = 16 * ri + (l & 15);
-    double kr, ki;
-    if (GEN && c0 + 32 <= G.rmin) {
-      if (r > c) hpx_gen_signal(G, c0 + r, c0 + c, kr, ki);
-      else { const double ac = G.a[c0 + c]; kr = 1.0 + ac * ac * G.cre[0]; ki = 0.0; }
-    } else {
-      const long off = HPX_LIDX(c0 + r, c0 + c, npad);
-      kr = Lre[off];
-      ki = Lim[off];
-    }
-    sh.Dre[r * WLD + c] = kr + sh.slab[t][0][v][l];
-    sh.Dim[r * WLD + c] = ki + sh.slab[t][1][v][l];
   }
   HPX_TICK(1);
   // fused Cholesky + inverse of the wj x wj block (unscaled columns; column q of L is
@@ -393,7 +421,7 @@ __device__ __noinline__ bool diag_panel(double* __restrict__ Lre, double* __rest
       double yr = (ib == q) ? 1.0 : 0.0, yi = 0.0;
       const int nsteps = (HPX_DIAG & 4) ? 0 : 16;
       for (int k = 0; k < nsteps; ++k) {
-        double* st = &sh.strip[k & 1][0][0];
+        lds_f64* st = &sh.strip[k & 1][0][0];
         if (q == k && ib >= k) { st[ib] = dr; st[16 + ib] = di; }          // column k of D
         if (ib == k && q <= k) { st[32 + q] = yr; st[48 + q] = yi; }        // row k of Y
         __syncthreads();
@@ -482,25 +510,37 @@ __device__ __noinline__ bool diag_panel(double* __restrict__ Lre, double* __rest
     }
   }
   __syncthreads();
-#if HPX_TOKEN
-  if (tid == 0) atomicExch(tok, 0);
+#if HPX_PRIO
+  __builtin_amdgcn_s_setprio(0);
 #endif
   HPX_TICK(3);
   return bad;
 }
 
-template <bool GEN>
-__global__ __launch_bounds__(256, 2) void k_factor(double* __restrict__ L_all,
+// NH = baselines per workgroup.  NH = 2 (512 threads): waves 0-3 factor baseline 2 blockIdx,
+// waves 4-7 baseline 2 blockIdx + 1, each with its own LDS block and both behind the same
+// barriers, so that the two baselines sharing the CU's SIMDs stay in phase: their latency-
+// bound eliminations run together (undisturbed by the other's MFMAs, which cost them 3x when
+// two independent workgroups drift apart) and their MFMA phases share the pipe.  The second
+// half takes its tiles in the opposite wave order, which evens out the per-SIMD tile counts.
+template <bool GEN, int NH>
+__global__ __launch_bounds__(256 * NH, NH == 1 ? HPX_WGS : 1) void k_factor(double* __restrict__ L_all,
                                                    double* __restrict__ Wre_all,
                                                    double* __restrict__ Wim_all,
                                                    int32_t* __restrict__ info, const int npad,
                                                    const int ld, const int iter_tag,
-                                                   const hpx_gen_batch GB) {
-  __shared__ FactorShared sh;
-  const int b = blockIdx.x;
+                                                   const hpx_gen_batch GB, const int b0) {
+  extern __shared__ double lds_raw[];
+  const int half = (NH == 1) ? 0 : (threadIdx.x >> 8);
+  FactorShared& sh = reinterpret_cast<FactorShared*>(lds_raw)[half];
+  const int b = b0 + blockIdx.x * NH + half;
   hpx_gen G;
   if (GEN) G = hpx_gen_for(GB, b);
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int tid = threadIdx.x & 255, wave = tid >> 6, lane = tid & 63;
+  // which wave takes the first tile below the diagonal block (the one that ends up with the
+  // extra tile) rotates with the block column, two steps apart for the two workgroups that
+  // share a CU's SIMDs (dispatch puts blocks b and b + 256 on the same CU)
+  const int rot0 = (NH == 2) ? 2 * half : 2 * ((b >> 8) & 1);
   double* Lre = L_all + (long)b * npad * ld * 2;
   double* Lim = Lre + 16;
   const int nblk = (npad + HPX_NB - 1) / HPX_NB;
@@ -509,23 +549,41 @@ __global__ __launch_bounds__(256, 2) void k_factor(double* __restrict__ L_all,
   const int nrt = ld >> 4;
   bool bad = false;
   long long st_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  gen_signal GS = {nullptr, nullptr, nullptr, 0};
+  if (GEN) GS = {(const glb_f64*)G.a, (const glb_f64*)G.cre, (const glb_f64*)G.cim, G.rmin};
 
   int c0 = 0;
   // ---- 32-wide block columns (the last one may be 16 wide)
   while (c0 < npad) {
     const int wj = min(HPX_NB, npad - c0);
     const int jb = c0 >> 5;
-    bad |= diag_panel<GEN>(Lre, Lim, Wgre + jb * 1024, Wgim + jb * 1024, sh, sh.Yre, sh.Yim, npad,
-                           c0, wj, tid, G, st_);
+    bad |= diag_panel<GEN>((glb_f64*)Lre, (glb_f64*)Lim, (glb_f64*)(Wgre + jb * 1024),
+                           (glb_f64*)(Wgim + jb * 1024), (lds_FactorShared*)&sh, npad, c0, wj, tid, GS, st_);
     // tiles below the diagonal block (incl. the right-hand-side rows): wave w owns tiles
     // rt0 + w + 4 i and works through them in groups
-    int rt = ((c0 + wj) >> 4) + wave;
+    int rt = ((c0 + wj) >> 4) + ((wave + rot0 + jb * HPX_ROT) & 3);
     if (wj == 32) {
+      // this wave's tiles in groups of 3 (2 + 2 rather than 3 + 1: a single-tile pass costs
+      // nearly as much as a three-tile one, its k-loop is bound by load latency)
+      int cnt = (nrt - rt + 3) >> 2;
+      while (cnt > 0) {
 #if HPX_RT3
-      for (; rt + 8 < nrt; rt += 12) offdiag_group<2, 3, GEN>(Lre, Lim, npad, c0, rt << 4, 64, sh.Yre, sh.Yim, lane, G, st_);
+        if (cnt >= 3 && cnt != 4) {
+          offdiag_group<2, 3, GEN>(Lre, Lim, npad, c0, rt << 4, 64, sh.Yre, sh.Yim, lane, G, st_);
+          rt += 12;
+          cnt -= 3;
+        } else
 #endif
-      for (; rt + 4 < nrt; rt += 8) offdiag_group<2, 2, GEN>(Lre, Lim, npad, c0, rt << 4, 64, sh.Yre, sh.Yim, lane, G, st_);
-      for (; rt < nrt; rt += 4) offdiag_group<2, 1, GEN>(Lre, Lim, npad, c0, rt << 4, 64, sh.Yre, sh.Yim, lane, G, st_);
+        if (cnt >= 2) {
+          offdiag_group<2, 2, GEN>(Lre, Lim, npad, c0, rt << 4, 64, sh.Yre, sh.Yim, lane, G, st_);
+          rt += 8;
+          cnt -= 2;
+        } else {
+          offdiag_group<2, 1, GEN>(Lre, Lim, npad, c0, rt << 4, 64, sh.Yre, sh.Yim, lane, G, st_);
+          rt += 4;
+          cnt -= 1;
+        }
+      }
     } else {
       for (; rt < nrt; rt += 4) offdiag_narrow<GEN>(Lre, Lim, npad, c0, rt << 4, sh.Yre, sh.Yim, lane, G, st_);
     }
@@ -767,17 +825,37 @@ __global__ void k_unpack_x(const double* __restrict__ Xre, const double* __restr
 
 }  // namespace
 
+template <bool GEN, int NH>
+static int launch_factor_nh(int nwg, int b0, int npad, int ld, double* L, double* Wre, double* Wim,
+                            int32_t* info, int iter_tag, const hpx_gen_batch& gen, hipStream_t st) {
+  const size_t lds = sizeof(FactorShared) * NH;
+  static bool attr_done = false;      // per instantiation
+  if (!attr_done) {
+    HPX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_factor<GEN, NH>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_done = true;
+  }
+  hipLaunchKernelGGL((k_factor<GEN, NH>), dim3(nwg), dim3(256 * NH), lds, st, L, Wre, Wim, info, npad,
+                     ld, iter_tag, gen, b0);
+  HPX_HIP(hipGetLastError());
+  return HPX_OK;
+}
+
 int hpx_launch_factor(int nbl, int npad, int ld, double* L, double* Wre, double* Wim,
                       int32_t* info, int iter_tag, const hpx_gen_batch* gen, hipStream_t st) {
-  if (gen) {
-    hipLaunchKernelGGL(k_factor<true>, dim3(nbl), dim3(256), 0, st, L, Wre, Wim, info, npad, ld,
-                       iter_tag, *gen);
-  } else {
-    hpx_gen_batch none = {};
-    hipLaunchKernelGGL(k_factor<false>, dim3(nbl), dim3(256), 0, st, L, Wre, Wim, info, npad, ld,
-                       iter_tag, none);
+  hpx_gen_batch g = {};
+  if (gen) g = *gen;
+  // pairs of baselines per workgroup once there are enough of them to give every CU a pair
+  const int npair = (nbl >= HPX_PAIR_MIN) ? nbl / 2 : 0;
+  if (npair > 0) {
+    if (gen) HPX_TRY((launch_factor_nh<true, 2>(npair, 0, npad, ld, L, Wre, Wim, info, iter_tag, g, st)));
+    else HPX_TRY((launch_factor_nh<false, 2>(npair, 0, npad, ld, L, Wre, Wim, info, iter_tag, g, st)));
   }
-  HPX_HIP(hipGetLastError());
+  const int rest = nbl - 2 * npair;
+  if (rest > 0) {
+    if (gen) HPX_TRY((launch_factor_nh<true, 1>(rest, 2 * npair, npad, ld, L, Wre, Wim, info, iter_tag, g, st)));
+    else HPX_TRY((launch_factor_nh<false, 1>(rest, 2 * npair, npad, ld, L, Wre, Wim, info, iter_tag, g, st)));
+  }
   return HPX_OK;
 }
 
