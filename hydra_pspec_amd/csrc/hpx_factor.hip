@@ -75,6 +75,7 @@ namespace {
 constexpr int WLD = HPX_WLD;
 
 struct FactorShared {
+  double part[3][2][4][64];      // next diagonal block: update over the columns done so far (12 KB)
   double strip[2][4][16];        // published column / row of the 16x16 elimination
   double piv[32];                // pivots d_k
   double Dre[32 * WLD], Dim[32 * WLD];   // diagonal block (lower), row-major [r][c]
@@ -88,8 +89,11 @@ struct FactorShared {
 typedef __attribute__((address_space(3))) FactorShared lds_FactorShared;
 typedef __attribute__((address_space(3))) double lds_f64;
 typedef __attribute__((address_space(1))) double glb_f64;
+template <bool GLDS> struct gen_ptr { typedef glb_f64 type; };
+template <> struct gen_ptr<true> { typedef lds_f64 type; };
+template <bool GLDS>
 struct gen_signal {             // the part of hpx_gen the diagonal block needs (by value)
-  const glb_f64 *a, *cre, *cim;
+  const typename gen_ptr<GLDS>::type *a, *cre, *cim;
   int rmin;
 };
 
@@ -106,32 +110,10 @@ __device__ HPX_INL void offdiag_group(double* __restrict__ Lre, double* __restri
   const int li = lane & 15, g = lane >> 4;
   HPX_T0();
   d4 ar[RT][CT], ai[RT][CT];
-#pragma unroll
-  for (int t = 0; t < RT; ++t)
-#pragma unroll
-    for (int ci = 0; ci < CT; ++ci) {
-      if (GEN && r0 + t * rstride < G.rmin) {      // signal x signal tile: closed form
-#pragma unroll
-        for (int v = 0; v < 4; ++v) {
-          double vr, vi;
-          hpx_gen_signal(G, r0 + t * rstride + li, c0 + 16 * ci + HPX_ACC_ROW(g, v), vr, vi);
-          ar[t][ci][v] = vr;
-          ai[t][ci][v] = vi;
-        }
-      } else {
-#pragma unroll
-        for (int v = 0; v < 4; ++v) {
-          const long off = HPX_LIDX(r0 + t * rstride + li, c0 + 16 * ci + HPX_ACC_ROW(g, v), npad);
-          ar[t][ci][v] = Lre[off];
-          ai[t][ci][v] = Lim[off];
-        }
-      }
-    }
   // acc^T[c][r] -= conj(L[c][k]) * L[r][k].  c0 is a multiple of 32, so the k range is a
   // whole number of chunk pairs; operands of the next chunk are fetched into the other
   // register buffer while the current one feeds the MFMAs (explicit double buffering:
   // hipcc does not software-pipeline across loop iterations).
-  HPX_TICK(4);
   constexpr int KC = (RT >= 3) ? 1 : 2;     // k-steps per chunk
   const int nch = (c0 >> 2) / KC;
   const double* pre = Lre + (long)g * 32;      // column k = 4 ks + g of every panel
@@ -164,8 +146,35 @@ __device__ HPX_INL void offdiag_group(double* __restrict__ Lre, double* __restri
         ai[t][ci] = mfma64(pi_[ci][s], br_[t][s], ai[t][ci]);                    \
       }                                                                          \
     }
+  // the first chunk's operands are requested before the accumulators are initialised, so
+  // that the two load latencies overlap
   if (nch > 0) {
     HPX_LOAD_CHUNK(b0r, b0i, p0r, p0i, pre, pim)
+  }
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int t = 0; t < RT; ++t)
+#pragma unroll
+    for (int ci = 0; ci < CT; ++ci) {
+      if (GEN && r0 + t * rstride < G.rmin) {      // signal x signal tile: closed form
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          double vr, vi;
+          hpx_gen_signal(G, r0 + t * rstride + li, c0 + 16 * ci + HPX_ACC_ROW(g, v), vr, vi);
+          ar[t][ci][v] = vr;
+          ai[t][ci][v] = vi;
+        }
+      } else {
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          const long off = HPX_LIDX(r0 + t * rstride + li, c0 + 16 * ci + HPX_ACC_ROW(g, v), npad);
+          ar[t][ci][v] = Lre[off];
+          ai[t][ci][v] = Lim[off];
+        }
+      }
+    }
+  HPX_TICK(4);
+  if (nch > 0) {
     for (int ch = 0; ch < nch; ch += 2) {
       const double* qre = pre + KC * kstep;
       const double* qim = pim + KC * kstep;
@@ -238,28 +247,38 @@ __device__ HPX_OUTLINE void offdiag_narrow(double* Lre, double* Lim, const int n
 #ifndef HPX_ROT
 #define HPX_ROT 1
 #endif
-#ifndef HPX_PAIR_MIN
-#define HPX_PAIR_MIN (1 << 30)   // batch size from which two baselines share a 512-thread workgroup (off)
-#endif
+
+// 1/sqrt(d): v_rsq_f64 (24 bits) + two Newton steps (measured 2.2e-16 max relative error,
+// tools/rcp64_probe.hip) -- a third of the fp64 ops of sqrt followed by an IEEE division.
+__device__ __forceinline__ double rsqrt_nr(const double d) {
+  double q = __builtin_amdgcn_rsq(d);
+  q = fma(q * 0.5, fma(-d * q, q, 1.0), q);
+  q = fma(q * 0.5, fma(-d * q, q, 1.0), q);
+  return q;
+}
 
 // One 16 x 16 tile of the diagonal block's update, acc^T[c][r] = -sum_{k<c0} conj(L[c][k]) L[r][k],
 // over the whole k range on one wave (tile 0 = (c-tile 0, r-tile 0), 1 = (0,1), 2 = (1,1)).
 // The three tiles of a 32-wide block go to three waves: nothing to reduce afterwards.  Operands
 // are fetched four k-steps at a time into two register sets (the next chunk is in flight while
-// the current one is multiplied); c0 is a multiple of 32, so the chunk count is even.
+// the current one is multiplied); the k range is a multiple of 32, so the chunk count is even.
+// The bulk of the sum (all columns but the last 32) is formed one block column EARLY, by the
+// waves with the fewest tiles in the off-diagonal pass of the previous block column
+// (diag_partial_next), and parked in LDS: the critical path between two passes only adds
+// the last 32 columns.
 template <int TILE>
 __device__ __forceinline__ void diag_tile(const glb_f64* __restrict__ Lre,
                                           const glb_f64* __restrict__ Lim, const int npad,
-                                          const int c0, const int lane, d4& ar, d4& ai) {
+                                          const int c0, const int k0, const int k1, const int lane,
+                                          d4& ar, d4& ai) {
+  // rows c0.. of the block, columns k0 <= k < k1 (both multiples of 32); ar/ai are added to
   const int li = lane & 15, g = lane >> 4;
-  ar = (d4){0., 0., 0., 0.};
-  ai = (d4){0., 0., 0., 0.};
-  const int nch = (HPX_DIAG & 8) ? 0 : (c0 >> 4);          // chunks of 4 k-steps (16 columns)
+  const int nch = (HPX_DIAG & 8) ? 0 : ((k1 - k0) >> 4);   // chunks of 4 k-steps (16 columns)
   if (nch == 0) return;
-  const glb_f64* pAr = Lre + HPX_LIDX(c0 + (TILE == 2 ? 16 : 0) + li, g, npad);
-  const glb_f64* pAi = Lim + HPX_LIDX(c0 + (TILE == 2 ? 16 : 0) + li, g, npad);
-  const glb_f64* pBr = Lre + HPX_LIDX(c0 + 16 + li, g, npad);
-  const glb_f64* pBi = Lim + HPX_LIDX(c0 + 16 + li, g, npad);
+  const glb_f64* pAr = Lre + HPX_LIDX(c0 + (TILE == 2 ? 16 : 0) + li, k0 + g, npad);
+  const glb_f64* pAi = Lim + HPX_LIDX(c0 + (TILE == 2 ? 16 : 0) + li, k0 + g, npad);
+  const glb_f64* pBr = Lre + HPX_LIDX(c0 + 16 + li, k0 + g, npad);
+  const glb_f64* pBi = Lim + HPX_LIDX(c0 + 16 + li, k0 + g, npad);
   double xr[2][4], xi[2][4], yr[2][4], yi[2][4];
 #define HPX_DT_LOAD(buf, ch)                                   \
   _Pragma("unroll") for (int u = 0; u < 4; ++u) {              \
@@ -297,16 +316,33 @@ __device__ __forceinline__ void diag_tile(const glb_f64* __restrict__ Lre,
 #undef HPX_DT_MUL
 }
 
+// Tile `t` of the diagonal block at c1, summed over the columns k < kend that are final already.
+__device__ HPX_OUTLINE void diag_partial_next(const glb_f64* __restrict__ Lre,
+                                              const glb_f64* __restrict__ Lim,
+                                              lds_FactorShared* __restrict__ shp, const int npad,
+                                              const int c1, const int kend, const int t,
+                                              const int lane) {
+  d4 ar = {0., 0., 0., 0.}, ai = {0., 0., 0., 0.};
+  if (t == 0) diag_tile<0>(Lre, Lim, npad, c1, 0, kend, lane, ar, ai);
+  else if (t == 1) diag_tile<1>(Lre, Lim, npad, c1, 0, kend, lane, ar, ai);
+  else diag_tile<2>(Lre, Lim, npad, c1, 0, kend, lane, ar, ai);
+#pragma unroll
+  for (int v = 0; v < 4; ++v) {
+    shp->part[t][0][v][lane] = ar[v];
+    shp->part[t][1][v][lane] = ai[v];
+  }
+}
+
 // Diagonal block at c0 (width wj = 16 or 32): D = K[j,j] - sum_{k<c0} L[j,k] L[j,k]^H
 // (one 16 x 16 tile per wave), then D = Ljj Ljj^H and Ljj^-1 by the fused in-LDS elimination.
 // On return (after the trailing barrier) Yre/Yim hold W = conj(Ljj^-1); Ljj and Ljj^-1 are
 // in global memory.
-template <bool GEN>
+template <bool GEN, bool GLDS>
 __device__ HPX_OUTLINE bool diag_panel(glb_f64* __restrict__ Lre, glb_f64* __restrict__ Lim,
                                            glb_f64* __restrict__ Wgre, glb_f64* __restrict__ Wgim,
                                            lds_FactorShared* __restrict__ shp,
                                            const int npad, const int c0, const int wj,
-                                           const int tid, const gen_signal G, long long* st_) {
+                                           const int tid, const gen_signal<GLDS> G, long long* st_) {
   lds_FactorShared& sh = *shp;
   lds_f64* const Yre = sh.Yre;
   lds_f64* const Yim = sh.Yim;
@@ -314,10 +350,20 @@ __device__ HPX_OUTLINE bool diag_panel(glb_f64* __restrict__ Lre, glb_f64* __res
   const int CT = wj >> 4;
   bool bad = false;
   HPX_T0();
-  d4 ar, ai;
-  if (wave == 0) diag_tile<0>(Lre, Lim, npad, c0, lane, ar, ai);
-  else if (CT == 2 && wave == 1) diag_tile<1>(Lre, Lim, npad, c0, lane, ar, ai);
-  else if (CT == 2 && wave == 2) diag_tile<2>(Lre, Lim, npad, c0, lane, ar, ai);
+  d4 ar = {0., 0., 0., 0.}, ai = {0., 0., 0., 0.};
+  if (c0 > 0 && wave < (CT == 2 ? 3 : 1)) {
+    const int kb = c0 - 32;
+    if (kb > 0) {
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        ar[v] = sh.part[wave][0][v][lane];
+        ai[v] = sh.part[wave][1][v][lane];
+      }
+    }
+    if (wave == 0) diag_tile<0>(Lre, Lim, npad, c0, kb, c0, lane, ar, ai);
+    else if (wave == 1) diag_tile<1>(Lre, Lim, npad, c0, kb, c0, lane, ar, ai);
+    else diag_tile<2>(Lre, Lim, npad, c0, kb, c0, lane, ar, ai);
+  }
   HPX_TICK(0);
 #if HPX_PRIO
   // the elimination is a chain of dependent fp64 vector ops that queue behind the co-resident
@@ -430,28 +476,33 @@ __device__ HPX_OUTLINE bool diag_panel(glb_f64* __restrict__ Lre, glb_f64* __res
         const double a0 = st[32 + q], a1 = st[48 + q], b0 = st[q], b1 = st[16 + q];
         if (!(dkk > 0.0)) bad = true;
         if (tid == 0) sh.piv[o + k] = dkk;
-        const double rinv2 = 1.0 / dkk;
+        // Only the reciprocal of the pivot is a dependent chain (the next pivot needs this
+        // step's update): v_rcp_f64 (24 bits) + one Newton step (2e-15) instead of the
+        // IEEE division sequence, and the product c * s is formed beside it.  Every dependent
+        // fp64 op queues behind a 64-cycle MFMA of the co-resident workgroup.
         const bool isY = q <= k;
         const double sr = isY ? a0 : b0, si = isY ? a1 : -b1;
-        const double lr = cr * rinv2, lm = cm * rinv2;
-        const double ur = lr * sr - lm * si, ui = lr * si + lm * sr;
+        const double pr = cr * sr - cm * si, pi = cr * si + cm * sr;
+        const double r0 = __builtin_amdgcn_rcp(dkk);
+        const double rinv = fma(r0, fma(-dkk, r0, 1.0), r0);
         const bool act = ib > k;
-        const bool toY = act && isY, toD = act && !isY && (q <= ib);
-        yr -= toY ? ur : 0.0;
-        yi -= toY ? ui : 0.0;
-        dr -= toD ? ur : 0.0;
-        di -= toD ? ui : 0.0;
+        const double my = (act && isY) ? -rinv : 0.0;
+        const double md = (act && !isY && (q <= ib)) ? -rinv : 0.0;
+        yr = fma(pr, my, yr);
+        yi = fma(pi, my, yi);
+        dr = fma(pr, md, dr);
+        di = fma(pi, md, di);
       }
       __syncthreads();
       // scaling: L block to global, W = conj(L^-1) block to LDS (Y), L^-1 block to the side buffer
       {
         double wr = 0.0, wi = 0.0;
         if (q <= ib) {
-          const double sq = 1.0 / sqrt(sh.piv[o + q]);
+          const double sq = rsqrt_nr(sh.piv[o + q]);
           const long off = HPX_LIDX(c0 + o + ib, c0 + o + q, npad);
           Lre[off] = dr * sq;
           Lim[off] = (ib == q) ? 0.0 : di * sq;
-          const double sv = 1.0 / sqrt(sh.piv[o + ib]);
+          const double sv = rsqrt_nr(sh.piv[o + ib]);
           wr = yr * sv;
           wi = yi * sv;
         }
@@ -517,30 +568,26 @@ __device__ HPX_OUTLINE bool diag_panel(glb_f64* __restrict__ Lre, glb_f64* __res
   return bad;
 }
 
-// NH = baselines per workgroup.  NH = 2 (512 threads): waves 0-3 factor baseline 2 blockIdx,
-// waves 4-7 baseline 2 blockIdx + 1, each with its own LDS block and both behind the same
-// barriers, so that the two baselines sharing the CU's SIMDs stay in phase: their latency-
-// bound eliminations run together (undisturbed by the other's MFMAs, which cost them 3x when
-// two independent workgroups drift apart) and their MFMA phases share the pipe.  The second
-// half takes its tiles in the opposite wave order, which evens out the per-SIMD tile counts.
-template <bool GEN, int NH>
-__global__ __launch_bounds__(256 * NH, NH == 1 ? HPX_WGS : 1) void k_factor(double* __restrict__ L_all,
+// GLDS: the per-baseline vectors the closed-form K' entries are made of (a, circ: 3 N doubles)
+// are staged in LDS behind FactorShared.  From global memory every tile group's initialisation
+// waits for loads that miss L1 and L2 (the factor streams through both), ~1e4 cycles a group.
+template <bool GEN, bool GLDS>
+__global__ __launch_bounds__(256, HPX_WGS) void k_factor(double* __restrict__ L_all,
                                                    double* __restrict__ Wre_all,
                                                    double* __restrict__ Wim_all,
                                                    int32_t* __restrict__ info, const int npad,
                                                    const int ld, const int iter_tag,
-                                                   const hpx_gen_batch GB, const int b0) {
+                                                   const hpx_gen_batch GB) {
   extern __shared__ double lds_raw[];
-  const int half = (NH == 1) ? 0 : (threadIdx.x >> 8);
-  FactorShared& sh = reinterpret_cast<FactorShared*>(lds_raw)[half];
-  const int b = b0 + blockIdx.x * NH + half;
+  FactorShared& sh = *reinterpret_cast<FactorShared*>(lds_raw);
+  const int b = blockIdx.x;
   hpx_gen G;
   if (GEN) G = hpx_gen_for(GB, b);
-  const int tid = threadIdx.x & 255, wave = tid >> 6, lane = tid & 63;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   // which wave takes the first tile below the diagonal block (the one that ends up with the
   // extra tile) rotates with the block column, two steps apart for the two workgroups that
   // share a CU's SIMDs (dispatch puts blocks b and b + 256 on the same CU)
-  const int rot0 = (NH == 2) ? 2 * half : 2 * ((b >> 8) & 1);
+  const int rot0 = 2 * ((b >> 8) & 1);
   double* Lre = L_all + (long)b * npad * ld * 2;
   double* Lim = Lre + 16;
   const int nblk = (npad + HPX_NB - 1) / HPX_NB;
@@ -549,16 +596,34 @@ __global__ __launch_bounds__(256 * NH, NH == 1 ? HPX_WGS : 1) void k_factor(doub
   const int nrt = ld >> 4;
   bool bad = false;
   long long st_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  gen_signal GS = {nullptr, nullptr, nullptr, 0};
-  if (GEN) GS = {(const glb_f64*)G.a, (const glb_f64*)G.cre, (const glb_f64*)G.cim, G.rmin};
+  typedef typename gen_ptr<GLDS>::type gsrc;
+  gen_signal<GLDS> GS = {nullptr, nullptr, nullptr, 0};
+  if (GEN) {
+    if (GLDS) {
+      double* ga = lds_raw + sizeof(FactorShared) / sizeof(double);
+      double* gcr = ga + G.N;
+      double* gci = gcr + G.N;
+      for (int i = tid; i < G.N; i += 256) {
+        ga[i] = G.a[i];
+        gcr[i] = G.cre[i];
+        gci[i] = G.cim[i];
+      }
+      G.a = ga;
+      G.cre = gcr;
+      G.cim = gci;
+      __syncthreads();
+    }
+    GS = {(const gsrc*)G.a, (const gsrc*)G.cre, (const gsrc*)G.cim, G.rmin};
+  }
 
   int c0 = 0;
   // ---- 32-wide block columns (the last one may be 16 wide)
   while (c0 < npad) {
     const int wj = min(HPX_NB, npad - c0);
     const int jb = c0 >> 5;
-    bad |= diag_panel<GEN>((glb_f64*)Lre, (glb_f64*)Lim, (glb_f64*)(Wgre + jb * 1024),
-                           (glb_f64*)(Wgim + jb * 1024), (lds_FactorShared*)&sh, npad, c0, wj, tid, GS, st_);
+    bad |= diag_panel<GEN, GLDS>((glb_f64*)Lre, (glb_f64*)Lim, (glb_f64*)(Wgre + jb * 1024),
+                                 (glb_f64*)(Wgim + jb * 1024), (lds_FactorShared*)&sh, npad, c0, wj, tid,
+                                 GS, st_);
     // tiles below the diagonal block (incl. the right-hand-side rows): wave w owns tiles
     // rt0 + w + 4 i and works through them in groups
     int rt = ((c0 + wj) >> 4) + ((wave + rot0 + jb * HPX_ROT) & 3);
@@ -582,6 +647,18 @@ __global__ __launch_bounds__(256 * NH, NH == 1 ? HPX_WGS : 1) void k_factor(doub
           offdiag_group<2, 1, GEN>(Lre, Lim, npad, c0, rt << 4, 64, sh.Yre, sh.Yim, lane, G, st_);
           rt += 4;
           cnt -= 1;
+        }
+      }
+      // early part of the next diagonal block (columns < c0): its tiles go to the waves that
+      // got the fewest off-diagonal tiles in this pass
+      const int c1 = c0 + 32;
+      if (c0 > 0 && c1 < npad) {
+        const int t = 3 - ((wave + rot0 + jb * HPX_ROT) & 3);
+        if (t < ((npad - c1 >= 32) ? 3 : 1)) {
+          HPX_T0();
+          diag_partial_next((const glb_f64*)Lre, (const glb_f64*)Lim, (lds_FactorShared*)&sh, npad, c1, c0,
+                            t, lane);
+          HPX_TICK(1);
         }
       }
     } else {
@@ -825,38 +902,33 @@ __global__ void k_unpack_x(const double* __restrict__ Xre, const double* __restr
 
 }  // namespace
 
-template <bool GEN, int NH>
-static int launch_factor_nh(int nwg, int b0, int npad, int ld, double* L, double* Wre, double* Wim,
-                            int32_t* info, int iter_tag, const hpx_gen_batch& gen, hipStream_t st) {
-  const size_t lds = sizeof(FactorShared) * NH;
-  static bool attr_done = false;      // per instantiation
-  if (!attr_done) {
-    HPX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_factor<GEN, NH>),
+template <bool GEN, bool GLDS>
+static int launch_factor_t(int nbl, size_t lds, int npad, int ld, double* L, double* Wre, double* Wim,
+                           int32_t* info, int iter_tag, const hpx_gen_batch& gen, hipStream_t st) {
+  static size_t attr_lds = 0;      // per instantiation
+  if (lds > attr_lds) {
+    HPX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_factor<GEN, GLDS>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_done = true;
+    attr_lds = lds;
   }
-  hipLaunchKernelGGL((k_factor<GEN, NH>), dim3(nwg), dim3(256 * NH), lds, st, L, Wre, Wim, info, npad,
-                     ld, iter_tag, gen, b0);
+  hipLaunchKernelGGL((k_factor<GEN, GLDS>), dim3(nbl), dim3(256), lds, st, L, Wre, Wim, info, npad, ld,
+                     iter_tag, gen);
   HPX_HIP(hipGetLastError());
   return HPX_OK;
 }
 
 int hpx_launch_factor(int nbl, int npad, int ld, double* L, double* Wre, double* Wim,
                       int32_t* info, int iter_tag, const hpx_gen_batch* gen, hipStream_t st) {
-  hpx_gen_batch g = {};
-  if (gen) g = *gen;
-  // pairs of baselines per workgroup once there are enough of them to give every CU a pair
-  const int npair = (nbl >= HPX_PAIR_MIN) ? nbl / 2 : 0;
-  if (npair > 0) {
-    if (gen) HPX_TRY((launch_factor_nh<true, 2>(npair, 0, npad, ld, L, Wre, Wim, info, iter_tag, g, st)));
-    else HPX_TRY((launch_factor_nh<false, 2>(npair, 0, npad, ld, L, Wre, Wim, info, iter_tag, g, st)));
+  const size_t base = sizeof(FactorShared);
+  if (!gen) {
+    hpx_gen_batch none = {};
+    return launch_factor_t<false, false>(nbl, base, npad, ld, L, Wre, Wim, info, iter_tag, none, st);
   }
-  const int rest = nbl - 2 * npair;
-  if (rest > 0) {
-    if (gen) HPX_TRY((launch_factor_nh<true, 1>(rest, 2 * npair, npad, ld, L, Wre, Wim, info, iter_tag, g, st)));
-    else HPX_TRY((launch_factor_nh<false, 1>(rest, 2 * npair, npad, ld, L, Wre, Wim, info, iter_tag, g, st)));
-  }
-  return HPX_OK;
+  // stage a / circ in LDS while two workgroups still fit on a CU (160 KB)
+  const size_t staged = base + (size_t)3 * gen->N * sizeof(double);
+  if (staged <= (size_t)80 * 1024)
+    return launch_factor_t<true, true>(nbl, staged, npad, ld, L, Wre, Wim, info, iter_tag, *gen, st);
+  return launch_factor_t<true, false>(nbl, base, npad, ld, L, Wre, Wim, info, iter_tag, *gen, st);
 }
 
 int hpx_launch_backsolve(int nbl, int npad, int TP, int ld, const double* L, const double* Wre,

@@ -6,7 +6,8 @@ import ctypes as C, numpy as np, sys, json, subprocess
 sys.path.insert(0, '.')
 import torch
 from hydra_pspec_amd import hpx, pspec, synthetic
-N,T,M,nbl=512,32,12,1024
+import os
+N,T,M,nbl=512,32,12,int(os.environ.get("NBL","1024"))
 d=synthetic.make_baselines(N,T,M,nbl=nbl,dense=False)
 gb=pspec.GibbsBatch(d["vis"],d["flags"],d["fgmodes"],d["ninv_diag"],d["ps_prior"],3,seed=1)
 ps0=np.broadcast_to(d["ps0"],(nbl,N)).copy()
@@ -16,7 +17,7 @@ n=nbl*4*8
 buf=(C.c_longlong*n)()
 assert L.hpx_debug_stamps(buf,n)==0
 a=np.frombuffer(buf,dtype=np.int64).reshape(nbl,4,8).astype(float)
-names=["diag_partial","reduce+combine","potf2 loop","final scale","tile init(gen)","k-loop","X mult+store","end barrier"]
+names=["diag last32+combine","next-diag partial","potf2 loop","final scale","tile init(gen)","k-loop","X mult+store","end barrier"]
 tot=a.sum(axis=2)
 print("cycles per wave (mean over %d WGs), total %.0f"%(nbl,tot.mean()))
 for i,nm in enumerate(names):
