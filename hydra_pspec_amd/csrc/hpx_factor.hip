@@ -75,9 +75,8 @@ namespace {
 constexpr int WLD = HPX_WLD;
 
 struct FactorShared {
-  double part[3][2][4][64];      // next diagonal block: update over the columns done so far (12 KB)
-  double strip[2][4][16];        // published column / row of the 16x16 elimination
-  double piv[32];                // pivots d_k
+  double part[3][2][4][64];      // next diagonal block: update over the columns done so far (12 KB);
+                                 // doubles as scratch of the 16 x 16 elimination (8.6 KB)
   double Dre[32 * WLD], Dim[32 * WLD];   // diagonal block (lower), row-major [r][c]
   double Yre[32 * WLD], Yim[32 * WLD];   // running inverse; finally W = conj(Ljj^-1)
 };
@@ -88,6 +87,8 @@ struct FactorShared {
 // wait becomes vmcnt(0)+lgkmcnt(0)).
 typedef __attribute__((address_space(3))) FactorShared lds_FactorShared;
 typedef __attribute__((address_space(3))) double lds_f64;
+typedef double cplx __attribute__((ext_vector_type(2)));     // (re, im): one 16-byte LDS access
+typedef __attribute__((address_space(3))) cplx lds_cplx;
 typedef __attribute__((address_space(1))) double glb_f64;
 template <bool GLDS> struct gen_ptr { typedef glb_f64 type; };
 template <> struct gen_ptr<true> { typedef lds_f64 type; };
@@ -346,6 +347,10 @@ __device__ HPX_OUTLINE bool diag_panel(glb_f64* __restrict__ Lre, glb_f64* __res
   lds_FactorShared& sh = *shp;
   lds_f64* const Yre = sh.Yre;
   lds_f64* const Yim = sh.Yim;
+  // scratch of the elimination, over `part` (dead between the reads below and the next pass)
+  lds_cplx* const Dm = reinterpret_cast<lds_cplx*>(&sh.part[0][0][0][0]);
+  lds_cplx* const Ym = Dm + 16 * 17;
+  lds_f64* const dg = reinterpret_cast<lds_f64*>(Ym + 16 * 17);
   const int wave = tid >> 6, lane = tid & 63;
   const int CT = wj >> 4;
   bool bad = false;
@@ -463,46 +468,51 @@ __device__ HPX_OUTLINE bool diag_panel(glb_f64* __restrict__ Lre, glb_f64* __res
       }
       if (hb == 1) __syncthreads();
       // ---- A / D: fused Cholesky + inverse of the 16 x 16 block at (o, o)
+      // Every thread stores its D and Y entry into LDS matrices each step, and D is kept
+      // STRICTLY lower there (the diagonal goes to a side vector): retired rows and columns
+      // then read back as zeros and a step needs no per-step masks, compares or selects --
+      // 13 fp64 vector ops and nothing else on the vector ALU, which a co-resident workgroup
+      // streaming MFMAs leaves only scraps of (tools/elim_step_probe.hip).  Retired entries
+      // never change, so one copy of the matrices is enough (a wave that runs ahead rewrites
+      // what the others still read with the same values).
+      const bool dia = (q == ib), low = (q < ib);
       double dr = sh.Dre[(o + ib) * WLD + o + q], di = sh.Dim[(o + ib) * WLD + o + q];
+      if (!low) Dm[ib * 17 + q] = (cplx){0.0, 0.0};      // diagonal and above stay zero in LDS
       double yr = (ib == q) ? 1.0 : 0.0, yi = 0.0;
       const int nsteps = (HPX_DIAG & 4) ? 0 : 16;
+#pragma unroll
       for (int k = 0; k < nsteps; ++k) {
-        lds_f64* st = &sh.strip[k & 1][0][0];
-        if (q == k && ib >= k) { st[ib] = dr; st[16 + ib] = di; }          // column k of D
-        if (ib == k && q <= k) { st[32 + q] = yr; st[48 + q] = yi; }        // row k of Y
+        if (dia) dg[ib] = dr; else if (low) Dm[ib * 17 + q] = (cplx){dr, di};
+        Ym[ib * 17 + q] = (cplx){yr, yi};
         __syncthreads();
-        const double dkk = st[k];
-        const double cr = st[ib], cm = st[16 + ib];
-        const double a0 = st[32 + q], a1 = st[48 + q], b0 = st[q], b1 = st[16 + q];
-        if (!(dkk > 0.0)) bad = true;
-        if (tid == 0) sh.piv[o + k] = dkk;
-        // Only the reciprocal of the pivot is a dependent chain (the next pivot needs this
-        // step's update): v_rcp_f64 (24 bits) + one Newton step (2e-15) instead of the
-        // IEEE division sequence, and the product c * s is formed beside it.  Every dependent
-        // fp64 op queues behind a 64-cycle MFMA of the co-resident workgroup.
-        const bool isY = q <= k;
-        const double sr = isY ? a0 : b0, si = isY ? a1 : -b1;
-        const double pr = cr * sr - cm * si, pi = cr * si + cm * sr;
+        const double dkk = dg[k];
+        const cplx c = Dm[ib * 17 + k], cq = Dm[q * 17 + k], sy = Ym[k * 17 + q];
+        // v_rcp_f64 (24 bits) + one Newton step (2e-15) instead of the IEEE division sequence
         const double r0 = __builtin_amdgcn_rcp(dkk);
         const double rinv = fma(r0, fma(-dkk, r0, 1.0), r0);
-        const bool act = ib > k;
-        const double my = (act && isY) ? -rinv : 0.0;
-        const double md = (act && !isY && (q <= ib)) ? -rinv : 0.0;
-        yr = fma(pr, my, yr);
-        yi = fma(pi, my, yi);
-        dr = fma(pr, md, dr);
-        di = fma(pi, md, di);
+        const double lr = c.x * rinv, lm = c.y * rinv;
+        yr = fma(-lr, sy.x, yr);
+        yr = fma(lm, sy.y, yr);
+        yi = fma(-lr, sy.y, yi);
+        yi = fma(-lm, sy.x, yi);
+        dr = fma(-lr, cq.x, dr);        // threads above the diagonal compute junk that is
+        dr = fma(-lm, cq.y, dr);        // never stored: cheaper than masking the update
+        di = fma(-lm, cq.x, di);
+        di = fma(lr, cq.y, di);
       }
+      if (nsteps == 0 && dia) dg[ib] = dr;
       __syncthreads();
       // scaling: L block to global, W = conj(L^-1) block to LDS (Y), L^-1 block to the side buffer
       {
         double wr = 0.0, wi = 0.0;
         if (q <= ib) {
-          const double sq = rsqrt_nr(sh.piv[o + q]);
+          const double pq = dg[q], pib = dg[ib];
+          if (!(pq > 0.0) || !(pib > 0.0)) bad = true;
+          const double sq = rsqrt_nr(pq);
           const long off = HPX_LIDX(c0 + o + ib, c0 + o + q, npad);
           Lre[off] = dr * sq;
           Lim[off] = (ib == q) ? 0.0 : di * sq;
-          const double sv = rsqrt_nr(sh.piv[o + ib]);
+          const double sv = rsqrt_nr(pib);
           wr = yr * sv;
           wi = yi * sv;
         }
