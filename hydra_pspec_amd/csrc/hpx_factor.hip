@@ -729,33 +729,58 @@ __device__ __forceinline__ void back_block(const double* __restrict__ Lre,
     // Y[c][t] -= sum_r conj(L[r][c]) X[r][t] over this slice's 16-row chunks.
     // lane (li, g) fetches rows rb+4g .. rb+4g+3 of column c (32 contiguous bytes)
     // and uses row rb+4g+s in k-step s; the X operand follows the same order.
+    // The chunks of this slice are taken in pairs with two register sets: the operands of the
+    // next chunk are in flight while the current one is multiplied (the factor was streamed
+    // out to HBM by k_factor, so every chunk is a full memory round trip otherwise).
     const int rbeg = c0 + 16 * CT, nch = (npad - rbeg) >> 4;
-    for (int ch = ksl; ch < nch; ch += nsl) {
-      const int rb = rbeg + (ch << 4);
-      double lr[CT][4], lm[CT][4];
-#pragma unroll
-      for (int ci = 0; ci < CT; ++ci) {
-        const long off = HPX_LIDX(rb + 4 * g, c0 + 16 * ci + li, npad);
-        const double2 a0 = *reinterpret_cast<const double2*>(Lre + off);
-        const double2 a1 = *reinterpret_cast<const double2*>(Lre + off + 2);
-        const double2 b0 = *reinterpret_cast<const double2*>(Lim + off);
-        const double2 b1 = *reinterpret_cast<const double2*>(Lim + off + 2);
-        lr[ci][0] = a0.x; lr[ci][1] = a0.y; lr[ci][2] = a1.x; lr[ci][3] = a1.y;
-        lm[ci][0] = b0.x; lm[ci][1] = b0.y; lm[ci][2] = b1.x; lm[ci][3] = b1.y;
-      }
-#pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        const long xo = (long)(rb + 4 * g + s) * TP + t0 + li;
-        const double xr = Xre[xo], xi = Xim[xo];
-#pragma unroll
-        for (int ci = 0; ci < CT; ++ci) {
-          yr[ci] = mfma64(-lr[ci][s], xr, yr[ci]);
-          yr[ci] = mfma64(-lm[ci][s], xi, yr[ci]);
-          yi[ci] = mfma64(-lr[ci][s], xi, yi[ci]);
-          yi[ci] = mfma64(lm[ci][s], xr, yi[ci]);
-        }
-      }
+    const int nmy = (nch > ksl) ? (nch - ksl + nsl - 1) / nsl : 0;
+    const int chlast = ksl + (nmy - 1) * nsl;
+    double lr0[CT][4], lm0[CT][4], lr1[CT][4], lm1[CT][4], xr0[4], xi0[4], xr1[4], xi1[4];
+#define HPX_BK_LOAD(lr, lm, xr_, xi_, ch_)                                               \
+  {                                                                                      \
+    const int rb_ = rbeg + ((ch_) << 4);                                                 \
+    _Pragma("unroll") for (int ci = 0; ci < CT; ++ci) {                                  \
+      const long off = HPX_LIDX(rb_ + 4 * g, c0 + 16 * ci + li, npad);                   \
+      const double2 a0 = *reinterpret_cast<const double2*>(Lre + off);                   \
+      const double2 a1 = *reinterpret_cast<const double2*>(Lre + off + 2);               \
+      const double2 b0 = *reinterpret_cast<const double2*>(Lim + off);                   \
+      const double2 b1 = *reinterpret_cast<const double2*>(Lim + off + 2);               \
+      lr[ci][0] = a0.x; lr[ci][1] = a0.y; lr[ci][2] = a1.x; lr[ci][3] = a1.y;            \
+      lm[ci][0] = b0.x; lm[ci][1] = b0.y; lm[ci][2] = b1.x; lm[ci][3] = b1.y;            \
+    }                                                                                    \
+    _Pragma("unroll") for (int s = 0; s < 4; ++s) {                                      \
+      const long xo = (long)(rb_ + 4 * g + s) * TP + t0 + li;                            \
+      xr_[s] = Xre[xo];                                                                  \
+      xi_[s] = Xim[xo];                                                                  \
+    }                                                                                    \
+  }
+#define HPX_BK_MMA(lr, lm, xr_, xi_)                                                     \
+  _Pragma("unroll") for (int s = 0; s < 4; ++s)                                          \
+    _Pragma("unroll") for (int ci = 0; ci < CT; ++ci) {                                  \
+      yr[ci] = mfma64(-lr[ci][s], xr_[s], yr[ci]);                                       \
+      yr[ci] = mfma64(-lm[ci][s], xi_[s], yr[ci]);                                       \
+      yi[ci] = mfma64(-lr[ci][s], xi_[s], yi[ci]);                                       \
+      yi[ci] = mfma64(lm[ci][s], xr_[s], yi[ci]);                                        \
     }
+    if (nmy > 0) {
+      int ch = ksl;
+      HPX_BK_LOAD(lr0, lm0, xr0, xi0, ch)
+      for (int i = 0; i + 1 < nmy; i += 2) {
+        HPX_BK_LOAD(lr1, lm1, xr1, xi1, ch + nsl)           // exists: i + 1 < nmy
+        __builtin_amdgcn_sched_barrier(0);
+        HPX_BK_MMA(lr0, lm0, xr0, xi0)
+        __builtin_amdgcn_sched_barrier(0);
+        const int nx = min(ch + 2 * nsl, chlast);            // branch-free: re-read at the end
+        HPX_BK_LOAD(lr0, lm0, xr0, xi0, nx)
+        __builtin_amdgcn_sched_barrier(0);
+        HPX_BK_MMA(lr1, lm1, xr1, xi1)
+        __builtin_amdgcn_sched_barrier(0);
+        ch += 2 * nsl;
+      }
+      if (nmy & 1) HPX_BK_MMA(lr0, lm0, xr0, xi0)            // the odd chunk is in set 0 already
+    }
+#undef HPX_BK_LOAD
+#undef HPX_BK_MMA
     if (ksl > 0) {
 #pragma unroll
       for (int ci = 0; ci < CT; ++ci)
@@ -810,7 +835,7 @@ __device__ __forceinline__ void back_block(const double* __restrict__ Lre,
   __syncthreads();
 }
 
-__global__ __launch_bounds__(256, 2) void k_backsolve(const double* __restrict__ L_all,
+__global__ __launch_bounds__(256, 3) void k_backsolve(const double* __restrict__ L_all,
                                                       const double* __restrict__ Wre_all,
                                                       const double* __restrict__ Wim_all,
                                                       double* __restrict__ Xre_all,
