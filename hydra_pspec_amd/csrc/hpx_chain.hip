@@ -432,9 +432,10 @@ struct DrawArgs {
 };
 
 __global__ __launch_bounds__(256) void k_draw(const DrawArgs A) {
-  extern __shared__ double dyn[];     // ngrid doubles
+  extern __shared__ double dyn[];     // ngrid doubles, then N ints (channels with a prior)
   __shared__ double red[4];
   __shared__ int redi[4];
+  __shared__ int pcount;
   const int b = blockIdx.x, tid = threadIdx.x, N = A.N;
   const double* beta = A.beta + (long)b * N;
   const double* bm = A.any_flags ? A.betam + (long)b * N : beta;
@@ -443,10 +444,18 @@ __global__ __launch_bounds__(256) void k_draw(const DrawArgs A) {
   // channels without a prior: x = beta * invgamma.ppf(U, a=T-1)   (pspec.py:125)
   for (int k = tid; k < N; k += 256)
     if (pmap[k] < 0) ps_out[k] = A.igy[k] * beta[k];
-  // channels with a prior: truncated draw with shape alpha+1 = T   (pspec.py:121-123)
-  for (int k = 0; k < N; ++k) {
-    const int row = pmap[k];
-    if (row < 0) continue;
+  // channels with a prior: truncated draw with shape alpha+1 = T   (pspec.py:121-123).
+  // They are collected first (a scan of pmap by one thread per channel would be N dependent
+  // global loads); each draw depends only on its own channel, so their order is immaterial.
+  int* plist = reinterpret_cast<int*>(dyn + (A.ngrid > 0 ? A.ngrid : 1));
+  if (tid == 0) pcount = 0;
+  __syncthreads();
+  for (int k = tid; k < N; k += 256)
+    if (pmap[k] >= 0) plist[atomicAdd(&pcount, 1)] = k;
+  __syncthreads();
+  const int np = pcount;
+  for (int i = 0; i < np; ++i) {
+    const int k = plist[i], row = pmap[k];
     const double v = inversion_draw(A.T, A.lgam_T, beta[k], A.uni[k], A.xgrid + (long)row * A.ngrid,
                                     A.ngrid, dyn, red, redi);
     if (tid == 0) ps_out[k] = v;
@@ -748,7 +757,8 @@ static int post_solve(hpx_plan* p, int it_abs, const double* rs, const IterOut& 
   D.N = N; D.T = T; D.ngrid = p->ngrid; D.prior_shared = p->prior_shared;
   D.any_flags = p->any_flags; D.lgam_T = p->lgam_T;
   D.lnpost_out = p->lnp1;   // staged per baseline, scattered to (nbl, niter) below
-  hipLaunchKernelGGL(k_draw, dim3(nbl), dim3(256), (size_t)(p->ngrid > 0 ? p->ngrid : 1) * 8, st, D);
+  hipLaunchKernelGGL(k_draw, dim3(nbl), dim3(256),
+                     (size_t)(p->ngrid > 0 ? p->ngrid : 1) * 8 + (size_t)N * sizeof(int), st, D);
   HPX_HIP(hipGetLastError());
   HPX_HIP(hipMemcpy2DAsync(O.lnpost_out, (size_t)O.lnpost_pitch * sizeof(double), p->lnp1,
                            sizeof(double), sizeof(double), nbl, hipMemcpyDeviceToDevice, st));

@@ -85,6 +85,55 @@ __global__ __launch_bounds__(256, 2) void k_dft(const double* Wre, const double*
 // plain one with sign flips on both sides (N % 4 == 0):
 //   (F v)[k] = (-1)^k sum_x (-1)^x v[x] e^{-2 pi i k x / N},   F^H likewise with e^{+...}.
 // Twiddles e^{-2 pi i j / N} are row N/2+1 of the operator itself (numpy's exp on the host).
+// R consecutive radix-2 DIF stages (starting at stage s) fused in registers: the 2^R elements
+// base + m (N >> (s + R)), m = 0 .. 2^R - 1, only interact with each other over these stages,
+// so one LDS round trip and one barrier serve R stages (N = 512: three passes instead of nine).
+// Same butterflies, twiddles and (bit-reversed) output order as the unfused stages.
+template <int R, int SIGN>
+__device__ __forceinline__ void fft_pass(double* __restrict__ fre, double* __restrict__ fim,
+                                         const double* __restrict__ tw, const int N, const int h,
+                                         const int logN, const int s, const int tcs,
+                                         const int tid) {
+  constexpr int E = 1 << R;
+  const int lq = logN - s - R;                 // log2 of the spacing between the E elements
+  const int Hq = 1 << lq;
+  const int ngroups = (N >> R) << tcs;
+  for (int gidx = tid; gidx < ngroups; gidx += 256) {
+    const int tc = gidx & ((1 << tcs) - 1), gi = gidx >> tcs;
+    const int j = gi & (Hq - 1), blk = gi >> lq;
+    const int base = (((blk << R) << lq) + j) << tcs;
+    double xr[E], xi[E];
+#pragma unroll
+    for (int m = 0; m < E; ++m) {
+      xr[m] = fre[base + ((m << lq) << tcs) + tc];
+      xi[m] = fim[base + ((m << lq) << tcs) + tc];
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      constexpr int dummy = 0;
+      (void)dummy;
+      const int dist = E >> (r + 1);
+#pragma unroll
+      for (int m = 0; m < E; ++m) {
+        if ((m / dist) & 1) continue;          // m is the upper element of its pair
+        const int pidx = (((m & (dist - 1)) << lq) + j) << (s + r);     // twiddle exponent
+        const double wr = tw[pidx], wi = (SIGN > 0 ? -1.0 : 1.0) * tw[h + pidx];
+        const double ar = xr[m], ai = xi[m], br = xr[m + dist], bi = xi[m + dist];
+        const double dr = ar - br, di = ai - bi;
+        xr[m] = ar + br;
+        xi[m] = ai + bi;
+        xr[m + dist] = dr * wr - di * wi;
+        xi[m + dist] = dr * wi + di * wr;
+      }
+    }
+#pragma unroll
+    for (int m = 0; m < E; ++m) {
+      fre[base + ((m << lq) << tcs) + tc] = xr[m];
+      fim[base + ((m << lq) << tcs) + tc] = xi[m];
+    }
+  }
+}
+
 template <int SIGN>
 __global__ __launch_bounds__(256) void k_fft(const double* __restrict__ Wre,
                                              const double* __restrict__ Wim,
@@ -95,17 +144,23 @@ __global__ __launch_bounds__(256) void k_fft(const double* __restrict__ Wre,
                                              double* __restrict__ outre,
                                              double* __restrict__ outim, const long out_bstride,
                                              const int out_ld, const int N, const int logN,
-                                             const int ncol, const int TC, const double scale) {
+                                             const int ncol, const int tcs, const double scale) {
   extern __shared__ double fl[];
+  const int TC = 1 << tcs;
   double* fre = fl;
-  double* fim = fl + (long)N * TC;
+  double* fim = fl + ((long)N << tcs);
+  double* tw = fim + ((long)N << tcs);         // cos(2 pi j / N), then -sin(2 pi j / N), j < N/2
   const int b = blockIdx.y, c0 = blockIdx.x * TC, tid = threadIdx.x;
   const double* ir = inre + (long)b * in_bstride;
   const double* ii = inim + (long)b * in_bstride;
   const double* rsb = rs ? rs + (long)b * rs_n : nullptr;
   const int h = N >> 1;
-  for (int e = tid; e < N * TC; e += 256) {
-    const int k = e / TC, tc = e % TC;
+  for (int j = tid; j < h; j += 256) {
+    tw[j] = Wre[(long)(h + 1) * N + h + j];
+    tw[h + j] = Wim[(long)(h + 1) * N + h + j];
+  }
+  for (int e = tid; e < (N << tcs); e += 256) {
+    const int k = e >> tcs, tc = e & (TC - 1);
     double vr = 0.0, vi = 0.0;
     if (c0 + tc < ncol) {
       double sc = (k & 1) ? -1.0 : 1.0;
@@ -116,29 +171,23 @@ __global__ __launch_bounds__(256) void k_fft(const double* __restrict__ Wre,
     fre[e] = vr;
     fim[e] = vi;
   }
-  const double* twr = Wre + (long)(h + 1) * N + h;   // cos(2 pi j / N)
-  const double* twi = Wim + (long)(h + 1) * N + h;   // -sin(2 pi j / N)
-  for (int s = 0; s < logN; ++s) {
-    const int half = N >> (s + 1);
+  int s = 0;
+  for (; s + 3 <= logN; s += 3) {
     __syncthreads();
-    for (int idx = tid; idx < h * TC; idx += 256) {
-      const int tc = idx % TC, bf = idx / TC;
-      const int j = bf & (half - 1), blk = bf >> (logN - 1 - s);
-      const int i0 = (blk * 2 * half + j) * TC + tc, i1 = i0 + half * TC;
-      const double ar = fre[i0], ai = fim[i0], br = fre[i1], bi = fim[i1];
-      const double dr = ar - br, di = ai - bi;
-      const double wr = twr[j << s], wi = (SIGN > 0 ? -1.0 : 1.0) * twi[j << s];
-      fre[i0] = ar + br;
-      fim[i0] = ai + bi;
-      fre[i1] = dr * wr - di * wi;
-      fim[i1] = dr * wi + di * wr;
-    }
+    fft_pass<3, SIGN>(fre, fim, tw, N, h, logN, s, tcs, tid);
+  }
+  if (logN - s == 2) {
+    __syncthreads();
+    fft_pass<2, SIGN>(fre, fim, tw, N, h, logN, s, tcs, tid);
+  } else if (logN - s == 1) {
+    __syncthreads();
+    fft_pass<1, SIGN>(fre, fim, tw, N, h, logN, s, tcs, tid);
   }
   __syncthreads();
   double* orr = outre + (long)b * out_bstride;
   double* oi = outim + (long)b * out_bstride;
-  for (int e = tid; e < N * TC; e += 256) {
-    const int pidx = e / TC, tc = e % TC;
+  for (int e = tid; e < (N << tcs); e += 256) {
+    const int pidx = e >> tcs, tc = e & (TC - 1);
     if (c0 + tc >= ncol) continue;
     const int x = (int)(__brev((unsigned)pidx) >> (32 - logN));
     const double sc = (x & 1) ? -scale : scale;
@@ -215,16 +264,27 @@ int hpx_launch_dft(int nbl, int NP, int ncol, const double* Wre, const double* W
   if (hpx_dft_use_fft && NP >= 16 && NP <= 4096 && (NP & (NP - 1)) == 0 && fft_ok && W_bstride == 0) {
     int logN = 0;
     while ((1 << logN) < NP) ++logN;
-    int TC = 4096 / NP;                 // 64 KiB of LDS per workgroup
+    int TC = 4096 / NP;                 // 64 KiB of LDS per workgroup (+ the twiddle table)
     if (TC > 16) TC = 16;
-    const size_t lds = (size_t)NP * TC * 2 * sizeof(double);
+    if (TC < 1) TC = 1;
+    int tcs = 0;
+    while ((1 << tcs) < TC) ++tcs;
+    const size_t lds = ((size_t)NP * TC * 2 + NP) * sizeof(double);
+    static bool attr_done = false;
+    if (!attr_done) {
+      HPX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fft<1>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
+      HPX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fft<-1>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
+      attr_done = true;
+    }
     dim3 grid((ncol + TC - 1) / TC, nbl);
     if (conjW)
       hipLaunchKernelGGL(k_fft<1>, grid, dim3(256), lds, st, Wre, Wim, inre, inim, in_bstride, in_ld,
-                         rs, rs_n, outre, outim, out_bstride, out_ld, NP, logN, ncol, TC, scale);
+                         rs, rs_n, outre, outim, out_bstride, out_ld, NP, logN, ncol, tcs, scale);
     else
       hipLaunchKernelGGL(k_fft<-1>, grid, dim3(256), lds, st, Wre, Wim, inre, inim, in_bstride, in_ld,
-                         rs, rs_n, outre, outim, out_bstride, out_ld, NP, logN, ncol, TC, scale);
+                         rs, rs_n, outre, outim, out_bstride, out_ld, NP, logN, ncol, tcs, scale);
     HPX_HIP(hipGetLastError());
     return HPX_OK;
   }
