@@ -193,13 +193,19 @@ __global__ void k_fg_planar(const double* __restrict__ fg, double* __restrict__ 
   }
 }
 
-__global__ void k_set_a(const double* __restrict__ ps, double* __restrict__ a,
-                        double* __restrict__ ps_cur, const long tot, const double invN) {
+// ia = 1/a = sqrt(N / ps); bandpowers below HPX_PS_FLOOR (incl. zero) are treated as the floor:
+// the channel's signal is then pinned to ~0, which is what a -> 0 means in the unscaled system.
+#define HPX_PS_FLOOR 1e-280
+__device__ __forceinline__ double inv_a(const double ps, const double dN) {
+  return sqrt(dN / fmax(ps, HPX_PS_FLOOR));
+}
+__global__ void k_set_a(const double* __restrict__ ps, double* __restrict__ ia,
+                        double* __restrict__ ps_cur, const long tot, const double dN) {
   for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < tot;
        e += (long)gridDim.x * blockDim.x) {
     const double v = ps[e];
     ps_cur[e] = v;
-    a[e] = sqrt(v * invN);
+    ia[e] = inv_a(v, dN);
   }
 }
 
@@ -238,7 +244,7 @@ __global__ void k_kaug_out(const double* __restrict__ L, double* __restrict__ ou
 
 // ---- residual, chi^2, first part of ln posterior, beta --------------------------
 struct ResArgs {
-  const double *Xre, *Xim, *Sre, *Sim, *Dre, *Dim, *Fre, *Fim, *ninv, *a;
+  const double *Xre, *Xim, *Sre, *Sim, *Dre, *Dim, *Fre, *Fim, *ninv;
   const uint8_t* flags;
   double *beta, *lnp1, *Gre, *Gim;      // G: masked signal (only if any_flags)
   double *cr_out, *fg_out, *chisq_out;  // already offset to the slot; may be NULL
@@ -276,7 +282,7 @@ __global__ __launch_bounds__(256) void k_resid(const ResArgs A) {
     const bool in = e < tot;
     const int x = in ? e / TP : 0, t = in ? e % TP : 0;
     const long o = (long)x * TP + t;
-    // beta partial: |y'_xt|^2 summed over 16 consecutive times
+    // beta partial: |z_xt|^2 summed over 16 consecutive times
     double v = 0.0;
     if (in) {
       const double yr = xre[o], yi = xim[o];
@@ -325,12 +331,11 @@ __global__ __launch_bounds__(256) void k_resid(const ResArgs A) {
   }
   const double total = block_sum(acc, red);          // (barrier inside: part[] is complete)
   if (tid == 0) A.lnp1[b] = -total;
-  // beta_k = N a_k^2 sum_t |y'_kt|^2   ( |F s|^2 with s = U D^1/2 y' )
+  // beta_k = N sum_t |z_kt|^2   ( |F s|^2 with s = U z )
   for (int k = tid; k < N; k += 256) {
     double sum = 0.0;
     for (int j = 0; j < TG; ++j) sum += part[k * TG + j];
-    const double ak = A.a[(long)b * N + k];
-    A.beta[(long)b * N + k] = (double)N * (ak * ak) * sum;
+    A.beta[(long)b * N + k] = (double)N * sum;
   }
 }
 
@@ -425,7 +430,7 @@ __device__ double inversion_draw(const int alpha, const double lgam, const doubl
 struct DrawArgs {
   const double *beta, *betam, *lnp1, *uni, *igy, *xgrid, *ps_forced;
   const int32_t* pmap;
-  double *a, *ps_cur, *ps_out, *lnpost_out;
+  double *ia, *ps_cur, *ps_out, *lnpost_out;
   long ps_bstride, forced_bstride;   // strides between baselines in ps_out / ps_forced
   int N, T, ngrid, prior_shared, any_flags;
   double lgam_T;
@@ -468,7 +473,7 @@ __global__ __launch_bounds__(256) void k_draw(const DrawArgs A) {
     acc += bm[k] / pn;
     const double nx = A.ps_forced ? A.ps_forced[(long)b * A.forced_bstride + k] : pn;
     A.ps_cur[(long)b * N + k] = nx;
-    A.a[(long)b * N + k] = sqrt(nx / (double)N);
+    A.ia[(long)b * N + k] = inv_a(nx, (double)N);
   }
   const double tot = block_sum(acc, red);
   if (tid == 0) A.lnpost_out[b] = A.lnp1[b] - tot;
@@ -527,7 +532,7 @@ extern "C" int hpx_plan_create(hpx_plan** out, int nbl, int T, int N, int M) {
   A_(Wre, nb * p->nblk * 1024); A_(Wim, nb * p->nblk * 1024);
   A_(Xre, nb * xsz); A_(Xim, nb * xsz);
   A_(info, nb);
-  A_(a, nb * N); A_(ps_cur, nb * N); A_(beta, nb * N); A_(betam, nb * N); A_(lnp1, nb);
+  A_(ia, nb * N); A_(ps_cur, nb * N); A_(beta, nb * N); A_(betam, nb * N); A_(lnp1, nb);
   A_(Rre, nb * rsz); A_(Rim, nb * rsz); A_(Zre, nb * rsz); A_(Zim, nb * rsz);
   A_(Cre, nb * N); A_(Cim, nb * N);
   A_(P2re, ssz); A_(P2im, ssz);
@@ -650,7 +655,7 @@ extern "C" int hpx_plan_set_rng(hpx_plan* p, const double* uniforms, const doubl
 
 static hpx_gen_batch gen_of(const hpx_plan* p) {
   hpx_gen_batch B;
-  B.a = p->a; B.cre = p->Cre; B.cim = p->Cim; B.rre = p->Rre; B.rim = p->Rim;
+  B.ia = p->ia; B.cre = p->Cre; B.cim = p->Cim; B.rre = p->Rre; B.rim = p->Rim;
   B.p2re = p->P2re; B.p2im = p->P2im; B.hre = p->Hre; B.him = p->Him;
   B.p4re = p->P4re; B.p4im = p->P4im;
   B.N = p->N; B.M = p->M; B.NP = p->NP; B.TP = p->TP; B.ncol = p->ncolR;
@@ -670,7 +675,7 @@ extern "C" int hpx_assemble_K(hpx_plan* p, const double* ps, double* k_out, void
   HPX_REQUIRE(p && p->have_static && ps, "hpx_assemble_K: plan not initialised or null ps");
   hipStream_t st = (hipStream_t)stream;
   const long tot = (long)p->nbl * p->N;
-  hipLaunchKernelGGL(k_set_a, dim3(256), dim3(256), 0, st, ps, p->a, p->ps_cur, tot, 1.0 / p->N);
+  hipLaunchKernelGGL(k_set_a, dim3(256), dim3(256), 0, st, ps, p->ia, p->ps_cur, tot, (double)p->N);
   HPX_HIP(hipGetLastError());
   HPX_TRY(launch_assemble(p, st, 0));
   if (k_out) {
@@ -720,16 +725,16 @@ struct IterOut {
   long cr_bstride, fg_bstride, chisq_bstride;
 };
 
-static int post_solve(hpx_plan* p, int it_abs, const double* rs, const IterOut& O, hipStream_t st) {
+static int post_solve(hpx_plan* p, int it_abs, const IterOut& O, hipStream_t st) {
   const int nbl = p->nbl, N = p->N, M = p->M, T = p->T, NP = p->NP, TP = p->TP;
   const double isn = 1.0 / sqrt((double)N);
-  // s = U s' = conj(F) (rs . X) / sqrt(N)
+  // s = U z = conj(F) X / sqrt(N)   (rows >= N of X meet the zero padding of the operator)
   HPX_TRY(hpx_launch_dft(nbl, NP, TP, p->Fopre, p->Fopim, 1, p->Xre, p->Xim, (long)p->npad * TP,
-                         TP, rs, N, p->Sre, p->Sim, (long)NP * TP, TP, isn, st, N == NP));
+                         TP, nullptr, 0, p->Sre, p->Sim, (long)NP * TP, TP, isn, st, N == NP));
   HPX_TRY(mark(p, st));
   ResArgs R;
   R.Xre = p->Xre; R.Xim = p->Xim; R.Sre = p->Sre; R.Sim = p->Sim; R.Dre = p->Dre; R.Dim = p->Dim;
-  R.Fre = p->Fre; R.Fim = p->Fim; R.ninv = p->ninv; R.a = p->a; R.flags = p->flags;
+  R.Fre = p->Fre; R.Fim = p->Fim; R.ninv = p->ninv; R.flags = p->flags;
   R.beta = p->beta; R.lnp1 = p->lnp1; R.Gre = p->Gre; R.Gim = p->Gim;
   R.cr_bstride = O.cr_bstride; R.fg_bstride = O.fg_bstride; R.chisq_bstride = O.chisq_bstride;
   R.cr_out = O.cr_out; R.fg_out = (M > 0) ? O.fg_out : nullptr; R.chisq_out = O.chisq_out;
@@ -752,7 +757,7 @@ static int post_solve(hpx_plan* p, int it_abs, const double* rs, const IterOut& 
   D.uni = p->uni + (long)it_abs * N; D.igy = p->igy + (long)it_abs * N;
   D.xgrid = p->xgrid; D.pmap = p->pmap;
   D.ps_forced = O.ps_forced; D.forced_bstride = O.forced_bstride;
-  D.a = p->a; D.ps_cur = p->ps_cur;
+  D.ia = p->ia; D.ps_cur = p->ps_cur;
   D.ps_out = O.ps_out; D.ps_bstride = O.ps_bstride;
   D.N = N; D.T = T; D.ngrid = p->ngrid; D.prior_shared = p->prior_shared;
   D.any_flags = p->any_flags; D.lgam_T = p->lgam_T;
@@ -804,8 +809,8 @@ extern "C" int hpx_gibbs_run(hpx_plan* p, const double* ps0, int iter0, int nite
   const int nbl = p->nbl, N = p->N, M = p->M, T = p->T, TP = p->TP;
   const int nkeep = (niter + thin - 1) / thin;
   if (ps0) {
-    hipLaunchKernelGGL(k_set_a, dim3(256), dim3(256), 0, st, ps0, p->a, p->ps_cur, (long)nbl * N,
-                       1.0 / N);
+    hipLaunchKernelGGL(k_set_a, dim3(256), dim3(256), 0, st, ps0, p->ia, p->ps_cur, (long)nbl * N,
+                       (double)N);
     HPX_HIP(hipGetLastError());
   }
   HPX_HIP(hipMemsetAsync(p->info, 0, (size_t)nbl * sizeof(int32_t), st));
@@ -835,7 +840,7 @@ extern "C" int hpx_gibbs_run(hpx_plan* p, const double* ps0, int iter0, int nite
     O.cr_out = (cr_out && keep) ? cr_out + slot * T * N * 2 : nullptr;
     O.fg_out = (fg_out && keep) ? fg_out + slot * T * M * 2 : nullptr;
     O.chisq_out = (chisq_out && keep) ? chisq_out + slot * T * N : nullptr;
-    HPX_TRY(post_solve(p, iter0 + it, p->a, O, st));
+    HPX_TRY(post_solve(p, iter0 + it, O, st));
   }
   return finish_run(p, niter, ps_last, st);
 }
@@ -921,15 +926,13 @@ __global__ __launch_bounds__(256) void k_assemble_general(
 // X rows [0,N) <- s' (from scratch G), a <- 1
 __global__ void k_take_sprime(const double* __restrict__ Gre, const double* __restrict__ Gim,
                               double* __restrict__ Xre, double* __restrict__ Xim,
-                              double* __restrict__ a, const int N, const int NP, const int TP,
-                              const int npad) {
+                              const int N, const int NP, const int TP, const int npad) {
   const int b = blockIdx.y;
   const long tot = (long)N * TP;
   for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < tot;
        e += (long)gridDim.x * blockDim.x) {
     Xre[(long)b * npad * TP + e] = Gre[(long)b * NP * TP + e];
     Xim[(long)b * npad * TP + e] = Gim[(long)b * NP * TP + e];
-    if (e < N) a[(long)b * N + e] = 1.0;
   }
 }
 }  // namespace
@@ -974,11 +977,11 @@ extern "C" int hpx_gibbs_step_general(hpx_plan* p, const double* shp, int iter0,
   HPX_TRY(mark(p, st));
   HPX_TRY(hpx_launch_backsolve(nbl, p->npad, TP, p->ld, p->L, p->Wre, p->Wim, p->Xre, p->Xim, st));
   HPX_TRY(mark(p, st));
-  // s' = Sh' y'  -> X rows [0,N);  a := 1 so that beta = N sum |s'|^2 and s = U s'
+  // s' = Sh' y'  -> X rows [0,N): beta = N sum |s'|^2 and s = U s' as in the scaled system
   HPX_TRY(hpx_launch_dft(nbl, NP, TP, p->SHre, p->SHim, 1, p->Xre, p->Xim, (long)p->npad * TP, TP,
                          nullptr, 0, p->Gre, p->Gim, (long)NP * TP, TP, 1.0, st, 0, mstr));
   hipLaunchKernelGGL(k_take_sprime, dim3(32, nbl), dim3(256), 0, st, p->Gre, p->Gim, p->Xre, p->Xim,
-                     p->a, N, NP, TP, p->npad);
+                     N, NP, TP, p->npad);
   HPX_HIP(hipGetLastError());
   IterOut O;
   O.ps_forced = nullptr; O.forced_bstride = 0;
@@ -986,7 +989,7 @@ extern "C" int hpx_gibbs_step_general(hpx_plan* p, const double* shp, int iter0,
   O.lnpost_out = lnpost_out; O.lnpost_pitch = 1;
   O.cr_bstride = (long)T * N * 2; O.fg_bstride = (long)T * M * 2; O.chisq_bstride = (long)T * N;
   O.cr_out = cr_out; O.fg_out = fg_out; O.chisq_out = chisq_out;
-  HPX_TRY(post_solve(p, iter0, nullptr, O, st));
+  HPX_TRY(post_solve(p, iter0, O, st));
   return finish_run(p, 1, ps_last, st);
 }
 

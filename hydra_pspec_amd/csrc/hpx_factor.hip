@@ -94,7 +94,7 @@ template <bool GLDS> struct gen_ptr { typedef glb_f64 type; };
 template <> struct gen_ptr<true> { typedef lds_f64 type; };
 template <bool GLDS>
 struct gen_signal {             // the part of hpx_gen the diagonal block needs (by value)
-  const typename gen_ptr<GLDS>::type *a, *cre, *cim;
+  const typename gen_ptr<GLDS>::type *ia, *cre, *cim;
   int rmin;
 };
 
@@ -390,10 +390,9 @@ __device__ HPX_OUTLINE bool diag_panel(glb_f64* __restrict__ Lre, glb_f64* __res
       double kr, ki;
       if (GEN && c0 + 32 <= G.rmin) {
         if (r > c) {
-          const double sc = G.a[c0 + r] * G.a[c0 + c];
-          kr = sc * G.cre[r - c];
-          ki = sc * G.cim[r - c];
-        } else { const double ac = G.a[c0 + c]; kr = 1.0 + ac * ac * G.cre[0]; ki = 0.0; }
+          kr = G.cre[r - c];
+          ki = G.cim[r - c];
+        } else { const double ic = G.ia[c0 + c]; kr = fma(ic, ic, G.cre[0]); ki = 0.0; }
       } else {
         const long off = HPX_LIDX(c0 + r, c0 + c, npad);
         kr = Lre[off];
@@ -578,7 +577,7 @@ __device__ HPX_OUTLINE bool diag_panel(glb_f64* __restrict__ Lre, glb_f64* __res
   return bad;
 }
 
-// GLDS: the per-baseline vectors the closed-form K' entries are made of (a, circ: 3 N doubles)
+// GLDS: the per-baseline vectors the closed-form entries are made of (1/a, circ: 3 N doubles)
 // are staged in LDS behind FactorShared.  From global memory every tile group's initialisation
 // waits for loads that miss L1 and L2 (the factor streams through both), ~1e4 cycles a group.
 template <bool GEN, bool GLDS>
@@ -614,16 +613,16 @@ __global__ __launch_bounds__(256, HPX_WGS) void k_factor(double* __restrict__ L_
       double* gcr = ga + G.N;
       double* gci = gcr + G.N;
       for (int i = tid; i < G.N; i += 256) {
-        ga[i] = G.a[i];
+        ga[i] = G.ia[i];
         gcr[i] = G.cre[i];
         gci[i] = G.cim[i];
       }
-      G.a = ga;
+      G.ia = ga;
       G.cre = gcr;
       G.cim = gci;
       __syncthreads();
     }
-    GS = {(const gsrc*)G.a, (const gsrc*)G.cre, (const gsrc*)G.cim, G.rmin};
+    GS = {(const gsrc*)G.ia, (const gsrc*)G.cre, (const gsrc*)G.cim, G.rmin};
   }
 
   int c0 = 0;

@@ -61,7 +61,7 @@ struct hpx_plan {
   double *Xre, *Xim;       // [nbl][npad][TP] solution [y' ; f]
   int32_t *info;           // [nbl]
   // chain state
-  double *a, *ps_cur;      // [nbl][N]
+  double *ia, *ps_cur;     // [nbl][N]: sqrt(N / ps) = 1/a, and the bandpowers themselves
   double *beta, *betam;    // [nbl][N]
   double *lnp1;            // [nbl]
   // invariants
@@ -91,15 +91,20 @@ struct hpx_plan {
   std::vector<void*> allocs;
 };
 
-// ---- K'_aug generator ---------------------------------------------------------
-// Entry (r, c), r >= c, of the augmented system of one baseline:
-//   r, c < N        : delta_rc + a_r a_c circ[r-c]            (I + D^1/2 C D^1/2)
-//   N <= r < N+M    : conj(G[c][m]) a_c  /  H[r-N][c-N]        (G^H D^1/2, H)
+// ---- augmented-system generator ------------------------------------------------
+// The system solved is K' [y'; f] = r' of DESIGN.md section 2 scaled symmetrically by
+// A^-1 = diag(1/a, 1), a = sqrt(ps/N):   M [z; f] = A^-1 r',  z = a . y',
+//   M = A^-1 K' A^-1 = [[C + diag(N/ps), G], [G^H, H]].
+// Only the diagonal of M depends on the bandpowers; Cholesky is insensitive to the symmetric
+// scaling, and s = U z, beta_k = N sum_t |z_kt|^2 need no further scaling.
+// Entry (r, c), r >= c, of the augmented matrix of one baseline (ia = 1/a):
+//   r, c < N        : circ[r-c] + delta_rc ia_c^2
+//   N <= r < N+M    : conj(G[c][m])  /  H[r-N][c-N]
 //   N+M <= r < npad : identity padding
-//   r >= npad       : conj of right-hand side t = r - npad     (a_c Q[c][t] + P2[c][t] ; P4[c-N][t])
+//   r >= npad       : conj of right-hand side t = r - npad     (Q[c][t] + ia_c P2[c][t] ; P4[c-N][t])
 // Pointers are per baseline (already offset), except P2 (shared).
 struct hpx_gen {
-  const double *a, *cre, *cim, *rre, *rim, *p2re, *p2im, *hre, *him, *p4re, *p4im;
+  const double *ia, *cre, *cim, *rre, *rim, *p2re, *p2im, *hre, *him, *p4re, *p4im;
   int N, M, TP, ncol, has_omega, rmin;
 };
 __device__ __forceinline__ void hpx_gen_entry(const hpx_gen& G, const int r, const int c,
@@ -109,23 +114,23 @@ __device__ __forceinline__ void hpx_gen_entry(const hpx_gen& G, const int r, con
   const int N = G.N, M = G.M;
   if (r < c) return;
   if (c < N) {
-    const double ac = G.a[c];
     if (r < N) {
-      const double s = G.a[r] * ac;
-      vr = s * G.cre[r - c] + (r == c ? 1.0 : 0.0);
-      vi = (r == c) ? 0.0 : s * G.cim[r - c];
+      const double ic = G.ia[c];
+      vr = G.cre[r - c] + (r == c ? ic * ic : 0.0);
+      vi = (r == c) ? 0.0 : G.cim[r - c];
     } else if (r < N + M) {
       const long o = (long)c * G.ncol + G.TP + (r - N);
-      vr = G.rre[o] * ac;
-      vi = -G.rim[o] * ac;
+      vr = G.rre[o];
+      vi = -G.rim[o];
     } else if (r >= npad) {
       const int t = r - npad;
       const long o = (long)c * G.ncol + t;
-      vr = ac * G.rre[o];
-      vi = ac * G.rim[o];
+      vr = G.rre[o];
+      vi = G.rim[o];
       if (G.has_omega) {
-        vr += G.p2re[(long)c * G.TP + t];
-        vi += G.p2im[(long)c * G.TP + t];
+        const double ic = G.ia[c];
+        vr = fma(ic, G.p2re[(long)c * G.TP + t], vr);
+        vi = fma(ic, G.p2im[(long)c * G.TP + t], vi);
       }
       vi = -vi;
     }
@@ -143,24 +148,23 @@ __device__ __forceinline__ void hpx_gen_entry(const hpx_gen& G, const int r, con
     vr = 1.0;
   }
 }
-// Signal x signal entry strictly below the diagonal: a_r a_c circ[r-c] (no branches).  Used by
+// Signal x signal entry strictly below the diagonal: circ[r-c] (no branches).  Used by
 // the factor kernel for all row tiles below `rmin` (= 32*floor(N/32)); rows >= rmin (foreground
 // modes, padding, right-hand sides) are written to the factor buffer by k_assemble beforehand.
 __device__ __forceinline__ void hpx_gen_signal(const hpx_gen& G, const int r, const int c,
                                                double& vr, double& vi) {
-  const double s = G.a[r] * G.a[c];
-  vr = s * G.cre[r - c];
-  vi = s * G.cim[r - c];
+  vr = G.cre[r - c];
+  vi = G.cim[r - c];
 }
 
 // batch-level description: per-baseline strides are implied by the plan dimensions
 struct hpx_gen_batch {
-  const double *a, *cre, *cim, *rre, *rim, *p2re, *p2im, *hre, *him, *p4re, *p4im;
+  const double *ia, *cre, *cim, *rre, *rim, *p2re, *p2im, *hre, *him, *p4re, *p4im;
   int N, M, NP, TP, ncol, has_omega, rmin;
 };
 __device__ __forceinline__ hpx_gen hpx_gen_for(const hpx_gen_batch& B, const int b) {
   hpx_gen G;
-  G.a = B.a + (long)b * B.N;
+  G.ia = B.ia + (long)b * B.N;
   G.cre = B.cre + (long)b * B.N;
   G.cim = B.cim + (long)b * B.N;
   G.rre = B.rre + (long)b * B.NP * B.ncol;

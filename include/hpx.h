@@ -127,9 +127,11 @@ int hpx_plan_stage_ms(hpx_plan* p, float* ms_host);
 
 /* ---- unit-testable stages (same kernels the run uses) ------------------- */
 
-/* K'_aug for the current bandpowers `ps` (nbl,N): lower triangle of
- * K' = [[I + D^1/2 C D^1/2, D^1/2 G],[G^H D^1/2, H]] plus the T right-hand-side
- * rows, written to the plan's factor buffer and copied to `k_out`
+/* Augmented system for the current bandpowers `ps` (nbl,N): lower triangle of
+ * M = A^-1 K' A^-1 = [[C + diag(N/ps), G],[G^H, H]]  (K' = [[I + D^1/2 C D^1/2, D^1/2 G],
+ * [G^H D^1/2, H]], A = diag(D^1/2, I): the symmetric scaling the device solves in, DESIGN.md
+ * section 2) plus the T right-hand-side rows A^-1 r', written to the plan's factor buffer and
+ * copied to `k_out`
  * (nbl, npad+Tpad, npad) c128 row-major (upper triangle zero) if non-NULL.
  * Replaces build_matrices + the RHS of gcr_fgmodes_1d (pspec.py:325-374,
  * :220-222) in Hermitian form. */

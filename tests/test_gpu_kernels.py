@@ -179,7 +179,12 @@ def test_assemble_K(T, Tn, N, M, frac):
     om = pspec.omega_table(Tn, N)
     n = N + M
     for b, psb in enumerate((ps, ps[::-1])):
-        K, r, _, _ = _reference_system(d["vis"][b], d["flags"][b], d["ninv_diag"][b], F, psb, om)
+        K, r, _, a = _reference_system(d["vis"][b], d["flags"][b], d["ninv_diag"][b], F, psb, om)
+        # the device works with the symmetrically scaled system M = A^-1 K' A^-1, A = diag(a, 1)
+        # (hpx_internal.h): K' entries and right-hand sides divided by a on the signal side
+        ainv = np.concatenate([1.0 / a, np.ones(M)])
+        K = ainv[:, None] * K * ainv[None, :]
+        r = ainv[:, None] * r
         got = Kd[b]
         assert relerr(np.tril(got[:n, :n]), np.tril(K)) < 1e-12
         assert relerr(got[npad:npad + Tn, :n], r.conj().T) < 1e-12
