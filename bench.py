@@ -156,7 +156,7 @@ def main():
         fac_tflops = nbl * flops_factor(N, M, T) / (fac_ms * 1e-3) / 1e12
         traffic = None
         try:   # HBM bytes per k_factor launch from the committed PMC passes (profiles/), same workload
-            pm = json.load(open(REPO / "profiles" / "pmc_traffic.json"))[args.config]["k_factor<true>"]
+            pm = json.load(open(REPO / "profiles" / "pmc_traffic.json"))[args.config]["k_factor"]
             traffic = pm["bytes_per_launch"] * nbl / pm["baselines"]
         except Exception:
             pass
