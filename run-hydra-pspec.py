@@ -15,7 +15,9 @@ fg-amps,chisq,ln-post}.npy`` (:498-502, utils.py:307-312) and ``timings.json`` k
 * all baselines of a rank run as ONE batch on the GPU;
 * inputs: ``.npy``/``.npz`` visibility cubes (``--file_paths cube.npy`` with shape
   (Nbl,Ntimes,Nfreqs), optional ``antpairs.npy``), or ``--synthetic Nbl,Ntimes,Nfreqs``;
-  UVH5 files are read directly with h5py when it is installed (no pyuvdata).
+  UVH5 files are read by the package's own HDF5 reader (hydra_pspec_amd/uvh5.py: no
+  pyuvdata, h5py or astropy), each rank only its own baselines, with the reference's
+  frequency selection, ant1<ant2 conjugation and XX+YY pseudo-Stokes I.
 """
 import argparse
 import json
@@ -111,26 +113,6 @@ def load_aux(path, file_name, bl_str):
     return np.load(fp)
 
 
-def read_uvh5_block(paths, lo, hi):
-    """Minimal UVH5 reader (h5py): pseudo-Stokes I = XX + YY per baseline
-    (utils.py:105-132), baselines in file order.  Returns (antpairs, vis (nbl,T,N), flags)."""
-    import h5py
-    assert len(paths) == 1, "one UVH5 file at a time"
-    with h5py.File(paths[0], "r") as f:
-        a1, a2 = f["Header/ant_1_array"][:], f["Header/ant_2_array"][:]
-        pol = list(f["Header/polarization_array"][:])
-        pairs = sorted(set(zip(a1.tolist(), a2.tolist())))
-        out_v, out_f, out_p = [], [], []
-        for (i, j) in pairs[lo:hi]:
-            sel = np.nonzero((a1 == i) & (a2 == j))[0]
-            v = f["Data/visdata"][sel]
-            fl = f["Data/flags"][sel]
-            out_v.append(v[:, :, pol.index(-5)] + v[:, :, pol.index(-6)])
-            out_f.append(fl[:, :, pol.index(-5)])
-            out_p.append((i, j))
-    return out_p, np.array(out_v), np.array(out_f), len(pairs)
-
-
 def main(argv=None):
     args = parse_args(argv)
     rank = int(os.environ.get("RANK", "0"))
@@ -167,9 +149,15 @@ def main(argv=None):
             flags_td = np.zeros(vis.shape, bool) if flags_all is None else np.array(flags_all[lo:hi], bool)
             antpairs = pairs_all[lo:hi] if pairs_all else [(0, k + 1) for k in range(lo, hi)]
         else:
-            _, _, _, nbl_all = read_uvh5_block([str(fp)], 0, 0)
-            lo, hi = block_range(nbl_all, world, rank)
-            antpairs, vis, flags_td, _ = read_uvh5_block([str(fp)], lo, hi)
+            from hydra_pspec_amd import uvh5
+            assert len(args.file_paths) == 1, "one UVH5 file at a time"
+            with uvh5.UVH5File(fp) as u:
+                pairs_all = u.antpairs(args.ant_str)
+                nbl_all = len(pairs_all)
+                lo, hi = block_range(nbl_all, world, rank)
+                fmask = uvh5.filter_freqs(args.freq_range, u.freqs_hz / 1e6) if args.freq_range else None
+                antpairs = pairs_all[lo:hi]
+                vis, flags_td = u.read_baselines(antpairs, fmask)
         T, N = vis.shape[1:]
         default_fg = default_ps0 = default_ninv = None
     nbl = vis.shape[0]

@@ -108,3 +108,31 @@ def test_driver_resume(tmp_path):
     for k in (1, 2):
         for f in ("dps-eor.npy", "gcr-eor.npy", "ln-post.npy", "chisq.npy", "fg-amps.npy"):
             assert np.array_equal(np.load(tmp_path / "part" / f"0-{k}" / f), np.load(tmp_path / "full" / f"0-{k}" / f))
+
+
+@pytest.mark.gpu
+def test_driver_config1_from_uvh5(golden, tmp_path):
+    """Config 1 straight from the reference's UVH5 test file (tests/golden/vis-eor-fgs.uvh5, a copy
+    of test_data/vis-eor-fgs.uvh5) through the package's own HDF5 reader: XX+YY of baseline (0, 1)
+    plus the noise realisation reproduces the reference chain (run-hydra-pspec.py:305-322, :415)."""
+    from hydra_pspec_amd import uvh5
+    drv = _driver()
+    g = golden("chain_testdata")
+    src = Path(__file__).parent / "golden" / "vis-eor-fgs.uvh5"
+    pairs, vis, flags, ntot, _ = uvh5.read_uvh5_block(src, 0, 1, ant_str="cross")
+    assert pairs == [(0, 1)] and ntot == 1 and not flags.any()
+    aux = tmp_path / "aux" / "0-1"
+    aux.mkdir(parents=True)
+    np.save(aux / "noise.npy", g["vis"] - vis[0])               # the golden cube is XX+YY + noise.npy
+    np.save(aux / "eor-cov.npy", g["S_initial"])
+    np.save(aux / "fgmodes.npy", g["fgmodes"])
+    np.save(aux / "noise-cov.npy", np.diag(1.0 / g["ninv_diag"]))
+    rc = drv.main(["--file_paths", str(src), "--sigcov0", str(tmp_path / "aux"), "--sigcov0_file", "eor-cov.npy",
+                   "--fgmodes", str(tmp_path / "aux"), "--fgmodes_file", "fgmodes.npy", "--Nfgmodes", "12",
+                   "--noise", str(tmp_path / "aux"), "--noise_file", "noise.npy",
+                   "--noise_cov", str(tmp_path / "aux"), "--noise_cov_file", "noise-cov.npy",
+                   "--ps_prior_lo", "0.1", "--ps_prior_hi", "2", "--seed", "7123689", "--Niter", "10",
+                   "--out_dir", str(tmp_path), "--dirname", "res"])
+    assert rc == 0
+    ps = np.load(tmp_path / "res" / "0-1" / "dps-eor.npy")
+    assert np.max(np.abs(ps / g["ref_ps"][:10] - 1)) < 1e-6
