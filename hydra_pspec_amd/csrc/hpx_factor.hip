@@ -939,12 +939,8 @@ __global__ void k_unpack_x(const double* __restrict__ Xre, const double* __restr
 template <bool GEN, bool GLDS>
 static int launch_factor_t(int nbl, size_t lds, int npad, int ld, double* L, double* Wre, double* Wim,
                            int32_t* info, int iter_tag, const hpx_gen_batch& gen, hipStream_t st) {
-  static size_t attr_lds = 0;      // per instantiation
-  if (lds > attr_lds) {
-    HPX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_factor<GEN, GLDS>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_lds = lds;
-  }
+  static hpx_lds_limit limit;      // per instantiation
+  HPX_TRY(limit.ensure(reinterpret_cast<const void*>(&k_factor<GEN, GLDS>), lds));
   hipLaunchKernelGGL((k_factor<GEN, GLDS>), dim3(nbl), dim3(256), lds, st, L, Wre, Wim, info, npad, ld,
                      iter_tag, gen);
   HPX_HIP(hipGetLastError());

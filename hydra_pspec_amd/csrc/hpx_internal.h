@@ -180,6 +180,21 @@ __device__ __forceinline__ hpx_gen hpx_gen_for(const hpx_gen_batch& B, const int
   return G;
 }
 
+// Raise a kernel's dynamic-LDS limit when a launch needs more than the current one.  The limit
+// is a property of the function ON A DEVICE: remembered per (call site, device), since one
+// process may drive several GPUs (hpx_set_device).
+struct hpx_lds_limit {
+  size_t set[32] = {};
+  int ensure(const void* func, size_t bytes) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 32) dev = 0;
+    if (bytes <= set[dev]) return HPX_OK;
+    HPX_HIP(hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    set[dev] = bytes;
+    return HPX_OK;
+  }
+};
+
 // ---- launchers (each returns HPX_OK / HPX_EHIP) -----------------------------
 // gen == nullptr: factor the matrix stored in L in place; otherwise K'_aug is generated on the
 // fly from *gen and L is write-only.

@@ -270,14 +270,9 @@ int hpx_launch_dft(int nbl, int NP, int ncol, const double* Wre, const double* W
     int tcs = 0;
     while ((1 << tcs) < TC) ++tcs;
     const size_t lds = ((size_t)NP * TC * 2 + NP) * sizeof(double);
-    static bool attr_done = false;
-    if (!attr_done) {
-      HPX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fft<1>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
-      HPX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fft<-1>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
-      attr_done = true;
-    }
+    static hpx_lds_limit lim_fwd, lim_inv;
+    HPX_TRY(lim_fwd.ensure(reinterpret_cast<const void*>(&k_fft<1>), lds));
+    HPX_TRY(lim_inv.ensure(reinterpret_cast<const void*>(&k_fft<-1>), lds));
     dim3 grid((ncol + TC - 1) / TC, nbl);
     if (conjW)
       hipLaunchKernelGGL(k_fft<1>, grid, dim3(256), lds, st, Wre, Wim, inre, inim, in_bstride, in_ld,
