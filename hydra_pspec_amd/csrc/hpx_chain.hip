@@ -686,6 +686,27 @@ extern "C" int hpx_assemble_K(hpx_plan* p, const double* ps, double* k_out, void
   return HPX_OK;
 }
 
+extern "C" int hpx_plan_set_solver(hpx_plan* p, int mode) {
+  HPX_REQUIRE(p && p->have_static, "hpx_plan_set_solver: plan has no static inputs");
+  HPX_REQUIRE(mode == HPX_SOLVER_DENSE || mode == HPX_SOLVER_FLAT, "hpx_plan_set_solver: unknown mode");
+  if (mode == HPX_SOLVER_FLAT) {
+    HPX_REQUIRE(!p->any_flags, "hpx_plan_set_solver: the flat-noise solver needs unflagged data");
+    HPX_REQUIRE(p->M <= 16 && p->TP <= 256, "hpx_plan_set_solver: the flat-noise solver needs M <= 16, T <= 256");
+    HPX_REQUIRE(hpx_flat_lds_bytes(p) <= 160 * 1024, "hpx_plan_set_solver: too many channels for the flat-noise solver");
+    std::vector<double> ni((size_t)p->nbl * p->N);
+    HPX_HIP(hipMemcpy(ni.data(), p->ni, ni.size() * sizeof(double), hipMemcpyDeviceToHost));
+    for (int b = 0; b < p->nbl; ++b)
+      for (int k = 1; k < p->N; ++k)
+        if (ni[(size_t)b * p->N + k] != ni[(size_t)b * p->N]) {
+          hpx_set_error("hpx_plan_set_solver: inverse noise variance of baseline %d is not flat (channel %d)",
+                        b, k);
+          return HPX_EINVAL;
+        }
+  }
+  p->solver = mode;
+  return HPX_OK;
+}
+
 extern "C" int hpx_plan_set_profiling(hpx_plan* p, int on) {
   HPX_REQUIRE(p, "null plan");
   p->profiling = on ? 1 : 0;
@@ -819,14 +840,23 @@ extern "C" int hpx_gibbs_run(hpx_plan* p, const double* ps0, int iter0, int nite
     HPX_TRY(mark(p, st));
     // Only the edge rows (foreground modes, padding, right-hand sides: rows >= rmin) are
     // assembled; the signal x signal part of K' is generated inside the factor kernel.
-    const hpx_gen_batch gen = gen_of(p);
-    HPX_TRY(launch_assemble(p, st, gen.rmin));
-    HPX_TRY(mark(p, st));
-    HPX_TRY(hpx_launch_factor(nbl, p->npad, p->ld, p->L, p->Wre, p->Wim, p->info, iter0 + it + 1,
-                              &gen, st));
-    HPX_TRY(mark(p, st));
-    HPX_TRY(hpx_launch_backsolve(nbl, p->npad, TP, p->ld, p->L, p->Wre, p->Wim, p->Xre, p->Xim, st));
-    HPX_TRY(mark(p, st));
+    if (p->solver == HPX_SOLVER_FLAT) {
+      // flat noise, no flags: diagonal + rank-M border, solved through the Schur complement
+      // (hpx_flat.hip); booked under the "factor" stage
+      HPX_TRY(mark(p, st));
+      HPX_TRY(hpx_launch_solve_flat(p, iter0 + it + 1, st));
+      HPX_TRY(mark(p, st));
+      HPX_TRY(mark(p, st));
+    } else {
+      const hpx_gen_batch gen = gen_of(p);
+      HPX_TRY(launch_assemble(p, st, gen.rmin));
+      HPX_TRY(mark(p, st));
+      HPX_TRY(hpx_launch_factor(nbl, p->npad, p->ld, p->L, p->Wre, p->Wim, p->info, iter0 + it + 1,
+                                &gen, st));
+      HPX_TRY(mark(p, st));
+      HPX_TRY(hpx_launch_backsolve(nbl, p->npad, TP, p->ld, p->L, p->Wre, p->Wim, p->Xre, p->Xim, st));
+      HPX_TRY(mark(p, st));
+    }
     const bool keep = (it % thin) == 0;
     const long slot = it / thin;
     IterOut O;

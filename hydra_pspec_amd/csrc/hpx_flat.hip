@@ -1,0 +1,259 @@
+// Structured solve for baselines with flat noise and no flags.
+//
+// With Ni = c I (no flagged channel, the same noise variance in every channel) the circulant
+// C = U^H Ni U is c I, and the scaled system of hpx_internal.h becomes diagonal + a rank-M border:
+//
+//     M = [[ diag(c + N/ps) , G ],      [z; f] = M^-1 [r1; r2],   r1 = Q + P2/a,  r2 = P4
+//          [ G^H            , H ]]
+//
+// solved exactly through the M x M Schur complement, O(N M (M + T)) instead of O(N^3):
+//
+//     Dinv = 1 / (c + N/ps)
+//     S  = H  - G^H Dinv G          (M x M)
+//     Rf = r2 - G^H Dinv r1         (M x T)
+//     f  = S^-1 Rf
+//     z  = Dinv (r1 - G f)
+//
+// This is the reference's own test configuration (test_data: noise-cov.npy = sigma^2 I, no
+// flags) and SURVEY 8(d)'s unflagged synthetic recipe.  One workgroup per baseline; the two
+// contractions over the N channels run on the f64 MFMA (K split over the 4 waves, fixed-order
+// reduction through LDS), the M x M solve is a Gauss-Jordan elimination in LDS.  The kernel
+// writes X = [z; f] in the layout k_backsolve produces, so everything downstream is shared
+// with the dense path.  Selected by hpx_plan_set_solver(); results agree with the dense
+// path to rounding (tests/test_gpu_chain.py).
+#include "hpx_internal.h"
+
+namespace {
+
+constexpr int FT_MAX = 3;          // t-tiles per pass of the first contraction
+
+struct FlatArgs {
+  const double *ia, *cre, *rre, *rim, *p2re, *p2im, *hre, *him, *p4re, *p4im;
+  double *Xre, *Xim;
+  int32_t* info;
+  int N, M, NP, TP, ncol, npad, has_omega, iter_tag;
+};
+
+__global__ __launch_bounds__(256) void k_solve_flat(const FlatArgs A) {
+  extern __shared__ double lds[];
+  const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int li = lane & 15, g = lane >> 4;
+  const int N = A.N, M = A.M, NP = A.NP, TP = A.TP, ncol = A.ncol, TT = TP >> 4;
+  const int SW = 16 + TP;                         // row length of the augmented M x M system
+  double* dinv = lds;                             // [NP]
+  double* iav = dinv + NP;                        // [NP]
+  double* slab = iav + NP;                        // [4][1 + FT_MAX][2][4][64]
+  double* sre = slab + 4 * (1 + FT_MAX) * 2 * 256;   // [16][SW]
+  double* sim = sre + 16 * SW;
+  __shared__ int bad_s;
+  const double* ia = A.ia + (long)b * N;
+  const double* rre = A.rre + (long)b * NP * ncol;
+  const double* rim = A.rim + (long)b * NP * ncol;
+  const double c0 = A.cre[(long)b * N];
+  if (tid == 0) bad_s = 0;
+  for (int k = tid; k < NP; k += 256) {
+    const double v = (k < N) ? ia[k] : 0.0;
+    iav[k] = v;
+    dinv[k] = (k < N) ? 1.0 / fma(v, v, c0) : 0.0;
+  }
+  __syncthreads();
+
+  // ---- S = H - G^H Dinv G  and  Rf = P4 - G^H Dinv r1, t-tiles in passes of FT_MAX
+  const int nks = NP >> 2;
+  for (int tb = 0; tb < TT; tb += FT_MAX) {
+    const int nt = min(FT_MAX, TT - tb);
+    const bool with_s = (tb == 0);
+    d4 ar[1 + FT_MAX], ai[1 + FT_MAX];
+#pragma unroll
+    for (int q = 0; q < 1 + FT_MAX; ++q) {
+      ar[q] = (d4){0., 0., 0., 0.};
+      ai[q] = (d4){0., 0., 0., 0.};
+    }
+    for (int ks = wave; ks < nks; ks += 4) {
+      const int k = 4 * ks + g;
+      const int kc = min(k, N - 1);               // padded channels: Dinv = 0, any finite operand
+      const long ro = (long)kc * ncol;
+      const double dk = dinv[k], ik = iav[k];
+      // A[m = li][k] = conj(G[k][m])
+      const double gr = rre[ro + TP + li], gi = rim[ro + TP + li];
+      const double a_r = gr, a_i = -gi;
+      if (with_s) {                               // B[k][m' = li] = Dinv_k G[k][m']
+        const double b_r = dk * gr, b_i = dk * gi;
+        ar[0] = mfma64(a_r, b_r, ar[0]);
+        ar[0] = mfma64(-a_i, b_i, ar[0]);
+        ai[0] = mfma64(a_r, b_i, ai[0]);
+        ai[0] = mfma64(a_i, b_r, ai[0]);
+      }
+#pragma unroll
+      for (int q = 0; q < FT_MAX; ++q) {
+        if (q >= nt) break;
+        const int t = ((tb + q) << 4) + li;        // B[k][t] = Dinv_k r1[k][t]
+        double b_r = rre[ro + t], b_i = rim[ro + t];
+        if (A.has_omega) {
+          b_r = fma(ik, A.p2re[(long)kc * TP + t], b_r);
+          b_i = fma(ik, A.p2im[(long)kc * TP + t], b_i);
+        }
+        b_r *= dk;
+        b_i *= dk;
+        ar[1 + q] = mfma64(a_r, b_r, ar[1 + q]);
+        ar[1 + q] = mfma64(-a_i, b_i, ar[1 + q]);
+        ai[1 + q] = mfma64(a_r, b_i, ai[1 + q]);
+        ai[1 + q] = mfma64(a_i, b_r, ai[1 + q]);
+      }
+    }
+    double* mine = slab + (long)wave * (1 + FT_MAX) * 512;
+#pragma unroll
+    for (int q = 0; q < 1 + FT_MAX; ++q)
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        mine[q * 512 + v * 64 + lane] = ar[q][v];
+        mine[q * 512 + 256 + v * 64 + lane] = ai[q][v];
+      }
+    __syncthreads();
+    // fixed-order sum of the four waves' partial tiles; element (q, v, l) is row m = (l>>4)+4v,
+    // column l&15 of tile q
+    for (int e = tid; e < (1 + nt) * 256; e += 256) {
+      const int q = e >> 8, v = (e >> 6) & 3, l = e & 63;
+      if (q == 0 && !with_s) continue;
+      double s_r = 0.0, s_i = 0.0;
+      for (int w = 0; w < 4; ++w) {
+        s_r += slab[(long)w * (1 + FT_MAX) * 512 + q * 512 + v * 64 + l];
+        s_i += slab[(long)w * (1 + FT_MAX) * 512 + q * 512 + 256 + v * 64 + l];
+      }
+      const int m = HPX_ACC_ROW(l >> 4, v), col = l & 15;
+      double o_r, o_i;
+      if (q == 0) {                               // S, identity padding beyond M
+        if (m < M && col < M) {
+          o_r = A.hre[(long)b * M * M + m * M + col] - s_r;
+          o_i = A.him[(long)b * M * M + m * M + col] - s_i;
+        } else {
+          o_r = (m == col) ? 1.0 : 0.0;
+          o_i = 0.0;
+        }
+        sre[m * SW + col] = o_r;
+        sim[m * SW + col] = o_i;
+      } else {
+        const int t = ((tb + q - 1) << 4) + col;
+        if (m < M) {
+          o_r = A.p4re[(long)b * M * TP + m * TP + t] - s_r;
+          o_i = A.p4im[(long)b * M * TP + m * TP + t] - s_i;
+        } else {
+          o_r = 0.0;
+          o_i = 0.0;
+        }
+        sre[m * SW + 16 + t] = o_r;
+        sim[m * SW + 16 + t] = o_i;
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- f = S^-1 Rf: Gauss-Jordan on the augmented 16 x (16 + TP) system (S Hermitian
+  // positive definite: no pivoting)
+  double* prow_r = slab;                           // scaled pivot row / pivot column of a step
+  double* prow_i = prow_r + SW;
+  double* pcol_r = prow_i + SW;
+  double* pcol_i = pcol_r + 16;
+  for (int k = 0; k < 16; ++k) {
+    const double piv = sre[k * SW + k];
+    if (tid == 0 && !(piv > 0.0)) bad_s = 1;
+    const double rinv = 1.0 / piv;
+    for (int j = tid; j < SW; j += 256) {
+      prow_r[j] = sre[k * SW + j] * rinv;
+      prow_i[j] = sim[k * SW + j] * rinv;
+    }
+    if (tid < 16) {
+      pcol_r[tid] = sre[tid * SW + k];
+      pcol_i[tid] = sim[tid * SW + k];
+    }
+    __syncthreads();
+    for (int e = tid; e < 16 * SW; e += 256) {
+      const int i = e / SW, j = e - i * SW;
+      const double pr = prow_r[j], pi = prow_i[j];
+      if (i == k) {
+        sre[e] = pr;
+        sim[e] = pi;
+      } else {
+        const double fr = pcol_r[i], fi = pcol_i[i];
+        sre[e] -= fr * pr - fi * pi;
+        sim[e] -= fr * pi + fi * pr;
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- z = Dinv (r1 - G f), written with f and the zero padding as X = [z; f; 0]
+  double* Xre = A.Xre + (long)b * A.npad * TP;
+  double* Xim = A.Xim + (long)b * A.npad * TP;
+  for (int kt = wave; kt < (NP >> 4); kt += 4) {
+    const int k0 = kt << 4;
+    // A[k = k0 + li][m = 4 ks + g] = -G[k][m]
+    double ga_r[4], ga_i[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const long o = (long)min(k0 + li, N - 1) * ncol + TP + 4 * ks + g;
+      const bool live = 4 * ks + g < M;
+      ga_r[ks] = live ? -rre[o] : 0.0;
+      ga_i[ks] = live ? -rim[o] : 0.0;
+    }
+    for (int tt = 0; tt < TT; ++tt) {
+      const int t = (tt << 4) + li;
+      d4 zr, zi;
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {               // start from r1[k][t], k = k0 + g + 4v
+        const int k = min(k0 + HPX_ACC_ROW(g, v), N - 1);
+        double r_r = rre[(long)k * ncol + t], r_i = rim[(long)k * ncol + t];
+        if (A.has_omega) {
+          r_r = fma(iav[k], A.p2re[(long)k * TP + t], r_r);
+          r_i = fma(iav[k], A.p2im[(long)k * TP + t], r_i);
+        }
+        zr[v] = r_r;
+        zi[v] = r_i;
+      }
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {            // B[m = 4 ks + g][t] = f[m][t]
+        const int m = 4 * ks + g;
+        const double f_r = sre[m * SW + 16 + t], f_i = sim[m * SW + 16 + t];
+        zr = mfma64(ga_r[ks], f_r, zr);
+        zr = mfma64(-ga_i[ks], f_i, zr);
+        zi = mfma64(ga_r[ks], f_i, zi);
+        zi = mfma64(ga_i[ks], f_r, zi);
+      }
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const int k = k0 + HPX_ACC_ROW(g, v);
+        if (k < N) {
+          Xre[(long)k * TP + t] = zr[v] * dinv[k];
+          Xim[(long)k * TP + t] = zi[v] * dinv[k];
+        }
+      }
+    }
+  }
+  for (int e = tid; e < (A.npad - N) * TP; e += 256) {
+    const int m = e / TP, t = e - m * TP;
+    Xre[(long)(N + m) * TP + t] = (m < M) ? sre[m * SW + 16 + t] : 0.0;
+    Xim[(long)(N + m) * TP + t] = (m < M) ? sim[m * SW + 16 + t] : 0.0;
+  }
+  if (tid == 0 && bad_s && A.info) atomicCAS(&A.info[b], 0, A.iter_tag);
+}
+
+}  // namespace
+
+size_t hpx_flat_lds_bytes(const hpx_plan* p) {
+  return ((size_t)2 * p->NP + (size_t)4 * (1 + FT_MAX) * 512 + (size_t)2 * 16 * (16 + p->TP)) * sizeof(double);
+}
+
+int hpx_launch_solve_flat(hpx_plan* p, int iter_tag, hipStream_t st) {
+  FlatArgs A;
+  A.ia = p->ia; A.cre = p->Cre; A.rre = p->Rre; A.rim = p->Rim; A.p2re = p->P2re; A.p2im = p->P2im;
+  A.hre = p->Hre; A.him = p->Him; A.p4re = p->P4re; A.p4im = p->P4im;
+  A.Xre = p->Xre; A.Xim = p->Xim; A.info = p->info;
+  A.N = p->N; A.M = p->M; A.NP = p->NP; A.TP = p->TP; A.ncol = p->ncolR; A.npad = p->npad;
+  A.has_omega = p->has_omega; A.iter_tag = iter_tag;
+  const size_t lds = hpx_flat_lds_bytes(p);
+  static hpx_lds_limit limit;
+  HPX_TRY(limit.ensure(reinterpret_cast<const void*>(&k_solve_flat), lds));
+  hipLaunchKernelGGL(k_solve_flat, dim3(p->nbl), dim3(256), lds, st, A);
+  HPX_HIP(hipGetLastError());
+  return HPX_OK;
+}

@@ -54,6 +54,7 @@ struct hpx_plan {
   int nblk;     // number of block columns
   int ngrid, nxrows, niter_tab;
   int fg_shared, prior_shared, has_omega, any_flags, have_static, profiling;
+  int solver;   // HPX_SOLVER_DENSE / HPX_SOLVER_FLAT (hpx_plan_set_solver)
   int64_t bytes;
   // factor / solution
   double *L;               // [nbl][ld/16 panels][npad][re16|im16]  (HPX_LIDX)
@@ -200,6 +201,9 @@ struct hpx_lds_limit {
 // fly from *gen and L is write-only.
 int hpx_launch_factor(int nbl, int npad, int ld, double* L, double* Wre, double* Wim,
                       int32_t* info, int iter_tag, const hpx_gen_batch* gen, hipStream_t st);
+// structured solve for flat noise without flags (hpx_flat.hip): writes X = [z; f]
+int hpx_launch_solve_flat(hpx_plan* p, int iter_tag, hipStream_t st);
+size_t hpx_flat_lds_bytes(const hpx_plan* p);
 int hpx_launch_backsolve(int nbl, int npad, int TP, int ld, const double* L, const double* Wre,
                          const double* Wim, double* Xre, double* Xim, hipStream_t st);
 // out[b][x][c] = scale * sum_k W[x][k] in[b][k][c] (W = fop or conj(fop)), optional

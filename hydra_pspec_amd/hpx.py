@@ -15,6 +15,7 @@ _LIB_PATH = Path(__file__).resolve().parent / "libhpx.so"
 
 HPX_OK, HPX_EINVAL, HPX_EHIP, HPX_ENOTPD = 0, -1, -2, -3
 NSTAGE = 6
+SOLVER_DENSE, SOLVER_FLAT = 0, 1
 STAGES = ("assemble", "factor", "backsolve", "transform", "residual", "draw")
 
 _vp, _i, _i64 = C.c_void_p, C.c_int, C.c_int64
@@ -34,6 +35,7 @@ SIGNATURES = {
     "hpx_gibbs_step_general": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "hpx_plan_info": (_i, [_vp, _vp]),
     "hpx_plan_set_profiling": (_i, [_vp, _i]),
+    "hpx_plan_set_solver": (_i, [_vp, _i]),
     "hpx_plan_stage_ms": (_i, [_vp, _vp]),
     "hpx_assemble_K": (_i, [_vp, _vp, _vp, _vp]),
     "hpx_plan_dims": (_i, [_vp, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),

@@ -141,7 +141,7 @@ class GibbsBatch:
     """
 
     def __init__(self, vis, flags, fgmodes, ninv_diag, ps_prior, Niter, seed=None,
-                 map_estimate=False, device=None, tables=None, omega=None):
+                 map_estimate=False, device=None, tables=None, omega=None, solver="auto"):
         torch = hpx.require_gpu()
         self.torch = torch
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None \
@@ -192,6 +192,17 @@ class GibbsBatch:
             d_igy = hpx.to_dev(torch, igy, f64, self.device)
             hpx.check(L.hpx_plan_set_rng(self.plan.handle, hpx.ptr(d_uni), hpx.ptr(d_igy),
                                          self.Niter), "hpx_plan_set_rng")
+            # "auto": unflagged baselines with the same noise variance in every channel take the
+            # structured (diagonal + rank-M border) solve, everything else the dense Cholesky
+            assert solver in ("auto", "dense", "flat"), "solver must be 'auto', 'dense' or 'flat'"
+            nv = d_ninv if solver != "dense" else None
+            qualifies = (solver != "dense" and not self.any_flags and M <= 16 and T <= 256
+                         and N <= 4096 and bool((nv == nv[:, :1]).all().item()))
+            if solver == "flat" and not qualifies:
+                raise ValueError("solver='flat' needs unflagged data, flat Ninv, Nmodes <= 16, Ntimes <= 256")
+            self.solver = "flat" if qualifies else "dense"
+            if qualifies:
+                hpx.check(L.hpx_plan_set_solver(self.plan.handle, hpx.SOLVER_FLAT), "hpx_plan_set_solver")
         self.iter_done = 0
 
     def close(self):
@@ -289,7 +300,7 @@ class GibbsBatch:
 def gibbs_sample_with_fg_batched(vis, flags, fgmodes, Ninv, ps_prior, S_initial=None,
                                  ps_initial=None, Niter=100, seed=None, map_estimate=False,
                                  keep=("ps", "ln_post"), thin=1, ps_forced=None, device=None,
-                                 as_numpy=True, iter0=0):
+                                 as_numpy=True, iter0=0, solver="auto"):
     """Run the Gibbs chain of ``gibbs_sample_with_fg`` for ``Nbl`` baselines at once.
 
     Parameters mirror the reference (pspec.py:493-571) with a leading baseline
@@ -304,6 +315,10 @@ def gibbs_sample_with_fg_batched(vis, flags, fgmodes, Ninv, ps_prior, S_initial=
     Returns a dict: ``signal_ps`` (Nbl,Niter,Nfreqs), ``ln_post`` (Nbl,Niter),
     ``ps_last`` and the histories named in ``keep`` (``"signal_cr"``,
     ``"fg_amps"``, ``"chisq"``; every ``thin``-th iteration).
+
+    ``solver``: ``"auto"`` (default) solves unflagged baselines with flat ``Ninv`` through the
+    diagonal + rank-Nmodes structure of the system (hpx_flat.hip) and everything else with the
+    batched dense Cholesky; ``"dense"`` forces the latter.  Both are exact solves.
 
     ``iter0 > 0`` continues interrupted chains: ``ps_initial`` must then be the bandpowers of
     iteration ``iter0 - 1`` and only iterations ``iter0 .. Niter-1`` are run and returned (the
@@ -320,7 +335,7 @@ def gibbs_sample_with_fg_batched(vis, flags, fgmodes, Ninv, ps_prior, S_initial=
             shp0 = np.ascontiguousarray(np.broadcast_to(sqrt_cov_delay_basis(S0), (nbl, N, N)))
     ninv = _ninv_diag(Ninv, nbl, T, N)
     gb = GibbsBatch(vis, flags, fgmodes, ninv, ps_prior, Niter, seed=seed,
-                    map_estimate=map_estimate, device=device)
+                    map_estimate=map_estimate, device=device, solver=solver)
     try:
         if shp0 is not None:
             assert iter0 == 0, "a general S_initial cannot be combined with iter0 > 0"
@@ -618,7 +633,7 @@ def gibbs_step_fgmodes(vis, flags, signal_S, fgmodes, Ninv, ps_prior=None, f0=No
 
 def gibbs_sample_with_fg(vis, flags, S_initial, fgmodes, Ninv, ps_prior, Niter=100, seed=None,
                          verbose=True, nproc=1, write_Niter=100, out_dir=None, map_estimate=False,
-                         resume=False):
+                         resume=False, solver="auto"):
     """Drop-in for the reference chain driver (pspec.py:493-658).
 
     Returns ``(signal_cr (Niter,Ntimes,Nfreqs) c128, signal_S (Nfreqs,Nfreqs)
@@ -648,7 +663,7 @@ def gibbs_sample_with_fg(vis, flags, S_initial, fgmodes, Ninv, ps_prior, Niter=1
     shp0 = sqrt_cov_delay_basis(np.asarray(S_initial))[None] if resid > FOURIER_FORM_TOL else None
     fop = utils.fourier_operator(Nfreqs)
     gb = GibbsBatch(vis[None], flags[None], fgmodes, _ninv_diag(Ninv, 1, Ntimes, Nfreqs), ps_prior,
-                    Niter, seed=seed, map_estimate=map_estimate)
+                    Niter, seed=seed, map_estimate=map_estimate, solver=solver)
     signal_cr = np.zeros((Niter, Ntimes, Nfreqs), dtype=complex)
     signal_ps = np.zeros((Niter, Nfreqs))
     fg_amps = np.zeros((Niter, Ntimes, Nmodes), dtype=complex)

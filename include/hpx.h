@@ -117,6 +117,17 @@ int hpx_gibbs_step_general(hpx_plan* p, const double* shp, int iter0,
  * 0 = ok, k>0 = non-positive pivot first seen at iteration k-1+iter0. */
 int hpx_plan_info(hpx_plan* p, int32_t* info_host);
 
+/* Solver of the per-iteration linear system.  HPX_SOLVER_DENSE (default): batched Cholesky of
+ * the (N+M) system (k_factor / k_backsolve), any diagonal Ninv and flags.  HPX_SOLVER_FLAT: for
+ * unflagged baselines whose inverse noise variance is the same in every channel the system is
+ * diagonal plus a rank-M border and is solved exactly through the M x M Schur complement
+ * (hpx_flat.hip), O(N M (M+T)) instead of O(N^3); -1 if the plan's inputs do not qualify
+ * (flags present, non-flat Ninv, M > 16, T > 256).  Both replace build_matrices + the
+ * preconditioned CG of gcr_fgmodes_1d (pspec.py:325-374, :228) and agree to rounding. */
+#define HPX_SOLVER_DENSE 0
+#define HPX_SOLVER_FLAT 1
+int hpx_plan_set_solver(hpx_plan* p, int mode);
+
 /* time (ms) spent in each stage of the last hpx_gibbs_run, measured with HIP
  * events on the run's stream; host array of HPX_NSTAGE floats
  * [assemble, factor, backsolve, transform, residual, draw]; needs

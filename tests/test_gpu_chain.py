@@ -135,14 +135,16 @@ def test_chain_synth_free_running(golden):
         assert np.percentile(dev, 99) < 20 * max(np.percentile(cdev, 99), 1e-9)
 
 
-def test_config1_testdata_chain(golden):
+@pytest.mark.parametrize("solver", ["dense", "auto"])
+def test_config1_testdata_chain(golden, solver):
     """BASELINE.json config 1: shipped test data (203 x 120, 12 modes), 200
-    iterations, through the drop-in single-baseline function."""
+    iterations, through the drop-in single-baseline function.  The data are unflagged with flat
+    noise: "auto" takes the structured solve, "dense" the batched Cholesky."""
     from hydra_pspec_amd import pspec
     g = golden("chain_testdata")
     Ninv = np.diag(g["ninv_diag"])
     res = pspec.gibbs_sample_with_fg(g["vis"], g["flags"], g["S_initial"], g["fgmodes"], Ninv, g["prior"],
-                                     Niter=200, seed=int(g["seed"]), verbose=False)
+                                     Niter=200, seed=int(g["seed"]), verbose=False, solver=solver)
     cr, S_last, ps, fg, chi, lp, wt = res
     ref, ctl = g["ref_ps"], g["exact_ps"]
     dev, cdev = np.abs(ps / ref - 1), np.abs(ctl / ref - 1)
@@ -160,13 +162,14 @@ def test_config1_testdata_chain(golden):
     assert np.max(np.abs(m_ours / m_ref - 1)) < 1e-3
 
 
-def test_config1_teacher_forced(golden):
+@pytest.mark.parametrize("solver", ["dense", "auto"])
+def test_config1_teacher_forced(golden, solver):
     from hydra_pspec_amd import pspec
     g = golden("chain_testdata")
     ref = g["ref_ps"]
     out = pspec.gibbs_sample_with_fg_batched(
         g["vis"][None], g["flags"][None], g["fgmodes"], g["ninv_diag"][None], g["prior"],
-        S_initial=g["S_initial"], Niter=200, seed=int(g["seed"]), ps_forced=ref[None])
+        S_initial=g["S_initial"], Niter=200, seed=int(g["seed"]), ps_forced=ref[None], solver=solver)
     dev = np.abs(out["signal_ps"][0] / ref - 1)
     print("T1 config1: max", dev.max(), "median", np.median(dev))
     assert dev.max() < RTOL
@@ -264,3 +267,40 @@ def test_build_matrices_and_gcr_vs_reference(golden, tag):
     smp = pspec.gcr_fgmodes(vis * fl, fl, [ops, sys_], F, nproc=3)
     assert smp.shape == (vis.shape[0], 19)
     assert relerr(smp[0], xs[0]) < RTOL and relerr(smp[3], xs[1]) < RTOL
+
+
+@pytest.mark.parametrize("shape", [(3, 8, 64, 6), (2, 32, 512, 12), (2, 203, 120, 12), (2, 5, 30, 0)])
+def test_flat_noise_solver_matches_dense(shape):
+    """Unflagged baselines with flat Ninv: the structured (diagonal + rank-M border) solve of
+    hpx_flat.hip against the dense Cholesky path on the same inputs -- same chains to rounding."""
+    from hydra_pspec_amd import pspec, synthetic
+    nbl, T, N, M = shape
+    d = synthetic.make_baselines(N, T, max(M, 1), k0=11, nbl=nbl, dense=False)
+    F = d["fgmodes"][:, :M] * (1 - 0.2j)
+    prior = d["ps_prior"] if N >= 64 else np.zeros((2, N))     # the recipe's prior box suits N >= 64
+    kw = dict(ps_initial=d["ps0"], Niter=4, seed=d["seed"], keep=("signal_cr", "fg_amps", "chisq"))
+    a = pspec.gibbs_sample_with_fg_batched(d["vis"], d["flags"], F, d["ninv_diag"], prior, solver="dense", **kw)
+    b = pspec.gibbs_sample_with_fg_batched(d["vis"], d["flags"], F, d["ninv_diag"], prior, solver="flat", **kw)
+    c = pspec.gibbs_sample_with_fg_batched(d["vis"], d["flags"], F, d["ninv_diag"], prior, **kw)
+    assert np.isfinite(a["signal_ps"]).all() and np.isfinite(b["signal_ps"]).all()
+    assert np.array_equal(b["signal_ps"], c["signal_ps"])            # "auto" picks the structured solve
+    assert np.max(np.abs(b["signal_ps"] / a["signal_ps"] - 1)) < 1e-7
+    assert np.max(np.abs(b["signal_cr"] - a["signal_cr"])) < 1e-7 * np.max(np.abs(a["signal_cr"]))
+    if M:
+        assert np.max(np.abs(b["fg_amps"] - a["fg_amps"])) < 1e-9 * np.max(np.abs(a["fg_amps"]))
+    assert np.allclose(b["ln_post"], a["ln_post"], rtol=1e-7)
+
+
+def test_flat_noise_solver_is_refused_when_it_does_not_apply():
+    from hydra_pspec_amd import pspec, synthetic
+    d = synthetic.make_baselines(64, 8, 6, k0=2, nbl=2, flag_frac=0.1, dense=False)
+    with pytest.raises(ValueError):
+        pspec.GibbsBatch(d["vis"], d["flags"], d["fgmodes"], d["ninv_diag"], d["ps_prior"], 2, seed=1, solver="flat")
+    d = synthetic.make_baselines(64, 8, 6, k0=2, nbl=2, dense=False)
+    ninv = d["ninv_diag"] * np.linspace(1.0, 1.1, 64)
+    gb = pspec.GibbsBatch(d["vis"], d["flags"], d["fgmodes"], ninv, d["ps_prior"], 2, seed=1)
+    assert gb.solver == "dense"                                      # auto falls back
+    from hydra_pspec_amd import hpx
+    assert hpx.lib().hpx_plan_set_solver(gb.plan.handle, hpx.SOLVER_FLAT) == hpx.HPX_EINVAL
+    assert "not flat" in hpx.last_error()
+    gb.close()

@@ -18,20 +18,22 @@ def _run(nbl, N, T=32, M=12, frac=0.0, niter=3, k0=0, **kw):
 def test_batch_independence_and_determinism(N, frac):
     """A baseline's chain does not depend on what else is in the batch, nor on the run:
     bit-identical P(k) alone, inside a batch, and across two runs."""
-    d, big = _run(24, N, frac=frac, niter=3)
-    _, again = _run(24, N, frac=frac, niter=3)
+    d, big = _run(24, N, frac=frac, niter=3, solver="dense")
+    _, again = _run(24, N, frac=frac, niter=3, solver="dense")
     assert np.array_equal(big["signal_ps"], again["signal_ps"])
     assert np.array_equal(big["ln_post"], again["ln_post"])
-    _, one = _run(1, N, frac=frac, niter=3, k0=17)
+    _, one = _run(1, N, frac=frac, niter=3, k0=17, solver="dense")
     assert np.array_equal(one["signal_ps"][0], big["signal_ps"][17])
 
 
-@pytest.mark.parametrize("N,frac", [(256, 0.0), (512, 0.0), (1024, 0.15)])
-def test_short_chain_vs_oracle(N, frac):
-    """2 iterations of one baseline at full channel count against the exact-solve oracle."""
+@pytest.mark.parametrize("N,frac,solver", [(256, 0.0, "dense"), (512, 0.0, "dense"), (512, 0.0, "auto"),
+                                           (1024, 0.15, "auto")])
+def test_short_chain_vs_oracle(N, frac, solver):
+    """2 iterations of one baseline at full channel count against the exact-solve oracle
+    (unflagged + "auto" = the flat-noise structured solve, otherwise the dense Cholesky)."""
     from hydra_pspec_amd import synthetic
     from oracle import pspec_ref
-    d, out = _run(2, N, frac=frac, niter=2, keep=("signal_cr", "fg_amps"))
+    d, out = _run(2, N, frac=frac, niter=2, keep=("signal_cr", "fg_amps"), solver=solver)
     dd = synthetic.make_baselines(N, 32, 12, k0=1, nbl=1, flag_frac=frac, dense=True)
     assert np.array_equal(dd["vis"][0], d["vis"][1])
     ref = pspec_ref.gibbs_sample_with_fg(dd["vis"][0], dd["flags"][0], dd["S_initial"], dd["fgmodes"], dd["Ninv"],
