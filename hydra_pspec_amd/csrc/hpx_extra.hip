@@ -263,16 +263,14 @@ __global__ void k_oqe_q(const double* __restrict__ Y, double* __restrict__ q, co
 
 extern "C" int hpx_mfma_probe(const double* a_host, const double* b_host, double* d_host) {
   HPX_REQUIRE(a_host && b_host && d_host, "hpx_mfma_probe: null argument");
-  double *a = nullptr, *b = nullptr, *d = nullptr;
-  HPX_HIP(hipMalloc(&a, 64 * 8));
-  HPX_HIP(hipMalloc(&b, 64 * 8));
-  HPX_HIP(hipMalloc(&d, 256 * 8));
+  hpx_devbuf buf;
+  HPX_TRY(buf.alloc(64 + 64 + 256));
+  double *a = buf.p, *b = a + 64, *d = b + 64;
   HPX_HIP(hipMemcpy(a, a_host, 64 * 8, hipMemcpyHostToDevice));
   HPX_HIP(hipMemcpy(b, b_host, 64 * 8, hipMemcpyHostToDevice));
   hipLaunchKernelGGL(k_probe, dim3(1), dim3(64), 0, 0, a, b, d);
   HPX_HIP(hipGetLastError());
   HPX_HIP(hipMemcpy(d_host, d, 256 * 8, hipMemcpyDeviceToHost));
-  (void)hipFree(a); (void)hipFree(b); (void)hipFree(d);
   return HPX_OK;
 }
 
@@ -282,20 +280,19 @@ extern "C" int hpx_mfma_f64_peak(int iters, double* tflops_host) {
   HPX_HIP(hipGetDevice(&dev));
   HPX_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
   const int nblk = ncu * 2;   // 2 workgroups of 4 waves per CU = 2 waves per SIMD
-  double* sink = nullptr;
-  HPX_HIP(hipMalloc(&sink, (size_t)nblk * 256 * 8));
-  hipEvent_t e0, e1;
-  HPX_HIP(hipEventCreate(&e0));
-  HPX_HIP(hipEventCreate(&e1));
-  hipLaunchKernelGGL(k_mfma_peak, dim3(nblk), dim3(256), 0, 0, sink, iters);   // warm-up
-  HPX_HIP(hipEventRecord(e0, 0));
-  hipLaunchKernelGGL(k_mfma_peak, dim3(nblk), dim3(256), 0, 0, sink, iters);
-  HPX_HIP(hipEventRecord(e1, 0));
-  HPX_HIP(hipEventSynchronize(e1));
+  hpx_devbuf sink;
+  HPX_TRY(sink.alloc((size_t)nblk * 256));
+  hpx_event e0, e1;
+  HPX_TRY(e0.create());
+  HPX_TRY(e1.create());
+  hipLaunchKernelGGL(k_mfma_peak, dim3(nblk), dim3(256), 0, 0, sink.p, iters);   // warm-up
+  HPX_HIP(hipEventRecord(e0.e, 0));
+  hipLaunchKernelGGL(k_mfma_peak, dim3(nblk), dim3(256), 0, 0, sink.p, iters);
+  HPX_HIP(hipEventRecord(e1.e, 0));
+  HPX_HIP(hipEventSynchronize(e1.e));
   float ms = 0.f;
-  HPX_HIP(hipEventElapsedTime(&ms, e0, e1));
+  HPX_HIP(hipEventElapsedTime(&ms, e0.e, e1.e));
   *tflops_host = (double)nblk * 4.0 * iters * 4.0 * 2048.0 / (ms * 1e-3) / 1e12;
-  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipFree(sink);
   return HPX_OK;
 }
 
@@ -306,11 +303,11 @@ extern "C" int hpx_dpss_project(int nb, int N, int nm, const double* d, const do
               "hpx_dpss_project: bad argument (need 0 < nmodes < 32)");
   hipStream_t st = (hipStream_t)stream;
   const int NP = ceil16(N), ncol = ceil16(nm + 1);
-  double *wre = nullptr, *wim = nullptr, *buf = nullptr;
   const size_t wsz = (size_t)NP * NP, bsz = (size_t)nb * NP * ncol;
-  HPX_HIP(hipMalloc(&wre, wsz * 8));
-  HPX_HIP(hipMalloc(&wim, wsz * 8));
-  HPX_HIP(hipMalloc(&buf, 4 * bsz * 8));
+  hpx_devbuf wbuf, dbuf;
+  HPX_TRY(wbuf.alloc(2 * wsz));
+  HPX_TRY(dbuf.alloc(4 * bsz));
+  double *wre = wbuf.p, *wim = wre + wsz, *buf = dbuf.p;
   double *ire = buf, *iim = buf + bsz, *ore = buf + 2 * bsz, *oim = buf + 3 * bsz;
   hipLaunchKernelGGL(k_herm_planar, dim3(256), dim3(256), 0, st, icov, wre, wim, N, NP);
   hipLaunchKernelGGL(k_dpss_in, dim3(32, nb), dim3(256), 0, st, d, tw, modes, ire, iim, N, nm, NP,
@@ -324,7 +321,6 @@ extern "C" int hpx_dpss_project(int nb, int N, int nm, const double* d, const do
     if (hipGetLastError() != hipSuccess) rc = HPX_EHIP;
   }
   hipError_t e = hipStreamSynchronize(st);
-  (void)hipFree(wre); (void)hipFree(wim); (void)hipFree(buf);
   if (e != hipSuccess) { hpx_set_error("hpx_dpss_project: %s", hipGetErrorString(e)); return HPX_EHIP; }
   return rc;
 }
@@ -334,10 +330,10 @@ extern "C" int hpx_oqe_fisher(int nb, int s, const double* R, double* F_out, int
   HPX_REQUIRE(nb > 0 && s > 0 && R && F_out && (variant == 0 || variant == 1),
               "hpx_oqe_fisher: bad argument");
   hipStream_t st = (hipStream_t)stream;
-  double* buf = nullptr;
   const size_t sz = (size_t)nb * s * s * 2;
-  HPX_HIP(hipMalloc(&buf, 3 * sz * 8));
-  double *T1 = buf, *X = buf + sz, *Wm = buf + 2 * sz;
+  hpx_devbuf dbuf;
+  HPX_TRY(dbuf.alloc(3 * sz));
+  double *T1 = dbuf.p, *X = T1 + sz, *Wm = T1 + 2 * sz;
   dim3 grid((s * s + 255) / 256, nb);
   // X = M R M^H
   hipLaunchKernelGGL(k_oqe_left, grid, dim3(256), 0, st, R, T1, s, 0);
@@ -349,7 +345,6 @@ extern "C" int hpx_oqe_fisher(int nb, int s, const double* R, double* F_out, int
   hipLaunchKernelGGL(k_oqe_combine, grid, dim3(256), 0, st, X, Wm, F_out, s, variant);
   hipError_t e = hipGetLastError();
   if (e == hipSuccess) e = hipStreamSynchronize(st);
-  (void)hipFree(buf);
   if (e != hipSuccess) { hpx_set_error("hpx_oqe_fisher: %s", hipGetErrorString(e)); return HPX_EHIP; }
   return HPX_OK;
 }
@@ -358,15 +353,15 @@ extern "C" int hpx_oqe_qh(int nb, int npair, int s, const double* R, const doubl
                           double* q_out, void* stream) {
   HPX_REQUIRE(nb > 0 && npair > 0 && s > 0 && R && V && q_out, "hpx_oqe_qh: bad argument");
   hipStream_t st = (hipStream_t)stream;
-  double* Y = nullptr;
-  HPX_HIP(hipMalloc(&Y, (size_t)nb * 2 * npair * s * 2 * 8));
+  hpx_devbuf ybuf;
+  HPX_TRY(ybuf.alloc((size_t)nb * 2 * npair * s * 2));
+  double* Y = ybuf.p;
   hipLaunchKernelGGL(k_oqe_rx, dim3((2 * npair * s + 255) / 256, nb), dim3(256), 0, st, R, V, Y, s,
                      2 * npair);
   hipLaunchKernelGGL(k_oqe_q, dim3((npair * s + 255) / 256, nb), dim3(256), 0, st, Y, q_out, s,
                      npair);
   hipError_t e = hipGetLastError();
   if (e == hipSuccess) e = hipStreamSynchronize(st);
-  (void)hipFree(Y);
   if (e != hipSuccess) { hpx_set_error("hpx_oqe_qh: %s", hipGetErrorString(e)); return HPX_EHIP; }
   return HPX_OK;
 }

@@ -181,6 +181,24 @@ __device__ __forceinline__ hpx_gen hpx_gen_for(const hpx_gen_batch& B, const int
   return G;
 }
 
+// Scratch device buffer of a stand-alone entry point: freed on every return path.
+struct hpx_devbuf {
+  double* p = nullptr;
+  hpx_devbuf() = default;
+  hpx_devbuf(const hpx_devbuf&) = delete;
+  hpx_devbuf& operator=(const hpx_devbuf&) = delete;
+  ~hpx_devbuf() { if (p) (void)hipFree(p); }
+  int alloc(size_t doubles) {
+    HPX_HIP(hipMalloc(&p, (doubles ? doubles : 1) * sizeof(double)));
+    return HPX_OK;
+  }
+};
+struct hpx_event {
+  hipEvent_t e = nullptr;
+  ~hpx_event() { if (e) (void)hipEventDestroy(e); }
+  int create() { HPX_HIP(hipEventCreate(&e)); return HPX_OK; }
+};
+
 // Raise a kernel's dynamic-LDS limit when a launch needs more than the current one.  The limit
 // is a property of the function ON A DEVICE: remembered per (call site, device), since one
 // process may drive several GPUs (hpx_set_device).

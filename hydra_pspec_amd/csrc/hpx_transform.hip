@@ -301,13 +301,12 @@ extern "C" int hpx_dft_batched(int nb, int T, int N, const double* fop, const do
   HPX_REQUIRE(nb > 0 && T > 0 && N > 0 && fop && in && out, "hpx_dft_batched: bad argument");
   hipStream_t st = (hipStream_t)stream;
   const int NP = ceil16(N), TP = ceil16(T);
-  double *wre = nullptr, *wim = nullptr, *buf = nullptr;
-  const size_t wb = (size_t)NP * NP * sizeof(double), pb = (size_t)nb * NP * TP * sizeof(double);
-  HPX_HIP(hipMalloc(&wre, wb));
-  HPX_HIP(hipMalloc(&wim, wb));
-  HPX_HIP(hipMalloc(&buf, 4 * pb));
-  double *ire = buf, *iim = buf + (size_t)nb * NP * TP, *ore = iim + (size_t)nb * NP * TP,
-         *oim = ore + (size_t)nb * NP * TP;
+  const size_t wn = (size_t)NP * NP, pn = (size_t)nb * NP * TP;
+  hpx_devbuf wbuf, dbuf;
+  HPX_TRY(wbuf.alloc(2 * wn));
+  HPX_TRY(dbuf.alloc(4 * pn));
+  double *wre = wbuf.p, *wim = wre + wn;
+  double *ire = dbuf.p, *iim = ire + pn, *ore = iim + pn, *oim = ore + pn;
   int rc = hpx_fop_to_planar(fop, wre, wim, N, NP, st);
   if (rc == HPX_OK) {
     hipLaunchKernelGGL(k_tn_to_planar, dim3(64, nb), dim3(256), 0, st, in, ire, iim, T, N, NP, TP);
@@ -319,7 +318,6 @@ extern "C" int hpx_dft_batched(int nb, int T, int N, const double* fop, const do
     if (hipGetLastError() != hipSuccess) rc = HPX_EHIP;
   }
   hipError_t e = hipStreamSynchronize(st);
-  (void)hipFree(wre); (void)hipFree(wim); (void)hipFree(buf);
   if (e != hipSuccess) { hpx_set_error("hpx_dft_batched: %s", hipGetErrorString(e)); return HPX_EHIP; }
   return rc;
 }
