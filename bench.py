@@ -84,6 +84,40 @@ def cpu_baseline(N, T, M, flag_frac, nbl=2, niter=3):
                        f"one process, default BLAS threads, {dt:.1f} s"), np.array(chains), d
 
 
+def cpu_baseline_multiproc(N, T, M, flag_frac, niter=8, max_procs=16):
+    """P independent single-BLAS-thread processes, one baseline stream each (the
+    reference's MPI deployment model), aggregate rate.  Child processes are plain `python -m
+    oracle.cpu_worker` runs: they never touch the GPU."""
+    import subprocess
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    P = max(1, min(avail, max_procs))
+    env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1",
+               HIP_VISIBLE_DEVICES="", ROCR_VISIBLE_DEVICES="")
+    t0 = time.perf_counter()
+    procs = [subprocess.Popen([sys.executable, "-m", "oracle.cpu_worker", str(N), str(T), str(M), str(flag_frac),
+                               str(k), str(niter)], cwd=str(REPO), env=env, stdout=subprocess.PIPE,
+                              stderr=subprocess.DEVNULL, text=True) for k in range(P)]
+    secs = []
+    for pr in procs:
+        try:
+            out, _ = pr.communicate(timeout=600)
+        except subprocess.TimeoutExpired:
+            pr.kill()
+            continue
+        for line in out.splitlines():
+            if line.startswith("CPU_WORKER_SECONDS"):
+                secs.append(float(line.split()[1]))
+    wall = time.perf_counter() - t0
+    if not secs:
+        return None
+    return dict(value=len(secs) * niter / max(secs), unit="baseline*iter/s", processes=len(secs), blas_threads=1,
+                sample=f"{len(secs)} processes x 1 baseline x {niter} iterations, slowest {max(secs):.1f} s, "
+                       f"wall incl. start-up {wall:.1f} s")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -220,6 +254,9 @@ def main():
             res["flat_noise_structured_solve"] = flat_extra
         if world == 1 and not args.no_cpu_baseline:
             cb, ref_ps, dd = cpu_baseline(N, T, M, frac)
+            mp = cpu_baseline_multiproc(N, T, M, frac)
+            if mp:
+                cb["multi_process"] = mp
             res["cpu_baseline"] = cb
             # P(k) deviation of the GPU chain from the CPU chain on the same baselines/seed
             chk = pspec.gibbs_sample_with_fg_batched(dd["vis"], dd["flags"], dd["fgmodes"], dd["ninv_diag"],
