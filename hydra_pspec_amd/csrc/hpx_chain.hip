@@ -5,6 +5,7 @@
 #include <stdarg.h>
 #include <string.h>
 #include "hpx_internal.h"
+#include "hpx_fft.h"
 
 // ---------------------------------------------------------------------------
 static thread_local char g_err[512] = "";
@@ -246,7 +247,11 @@ __global__ void k_kaug_out(const double* __restrict__ L, double* __restrict__ ou
 struct ResArgs {
   const double *Xre, *Xim, *Sre, *Sim, *Dre, *Dim, *Fre, *Fim, *ninv;
   const uint8_t* flags;
-  double *beta, *lnp1, *Gre, *Gim;      // G: masked signal (only if any_flags)
+  double *bpart, *lnpart, *Gre, *Gim;   // partial sums (HPX_NPART slots per baseline); G: masked
+                                        // signal (only if any_flags)
+  const double *twre, *twim;            // centred Fourier operator (twiddles of the fused kernel)
+  double isn;                           // 1 / sqrt(N)
+  int logN, tcs;                        // fused kernel: log2 N, log2 of the time columns per block
   double *cr_out, *fg_out, *chisq_out;  // already offset to the slot; may be NULL
   long cr_bstride, fg_bstride, chisq_bstride;
   int N, M, T, NP, TP, npad, fg_shared, any_flags;
@@ -330,13 +335,115 @@ __global__ __launch_bounds__(256) void k_resid(const ResArgs A) {
     }
   }
   const double total = block_sum(acc, red);          // (barrier inside: part[] is complete)
-  if (tid == 0) A.lnp1[b] = -total;
-  // beta_k = N sum_t |z_kt|^2   ( |F s|^2 with s = U z )
+  if (tid == 0) A.lnpart[(long)b * HPX_NPART] = total;
+  // sum_t |z_kt|^2; k_draw turns it into beta_k = N sum_t |z_kt|^2  ( |F s|^2 with s = U z )
   for (int k = tid; k < N; k += 256) {
     double sum = 0.0;
     for (int j = 0; j < TG; ++j) sum += part[k * TG + j];
-    A.beta[(long)b * N + k] = (double)N * sum;
+    A.bpart[(long)b * HPX_NPART * N + k] = sum;
   }
+}
+
+// Back transform s = U z and everything k_resid does, in one kernel (N a power of two): the
+// block that holds TC time columns of the signal in LDS after the FFT goes straight on to the
+// model, residual, chi^2 and the optional sample write-back for those columns, so s never goes
+// to HBM and back.  Blocks of one baseline leave their partial sums (|z|^2 per channel, the
+// chi^2 total) in slot blockIdx.x; k_draw adds the slots in a fixed order.
+__global__ __launch_bounds__(256) void k_fft_resid(const ResArgs A) {
+  extern __shared__ double fl[];
+  __shared__ double red[4];
+  const int N = A.N, M = A.M, T = A.T, TP = A.TP, tcs = A.tcs, TC = 1 << tcs, logN = A.logN;
+  const int b = blockIdx.y, c0 = blockIdx.x * TC, tid = threadIdx.x, h = N >> 1;
+  double* fre = fl;
+  double* fim = fl + ((long)N << tcs);
+  double* tw = fim + ((long)N << tcs);              // N doubles
+  double* lfr = tw + N;                             // f[m][tc]: M * TC
+  double* lfi = lfr + (M << tcs);
+  const double* xre = A.Xre + (long)b * A.npad * TP;
+  const double* xim = A.Xim + (long)b * A.npad * TP;
+  for (int j = tid; j < h; j += 256) {
+    tw[j] = A.twre[(long)(h + 1) * N + h + j];
+    tw[h + j] = A.twim[(long)(h + 1) * N + h + j];
+  }
+  for (int e = tid; e < (M << tcs); e += 256) {
+    const int m = e >> tcs, tc = e & (TC - 1);
+    lfr[e] = xre[(long)(N + m) * TP + c0 + tc];
+    lfi[e] = xim[(long)(N + m) * TP + c0 + tc];
+  }
+  double* bp = A.bpart + ((long)b * HPX_NPART + blockIdx.x) * N;
+  for (int e = tid; e < (N << tcs); e += 256) {      // N * TC is a multiple of 256
+    const int k = e >> tcs, tc = e & (TC - 1);
+    const double zr = xre[(long)k * TP + c0 + tc], zi = xim[(long)k * TP + c0 + tc];
+    const double sg = (k & 1) ? -1.0 : 1.0;
+    fre[e] = zr * sg;
+    fim[e] = zi * sg;
+    double v = zr * zr + zi * zi;                    // sum over this block's time columns
+    for (int o = TC >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    if (tc == 0) bp[k] = v;
+  }
+  int s = 0;
+  for (; s + 3 <= logN; s += 3) {
+    __syncthreads();
+    fft_pass<3, 1>(fre, fim, tw, N, h, logN, s, tcs, tid);
+  }
+  if (logN - s == 2) {
+    __syncthreads();
+    fft_pass<2, 1>(fre, fim, tw, N, h, logN, s, tcs, tid);
+  } else if (logN - s == 1) {
+    __syncthreads();
+    fft_pass<1, 1>(fre, fim, tw, N, h, logN, s, tcs, tid);
+  }
+  __syncthreads();
+  const double* dre = A.Dre + (long)b * A.NP * TP;
+  const double* dim_ = A.Dim + (long)b * A.NP * TP;
+  const double* fmr = A.Fre + (A.fg_shared ? 0 : (long)b * N * M);
+  const double* fmi = A.Fim + (A.fg_shared ? 0 : (long)b * N * M);
+  const double* ninv = A.ninv + (long)b * N;
+  const uint8_t* fl8 = A.flags + (long)b * N;
+  double acc = 0.0;
+  for (int e = tid; e < (N << tcs); e += 256) {
+    const int pidx = e >> tcs, tc = e & (TC - 1), t = c0 + tc;
+    const int x = (int)(__brev((unsigned)pidx) >> (32 - logN));
+    const long o = (long)x * TP + t;
+    if (t >= T) {
+      if (A.any_flags) { A.Gre[(long)b * A.NP * TP + o] = 0.0; A.Gim[(long)b * A.NP * TP + o] = 0.0; }
+      continue;
+    }
+    const double sc = (x & 1) ? -A.isn : A.isn;
+    const double sr = fre[e] * sc, si = fim[e] * sc;
+    double mr = sr, mi = si;
+    for (int m = 0; m < M; ++m) {
+      const double fr = fmr[(long)x * M + m], fi = fmi[(long)x * M + m];
+      const double gr = lfr[(m << tcs) + tc], gi = lfi[(m << tcs) + tc];
+      mr += gr * fr - gi * fi;
+      mi += gr * fi + gi * fr;
+    }
+    const double rr = dre[o] - mr, ri = dim_[o] - mi;
+    const double w = fl8[x] ? 1.0 : 0.0;
+    const double c2 = (rr * rr + ri * ri) * ninv[x];
+    acc += w * c2;
+    if (A.any_flags) {
+      A.Gre[(long)b * A.NP * TP + o] = w * sr;
+      A.Gim[(long)b * A.NP * TP + o] = w * si;
+    }
+    if (A.cr_out) {
+      double* q = A.cr_out + (long)b * A.cr_bstride + ((long)t * N + x) * 2;
+      q[0] = sr;
+      q[1] = si;
+    }
+    if (A.chisq_out) A.chisq_out[(long)b * A.chisq_bstride + (long)t * N + x] = c2;
+  }
+  if (A.fg_out) {
+    for (int e = tid; e < (M << tcs); e += 256) {
+      const int m = e >> tcs, t = c0 + (e & (TC - 1));
+      if (t >= T) continue;
+      double* q = A.fg_out + (long)b * A.fg_bstride + ((long)t * M + m) * 2;
+      q[0] = lfr[e];
+      q[1] = lfi[e];
+    }
+  }
+  const double total = block_sum(acc, red);
+  if (tid == 0) A.lnpart[(long)b * HPX_NPART + blockIdx.x] = total;
 }
 
 // betam_k = sum_t |SK[k][t]|^2 (SK = F (w s), in the Z scratch with leading dim ncol)
@@ -428,9 +535,11 @@ __device__ double inversion_draw(const int alpha, const double lgam, const doubl
 }
 
 struct DrawArgs {
-  const double *beta, *betam, *lnp1, *uni, *igy, *xgrid, *ps_forced;
+  const double *bpart, *lnpart, *betam, *uni, *igy, *xgrid, *ps_forced;
+  double *beta, *lnp1;
+  int npart;
   const int32_t* pmap;
-  double *ia, *ps_cur, *ps_out, *lnpost_out;
+  double *ia, *ps_cur, *ps_out;
   long ps_bstride, forced_bstride;   // strides between baselines in ps_out / ps_forced
   int N, T, ngrid, prior_shared, any_flags;
   double lgam_T;
@@ -442,7 +551,20 @@ __global__ __launch_bounds__(256) void k_draw(const DrawArgs A) {
   __shared__ int redi[4];
   __shared__ int pcount;
   const int b = blockIdx.x, tid = threadIdx.x, N = A.N;
-  const double* beta = A.beta + (long)b * N;
+  // beta_k = N sum_t |z_kt|^2 and the chi^2 total from the partial sums of the residual kernel
+  // (one slot per block of a baseline there), added in slot order
+  double* beta = A.beta + (long)b * N;
+  for (int k = tid; k < N; k += 256) {
+    double sum = 0.0;
+    for (int j = 0; j < A.npart; ++j) sum += A.bpart[((long)b * HPX_NPART + j) * N + k];
+    beta[k] = (double)N * sum;
+  }
+  if (tid == 0) {
+    double tot = 0.0;
+    for (int j = 0; j < A.npart; ++j) tot += A.lnpart[(long)b * HPX_NPART + j];
+    A.lnp1[b] = -tot;
+  }
+  __syncthreads();
   const double* bm = A.any_flags ? A.betam + (long)b * N : beta;
   const int32_t* pmap = A.pmap + (A.prior_shared ? 0 : (long)b * N);
   double* ps_out = A.ps_out + (long)b * A.ps_bstride;
@@ -476,7 +598,7 @@ __global__ __launch_bounds__(256) void k_draw(const DrawArgs A) {
     A.ia[(long)b * N + k] = inv_a(nx, (double)N);
   }
   const double tot = block_sum(acc, red);
-  if (tid == 0) A.lnpost_out[b] = A.lnp1[b] - tot;
+  if (tid == 0) A.lnp1[b] = A.lnp1[b] - tot;          // -> ln posterior, scattered by the host code
 }
 
 __global__ void k_inv_test(const int alpha, const double lgam, const double* __restrict__ beta,
@@ -533,6 +655,7 @@ extern "C" int hpx_plan_create(hpx_plan** out, int nbl, int T, int N, int M) {
   A_(Xre, nb * xsz); A_(Xim, nb * xsz);
   A_(info, nb);
   A_(ia, nb * N); A_(ps_cur, nb * N); A_(beta, nb * N); A_(betam, nb * N); A_(lnp1, nb);
+  A_(bpart, nb * HPX_NPART * N); A_(lnpart, nb * HPX_NPART);
   A_(Rre, nb * rsz); A_(Rim, nb * rsz); A_(Zre, nb * rsz); A_(Zim, nb * rsz);
   A_(Cre, nb * N); A_(Cim, nb * N);
   A_(P2re, ssz); A_(P2im, ssz);
@@ -749,21 +872,40 @@ struct IterOut {
 static int post_solve(hpx_plan* p, int it_abs, const IterOut& O, hipStream_t st) {
   const int nbl = p->nbl, N = p->N, M = p->M, T = p->T, NP = p->NP, TP = p->TP;
   const double isn = 1.0 / sqrt((double)N);
-  // s = U z = conj(F) X / sqrt(N)   (rows >= N of X meet the zero padding of the operator)
-  HPX_TRY(hpx_launch_dft(nbl, NP, TP, p->Fopre, p->Fopim, 1, p->Xre, p->Xim, (long)p->npad * TP,
-                         TP, nullptr, 0, p->Sre, p->Sim, (long)NP * TP, TP, isn, st, N == NP));
-  HPX_TRY(mark(p, st));
   ResArgs R;
   R.Xre = p->Xre; R.Xim = p->Xim; R.Sre = p->Sre; R.Sim = p->Sim; R.Dre = p->Dre; R.Dim = p->Dim;
   R.Fre = p->Fre; R.Fim = p->Fim; R.ninv = p->ninv; R.flags = p->flags;
-  R.beta = p->beta; R.lnp1 = p->lnp1; R.Gre = p->Gre; R.Gim = p->Gim;
+  R.bpart = p->bpart; R.lnpart = p->lnpart; R.Gre = p->Gre; R.Gim = p->Gim;
   R.cr_bstride = O.cr_bstride; R.fg_bstride = O.fg_bstride; R.chisq_bstride = O.chisq_bstride;
   R.cr_out = O.cr_out; R.fg_out = (M > 0) ? O.fg_out : nullptr; R.chisq_out = O.chisq_out;
   R.N = N; R.M = M; R.T = T; R.NP = NP; R.TP = TP; R.npad = p->npad;
   R.fg_shared = p->fg_shared; R.any_flags = p->any_flags;
-  hipLaunchKernelGGL(k_resid, dim3(nbl), dim3(256),
-                     (size_t)(2 * M * TP + N * (TP / 16)) * sizeof(double), st, R);
-  HPX_HIP(hipGetLastError());
+  R.twre = p->Fopre; R.twim = p->Fopim; R.isn = isn; R.logN = 0; R.tcs = 0;
+  // time columns per block of the fused kernel: 64 KiB of LDS for the signal, as k_fft
+  int npart = 1, TC = 4096 / NP;
+  if (TC > 16) TC = 16;
+  const bool pow2 = N == NP && (N & (N - 1)) == 0 && N >= 32 && N <= 4096;
+  if (pow2 && hpx_dft_use_fft && TC >= 1 && TP / TC <= HPX_NPART) {
+    while ((1 << R.logN) < N) ++R.logN;
+    while ((1 << R.tcs) < TC) ++R.tcs;
+    npart = TP / TC;
+    // s = U z, residual, chi^2, |z|^2 sums in one pass (k_fft_resid); the two event marks
+    // book it under "transform"
+    const size_t lds = ((size_t)N * TC * 2 + N + (size_t)2 * M * TC) * sizeof(double);
+    static hpx_lds_limit limit;
+    HPX_TRY(limit.ensure(reinterpret_cast<const void*>(&k_fft_resid), lds));
+    hipLaunchKernelGGL(k_fft_resid, dim3(npart, nbl), dim3(256), lds, st, R);
+    HPX_HIP(hipGetLastError());
+    HPX_TRY(mark(p, st));
+  } else {
+    // s = U z = conj(F) X / sqrt(N)   (rows >= N of X meet the zero padding of the operator)
+    HPX_TRY(hpx_launch_dft(nbl, NP, TP, p->Fopre, p->Fopim, 1, p->Xre, p->Xim, (long)p->npad * TP,
+                           TP, nullptr, 0, p->Sre, p->Sim, (long)NP * TP, TP, isn, st, N == NP));
+    HPX_TRY(mark(p, st));
+    hipLaunchKernelGGL(k_resid, dim3(nbl), dim3(256),
+                       (size_t)(2 * M * TP + N * (TP / 16)) * sizeof(double), st, R);
+    HPX_HIP(hipGetLastError());
+  }
   if (p->any_flags) {   // |F (w s)|^2 for the masked S^-1 quadratic form (pspec.py:479-483)
     HPX_TRY(hpx_launch_dft(nbl, NP, TP, p->Fopre, p->Fopim, 0, p->Gre, p->Gim, (long)NP * TP, TP,
                            nullptr, 0, p->Zre, p->Zim, (long)NP * p->ncolR, p->ncolR, 1.0, st,
@@ -775,6 +917,7 @@ static int post_solve(hpx_plan* p, int it_abs, const IterOut& O, hipStream_t st)
   HPX_TRY(mark(p, st));
   DrawArgs D;
   D.beta = p->beta; D.betam = p->betam; D.lnp1 = p->lnp1;
+  D.bpart = p->bpart; D.lnpart = p->lnpart; D.npart = npart;
   D.uni = p->uni + (long)it_abs * N; D.igy = p->igy + (long)it_abs * N;
   D.xgrid = p->xgrid; D.pmap = p->pmap;
   D.ps_forced = O.ps_forced; D.forced_bstride = O.forced_bstride;
@@ -782,7 +925,6 @@ static int post_solve(hpx_plan* p, int it_abs, const IterOut& O, hipStream_t st)
   D.ps_out = O.ps_out; D.ps_bstride = O.ps_bstride;
   D.N = N; D.T = T; D.ngrid = p->ngrid; D.prior_shared = p->prior_shared;
   D.any_flags = p->any_flags; D.lgam_T = p->lgam_T;
-  D.lnpost_out = p->lnp1;   // staged per baseline, scattered to (nbl, niter) below
   hipLaunchKernelGGL(k_draw, dim3(nbl), dim3(256),
                      (size_t)(p->ngrid > 0 ? p->ngrid : 1) * 8 + (size_t)N * sizeof(int), st, D);
   HPX_HIP(hipGetLastError());

@@ -39,6 +39,7 @@ __device__ __forceinline__ d4 mfma64(double a, double b, d4 c) {
 // Factor storage: 16-row panels, each a contiguous [npad columns][re 16 | im 16] strip.
 #define HPX_LIDX(r, c, npad) ((((long)((r) >> 4) * (npad) + (c)) << 5) + ((r) & 15))
 #define HPX_NB 32          // block-column width of the factorisation
+#define HPX_NPART 16       // slots for per-block partial sums of the residual kernel
 #define HPX_WLD 34         // LDS leading dimension (doubles) of 32x32 blocks
 
 // ---- plan -------------------------------------------------------------------
@@ -64,6 +65,7 @@ struct hpx_plan {
   // chain state
   double *ia, *ps_cur;     // [nbl][N]: sqrt(N / ps) = 1/a, and the bandpowers themselves
   double *beta, *betam;    // [nbl][N]
+  double *bpart, *lnpart;  // [nbl][HPX_NPART][N], [nbl][HPX_NPART]: partial sums of the residual kernel
   double *lnp1;            // [nbl]
   // invariants
   double *Rre, *Rim;       // [nbl][NP][ncolR]
@@ -226,6 +228,7 @@ int hpx_launch_backsolve(int nbl, int npad, int TP, int ld, const double* L, con
                          const double* Wim, double* Xre, double* Xim, hipStream_t st);
 // out[b][x][c] = scale * sum_k W[x][k] in[b][k][c] (W = fop or conj(fop)), optional
 // row scaling of the input by rs[b][k]; ncol multiple of 16; matrices [NP][NP].
+extern int hpx_dft_use_fft;
 int hpx_launch_dft(int nbl, int NP, int ncol, const double* Wre, const double* Wim,
                    int conjW, const double* inre, const double* inim, long in_bstride,
                    int in_ld, const double* rs, int rs_n, double* outre, double* outim,
