@@ -401,7 +401,22 @@ __global__ __launch_bounds__(256) void k_fft_resid(const ResArgs A) {
   const double* ninv = A.ninv + (long)b * N;
   const uint8_t* fl8 = A.flags + (long)b * N;
   double acc = 0.0;
-  for (int e = tid; e < (N << tcs); e += 256) {
+  // 256 elements (256 / TC channels x TC times) per round; the foreground-mode rows F[x][:] of
+  // the round's channels are staged in LDS first (TC threads share a channel: from global
+  // memory each of them would fetch the same 2 M values again)
+  double* sfr = lfi + (M << tcs);                   // [256 / TC][M]
+  double* sfi = sfr + (256 >> tcs) * M;
+  const int xper = 256 >> tcs;
+  for (int e0 = 0; e0 < (N << tcs); e0 += 256) {
+    __syncthreads();
+    for (int q = tid; q < xper * M; q += 256) {
+      const int xi = q / M, m = q - xi * M;
+      const int xx = (int)(__brev((unsigned)((e0 >> tcs) + xi)) >> (32 - logN));
+      sfr[q] = fmr[(long)xx * M + m];
+      sfi[q] = fmi[(long)xx * M + m];
+    }
+    __syncthreads();
+    const int e = e0 + tid;
     const int pidx = e >> tcs, tc = e & (TC - 1), t = c0 + tc;
     const int x = (int)(__brev((unsigned)pidx) >> (32 - logN));
     const long o = (long)x * TP + t;
@@ -412,8 +427,10 @@ __global__ __launch_bounds__(256) void k_fft_resid(const ResArgs A) {
     const double sc = (x & 1) ? -A.isn : A.isn;
     const double sr = fre[e] * sc, si = fim[e] * sc;
     double mr = sr, mi = si;
+    const double* myfr = sfr + (tid >> tcs) * M;
+    const double* myfi = sfi + (tid >> tcs) * M;
     for (int m = 0; m < M; ++m) {
-      const double fr = fmr[(long)x * M + m], fi = fmi[(long)x * M + m];
+      const double fr = myfr[m], fi = myfi[m];
       const double gr = lfr[(m << tcs) + tc], gi = lfi[(m << tcs) + tc];
       mr += gr * fr - gi * fi;
       mi += gr * fi + gi * fr;
@@ -891,7 +908,7 @@ static int post_solve(hpx_plan* p, int it_abs, const IterOut& O, hipStream_t st)
     npart = TP / TC;
     // s = U z, residual, chi^2, |z|^2 sums in one pass (k_fft_resid); the two event marks
     // book it under "transform"
-    const size_t lds = ((size_t)N * TC * 2 + N + (size_t)2 * M * TC) * sizeof(double);
+    const size_t lds = ((size_t)N * TC * 2 + N + (size_t)2 * M * TC + (size_t)2 * M * (256 / TC)) * sizeof(double);
     static hpx_lds_limit limit;
     HPX_TRY(limit.ensure(reinterpret_cast<const void*>(&k_fft_resid), lds));
     hipLaunchKernelGGL(k_fft_resid, dim3(npart, nbl), dim3(256), lds, st, R);
