@@ -228,6 +228,69 @@ __global__ __launch_bounds__(256) void k_assemble(const hpx_gen_batch B, double*
   }
 }
 
+// The rows the factor does not generate itself (r >= rmin: foreground rows, padding, right-hand
+// sides), one workgroup per baseline.  The bulk -- rows >= N of the signal columns -- is copied
+// from the invariant block R with unit-stride reads along the row index (16 columns x 16 rows per
+// round of the block); what is left (signal rows rmin..N-1 when N is not a multiple of 32, and
+// the last columns c >= N) goes through the generic entry function.
+__global__ __launch_bounds__(256) void k_assemble_edge(const hpx_gen_batch B, double* __restrict__ L_all,
+                                                       const int npad, const int ld) {
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const hpx_gen G = hpx_gen_for(B, b);
+  const int N = B.N, M = B.M, TP = B.TP, ncol = B.ncol, rmin = B.rmin;
+  double* L = L_all + (long)b * npad * ld * 2;
+  const int ci = tid >> 4, ri = tid & 15;
+  for (int c0 = 16 * blockIdx.y; c0 < N; c0 += 16 * gridDim.y) {     // column blocks over grid.y
+    const int c = c0 + ci;
+    if (c >= N) continue;
+    const double ic = G.ia[c];
+    for (int r = N + ri; r < ld; r += 16) {
+      double vr = 0.0, vi = 0.0;
+      if (r < N + M) {
+        const long o = (long)c * ncol + TP + (r - N);
+        vr = G.rre[o];
+        vi = -G.rim[o];
+      } else if (r >= npad) {
+        const int t = r - npad;
+        const long o = (long)c * ncol + t;
+        vr = G.rre[o];
+        vi = G.rim[o];
+        if (G.has_omega) {
+          vr = fma(ic, G.p2re[(long)c * TP + t], vr);
+          vi = fma(ic, G.p2im[(long)c * TP + t], vi);
+        }
+        vi = -vi;
+      }
+      const long o = HPX_LIDX(r, c, npad);
+      L[o] = vr;
+      L[o + 16] = vi;
+    }
+  }
+  if (blockIdx.y != 0) return;
+  // signal rows rmin <= r < N of the signal columns (N not a multiple of 32)
+  const int nsr = N - rmin;
+  for (int e = tid; e < nsr * N; e += 256) {
+    const int c = e / nsr, r = rmin + e - c * nsr;
+    if (r < c) continue;
+    double vr, vi;
+    hpx_gen_entry(G, r, c, npad, vr, vi);
+    const long o = HPX_LIDX(r, c, npad);
+    L[o] = vr;
+    L[o + 16] = vi;
+  }
+  // columns c >= N (foreground x foreground block, padding, their right-hand sides)
+  const int ncl = npad - N, nrl = ld - N;
+  for (int e = tid; e < ncl * nrl; e += 256) {
+    const int c = N + e / nrl, r = N + e % nrl;
+    if (r < c) continue;
+    double vr, vi;
+    hpx_gen_entry(G, r, c, npad, vr, vi);
+    const long o = HPX_LIDX(r, c, npad);
+    L[o] = vr;
+    L[o + 16] = vi;
+  }
+}
+
 __global__ void k_kaug_out(const double* __restrict__ L, double* __restrict__ out, const int npad,
                            const int ld) {
   // (nbl, ld, npad) c128 row-major
@@ -804,6 +867,12 @@ static hpx_gen_batch gen_of(const hpx_plan* p) {
   return B;
 }
 
+static int launch_assemble_edge(hpx_plan* p, hipStream_t st) {
+  hipLaunchKernelGGL(k_assemble_edge, dim3(p->nbl, 1), dim3(256), 0, st, gen_of(p), p->L, p->npad, p->ld);
+  HPX_HIP(hipGetLastError());
+  return HPX_OK;
+}
+
 static int launch_assemble(hpx_plan* p, hipStream_t st, int rlo) {
   hipLaunchKernelGGL(k_assemble, dim3(p->npad / 16, p->nbl), dim3(256), 0, st, gen_of(p), p->L,
                      p->npad, p->ld, rlo);
@@ -1008,7 +1077,7 @@ extern "C" int hpx_gibbs_run(hpx_plan* p, const double* ps0, int iter0, int nite
       HPX_TRY(mark(p, st));
     } else {
       const hpx_gen_batch gen = gen_of(p);
-      HPX_TRY(launch_assemble(p, st, gen.rmin));
+      HPX_TRY(launch_assemble_edge(p, st));
       HPX_TRY(mark(p, st));
       HPX_TRY(hpx_launch_factor(nbl, p->npad, p->ld, p->L, p->Wre, p->Wim, p->info, iter0 + it + 1,
                                 &gen, st));
