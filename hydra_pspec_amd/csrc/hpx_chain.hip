@@ -971,7 +971,7 @@ static int post_solve(hpx_plan* p, int it_abs, const IterOut& O, hipStream_t st)
   int npart = 1, TC = 4096 / NP;
   if (TC > 16) TC = 16;
   const bool pow2 = N == NP && (N & (N - 1)) == 0 && N >= 32 && N <= 4096;
-  if (pow2 && hpx_dft_use_fft && TC >= 1 && TP / TC <= HPX_NPART) {
+  if (pow2 && hpx_dft_use_fft && TC >= 8 && TP / TC <= HPX_NPART) {   // fewer columns per block: two kernels win
     while ((1 << R.logN) < N) ++R.logN;
     while ((1 << R.tcs) < TC) ++R.tcs;
     npart = TP / TC;
