@@ -42,8 +42,8 @@ __global__ __launch_bounds__(256) void k_solve_flat(const FlatArgs A) {
   const int SW = 16 + TP;                         // row length of the augmented M x M system
   double* dinv = lds;                             // [NP]
   double* iav = dinv + NP;                        // [NP]
-  double* slab = iav + NP;                        // [4][1 + FT_MAX][2][4][64]
-  double* sre = slab + 4 * (1 + FT_MAX) * 2 * 256;   // [16][SW]
+  double* slab = iav + NP;                        // [1 + FT_MAX][2][4][64]
+  double* sre = slab + (1 + FT_MAX) * 2 * 256;    // [16][SW]
   double* sim = sre + 16 * SW;
   __shared__ int bad_s;
   const double* ia = A.ia + (long)b * N;
@@ -69,57 +69,95 @@ __global__ __launch_bounds__(256) void k_solve_flat(const FlatArgs A) {
       ar[q] = (d4){0., 0., 0., 0.};
       ai[q] = (d4){0., 0., 0., 0.};
     }
-    for (int ks = wave; ks < nks; ks += 4) {
-      const int k = 4 * ks + g;
-      const int kc = min(k, N - 1);               // padded channels: Dinv = 0, any finite operand
-      const long ro = (long)kc * ncol;
-      const double dk = dinv[k], ik = iav[k];
-      // A[m = li][k] = conj(G[k][m])
-      const double gr = rre[ro + TP + li], gi = rim[ro + TP + li];
-      const double a_r = gr, a_i = -gi;
-      if (with_s) {                               // B[k][m' = li] = Dinv_k G[k][m']
-        const double b_r = dk * gr, b_i = dk * gi;
-        ar[0] = mfma64(a_r, b_r, ar[0]);
-        ar[0] = mfma64(-a_i, b_i, ar[0]);
-        ai[0] = mfma64(a_r, b_i, ai[0]);
-        ai[0] = mfma64(a_i, b_r, ai[0]);
+    // operands of the next k-step are in flight while the current one is multiplied
+    double gr0, gi0, gr1, gi1, dk0, dk1, br0[FT_MAX], bi0[FT_MAX], br1[FT_MAX], bi1[FT_MAX];
+#define HPX_FL_LOAD(gr_, gi_, dk_, br_, bi_, ks_)                                          \
+  {                                                                                        \
+    const int k_ = 4 * (ks_) + g;                                                          \
+    const int kc_ = min(k_, N - 1);          /* padded channels: Dinv = 0, finite operand */ \
+    const long ro_ = (long)kc_ * ncol;                                                     \
+    gr_ = rre[ro_ + TP + li];                                                              \
+    gi_ = rim[ro_ + TP + li];                                                              \
+    dk_ = dinv[k_];                                                                        \
+    const double ik_ = iav[k_];                                                            \
+    _Pragma("unroll") for (int q = 0; q < FT_MAX; ++q) {                                   \
+      if (q < nt) {                                                                        \
+        const int t_ = ((tb + q) << 4) + li;                                               \
+        double x_ = rre[ro_ + t_], y_ = rim[ro_ + t_];                                     \
+        if (A.has_omega) {                                                                 \
+          x_ = fma(ik_, A.p2re[(long)kc_ * TP + t_], x_);                                  \
+          y_ = fma(ik_, A.p2im[(long)kc_ * TP + t_], y_);                                  \
+        }                                                                                  \
+        br_[q] = x_;                                                                       \
+        bi_[q] = y_;                                                                       \
+      }                                                                                    \
+    }                                                                                      \
+  }
+#define HPX_FL_MMA(gr_, gi_, dk_, br_, bi_)                                                \
+  {                                                                                        \
+    const double a_r = gr_, a_i = -gi_;      /* A[m = li][k] = conj(G[k][m]) */            \
+    if (with_s) {                            /* B[k][m' = li] = Dinv_k G[k][m'] */         \
+      const double b_r = dk_ * gr_, b_i = dk_ * gi_;                                       \
+      ar[0] = mfma64(a_r, b_r, ar[0]);                                                     \
+      ar[0] = mfma64(-a_i, b_i, ar[0]);                                                    \
+      ai[0] = mfma64(a_r, b_i, ai[0]);                                                     \
+      ai[0] = mfma64(a_i, b_r, ai[0]);                                                     \
+    }                                                                                      \
+    _Pragma("unroll") for (int q = 0; q < FT_MAX; ++q) {                                   \
+      if (q < nt) {                          /* B[k][t] = Dinv_k r1[k][t] */               \
+        const double b_r = dk_ * br_[q], b_i = dk_ * bi_[q];                               \
+        ar[1 + q] = mfma64(a_r, b_r, ar[1 + q]);                                           \
+        ar[1 + q] = mfma64(-a_i, b_i, ar[1 + q]);                                          \
+        ai[1 + q] = mfma64(a_r, b_i, ai[1 + q]);                                           \
+        ai[1 + q] = mfma64(a_i, b_r, ai[1 + q]);                                           \
+      }                                                                                    \
+    }                                                                                      \
+  }
+    const int nmy = (nks > wave) ? (nks - wave + 3) / 4 : 0;
+    if (nmy > 0) {
+      int ks = wave;
+      const int kslast = wave + 4 * (nmy - 1);
+      HPX_FL_LOAD(gr0, gi0, dk0, br0, bi0, ks)
+      for (int i = 0; i + 1 < nmy; i += 2) {
+        HPX_FL_LOAD(gr1, gi1, dk1, br1, bi1, ks + 4)
+        __builtin_amdgcn_sched_barrier(0);
+        HPX_FL_MMA(gr0, gi0, dk0, br0, bi0)
+        __builtin_amdgcn_sched_barrier(0);
+        const int nx = min(ks + 8, kslast);
+        HPX_FL_LOAD(gr0, gi0, dk0, br0, bi0, nx)
+        __builtin_amdgcn_sched_barrier(0);
+        HPX_FL_MMA(gr1, gi1, dk1, br1, bi1)
+        __builtin_amdgcn_sched_barrier(0);
+        ks += 8;
       }
-#pragma unroll
-      for (int q = 0; q < FT_MAX; ++q) {
-        if (q >= nt) break;
-        const int t = ((tb + q) << 4) + li;        // B[k][t] = Dinv_k r1[k][t]
-        double b_r = rre[ro + t], b_i = rim[ro + t];
-        if (A.has_omega) {
-          b_r = fma(ik, A.p2re[(long)kc * TP + t], b_r);
-          b_i = fma(ik, A.p2im[(long)kc * TP + t], b_i);
-        }
-        b_r *= dk;
-        b_i *= dk;
-        ar[1 + q] = mfma64(a_r, b_r, ar[1 + q]);
-        ar[1 + q] = mfma64(-a_i, b_i, ar[1 + q]);
-        ai[1 + q] = mfma64(a_r, b_i, ai[1 + q]);
-        ai[1 + q] = mfma64(a_i, b_r, ai[1 + q]);
-      }
+      if (nmy & 1) HPX_FL_MMA(gr0, gi0, dk0, br0, bi0)
     }
-    double* mine = slab + (long)wave * (1 + FT_MAX) * 512;
+#undef HPX_FL_LOAD
+#undef HPX_FL_MMA
+    // fixed-order sum of the four waves' partial tiles through ONE slab (waves 3, 2, 1, 0 in
+    // turn): a slab per wave would cost 64 KB of LDS and leave one workgroup per CU
+    for (int w = 3; w >= 0; --w) {
+      if (wave == w) {
 #pragma unroll
-    for (int q = 0; q < 1 + FT_MAX; ++q)
+        for (int q = 0; q < 1 + FT_MAX; ++q)
 #pragma unroll
-      for (int v = 0; v < 4; ++v) {
-        mine[q * 512 + v * 64 + lane] = ar[q][v];
-        mine[q * 512 + 256 + v * 64 + lane] = ai[q][v];
+          for (int v = 0; v < 4; ++v) {
+            if (w == 3) {
+              slab[q * 512 + v * 64 + lane] = ar[q][v];
+              slab[q * 512 + 256 + v * 64 + lane] = ai[q][v];
+            } else {
+              slab[q * 512 + v * 64 + lane] += ar[q][v];
+              slab[q * 512 + 256 + v * 64 + lane] += ai[q][v];
+            }
+          }
       }
-    __syncthreads();
-    // fixed-order sum of the four waves' partial tiles; element (q, v, l) is row m = (l>>4)+4v,
-    // column l&15 of tile q
+      __syncthreads();
+    }
+    // element (q, v, l) is row m = (l>>4)+4v, column l&15 of tile q
     for (int e = tid; e < (1 + nt) * 256; e += 256) {
       const int q = e >> 8, v = (e >> 6) & 3, l = e & 63;
       if (q == 0 && !with_s) continue;
-      double s_r = 0.0, s_i = 0.0;
-      for (int w = 0; w < 4; ++w) {
-        s_r += slab[(long)w * (1 + FT_MAX) * 512 + q * 512 + v * 64 + l];
-        s_i += slab[(long)w * (1 + FT_MAX) * 512 + q * 512 + 256 + v * 64 + l];
-      }
+      const double s_r = slab[q * 512 + v * 64 + l], s_i = slab[q * 512 + 256 + v * 64 + l];
       const int m = HPX_ACC_ROW(l >> 4, v), col = l & 15;
       double o_r, o_i;
       if (q == 0) {                               // S, identity padding beyond M
@@ -240,7 +278,7 @@ __global__ __launch_bounds__(256) void k_solve_flat(const FlatArgs A) {
 }  // namespace
 
 size_t hpx_flat_lds_bytes(const hpx_plan* p) {
-  return ((size_t)2 * p->NP + (size_t)4 * (1 + FT_MAX) * 512 + (size_t)2 * 16 * (16 + p->TP)) * sizeof(double);
+  return ((size_t)2 * p->NP + (size_t)(1 + FT_MAX) * 512 + (size_t)2 * 16 * (16 + p->TP)) * sizeof(double);
 }
 
 int hpx_launch_solve_flat(hpx_plan* p, int iter_tag, hipStream_t st) {
