@@ -464,54 +464,113 @@ __global__ __launch_bounds__(256) void k_fft_resid(const ResArgs A) {
   const double* ninv = A.ninv + (long)b * N;
   const uint8_t* fl8 = A.flags + (long)b * N;
   double acc = 0.0;
-  // 256 elements (256 / TC channels x TC times) per round; the foreground-mode rows F[x][:] of
-  // the round's channels are staged in LDS first (TC threads share a channel: from global
-  // memory each of them would fetch the same 2 M values again)
-  double* sfr = lfi + (M << tcs);                   // [256 / TC][M]
-  double* sfi = sfr + (256 >> tcs) * M;
-  const int xper = 256 >> tcs;
-  for (int e0 = 0; e0 < (N << tcs); e0 += 256) {
-    __syncthreads();
-    for (int q = tid; q < xper * M; q += 256) {
-      const int xi = q / M, m = q - xi * M;
-      const int xx = (int)(__brev((unsigned)((e0 >> tcs) + xi)) >> (32 - logN));
-      sfr[q] = fmr[(long)xx * M + m];
-      sfi[q] = fmi[(long)xx * M + m];
+  if (M <= 16) {
+    // Model term F f on the matrix pipe: tiles of 16 channels (consecutive positions of the
+    // bit-reversed FFT output) x the block's time columns, K = the (padded) mode index.  The
+    // accumulator lane (li, g) then holds rows p0 + g + 4v, column tc = li: the residual is
+    // finished from there with a handful of vector ops per element instead of 8 per mode.
+    const int wave = tid >> 6, lane = tid & 63, li = lane & 15, g = lane >> 4;
+    double bfr[4], bfi[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {                  // B[m = 4 ks + g][tc = li] = f[m][tc]
+      const int m = 4 * ks + g;
+      const bool ok = (m < M) && (li < TC);
+      bfr[ks] = ok ? lfr[(m << tcs) + li] : 0.0;
+      bfi[ks] = ok ? lfi[(m << tcs) + li] : 0.0;
     }
-    __syncthreads();
-    const int e = e0 + tid;
-    const int pidx = e >> tcs, tc = e & (TC - 1), t = c0 + tc;
-    const int x = (int)(__brev((unsigned)pidx) >> (32 - logN));
-    const long o = (long)x * TP + t;
-    if (t >= T) {
-      if (A.any_flags) { A.Gre[(long)b * A.NP * TP + o] = 0.0; A.Gim[(long)b * A.NP * TP + o] = 0.0; }
-      continue;
+    const int t = c0 + li;
+    for (int pt = wave; pt < (N >> 4); pt += 4) {
+      const int p0 = pt << 4;
+      const int xa = (int)(__brev((unsigned)(p0 + li)) >> (32 - logN));
+      d4 mr = {0., 0., 0., 0.}, mi = {0., 0., 0., 0.};
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {                // A[channel p0 + li][m = 4 ks + g] = F[x][m]
+        const int m = 4 * ks + g;
+        const double fr = (m < M) ? fmr[(long)xa * M + m] : 0.0;
+        const double fi = (m < M) ? fmi[(long)xa * M + m] : 0.0;
+        mr = mfma64(fr, bfr[ks], mr);
+        mr = mfma64(-fi, bfi[ks], mr);
+        mi = mfma64(fr, bfi[ks], mi);
+        mi = mfma64(fi, bfr[ks], mi);
+      }
+      if (li >= TC) continue;
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const int pidx = p0 + HPX_ACC_ROW(g, v);
+        const int x = (int)(__brev((unsigned)pidx) >> (32 - logN));
+        const long o = (long)x * TP + t;
+        if (t >= T) {
+          if (A.any_flags) { A.Gre[(long)b * A.NP * TP + o] = 0.0; A.Gim[(long)b * A.NP * TP + o] = 0.0; }
+          continue;
+        }
+        const double sc = (x & 1) ? -A.isn : A.isn;
+        const double sr = fre[(pidx << tcs) + li] * sc, si = fim[(pidx << tcs) + li] * sc;
+        const double rr = dre[o] - (sr + mr[v]), ri = dim_[o] - (si + mi[v]);
+        const double w = fl8[x] ? 1.0 : 0.0;
+        const double c2 = (rr * rr + ri * ri) * ninv[x];
+        acc += w * c2;
+        if (A.any_flags) {
+          A.Gre[(long)b * A.NP * TP + o] = w * sr;
+          A.Gim[(long)b * A.NP * TP + o] = w * si;
+        }
+        if (A.cr_out) {
+          double* q = A.cr_out + (long)b * A.cr_bstride + ((long)t * N + x) * 2;
+          q[0] = sr;
+          q[1] = si;
+        }
+        if (A.chisq_out) A.chisq_out[(long)b * A.chisq_bstride + (long)t * N + x] = c2;
+      }
     }
-    const double sc = (x & 1) ? -A.isn : A.isn;
-    const double sr = fre[e] * sc, si = fim[e] * sc;
-    double mr = sr, mi = si;
-    const double* myfr = sfr + (tid >> tcs) * M;
-    const double* myfi = sfi + (tid >> tcs) * M;
-    for (int m = 0; m < M; ++m) {
-      const double fr = myfr[m], fi = myfi[m];
-      const double gr = lfr[(m << tcs) + tc], gi = lfi[(m << tcs) + tc];
-      mr += gr * fr - gi * fi;
-      mi += gr * fi + gi * fr;
+  } else {
+    // 256 elements (256 / TC channels x TC times) per round; the foreground-mode rows F[x][:] of
+    // the round's channels are staged in LDS first (TC threads share a channel: from global
+    // memory each of them would fetch the same 2 M values again)
+    double* sfr = lfi + (M << tcs);                   // [256 / TC][M]
+    double* sfi = sfr + (256 >> tcs) * M;
+    const int xper = 256 >> tcs;
+    for (int e0 = 0; e0 < (N << tcs); e0 += 256) {
+      __syncthreads();
+      for (int q = tid; q < xper * M; q += 256) {
+        const int xi = q / M, m = q - xi * M;
+        const int xx = (int)(__brev((unsigned)((e0 >> tcs) + xi)) >> (32 - logN));
+        sfr[q] = fmr[(long)xx * M + m];
+        sfi[q] = fmi[(long)xx * M + m];
+      }
+      __syncthreads();
+      const int e = e0 + tid;
+      const int pidx = e >> tcs, tc = e & (TC - 1), t = c0 + tc;
+      const int x = (int)(__brev((unsigned)pidx) >> (32 - logN));
+      const long o = (long)x * TP + t;
+      if (t >= T) {
+        if (A.any_flags) { A.Gre[(long)b * A.NP * TP + o] = 0.0; A.Gim[(long)b * A.NP * TP + o] = 0.0; }
+        continue;
+      }
+      const double sc = (x & 1) ? -A.isn : A.isn;
+      const double sr = fre[e] * sc, si = fim[e] * sc;
+      double mr = sr, mi = si;
+      const double* myfr = sfr + (tid >> tcs) * M;
+      const double* myfi = sfi + (tid >> tcs) * M;
+      for (int m = 0; m < M; ++m) {
+        const double fr = myfr[m], fi = myfi[m];
+        const double gr = lfr[(m << tcs) + tc], gi = lfi[(m << tcs) + tc];
+        mr += gr * fr - gi * fi;
+        mi += gr * fi + gi * fr;
+      }
+      const double rr = dre[o] - mr, ri = dim_[o] - mi;
+      const double w = fl8[x] ? 1.0 : 0.0;
+      const double c2 = (rr * rr + ri * ri) * ninv[x];
+      acc += w * c2;
+      if (A.any_flags) {
+        A.Gre[(long)b * A.NP * TP + o] = w * sr;
+        A.Gim[(long)b * A.NP * TP + o] = w * si;
+      }
+      if (A.cr_out) {
+        double* q = A.cr_out + (long)b * A.cr_bstride + ((long)t * N + x) * 2;
+        q[0] = sr;
+        q[1] = si;
+      }
+      if (A.chisq_out) A.chisq_out[(long)b * A.chisq_bstride + (long)t * N + x] = c2;
     }
-    const double rr = dre[o] - mr, ri = dim_[o] - mi;
-    const double w = fl8[x] ? 1.0 : 0.0;
-    const double c2 = (rr * rr + ri * ri) * ninv[x];
-    acc += w * c2;
-    if (A.any_flags) {
-      A.Gre[(long)b * A.NP * TP + o] = w * sr;
-      A.Gim[(long)b * A.NP * TP + o] = w * si;
-    }
-    if (A.cr_out) {
-      double* q = A.cr_out + (long)b * A.cr_bstride + ((long)t * N + x) * 2;
-      q[0] = sr;
-      q[1] = si;
-    }
-    if (A.chisq_out) A.chisq_out[(long)b * A.chisq_bstride + (long)t * N + x] = c2;
   }
   if (A.fg_out) {
     for (int e = tid; e < (M << tcs); e += 256) {
