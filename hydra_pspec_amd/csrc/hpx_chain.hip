@@ -465,10 +465,10 @@ __global__ __launch_bounds__(256) void k_fft_resid(const ResArgs A) {
   const uint8_t* fl8 = A.flags + (long)b * N;
   double acc = 0.0;
   if (M <= 16) {
-    // Model term F f on the matrix pipe: tiles of 16 channels (consecutive positions of the
-    // bit-reversed FFT output) x the block's time columns, K = the (padded) mode index.  The
-    // accumulator lane (li, g) then holds rows p0 + g + 4v, column tc = li: the residual is
-    // finished from there with a handful of vector ops per element instead of 8 per mode.
+    // Model term F f on the matrix pipe: tiles of 16 channels x the block's time columns, K =
+    // the (padded) mode index.  The accumulator lane (li, g) then holds channels x0 + g + 4v,
+    // column tc = li: the residual is finished from there with a handful of vector ops per
+    // element instead of 8 per mode.
     const int wave = tid >> 6, lane = tid & 63, li = lane & 15, g = lane >> 4;
     double bfr[4], bfi[4];
 #pragma unroll
@@ -479,12 +479,15 @@ __global__ __launch_bounds__(256) void k_fft_resid(const ResArgs A) {
       bfi[ks] = ok ? lfi[(m << tcs) + li] : 0.0;
     }
     const int t = c0 + li;
-    for (int pt = wave; pt < (N >> 4); pt += 4) {
-      const int p0 = pt << 4;
-      const int xa = (int)(__brev((unsigned)(p0 + li)) >> (32 - logN));
+    for (int xt = wave; xt < (N >> 4); xt += 4) {
+      // tiles run over channels in NATURAL order, so that everything in global memory (data,
+      // mode rows, noise, outputs) is touched with unit stride; the bit reversal of the FFT
+      // output is undone by the LDS read of s instead
+      const int x0 = xt << 4;
+      const int xa = x0 + li;
       d4 mr = {0., 0., 0., 0.}, mi = {0., 0., 0., 0.};
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {                // A[channel p0 + li][m = 4 ks + g] = F[x][m]
+      for (int ks = 0; ks < 4; ++ks) {                // A[channel x0 + li][m = 4 ks + g] = F[x][m]
         const int m = 4 * ks + g;
         const double fr = (m < M) ? fmr[(long)xa * M + m] : 0.0;
         const double fi = (m < M) ? fmi[(long)xa * M + m] : 0.0;
@@ -496,8 +499,8 @@ __global__ __launch_bounds__(256) void k_fft_resid(const ResArgs A) {
       if (li >= TC) continue;
 #pragma unroll
       for (int v = 0; v < 4; ++v) {
-        const int pidx = p0 + HPX_ACC_ROW(g, v);
-        const int x = (int)(__brev((unsigned)pidx) >> (32 - logN));
+        const int x = x0 + HPX_ACC_ROW(g, v);
+        const int pidx = (int)(__brev((unsigned)x) >> (32 - logN));
         const long o = (long)x * TP + t;
         if (t >= T) {
           if (A.any_flags) { A.Gre[(long)b * A.NP * TP + o] = 0.0; A.Gim[(long)b * A.NP * TP + o] = 0.0; }
