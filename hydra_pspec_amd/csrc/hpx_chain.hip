@@ -479,22 +479,47 @@ __global__ __launch_bounds__(256) void k_fft_resid(const ResArgs A) {
       bfi[ks] = ok ? lfi[(m << tcs) + li] : 0.0;
     }
     const int t = c0 + li;
-    for (int xt = wave; xt < (N >> 4); xt += 4) {
-      // tiles run over channels in NATURAL order, so that everything in global memory (data,
-      // mode rows, noise, outputs) is touched with unit stride; the bit reversal of the FFT
-      // output is undone by the LDS read of s instead
+    // Tiles run over channels in NATURAL order, so that everything in global memory (data, mode
+    // rows, noise, outputs) is touched with unit stride; the bit reversal of the FFT output is
+    // undone by the LDS read of s instead.  The global operands of the next tile are requested
+    // before the current one is worked on (two workgroups per CU: nothing else hides them).
+    const int ntile = N >> 4;
+    const int tlast = wave + 4 * ((ntile - 1 - wave) >> 2);       // this wave's last tile
+    const bool tvalid = (li < TC) && (t < T);
+    double nfr[4], nfi[4], ndr[4], ndi[4], nnv[4], nw[4];
+#define HPX_FR_LOAD(xt_)                                                              \
+  {                                                                                   \
+    const int x0_ = (xt_) << 4;                                                       \
+    _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {                                \
+      const int m = 4 * ks + g;                                                       \
+      nfr[ks] = (m < M) ? fmr[(long)(x0_ + li) * M + m] : 0.0;                        \
+      nfi[ks] = (m < M) ? fmi[(long)(x0_ + li) * M + m] : 0.0;                        \
+    }                                                                                 \
+    _Pragma("unroll") for (int v = 0; v < 4; ++v) {                                   \
+      const int x_ = x0_ + HPX_ACC_ROW(g, v);                                         \
+      const long o_ = (long)x_ * TP + (tvalid ? t : 0);                               \
+      ndr[v] = dre[o_];                                                               \
+      ndi[v] = dim_[o_];                                                              \
+      nnv[v] = ninv[x_];                                                              \
+      nw[v] = fl8[x_] ? 1.0 : 0.0;                                                    \
+    }                                                                                 \
+  }
+    if (wave < ntile) HPX_FR_LOAD(wave)
+    for (int xt = wave; xt < ntile; xt += 4) {
       const int x0 = xt << 4;
-      const int xa = x0 + li;
+      double cfr[4], cfi[4], cdr[4], cdi[4], cnv[4], cw[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        cfr[q] = nfr[q]; cfi[q] = nfi[q]; cdr[q] = ndr[q]; cdi[q] = ndi[q]; cnv[q] = nnv[q]; cw[q] = nw[q];
+      }
+      HPX_FR_LOAD(min(xt + 4, tlast))                 // branch-free: re-read at the end
       d4 mr = {0., 0., 0., 0.}, mi = {0., 0., 0., 0.};
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {                // A[channel x0 + li][m = 4 ks + g] = F[x][m]
-        const int m = 4 * ks + g;
-        const double fr = (m < M) ? fmr[(long)xa * M + m] : 0.0;
-        const double fi = (m < M) ? fmi[(long)xa * M + m] : 0.0;
-        mr = mfma64(fr, bfr[ks], mr);
-        mr = mfma64(-fi, bfi[ks], mr);
-        mi = mfma64(fr, bfi[ks], mi);
-        mi = mfma64(fi, bfr[ks], mi);
+        mr = mfma64(cfr[ks], bfr[ks], mr);
+        mr = mfma64(-cfi[ks], bfi[ks], mr);
+        mi = mfma64(cfr[ks], bfi[ks], mi);
+        mi = mfma64(cfi[ks], bfr[ks], mi);
       }
       if (li >= TC) continue;
 #pragma unroll
@@ -508,9 +533,9 @@ __global__ __launch_bounds__(256) void k_fft_resid(const ResArgs A) {
         }
         const double sc = (x & 1) ? -A.isn : A.isn;
         const double sr = fre[(pidx << tcs) + li] * sc, si = fim[(pidx << tcs) + li] * sc;
-        const double rr = dre[o] - (sr + mr[v]), ri = dim_[o] - (si + mi[v]);
-        const double w = fl8[x] ? 1.0 : 0.0;
-        const double c2 = (rr * rr + ri * ri) * ninv[x];
+        const double rr = cdr[v] - (sr + mr[v]), ri = cdi[v] - (si + mi[v]);
+        const double w = cw[v];
+        const double c2 = (rr * rr + ri * ri) * cnv[v];
         acc += w * c2;
         if (A.any_flags) {
           A.Gre[(long)b * A.NP * TP + o] = w * sr;
@@ -524,6 +549,7 @@ __global__ __launch_bounds__(256) void k_fft_resid(const ResArgs A) {
         if (A.chisq_out) A.chisq_out[(long)b * A.chisq_bstride + (long)t * N + x] = c2;
       }
     }
+#undef HPX_FR_LOAD
   } else {
     // 256 elements (256 / TC channels x TC times) per round; the foreground-mode rows F[x][:] of
     // the round's channels are staged in LDS first (TC threads share a channel: from global
