@@ -131,7 +131,10 @@ int hpx_plan_set_solver(hpx_plan* p, int mode);
 /* time (ms) spent in each stage of the last hpx_gibbs_run, measured with HIP
  * events on the run's stream; host array of HPX_NSTAGE floats
  * [assemble, factor, backsolve, transform, residual, draw]; needs
- * hpx_plan_set_profiling(p,1) before the run (adds event records only). */
+ * hpx_plan_set_profiling(p,1) before the run (adds event records only).
+ * For power-of-two N <= 512 the back transform and the residual are one kernel,
+ * booked under "transform" ("residual" then only holds the masked transform of
+ * flagged data); HPX_SOLVER_FLAT books its solve under "factor". */
 #define HPX_NSTAGE 6
 int hpx_plan_set_profiling(hpx_plan* p, int on);
 int hpx_plan_stage_ms(hpx_plan* p, float* ms_host);
