@@ -1,5 +1,5 @@
 // Plan management, iteration-invariant operators, and the per-iteration
-// kernels around the factor/solve: assembly of K'_aug, residual / chi^2 /
+// kernels around the factor/solve: assembly of the augmented system, residual / chi^2 /
 // log-posterior reductions, and the inverse-gamma bandpower draw.
 #include <math.h>
 #include <stdarg.h>
@@ -210,7 +210,7 @@ __global__ void k_set_a(const double* __restrict__ ps, double* __restrict__ ia,
   }
 }
 
-// ---- K'_aug assembly ----------------------------------------------------------
+// ---- assembly of the augmented (scaled) system M_aug ----------------------------
 // rows >= rlo only (rlo = 0: the whole lower triangle + right-hand sides)
 __global__ __launch_bounds__(256) void k_assemble(const hpx_gen_batch B, double* __restrict__ L_all,
                                                   const int npad, const int ld, const int rlo) {
@@ -1155,7 +1155,7 @@ extern "C" int hpx_gibbs_run(hpx_plan* p, const double* ps0, int iter0, int nite
   for (int it = 0; it < niter; ++it) {
     HPX_TRY(mark(p, st));
     // Only the edge rows (foreground modes, padding, right-hand sides: rows >= rmin) are
-    // assembled; the signal x signal part of K' is generated inside the factor kernel.
+    // assembled; the signal x signal part of the matrix is generated inside the factor kernel.
     if (p->solver == HPX_SOLVER_FLAT) {
       // flat noise, no flags: diagonal + rank-M border, solved through the Schur complement
       // (hpx_flat.hip); booked under the "factor" stage

@@ -217,7 +217,7 @@ struct hpx_lds_limit {
 };
 
 // ---- launchers (each returns HPX_OK / HPX_EHIP) -----------------------------
-// gen == nullptr: factor the matrix stored in L in place; otherwise K'_aug is generated on the
+// gen == nullptr: factor the matrix stored in L in place; otherwise the augmented matrix is generated on the
 // fly from *gen and L is write-only.
 int hpx_launch_factor(int nbl, int npad, int ld, double* L, double* Wre, double* Wim,
                       int32_t* info, int iter_tag, const hpx_gen_batch* gen, hipStream_t st);

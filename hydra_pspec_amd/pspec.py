@@ -10,8 +10,9 @@ MT19937) and lays out outputs.
 Formulation: with ``S = U diag(ps/N) U^H`` (``U = F^H/sqrt N``)
 and diagonal ``Ninv``, the reference's non-Hermitian system ``A x = b``
 (pspec.py:365-369) is solved as the Hermitian positive-definite system
-``K' [y'; f] = r'`` in the delay basis by a batched Cholesky factorisation;
-``s = U D^{1/2} y'``.  The accelerated entry point is
+``K' [y'; f] = r'`` in the delay basis -- on the device in the symmetrically scaled form
+``M [z; f] = A^-1 r'``, ``z = a . y'`` -- by a batched Cholesky factorisation (or, for unflagged
+flat-noise data, through the diagonal + rank-Nmodes structure of ``M``); ``s = U z``.  The accelerated entry point is
 :func:`gibbs_sample_with_fg_batched`; :func:`gibbs_sample_with_fg` is its
 ``Nbl = 1`` drop-in special case.
 """
