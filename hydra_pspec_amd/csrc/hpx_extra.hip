@@ -237,6 +237,32 @@ __global__ void k_oqe_rx(const double* __restrict__ R, const double* __restrict_
   }
 }
 
+// y[b][2v][j] = sum_k R[b][k][j] V[b][v][k] (R^T x),  y[b][2v+1][j] = sum_k R[b][j][k] V[b][v][k] (R x)
+__global__ void k_oqe_rx2(const double* __restrict__ R, const double* __restrict__ V,
+                          double* __restrict__ Y, const int s, const int nv) {
+  const int b = blockIdx.y;
+  const double* Rb = R + (long)b * s * s * 2;
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < nv * s; e += gridDim.x * blockDim.x) {
+    const int v = e / s, j = e % s;
+    const double* x = V + ((long)b * nv + v) * s * 2;
+    double tr = 0.0, ti = 0.0, sr = 0.0, si = 0.0;
+    for (int k = 0; k < s; ++k) {
+      const double xr = x[2 * k], xi = x[2 * k + 1];
+      const double ar = Rb[((long)k * s + j) * 2], ai = Rb[((long)k * s + j) * 2 + 1];
+      const double rr = Rb[((long)j * s + k) * 2], ri = Rb[((long)j * s + k) * 2 + 1];
+      tr += ar * xr - ai * xi;
+      ti += ar * xi + ai * xr;
+      sr += rr * xr - ri * xi;
+      si += rr * xi + ri * xr;
+    }
+    double* y = Y + (((long)b * 2 * nv + 2 * v) * s + j) * 2;
+    y[0] = tr;
+    y[1] = ti;
+    y[(long)s * 2] = sr;
+    y[(long)s * 2 + 1] = si;
+  }
+}
+
 // q[b][p][t] = 1/2 conj(FFT(y1))[t] FFT(y2)[t]
 __global__ void k_oqe_q(const double* __restrict__ Y, double* __restrict__ q, const int s,
                         const int npair) {
@@ -363,5 +389,19 @@ extern "C" int hpx_oqe_qh(int nb, int npair, int s, const double* R, const doubl
   hipError_t e = hipGetLastError();
   if (e == hipSuccess) e = hipStreamSynchronize(st);
   if (e != hipSuccess) { hpx_set_error("hpx_oqe_qh: %s", hipGetErrorString(e)); return HPX_EHIP; }
+  return HPX_OK;
+}
+
+extern "C" int hpx_oqe_qauto(int nb, int nvis, int s, const double* R, const double* V,
+                             double* q_out, void* stream) {
+  HPX_REQUIRE(nb > 0 && nvis > 0 && s > 0 && R && V && q_out, "hpx_oqe_qauto: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  hpx_devbuf ybuf;
+  HPX_TRY(ybuf.alloc((size_t)nb * 2 * nvis * s * 2));
+  hipLaunchKernelGGL(k_oqe_rx2, dim3((nvis * s + 255) / 256, nb), dim3(256), 0, st, R, V, ybuf.p, s, nvis);
+  hipLaunchKernelGGL(k_oqe_q, dim3((nvis * s + 255) / 256, nb), dim3(256), 0, st, ybuf.p, q_out, s, nvis);
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  if (e != hipSuccess) { hpx_set_error("hpx_oqe_qauto: %s", hipGetErrorString(e)); return HPX_EHIP; }
   return HPX_OK;
 }

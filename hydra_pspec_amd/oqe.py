@@ -75,9 +75,22 @@ def bias(tau, s, R, C_noise_total):  # oqe.py:23-24
     return 0.5 * np.trace(C_noise_total @ R.conj() @ Q(tau, s) @ R)
 
 
+def _q_auto(V, s, R):
+    """1/2 x^H (R^* Q_tau R) x for every row x of V and every tau, on the device (closed form
+    1/2 conj(FFT(R^T x)) FFT(R x): Q_tau is the rank-one outer(conj m_tau, m_tau))."""
+    torch = hpx.require_gpu()
+    V = np.atleast_2d(np.asarray(V, dtype=complex))
+    dev = torch.device("cuda", torch.cuda.current_device())
+    d_R = hpx.to_dev(torch, np.asarray(R, dtype=complex)[None], torch.complex128, dev)
+    d_V = hpx.to_dev(torch, V[None], torch.complex128, dev)
+    d_q = torch.zeros((1, len(V), s), dtype=torch.complex128, device=dev)
+    hpx.check(hpx.lib().hpx_oqe_qauto(1, len(V), s, hpx.ptr(d_R), hpx.ptr(d_V), hpx.ptr(d_q),
+                                      hpx.stream_ptr(torch)), "hpx_oqe_qauto")
+    return d_q[0].cpu().numpy()
+
+
 def qhat(x, tau, s, R, bias):       # oqe.py:27-30
-    E = R.conj() @ Q(tau, s) @ R
-    return 0.5 * (x.conj().T @ E @ x) - bias
+    return _q_auto(np.asarray(x).reshape(1, s), s, R)[0, tau] - bias
 
 
 def q_h(V, s, R, taper=None):
@@ -103,11 +116,8 @@ def q_hp(V, s, R, ncpu):            # oqe.py:147-158 (the process pool is not ne
     return list(q_h(V, s, R))
 
 
-def q(V, s, R, bias):               # oqe.py:88-101
-    out = np.zeros((len(V), s))
-    for i in range(len(V)):
-        out[i] = np.array([qhat(V[i], tau, s, R, bias[tau]) for tau in range(s)])
-    return out
+def q(V, s, R, bias):               # oqe.py:88-101 (real array, as the reference allocates it)
+    return (_q_auto(V, s, R) - np.asarray(bias)[None, :]).real.copy()
 
 
 def p(q, M):                        # oqe.py:117-118

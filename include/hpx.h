@@ -192,6 +192,13 @@ int hpx_oqe_fisher(int nb, int s, const double* R, double* F_out, int variant,
 int hpx_oqe_qh(int nb, int npair, int s, const double* R, const double* V,
                double* q_out, void* stream);
 
+/* Auto-correlation estimator without the noise bias: q[v][tau] = 1/2 x_v^H (R^* Q_tau R) x_v
+ * = 1/2 conj(FFT(R^T x_v))[tau] FFT(R x_v)[tau] for every visibility x_v of V (nb,nvis,s) c128;
+ * R (nb,s,s) c128, q_out (nb,nvis,s) c128.  Replaces the double loop of oqe.q / oqe.qhat
+ * (oqe.py:27-30, :88-101); the caller subtracts bias[tau]. */
+int hpx_oqe_qauto(int nb, int nvis, int s, const double* R, const double* V, double* q_out,
+                  void* stream);
+
 /* Empirical lane map of v_mfma_f64_16x16x4_f64 (diagnostic used by the tests):
  * computes D = A(16x4) * B(4x16) and writes, for lane l and register v, the
  * value D holds; host (64*4) doubles. */

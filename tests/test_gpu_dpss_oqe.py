@@ -70,6 +70,14 @@ def test_oqe_vs_reference(golden, s):
     assert relerr(qs, g[f"F11_{s}_qh"]) < 1e-12 and relerr(F2, g[f"F11_{s}_F"]) < 1e-12
     b = np.array([oqe.bias(t, s, R, Cn) for t in range(s)])
     assert relerr(b, g[f"F11_{s}_bias"]) < 1e-12
+    assert relerr(oqe.q(V, s, R, b.real), g[f"F11_{s}_q"]) < 1e-12          # the reference's own output
+    # auto-estimator with a general (non-Hermitian, non-symmetric) weighting too: the device form is
+    # 1/2 conj(FFT(R^T x)) FFT(R x), the reference's is the explicit x^H (R^* Q_tau R) x
+    for W in (R, Rg):
+        ref = np.array([[0.5 * (x.conj() @ (W.conj() @ oqe.Q(t, s) @ W) @ x) - 0.25 * t for t in range(s)] for x in V])
+        got = np.array([[oqe.qhat(x, t, s, W, 0.25 * t) for t in range(s)] for x in V[:2]])
+        assert relerr(got, ref[:2]) < 1e-12
+        assert relerr(oqe.q(V, s, W, 0.25 * np.arange(s)), ref.real) < 1e-12
     assert relerr(oqe.Sig_QEN(R, Cn, 0.37), g[f"F11_{s}_SigN"]) < 1e-12
     assert relerr(oqe.Sig_QESN(R, Cn, R, 0.37), g[f"F11_{s}_SigSN"]) < 1e-12
 
