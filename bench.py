@@ -121,8 +121,8 @@ def cpu_baseline_multiproc(N, T, M, flag_frac, niter=8, max_procs=16):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", default="C3", choices=sorted(CONFIGS))
     ap.add_argument("--nbl", type=int, default=None, help="baselines per GPU (default: config)")
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -6,7 +6,7 @@
 TAG=${1:-r01}
 export TMPDIR=/tmp
 R=$PWD; O=$R/gpurun_out/prof; mkdir -p $O
-timeout -k 10 400 python3 bench.py --steps 10 --warmup 2 > $O/bench_c3.log 2>&1 || { tail -5 $O/bench_c3.log; exit 1; }
+timeout -k 10 400 python3 bench.py > $O/bench_c3.log 2>&1 || { tail -5 $O/bench_c3.log; exit 1; }
 grep -o '{"metric.*' $O/bench_c3.log > $O/${TAG}_bench_c3.json; echo "C3 done"
 timeout -k 10 300 python3 bench.py --steps 5 --warmup 1 --config C5 --no-cpu-baseline > $O/bench_c5.log 2>&1 && grep -o '{"metric.*' $O/bench_c5.log > $O/${TAG}_bench_c5.json; echo "C5 done"
 timeout -k 10 300 python3 bench.py --steps 20 --warmup 2 --config C2 --no-cpu-baseline > $O/bench_c2.log 2>&1 && grep -o '{"metric.*' $O/bench_c2.log > $O/${TAG}_bench_c2.json; echo "C2 done"
