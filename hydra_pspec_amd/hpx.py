@@ -112,7 +112,9 @@ def to_dev(torch, x, dtype, device):
     """numpy / torch (any device) -> contiguous torch tensor of `dtype` on `device`."""
     if isinstance(x, np.ndarray):
         x = np.ascontiguousarray(x)
-        if not x.flags.writeable:          # e.g. broadcast views, arrays out of an .npz
+        # torch refuses read-only arrays (broadcast views, arrays out of an .npz) and negative
+        # strides (which survive ascontiguousarray in length-1 dimensions)
+        if not x.flags.writeable or any(st < 0 for st in x.strides):
             x = x.copy()
         x = torch.from_numpy(x)
     return x.to(device=device, dtype=dtype, non_blocking=False).contiguous()

@@ -89,7 +89,12 @@ def _ninv_diag(Ninv, nbl, T, N):
     """Accept (N,), (nbl,N) diagonals or (N,N)/(nbl,N,N) dense matrices that are
     diagonal; return (nbl,N).  Dense non-diagonal inverse covariances make the
     reference's column-masked ``Ni`` non-Hermitian (pspec.py:361 FIXME) and are
-    not supported by the Cholesky formulation."""
+    not supported by the Cholesky formulation.  A torch tensor that already is an (nbl,N)
+    diagonal stays where it is (device inputs are used in place)."""
+    if not isinstance(Ninv, np.ndarray) and hasattr(Ninv, "detach"):
+        if tuple(Ninv.shape) == (nbl, N):
+            return Ninv
+        Ninv = Ninv.detach().cpu().numpy()
     Ninv = np.asarray(Ninv)
     if Ninv.ndim == 3 and Ninv.shape[0] == T and Ninv.shape[0] != nbl:
         raise NotImplementedError("time-dependent Ninv (Ntimes,Nfreqs,Nfreqs) is not supported "

@@ -304,3 +304,45 @@ def test_flat_noise_solver_is_refused_when_it_does_not_apply():
     assert hpx.lib().hpx_plan_set_solver(gb.plan.handle, hpx.SOLVER_FLAT) == hpx.HPX_EINVAL
     assert "not flat" in hpx.last_error()
     gb.close()
+
+
+@pytest.mark.parametrize("nbl,T,N,M,frac", [(1, 2, 16, 1, 0.0), (3, 3, 17, 2, 0.2), (2, 7, 48, 16, 0.1),
+                                            (1, 40, 33, 5, 0.0), (5, 16, 96, 20, 0.05)])
+def test_edge_shapes_vs_exact_oracle(nbl, T, N, M, frac):
+    """Smallest / odd / padded shapes through the dense path (minimum Ntimes = 2, few modes, Nmodes
+    > 16, Nfreqs not a multiple of 16, flags): two iterations against the exact-solve oracle."""
+    from hydra_pspec_amd import pspec, synthetic
+    from oracle import pspec_ref
+    d = synthetic.make_baselines(N, T, max(M, 1), k0=31, nbl=nbl, flag_frac=frac, dense=True)
+    F = (d["fgmodes"] if M <= d["fgmodes"].shape[1] else d["fgmodes"])[:, :M]
+    if M > F.shape[1]:
+        pytest.skip("recipe cannot provide that many modes")
+    prior = np.zeros((2, N))
+    out = pspec.gibbs_sample_with_fg_batched(d["vis"], d["flags"], F, d["Ninv"], prior, S_initial=d["S_initial"],
+                                             Niter=2, seed=5, keep=("signal_cr", "fg_amps", "chisq"), solver="dense")
+    for b in range(nbl):
+        ref = pspec_ref.gibbs_sample_with_fg(d["vis"][b], d["flags"][b], d["S_initial"], F, d["Ninv"], prior,
+                                             Niter=2, seed=5, solver="direct")
+        assert np.max(np.abs(out["signal_ps"][b] / ref[2] - 1)) < RTOL
+        assert relerr(out["signal_cr"][b], ref[0]) < RTOL
+        if M:
+            assert relerr(out["fg_amps"][b], ref[3]) < RTOL
+        assert np.allclose(out["ln_post"][b], ref[5], rtol=1e-6)
+
+
+def test_device_tensors_in_and_out():
+    """torch tensors already on the GPU are used in place (no host round trip) and
+    ``as_numpy=False`` hands device tensors back; results equal the numpy-in / numpy-out call."""
+    import torch
+    from hydra_pspec_amd import pspec, synthetic
+    d = synthetic.make_baselines(64, 8, 6, k0=4, nbl=3, flag_frac=0.1, dense=False)
+    kw = dict(ps_initial=d["ps0"], Niter=3, seed=9, keep=("signal_cr",))
+    a = pspec.gibbs_sample_with_fg_batched(d["vis"], d["flags"], d["fgmodes"], d["ninv_diag"], d["ps_prior"], **kw)
+    dev = torch.device("cuda")
+    b = pspec.gibbs_sample_with_fg_batched(torch.from_numpy(d["vis"]).to(dev), torch.from_numpy(d["flags"]).to(dev),
+                                           torch.from_numpy(d["fgmodes"]).to(dev),
+                                           torch.from_numpy(d["ninv_diag"]).to(dev), d["ps_prior"],
+                                           as_numpy=False, **kw)
+    assert all(v.is_cuda for v in b.values())
+    assert np.array_equal(b["signal_ps"].cpu().numpy(), a["signal_ps"])
+    assert np.array_equal(b["signal_cr"].cpu().numpy(), a["signal_cr"])
