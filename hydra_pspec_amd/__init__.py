@@ -15,7 +15,7 @@ from . import utils  # noqa: F401  (pure host helpers, no GPU needed)
 def __getattr__(name):
     # pspec/dpss/oqe bind the HIP library; import them lazily so that host-only
     # tools (synthetic data, file writers) work on a machine without a GPU.
-    if name in ("pspec", "dpss", "oqe", "synthetic", "hpx"):
+    if name in ("pspec", "dpss", "oqe", "synthetic", "hpx", "fgmodes", "uvh5", "h5lite"):
         import importlib
         return importlib.import_module(f"{__name__}.{name}")
     raise AttributeError(name)

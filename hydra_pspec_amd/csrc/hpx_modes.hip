@@ -1,0 +1,299 @@
+// Foreground modes from the data: leading eigenvectors of the per-baseline frequency-frequency
+// covariance over time, cov = np.cov(bl_data.T)  (reference scripts/calc-vis-cov-matrices.py:
+// 235-249; the driver then keeps the first Nfgmodes columns, run-hydra-pspec.py:453).
+//
+// The covariance C = A A^H, A = Xc^T / sqrt(T-1) (Xc = data minus its time mean), has rank at
+// most T-1, so for T <= N its eigenvectors come from the T x T Gram matrix A^H A:
+// (lambda, v) -> u = A v / sqrt(lambda).  Either way a Hermitian n x n problem with
+// n = min(T, N) <= 256 is diagonalised per baseline by a cyclic two-sided Jacobi method with the
+// round-robin parallel ordering: n/2 disjoint rotations per step, applied as a column phase and
+// a row phase by the whole workgroup.  One workgroup per baseline; the matrices live in global
+// memory (L2-resident, <= 1 MB per baseline).
+#include "hpx_internal.h"
+
+namespace {
+
+// Xc[b][t][k] = vis - mean over t, interleaved complex in, planar out
+__global__ void k_center(const double* __restrict__ vis, double* __restrict__ xr,
+                         double* __restrict__ xi, const int T, const int N) {
+  const int b = blockIdx.y;
+  for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < N; k += gridDim.x * blockDim.x) {
+    double mr = 0.0, mi = 0.0;
+    for (int t = 0; t < T; ++t) {
+      mr += vis[(((long)b * T + t) * N + k) * 2];
+      mi += vis[(((long)b * T + t) * N + k) * 2 + 1];
+    }
+    mr /= T;
+    mi /= T;
+    for (int t = 0; t < T; ++t) {
+      xr[((long)b * T + t) * N + k] = vis[(((long)b * T + t) * N + k) * 2] - mr;
+      xi[((long)b * T + t) * N + k] = vis[(((long)b * T + t) * N + k) * 2 + 1] - mi;
+    }
+  }
+}
+
+// gram != 0:  G[t][t'] = sum_k conj(xc_t(k)) xc_t'(k) / (T-1)      (n = T)
+// gram == 0:  G[i][j]  = sum_t xc_t(i) conj(xc_t(j)) / (T-1)       (n = N, the covariance itself)
+__global__ void k_gram(const double* __restrict__ xr, const double* __restrict__ xi,
+                       double* __restrict__ gr, double* __restrict__ gi, const int T, const int N,
+                       const int n, const int pitch, const int gram) {
+  const int b = blockIdx.y;
+  const double* ar = xr + (long)b * T * N;
+  const double* ai = xi + (long)b * T * N;
+  const double sc = 1.0 / (double)(T - 1);
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < n * n; e += gridDim.x * blockDim.x) {
+    const int i = e / n, j = e % n;
+    double sr = 0.0, si = 0.0;
+    if (gram) {
+      for (int k = 0; k < N; ++k) {
+        const double pr = ar[(long)i * N + k], pi = ai[(long)i * N + k];
+        const double qr = ar[(long)j * N + k], qi = ai[(long)j * N + k];
+        sr += pr * qr + pi * qi;        // conj(p) q
+        si += pr * qi - pi * qr;
+      }
+    } else {
+      for (int t = 0; t < T; ++t) {
+        const double pr = ar[(long)t * N + i], pi = ai[(long)t * N + i];
+        const double qr = ar[(long)t * N + j], qi = ai[(long)t * N + j];
+        sr += pr * qr + pi * qi;        // p conj(q)
+        si += pi * qr - pr * qi;
+      }
+    }
+    gr[(long)b * pitch * pitch + (long)i * pitch + j] = sr * sc;      // order n inside a pitch x pitch slot
+    gi[(long)b * pitch * pitch + (long)i * pitch + j] = si * sc;
+  }
+}
+
+// round-robin pairing of step s: pair i of n/2 (n even) -> (p, q), p < q
+__device__ __forceinline__ void rr_pair(const int n, const int s, const int i, int& p, int& q) {
+  const int m = n - 1;
+  int a, b;
+  if (i == 0) {
+    a = m;
+    b = s % m;
+  } else {
+    a = (s + i) % m;
+    b = (s - i + m) % m;
+  }
+  p = min(a, b);
+  q = max(a, b);
+}
+
+// Cyclic two-sided Jacobi: G -> diag(lambda), V -> eigenvectors (columns).  n even (the caller
+// pads an odd order with an isolated zero row/column).
+__global__ __launch_bounds__(256) void k_jacobi(double* __restrict__ gr_all, double* __restrict__ gi_all,
+                                                double* __restrict__ vr_all, double* __restrict__ vi_all,
+                                                const int n, const int max_sweeps) {
+  extern __shared__ double rot[];             // [n/2][4]: cs, sn, cos(phi), sin(phi)
+  __shared__ double red[4];
+  __shared__ int done;
+  const int b = blockIdx.x, tid = threadIdx.x, half = n >> 1;
+  double* gr = gr_all + (long)b * n * n;
+  double* gi = gi_all + (long)b * n * n;
+  double* vr = vr_all + (long)b * n * n;
+  double* vi = vi_all + (long)b * n * n;
+  for (int e = tid; e < n * n; e += 256) {
+    vr[e] = (e / n == e % n) ? 1.0 : 0.0;
+    vi[e] = 0.0;
+  }
+  __syncthreads();
+  for (int sweep = 0; sweep < max_sweeps; ++sweep) {
+    // converged when every off-diagonal entry is negligible against its two diagonal entries
+    double worst = 0.0;
+    for (int e = tid; e < n * n; e += 256) {
+      const int i = e / n, j = e % n;
+      if (i >= j) continue;
+      const double off = gr[e] * gr[e] + gi[e] * gi[e];
+      const double dd = fabs(gr[(long)i * n + i] * gr[(long)j * n + j]);
+      if (off > 0.0) worst = fmax(worst, (dd > 0.0) ? off / dd : 1.0);
+    }
+    // block max through LDS
+    for (int o = 32; o > 0; o >>= 1) worst = fmax(worst, __shfl_xor(worst, o, 64));
+    if ((tid & 63) == 0) red[tid >> 6] = worst;
+    __syncthreads();
+    if (tid == 0) done = fmax(fmax(red[0], red[1]), fmax(red[2], red[3])) < 1e-30;
+    __syncthreads();
+    if (done) break;
+    for (int s = 0; s < n - 1; ++s) {
+      for (int i = tid; i < half; i += 256) {      // rotation parameters of the step's pairs
+        int p, q;
+        rr_pair(n, s, i, p, q);
+        const double a = gr[(long)p * n + p], bq = gr[(long)q * n + q];
+        const double cr = gr[(long)p * n + q], ci = gi[(long)p * n + q];
+        const double ac = sqrt(cr * cr + ci * ci);
+        double cs = 1.0, sn = 0.0, cp = 1.0, sp = 0.0;
+        if (ac > 0.0 && ac * ac > 1e-34 * fabs(a * bq)) {
+          const double tau = (bq - a) / (2.0 * ac);
+          const double t = ((tau >= 0.0) ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
+          cs = 1.0 / sqrt(1.0 + t * t);
+          sn = t * cs;
+          cp = cr / ac;
+          sp = ci / ac;
+        }
+        rot[4 * i] = cs; rot[4 * i + 1] = sn; rot[4 * i + 2] = cp; rot[4 * i + 3] = sp;
+      }
+      __syncthreads();
+      // columns: [x_p, x_q] <- [cs x_p - sn e^{-i phi} x_q, sn e^{i phi} x_p + cs x_q]  (G and V)
+      for (int e = tid; e < half * n; e += 256) {
+        const int i = e / n, k = e % n;
+        int p, q;
+        rr_pair(n, s, i, p, q);
+        const double cs = rot[4 * i], sn = rot[4 * i + 1], cp = rot[4 * i + 2], sp = rot[4 * i + 3];
+#pragma unroll
+        for (int which = 0; which < 2; ++which) {
+          double* mr = which ? vr : gr;
+          double* mi = which ? vi : gi;
+          const double pr = mr[(long)k * n + p], pi = mi[(long)k * n + p];
+          const double qr = mr[(long)k * n + q], qi = mi[(long)k * n + q];
+          // e^{-i phi} x_q = (cp - i sp)(qr + i qi);  e^{i phi} x_p = (cp + i sp)(pr + i pi)
+          const double eqr = cp * qr + sp * qi, eqi = cp * qi - sp * qr;
+          const double epr = cp * pr - sp * pi, epi = cp * pi + sp * pr;
+          mr[(long)k * n + p] = cs * pr - sn * eqr;
+          mi[(long)k * n + p] = cs * pi - sn * eqi;
+          mr[(long)k * n + q] = sn * epr + cs * qr;
+          mi[(long)k * n + q] = sn * epi + cs * qi;
+        }
+      }
+      __syncthreads();
+      // rows of G: [y_p, y_q] <- [cs y_p - sn e^{i phi} y_q, sn e^{-i phi} y_p + cs y_q]
+      for (int e = tid; e < half * n; e += 256) {
+        const int i = e / n, k = e % n;
+        int p, q;
+        rr_pair(n, s, i, p, q);
+        const double cs = rot[4 * i], sn = rot[4 * i + 1], cp = rot[4 * i + 2], sp = rot[4 * i + 3];
+        const double pr = gr[(long)p * n + k], pi = gi[(long)p * n + k];
+        const double qr = gr[(long)q * n + k], qi = gi[(long)q * n + k];
+        const double eqr = cp * qr - sp * qi, eqi = cp * qi + sp * qr;      // e^{i phi} y_q
+        const double epr = cp * pr + sp * pi, epi = cp * pi - sp * pr;      // e^{-i phi} y_p
+        gr[(long)p * n + k] = cs * pr - sn * eqr;
+        gi[(long)p * n + k] = cs * pi - sn * eqi;
+        gr[(long)q * n + k] = sn * epr + cs * qr;
+        gi[(long)q * n + k] = sn * epi + cs * qi;
+      }
+      __syncthreads();
+    }
+  }
+}
+
+// Pick the nm largest eigenvalues (descending), build the modes and fix their phase (largest
+// component real and positive).  gram: u[k] = sum_t xc_t(k) v[t] / sqrt(lambda (T-1)).
+__global__ __launch_bounds__(256) void k_modes_out(const double* __restrict__ gr,
+                                                   const double* __restrict__ vr_all,
+                                                   const double* __restrict__ vi_all,
+                                                   const double* __restrict__ xr,
+                                                   const double* __restrict__ xi,
+                                                   double* __restrict__ modes,
+                                                   double* __restrict__ evals, const int T, const int N,
+                                                   const int n, const int nreal, const int nm,
+                                                   const int gram) {
+  extern __shared__ double sh[];               // lam[n], then u_re[N], u_im[N]
+  __shared__ int order[256];
+  __shared__ double red[4];
+  __shared__ int redi[4];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  double* lam = sh;
+  double* ur = sh + n;
+  double* ui = ur + N;
+  for (int i = tid; i < n; i += 256) lam[i] = (i < nreal) ? gr[(long)b * n * n + (long)i * n + i] : -INFINITY;
+  __syncthreads();
+  if (tid == 0) {                              // selection of the nm largest (n <= 256: trivial)
+    for (int m = 0; m < nm; ++m) {
+      int best = 0;
+      for (int i = 1; i < n; ++i)
+        if (lam[i] > lam[best]) best = i;
+      order[m] = best;
+      evals[(long)b * nm + m] = lam[best];
+      lam[best] = -INFINITY;
+    }
+  }
+  __syncthreads();
+  const double* vr = vr_all + (long)b * n * n;
+  const double* vi = vi_all + (long)b * n * n;
+  const double* ar = xr + (long)b * T * N;
+  const double* ai = xi + (long)b * T * N;
+  for (int m = 0; m < nm; ++m) {
+    const int col = order[m];
+    const double lm = evals[(long)b * nm + m];
+    for (int k = tid; k < N; k += 256) {
+      double sr = 0.0, si = 0.0;
+      if (gram) {
+        for (int t = 0; t < T; ++t) {
+          const double pr = ar[(long)t * N + k], pi = ai[(long)t * N + k];
+          const double qr = vr[(long)t * n + col], qi = vi[(long)t * n + col];
+          sr += pr * qr - pi * qi;
+          si += pr * qi + pi * qr;
+        }
+      } else {
+        sr = vr[(long)k * n + col];
+        si = vi[(long)k * n + col];
+      }
+      ur[k] = sr;
+      ui[k] = si;
+    }
+    __syncthreads();
+    // norm and the component of largest magnitude (first one on ties)
+    double nn = 0.0, big = -1.0;
+    int at = 0;
+    for (int k = tid; k < N; k += 256) {
+      const double a2 = ur[k] * ur[k] + ui[k] * ui[k];
+      nn += a2;
+      if (a2 > big) { big = a2; at = k; }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+      nn += __shfl_xor(nn, o, 64);
+      const double ob = __shfl_xor(big, o, 64);
+      const int oa = __shfl_xor(at, o, 64);
+      if (ob > big || (ob == big && oa < at)) { big = ob; at = oa; }
+    }
+    if ((tid & 63) == 0) { red[tid >> 6] = nn; redi[tid >> 6] = at; }
+    __syncthreads();
+    nn = red[0] + red[1] + red[2] + red[3];
+    int best = redi[0];
+    for (int w = 1; w < 4; ++w) {
+      const int c = redi[w];
+      const double a2 = ur[c] * ur[c] + ui[c] * ui[c], b2 = ur[best] * ur[best] + ui[best] * ui[best];
+      if (a2 > b2 || (a2 == b2 && c < best)) best = c;
+    }
+    const double mag = sqrt(ur[best] * ur[best] + ui[best] * ui[best]);
+    const double scale = (nn > 0.0 && mag > 0.0) ? 1.0 / sqrt(nn) : 0.0;
+    const double pr = (mag > 0.0) ? ur[best] / mag : 1.0, pi = (mag > 0.0) ? -ui[best] / mag : 0.0;   // e^{-i arg}
+    (void)lm;
+    for (int k = tid; k < N; k += 256) {
+      double* o = modes + (((long)b * N + k) * nm + m) * 2;
+      o[0] = (ur[k] * pr - ui[k] * pi) * scale;
+      o[1] = (ur[k] * pi + ui[k] * pr) * scale;
+    }
+    __syncthreads();
+  }
+}
+
+}  // namespace
+
+extern "C" int hpx_fgmodes_eig(int nb, int T, int N, int nmodes, const double* vis, double* modes,
+                               double* evals, void* stream) {
+  HPX_REQUIRE(nb > 0 && T > 1 && N > 0 && vis && modes && evals, "hpx_fgmodes_eig: bad argument");
+  const int gram = (T <= N) ? 1 : 0;
+  const int nreal = gram ? T : N;
+  HPX_REQUIRE(nreal <= 256, "hpx_fgmodes_eig: min(Ntimes, Nfreqs) must be <= 256");
+  HPX_REQUIRE(nmodes > 0 && nmodes <= nreal && nmodes <= 256, "hpx_fgmodes_eig: bad number of modes");
+  const int n = nreal + (nreal & 1);           // even order for the round-robin pairing
+  hipStream_t st = (hipStream_t)stream;
+  hpx_devbuf xbuf, gbuf;
+  HPX_TRY(xbuf.alloc((size_t)2 * nb * T * N));
+  HPX_TRY(gbuf.alloc((size_t)4 * nb * n * n));
+  double *xr = xbuf.p, *xi = xr + (size_t)nb * T * N;
+  double *gr = gbuf.p, *gi = gr + (size_t)nb * n * n, *vr = gi + (size_t)nb * n * n, *vi = vr + (size_t)nb * n * n;
+  HPX_HIP(hipMemsetAsync(gbuf.p, 0, (size_t)4 * nb * n * n * sizeof(double), st));
+  hipLaunchKernelGGL(k_center, dim3((N + 255) / 256, nb), dim3(256), 0, st, vis, xr, xi, T, N);
+  // an odd order is padded with an isolated zero row / column (never rotated, never selected)
+  hipLaunchKernelGGL(k_gram, dim3((nreal * nreal + 255) / 256, nb), dim3(256), 0, st, xr, xi, gr, gi, T, N, nreal, n,
+                     gram);
+  HPX_HIP(hipGetLastError());
+  hipLaunchKernelGGL(k_jacobi, dim3(nb), dim3(256), (size_t)(n / 2) * 4 * sizeof(double), st, gr, gi, vr, vi, n, 30);
+  hipLaunchKernelGGL(k_modes_out, dim3(nb), dim3(256), (size_t)(n + 2 * N) * sizeof(double), st, gr, vr, vi, xr, xi,
+                     modes, evals, T, N, n, nreal, nmodes, gram);
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  if (e != hipSuccess) { hpx_set_error("hpx_fgmodes_eig: %s", hipGetErrorString(e)); return HPX_EHIP; }
+  return HPX_OK;
+}

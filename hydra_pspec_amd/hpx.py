@@ -46,6 +46,7 @@ SIGNATURES = {
     "hpx_dpss_project": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "hpx_oqe_fisher": (_i, [_i, _i, _vp, _vp, _i, _vp]),
     "hpx_oqe_qh": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp]),
+    "hpx_fgmodes_eig": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "hpx_oqe_qauto": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp]),
     "hpx_mfma_probe": (_i, [_vp, _vp, _vp]),
     "hpx_mfma_f64_peak": (_i, [_i, _vp]),

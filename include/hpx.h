@@ -192,6 +192,15 @@ int hpx_oqe_fisher(int nb, int s, const double* R, double* F_out, int variant,
 int hpx_oqe_qh(int nb, int npair, int s, const double* R, const double* V,
                double* q_out, void* stream);
 
+/* Foreground modes from the data: for each baseline the `nmodes` leading
+ * eigenvectors (unit norm, largest component real positive, eigenvalues descending) of the
+ * frequency-frequency covariance over time np.cov(vis_b.T) -- what
+ * scripts/calc-vis-cov-matrices.py:235-249 writes and run-hydra-pspec.py:453 truncates to
+ * Nfgmodes columns.  vis (nb,T,N) c128; modes (nb,N,nmodes) c128; evals (nb,nmodes) f64.
+ * Needs min(T,N) <= 256 (T <= N goes through the T x T Gram matrix). */
+int hpx_fgmodes_eig(int nb, int T, int N, int nmodes, const double* vis, double* modes,
+                    double* evals, void* stream);
+
 /* Auto-correlation estimator without the noise bias: q[v][tau] = 1/2 x_v^H (R^* Q_tau R) x_v
  * = 1/2 conj(FFT(R^T x_v))[tau] FFT(R x_v)[tau] for every visibility x_v of V (nb,nvis,s) c128;
  * R (nb,s,s) c128, q_out (nb,nvis,s) c128.  Replaces the double loop of oqe.q / oqe.qhat

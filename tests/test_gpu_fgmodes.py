@@ -1,0 +1,70 @@
+"""Foreground modes from the data: the batched Jacobi eigensolver behind
+``fgmodes.cov_eig_modes`` against numpy's eigendecomposition of ``np.cov(bl_data.T)``
+(reference scripts/calc-vis-cov-matrices.py:235-249)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _fg_like(rng, nbl, T, N, nstrong=5):
+    """Smooth-spectrum 'foregrounds' with a steep eigenvalue spectrum plus a little noise."""
+    nu = np.linspace(-1, 1, N)
+    basis = np.stack([np.cos(np.pi * k * nu / 2 + 0.3 * k) * np.exp(0.2j * k * nu) for k in range(nstrong)], axis=1)
+    amps = (rng.standard_normal((nbl, T, nstrong)) + 1j * rng.standard_normal((nbl, T, nstrong))) \
+        * (10.0 ** -np.arange(nstrong))[None, None, :] * 100
+    noise = 1e-6 * (rng.standard_normal((nbl, T, N)) + 1j * rng.standard_normal((nbl, T, N)))
+    return amps @ basis.T + 3.0 + noise                 # + a constant that np.cov removes
+
+
+@pytest.mark.parametrize("nbl,T,N,nm", [(3, 32, 96, 4), (2, 40, 24, 4), (2, 31, 64, 3), (1, 60, 25, 5),
+                                        (2, 203, 120, 4)])
+def test_cov_eig_modes_vs_numpy(nbl, T, N, nm):
+    from hydra_pspec_amd import fgmodes
+    rng = np.random.default_rng(100 * T + N)
+    vis = _fg_like(rng, nbl, T, N)
+    modes, evals = fgmodes.cov_eig_modes(vis, nm, return_evals=True)
+    assert modes.shape == (nbl, N, nm) and evals.shape == (nbl, nm)
+    for b in range(nbl):
+        C = np.cov(vis[b].T)
+        lam, U = np.linalg.eigh(C)
+        lam, U = lam[::-1][:nm], U[:, ::-1][:, :nm]
+        assert np.allclose(evals[b], lam, rtol=1e-9)
+        # eigenvectors agree up to a phase; ours are unit norm with the largest component real > 0
+        assert np.allclose(np.linalg.norm(modes[b], axis=0), 1.0, rtol=1e-12)
+        for m in range(nm):
+            k = np.argmax(np.abs(modes[b][:, m]))
+            assert abs(modes[b][k, m].imag) < 1e-12 and modes[b][k, m].real > 0
+            overlap = abs(np.vdot(U[:, m], modes[b][:, m]))
+            assert overlap > 1 - 1e-9
+        # and they are eigenvectors of the covariance
+        assert np.max(np.abs(C @ modes[b] - modes[b] * evals[b][None, :])) < 1e-9 * lam[0]
+
+
+def test_cov_eig_modes_single_baseline_and_errors():
+    from hydra_pspec_amd import fgmodes
+    rng = np.random.default_rng(5)
+    vis = _fg_like(rng, 2, 16, 48)
+    both = fgmodes.cov_eig_modes(vis, 3)
+    one = fgmodes.cov_eig_modes(vis[1], 3)
+    assert one.shape == (48, 3) and np.array_equal(one, both[1])
+    with pytest.raises(ValueError):
+        fgmodes.cov_eig_modes(vis, 16)                   # rank of the covariance is Ntimes - 1
+    with pytest.raises(NotImplementedError):
+        fgmodes.cov_eig_modes(np.zeros((1, 300, 400), complex), 2)
+
+
+def test_modes_drive_the_sampler():
+    """End to end: modes estimated from a foreground-only cube are a usable `fgmodes` input."""
+    from hydra_pspec_amd import fgmodes, pspec, synthetic
+    d = synthetic.make_baselines(64, 16, 6, k0=3, nbl=2, dense=False)
+    rng = np.random.default_rng(8)
+    fg_only = (rng.standard_normal((2, 16, 6)) + 1j * rng.standard_normal((2, 16, 6))) @ d["fgmodes"].T * 50
+    F = fgmodes.cov_eig_modes(fg_only, 6)                # (nbl, N, 6): per-baseline modes
+    # the estimated modes span the true ones
+    for b in range(2):
+        P = F[b] @ F[b].conj().T
+        assert np.max(np.abs(P @ d["fgmodes"] - d["fgmodes"])) < 1e-8 * np.abs(d["fgmodes"]).max()
+    out = pspec.gibbs_sample_with_fg_batched(d["vis"], d["flags"], F, d["ninv_diag"], d["ps_prior"],
+                                             ps_initial=d["ps0"], Niter=3, seed=2)
+    assert np.isfinite(out["signal_ps"]).all()
