@@ -32,6 +32,21 @@ class H5Error(Exception):
     pass
 
 
+_LOW_LEVEL = (zlib.error, ValueError, OverflowError, IndexError, struct.error, RecursionError, MemoryError,
+              UnicodeDecodeError, TypeError)
+
+
+def _guard(fn):
+    """Malformed files must fail with H5Error, whatever the decoder tripped over."""
+    def wrapped(*a, **k):
+        try:
+            return fn(*a, **k)
+        except _LOW_LEVEL as e:
+            raise H5Error(f"corrupt or unsupported HDF5 structure ({type(e).__name__}: {e})") from e
+    wrapped.__name__, wrapped.__doc__ = fn.__name__, fn.__doc__
+    return wrapped
+
+
 def lzf_decompress(src, out_len):
     """LibLZF decompression (the algorithm behind HDF5 filter 32000)."""
     src = memoryview(src)
@@ -286,6 +301,7 @@ class Group:
                 links[r.cstr(heap_data + name_off)] = ohdr
                 q += 2 * r.so + 4 + 4 + 16
 
+    @_guard
     def keys(self):
         self._load()
         return sorted(self._links)
@@ -297,6 +313,7 @@ class Group:
         except KeyError:
             return False
 
+    @_guard
     def __getitem__(self, path):
         node = self
         for part in [p for p in path.split("/") if p]:
@@ -415,6 +432,7 @@ class Dataset:
             else:
                 yield offs, child, size, mask
 
+    @_guard
     def read(self):
         """The whole dataset as a numpy array (native byte order)."""
         kind = self.layout[0]
@@ -482,7 +500,11 @@ class File(Group):
             self.close()
             raise H5Error(f"{path}: unknown superblock version {ver}")
         self.f = self
-        Group.__init__(self, self, _Object(self, root_ohdr), "/")
+        try:
+            Group.__init__(self, self, _Object(self, root_ohdr), "/")
+        except _LOW_LEVEL as e:
+            self.close()
+            raise H5Error(f"{path}: corrupt root group ({type(e).__name__}: {e})") from e
 
     def close(self):
         try:

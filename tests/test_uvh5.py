@@ -91,3 +91,32 @@ def test_read_block_and_frequency_selection(expected):
     assert np.array_equal(np.nonzero(uvh5.filter_freqs("102", f))[0], [4])
     assert not uvh5.filter_freqs("300-400", f).any()
     assert uvh5.read_uvh5_block(GOLD / "mini.uvh5", 7, 9)[0] == []                   # empty block of a rank
+
+
+def test_h5lite_corrupt_files_fail_cleanly(tmp_path):
+    """Random byte corruption must surface as H5Error / KeyError / NotImplementedError -- never as
+    a decoder's own exception, a hang or a crash."""
+    from hydra_pspec_amd import h5lite
+    src = (GOLD / "mini.uvh5").read_bytes()
+    rng = np.random.default_rng(0)
+    names = ("Data/visdata", "Data/flags", "Header/freq_array", "Extra/gzip_shuffle", "Extra/many/item_003")
+    ok = (h5lite.H5Error, KeyError, NotImplementedError)
+    for trial in range(150):
+        b = bytearray(src)
+        for _ in range(int(rng.integers(1, 6))):
+            b[int(rng.integers(0, len(b)))] = int(rng.integers(0, 256))
+        p = tmp_path / "fuzz.h5"
+        p.write_bytes(b)
+        try:
+            with h5lite.File(p) as f:
+                for name in names:
+                    try:
+                        f[name].read()
+                    except ok:
+                        pass
+        except ok:
+            pass
+    (tmp_path / "trunc.h5").write_bytes(src[:5000])
+    with pytest.raises(ok):
+        with h5lite.File(tmp_path / "trunc.h5") as f:
+            f["Data/visdata"].read()
