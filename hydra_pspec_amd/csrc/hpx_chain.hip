@@ -198,7 +198,8 @@ __global__ void k_fg_planar(const double* __restrict__ fg, double* __restrict__ 
 // the channel's signal is then pinned to ~0, which is what a -> 0 means in the unscaled system.
 #define HPX_PS_FLOOR 1e-280
 __device__ __forceinline__ double inv_a(const double ps, const double dN) {
-  return sqrt(dN / fmax(ps, HPX_PS_FLOOR));
+  // (ps < floor) is false for a NaN, which therefore propagates into the pivots and is reported
+  return sqrt(dN / ((ps < HPX_PS_FLOOR) ? HPX_PS_FLOOR : ps));
 }
 __global__ void k_set_a(const double* __restrict__ ps, double* __restrict__ ia,
                         double* __restrict__ ps_cur, const long tot, const double dN) {

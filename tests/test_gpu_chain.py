@@ -373,3 +373,22 @@ def test_per_baseline_modes_priors_and_thinning():
         full = pspec.gibbs_sample_with_fg_batched(d["vis"], d["flags"], F, d["ninv_diag"], prior,
                                                   **dict(kw, thin=1))
         assert np.array_equal(full["signal_cr"][:, ::3], big["signal_cr"])
+
+
+@pytest.mark.parametrize("solver", ["dense", "flat"])
+def test_non_positive_definite_system_is_reported(solver):
+    """A NaN in the data poisons that baseline's system: the run must say which baseline and
+    iteration failed (FloatingPointError from HPX_ENOTPD) instead of returning garbage silently,
+    and a negative inverse variance must be caught the same way."""
+    from hydra_pspec_amd import pspec, synthetic
+    d = synthetic.make_baselines(64, 8, 6, k0=2, nbl=3, dense=False)
+    ninv = d["ninv_diag"].copy()
+    ninv[1] = -ninv[1]                                    # baseline 1: indefinite system
+    with pytest.raises(FloatingPointError, match="baseline 1"):
+        pspec.gibbs_sample_with_fg_batched(d["vis"], d["flags"], d["fgmodes"], ninv, d["ps_prior"],
+                                           ps_initial=d["ps0"], Niter=2, seed=1, solver=solver)
+    ps0 = np.broadcast_to(d["ps0"], (3, 64)).copy()
+    ps0[2, 10] = np.nan                                    # baseline 2: NaN bandpower
+    with pytest.raises(FloatingPointError, match="baseline 2"):
+        pspec.gibbs_sample_with_fg_batched(d["vis"], d["flags"], d["fgmodes"], d["ninv_diag"], d["ps_prior"],
+                                           ps_initial=ps0, Niter=2, seed=1, solver=solver)
