@@ -124,6 +124,7 @@ def main(argv=None):
     from hydra_pspec_amd.sharding import block_range
 
     # ---- inputs of this rank's block --------------------------------------------------
+    freq_str = None          # known for UVH5 inputs only: names default files / directories as the reference does
     if args.synthetic:
         nbl_all, T, N = (int(v) for v in args.synthetic.split(","))
         lo, hi = block_range(nbl_all, world, rank)
@@ -158,6 +159,8 @@ def main(argv=None):
                 fmask = uvh5.filter_freqs(args.freq_range, u.freqs_hz / 1e6) if args.freq_range else None
                 antpairs = pairs_all[lo:hi]
                 vis, flags_td = u.read_baselines(antpairs, fmask)
+                fkeep = u.freqs_hz if fmask is None else u.freqs_hz[fmask]
+                freq_str = f"{fkeep.min() / 1e6:.3f}-{fkeep.max() / 1e6:.3f}MHz"       # reference :332-335
         T, N = vis.shape[1:]
         default_fg = default_ps0 = default_ninv = None
     nbl = vis.shape[0]
@@ -197,7 +200,9 @@ def main(argv=None):
         else:
             ninv[b] = default_ninv[b] if default_ninv is not None else 1.0 / 10.0 ** 2   # :438
         if args.fgmodes:
-            f_b = load_aux(args.fgmodes, args.fgmodes_file or "fgmodes.npy", bl)[:, :args.Nfgmodes]
+            # default file name of scripts/calc-vis-cov-matrices.py (reference :444-449)
+            default_name = f"evecs-{freq_str}.npy" if freq_str else "fgmodes.npy"
+            f_b = load_aux(args.fgmodes, args.fgmodes_file or default_name, bl)[:, :args.Nfgmodes]
         elif default_fg is not None:
             f_b = default_fg
         else:   # Legendre polynomials (:456-460)
@@ -211,9 +216,21 @@ def main(argv=None):
 
     # ---- output tree ---------------------------------------------------------------------
     out_dir = Path(args.out_dir)
-    dirname = args.dirname or f"results-seed-{args.seed}-Niter-{args.Niter}"
+    if args.dirname:                                       # reference :336-342
+        dirname = args.dirname + ("-map-estimate" if args.map_estimate else "")
+    elif freq_str:
+        dirname = f"results-{freq_str}-Niter-{args.Niter}"
+    else:
+        dirname = f"results-seed-{args.seed}-Niter-{args.Niter}"
     results = out_dir / dirname
     if rank == 0:
+        if results.exists() and not args.clobber and not args.resume and world == 1:
+            # keep earlier results: move them aside under their modification time (reference :343-345,
+            # utils.add_mtime_to_filepath); single-process runs only -- ranks do not synchronise here
+            from datetime import datetime
+            import shutil
+            mtime = datetime.fromtimestamp(os.path.getmtime(results)).isoformat()
+            shutil.move(str(results), str(results.with_name(f"{results.name}-{mtime}")))
         results.mkdir(parents=True, exist_ok=True)
         with open(results / "args.json", "w") as f:
             json.dump(vars(args), f, indent=2)

@@ -136,3 +136,24 @@ def test_driver_config1_from_uvh5(golden, tmp_path):
     assert rc == 0
     ps = np.load(tmp_path / "res" / "0-1" / "dps-eor.npy")
     assert np.max(np.abs(ps / g["ref_ps"][:10] - 1)) < 1e-6
+
+
+@pytest.mark.gpu
+def test_driver_output_naming_and_no_clobber(tmp_path):
+    """Directory naming of the reference driver (:336-345): '<dirname>-map-estimate', the
+    'results-<fmin>-<fmax>MHz-Niter-<n>' default for UVH5 input, and earlier results moved aside
+    under their mtime unless --clobber."""
+    drv = _driver()
+    src = Path(__file__).parent / "golden" / "mini.uvh5"
+    common = ["--file_paths", str(src), "--Nfgmodes", "3", "--Niter", "2", "--seed", "3", "--out_dir", str(tmp_path),
+              "--ant_str", "cross", "--outputs", "ps"]
+    assert drv.main(common) == 0
+    res = tmp_path / "results-100.000-105.500MHz-Niter-2"
+    assert (res / "0-1" / "dps-eor.npy").exists() and (res / "1-2" / "dps-eor.npy").exists()
+    assert drv.main(common) == 0                                   # again: the first tree is kept aside
+    moved = [p for p in tmp_path.iterdir() if p.name.startswith(res.name + "-")]
+    assert len(moved) == 1 and (moved[0] / "0-1" / "dps-eor.npy").exists() and (res / "0-2" / "dps-eor.npy").exists()
+    assert drv.main(common + ["--clobber"]) == 0
+    assert len([p for p in tmp_path.iterdir() if p.name.startswith(res.name)]) == 2
+    assert drv.main(common + ["--dirname", "run", "--map_estimate"]) == 0
+    assert (tmp_path / "run-map-estimate" / "0-1" / "dps-eor.npy").exists()
