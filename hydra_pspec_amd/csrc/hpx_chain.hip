@@ -986,7 +986,8 @@ extern "C" int hpx_assemble_K(hpx_plan* p, const double* ps, double* k_out, void
 
 extern "C" int hpx_plan_set_solver(hpx_plan* p, int mode) {
   HPX_REQUIRE(p && p->have_static, "hpx_plan_set_solver: plan has no static inputs");
-  HPX_REQUIRE(mode == HPX_SOLVER_DENSE || mode == HPX_SOLVER_FLAT, "hpx_plan_set_solver: unknown mode");
+  HPX_REQUIRE(mode == HPX_SOLVER_DENSE || mode == HPX_SOLVER_FLAT || mode == HPX_SOLVER_LOWRANK,
+              "hpx_plan_set_solver: unknown mode");
   if (mode == HPX_SOLVER_FLAT) {
     HPX_REQUIRE(!p->any_flags, "hpx_plan_set_solver: the flat-noise solver needs unflagged data");
     HPX_REQUIRE(p->M <= 16 && p->TP <= 256, "hpx_plan_set_solver: the flat-noise solver needs M <= 16, T <= 256");
@@ -1000,6 +1001,61 @@ extern "C" int hpx_plan_set_solver(hpx_plan* p, int mode) {
                         b, k);
           return HPX_EINVAL;
         }
+  }
+  if (mode == HPX_SOLVER_LOWRANK) {
+    HPX_REQUIRE(p->TP <= 256, "hpx_plan_set_solver: the low-rank solver needs T <= 256");
+    const int nbl = p->nbl, N = p->N;
+    std::vector<double> ni((size_t)nbl * N);
+    std::vector<uint8_t> fl((size_t)nbl * N);
+    HPX_HIP(hipMemcpy(ni.data(), p->ni, ni.size() * sizeof(double), hipMemcpyDeviceToHost));
+    HPX_HIP(hipMemcpy(fl.data(), p->flags, fl.size(), hipMemcpyDeviceToHost));
+    std::vector<int32_t> cnt(nbl, 0);
+    std::vector<double> cv(nbl, 0.0);
+    int fmax = 0;
+    for (int b = 0; b < nbl; ++b) {
+      bool have = false;
+      for (int k = 0; k < N; ++k) {
+        if (!fl[(size_t)b * N + k]) { ++cnt[b]; continue; }
+        const double v = ni[(size_t)b * N + k];
+        if (!have) { cv[b] = v; have = true; }
+        else if (v != cv[b]) {
+          hpx_set_error("hpx_plan_set_solver: inverse noise variance of baseline %d is not flat over its "
+                        "unflagged channels (channel %d)", b, k);
+          return HPX_EINVAL;
+        }
+      }
+      if (!have || !(cv[b] > 0.0)) {
+        hpx_set_error("hpx_plan_set_solver: baseline %d has no usable channel", b);
+        return HPX_EINVAL;
+      }
+      fmax = cnt[b] > fmax ? cnt[b] : fmax;
+    }
+    HPX_REQUIRE(p->M + fmax <= 240, "hpx_plan_set_solver: too many flagged channels for the low-rank solver (M + f <= 240)");
+    if (fmax < 1) fmax = 1;
+    std::vector<int32_t> list((size_t)nbl * fmax, 0);
+    for (int b = 0; b < nbl; ++b) {
+      int j = 0;
+      for (int k = 0; k < N; ++k)
+        if (!fl[(size_t)b * N + k]) list[(size_t)b * fmax + j++] = k;
+    }
+    p->lr_fmax = fmax;
+    p->lr_npad = ceil16(p->M + fmax);
+    const size_t nb = nbl, ns = p->lr_npad, lds_ = ns + p->TP, nblkS = (ns + HPX_NB - 1) / HPX_NB;
+    p->lr_flist = nullptr; p->lr_fcount = nullptr; p->lr_c = nullptr; p->lr_L = nullptr;
+    HPX_TRY(dev_alloc(p, &p->lr_flist, nb * fmax));
+    HPX_TRY(dev_alloc(p, &p->lr_fcount, nb));
+    HPX_TRY(dev_alloc(p, &p->lr_c, nb));
+    HPX_TRY(dev_alloc(p, &p->lr_L, nb * ns * lds_ * 2));
+    HPX_TRY(dev_alloc(p, &p->lr_Wre, nb * nblkS * 1024));
+    HPX_TRY(dev_alloc(p, &p->lr_Wim, nb * nblkS * 1024));
+    HPX_TRY(dev_alloc(p, &p->lr_Yre, nb * ns * p->TP));
+    HPX_TRY(dev_alloc(p, &p->lr_Yim, nb * ns * p->TP));
+    HPX_HIP(hipMemcpy(p->lr_flist, list.data(), list.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    HPX_HIP(hipMemcpy(p->lr_fcount, cnt.data(), cnt.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    HPX_HIP(hipMemcpy(p->lr_c, cv.data(), cv.size() * sizeof(double), hipMemcpyHostToDevice));
+    HPX_HIP(hipMemset(p->lr_L, 0, nb * ns * lds_ * 2 * sizeof(double)));
+    HPX_HIP(hipMemset(p->lr_Yre, 0, nb * ns * p->TP * sizeof(double)));
+    HPX_HIP(hipMemset(p->lr_Yim, 0, nb * ns * p->TP * sizeof(double)));
   }
   p->solver = mode;
   return HPX_OK;
@@ -1157,11 +1213,12 @@ extern "C" int hpx_gibbs_run(hpx_plan* p, const double* ps0, int iter0, int nite
     HPX_TRY(mark(p, st));
     // Only the edge rows (foreground modes, padding, right-hand sides: rows >= rmin) are
     // assembled; the signal x signal part of the matrix is generated inside the factor kernel.
-    if (p->solver == HPX_SOLVER_FLAT) {
-      // flat noise, no flags: diagonal + rank-M border, solved through the Schur complement
-      // (hpx_flat.hip); booked under the "factor" stage
+    if (p->solver == HPX_SOLVER_FLAT || p->solver == HPX_SOLVER_LOWRANK) {
+      // flat noise: diagonal + border system solved through its Schur complement (hpx_flat.hip
+      // without flags, hpx_lowrank.hip with flags); booked under the "factor" stage
       HPX_TRY(mark(p, st));
-      HPX_TRY(hpx_launch_solve_flat(p, iter0 + it + 1, st));
+      if (p->solver == HPX_SOLVER_FLAT) HPX_TRY(hpx_launch_solve_flat(p, iter0 + it + 1, st));
+      else HPX_TRY(hpx_launch_solve_lowrank(p, iter0 + it + 1, st));
       HPX_TRY(mark(p, st));
       HPX_TRY(mark(p, st));
     } else {

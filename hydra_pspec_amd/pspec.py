@@ -198,17 +198,30 @@ class GibbsBatch:
             d_igy = hpx.to_dev(torch, igy, f64, self.device)
             hpx.check(L.hpx_plan_set_rng(self.plan.handle, hpx.ptr(d_uni), hpx.ptr(d_igy),
                                          self.Niter), "hpx_plan_set_rng")
-            # "auto": unflagged baselines with the same noise variance in every channel take the
-            # structured (diagonal + rank-M border) solve, everything else the dense Cholesky
-            assert solver in ("auto", "dense", "flat"), "solver must be 'auto', 'dense' or 'flat'"
-            nv = d_ninv if solver != "dense" else None
-            qualifies = (solver != "dense" and not self.any_flags and M <= 16 and T <= 256
-                         and N <= 4096 and bool((nv == nv[:, :1]).all().item()))
-            if solver == "flat" and not qualifies:
-                raise ValueError("solver='flat' needs unflagged data, flat Ninv, Nmodes <= 16, Ntimes <= 256")
-            self.solver = "flat" if qualifies else "dense"
-            if qualifies:
-                hpx.check(L.hpx_plan_set_solver(self.plan.handle, hpx.SOLVER_FLAT), "hpx_plan_set_solver")
+            # "auto": baselines whose unflagged channels share one noise variance take a structured
+            # solve (diagonal + border system): hpx_flat.hip without flags, hpx_lowrank.hip with
+            # flags (border widened by one column per flagged channel); everything else the dense
+            # Cholesky.  "flat" / "lowrank" insist on the structured solve, "dense" forbids it.
+            assert solver in ("auto", "dense", "flat", "lowrank"), "solver must be auto, dense, flat or lowrank"
+            self.solver = "dense"
+            if solver != "dense":
+                use = d_flags.bool()
+                ref = torch.where(use, d_ninv, torch.nan).nan_to_num(nan=-1.0).max(dim=1, keepdim=True).values
+                flat_unflagged = bool((torch.where(use, d_ninv, ref) == ref).all().item()) and bool((ref > 0).all().item())
+                nflag = int((~use).sum(dim=1).max().item())
+                if flat_unflagged and T <= 256:
+                    if not self.any_flags and M <= 16 and N <= 4096:
+                        self.solver = "flat"
+                    elif self.any_flags and M + nflag <= 240:
+                        self.solver = "lowrank"
+                if solver in ("flat", "lowrank") and self.solver != solver:
+                    raise ValueError(f"solver={solver!r} does not apply: it needs one inverse noise variance over the "
+                                     "unflagged channels of every baseline, Ntimes <= 256 and "
+                                     + ("no flags, Nmodes <= 16" if solver == "flat"
+                                        else "flags with Nmodes + max flagged channels <= 240"))
+            if self.solver != "dense":
+                hpx.check(L.hpx_plan_set_solver(self.plan.handle, hpx.SOLVER_FLAT if self.solver == "flat"
+                                                else hpx.SOLVER_LOWRANK), "hpx_plan_set_solver")
         self.iter_done = 0
 
     def close(self):
@@ -322,9 +335,10 @@ def gibbs_sample_with_fg_batched(vis, flags, fgmodes, Ninv, ps_prior, S_initial=
     ``ps_last`` and the histories named in ``keep`` (``"signal_cr"``,
     ``"fg_amps"``, ``"chisq"``; every ``thin``-th iteration).
 
-    ``solver``: ``"auto"`` (default) solves unflagged baselines with flat ``Ninv`` through the
-    diagonal + rank-Nmodes structure of the system (hpx_flat.hip) and everything else with the
-    batched dense Cholesky; ``"dense"`` forces the latter.  Both are exact solves.
+    ``solver``: ``"auto"`` (default) solves baselines whose unflagged channels share one ``Ninv``
+    value through the diagonal + border structure of the system (hpx_flat.hip without flags,
+    hpx_lowrank.hip with flags) and everything else with the batched dense Cholesky; ``"dense"``
+    forces the latter.  All are exact solves.
 
     ``iter0 > 0`` continues interrupted chains: ``ps_initial`` must then be the bandpowers of
     iteration ``iter0 - 1`` and only iterations ``iter0 .. Niter-1`` are run and returned (the

@@ -126,6 +126,13 @@ int hpx_plan_info(hpx_plan* p, int32_t* info_host);
  * preconditioned CG of gcr_fgmodes_1d (pspec.py:325-374, :228) and agree to rounding. */
 #define HPX_SOLVER_DENSE 0
 #define HPX_SOLVER_FLAT 1
+/* HPX_SOLVER_LOWRANK: flagged baselines whose UNFLAGGED channels share one inverse noise
+ * variance (the reference driver's default noise model, run-hydra-pspec.py:436-438, with data
+ * flags): C = c I - c Vf Vf^H with one column of Vf per flagged channel, so the system is
+ * diagonal plus a border of width M + f and is solved exactly through the (M+f) x (M+f) Schur
+ * complement (hpx_lowrank.hip; the small dense system reuses the batched Cholesky);
+ * -1 unless every baseline qualifies and M + max f <= 240, T <= 256. */
+#define HPX_SOLVER_LOWRANK 2
 int hpx_plan_set_solver(hpx_plan* p, int mode);
 
 /* time (ms) spent in each stage of the last hpx_gibbs_run, measured with HIP
