@@ -91,11 +91,13 @@ def _batched_synth(g, **kw):
         seed=int(g["seed"]), **kw)
 
 
-def test_chain_synth_teacher_forced(golden):
-    """T1 on 3 synthetic baselines x 200 iterations (one flagged), all channels."""
+@pytest.mark.parametrize("solver", ["dense", "auto"])
+def test_chain_synth_teacher_forced(golden, solver):
+    """T1 on 3 synthetic baselines x 200 iterations (one flagged), all channels; "auto" takes the
+    low-rank structured solve for this batch (flat noise, flags), "dense" the batched Cholesky."""
     g = golden("chain_synth")
     ref = np.stack([g[f"b{b}_ref_ps"] for b in range(3)])
-    out = _batched_synth(g, ps_forced=ref, keep=("signal_cr", "fg_amps", "chisq"))
+    out = _batched_synth(g, ps_forced=ref, keep=("signal_cr", "fg_amps", "chisq"), solver=solver)
     dev = np.abs(out["signal_ps"] / ref - 1)
     # One channel of the flagged baseline collapses towards P(k) -> 0 in the reference chain
     # (bandpowers down to 1e-17 against a true level of 0.06-1): an absorbing state in which
@@ -115,11 +117,12 @@ def test_chain_synth_teacher_forced(golden):
         assert relerr(out["chisq"][b][sel], g[f"b{b}_ref_chisq_sel"]) < 2e-3   # reference CG noise
 
 
-def test_chain_synth_free_running(golden):
+@pytest.mark.parametrize("solver", ["dense", "auto"])
+def test_chain_synth_free_running(golden, solver):
     """T2: whole chains; gate median / p99 and the first 50 iterations; report the
     reference-vs-exact-solver control next to it."""
     g = golden("chain_synth")
-    out = _batched_synth(g)
+    out = _batched_synth(g, solver=solver)
     for b in range(3):
         ref, ctl = g[f"b{b}_ref_ps"], g[f"b{b}_exact_ps"]
         dev = np.abs(out["signal_ps"][b] / ref - 1)
@@ -384,9 +387,12 @@ def test_non_positive_definite_system_is_reported(solver):
     d = synthetic.make_baselines(64, 8, 6, k0=2, nbl=3, dense=False)
     ninv = d["ninv_diag"].copy()
     ninv[1] = -ninv[1]                                    # baseline 1: indefinite system
-    with pytest.raises(FloatingPointError, match="baseline 1"):
+    with pytest.raises(FloatingPointError, match="baseline 1"):          # not a flat-noise batch: dense path
         pspec.gibbs_sample_with_fg_batched(d["vis"], d["flags"], d["fgmodes"], ninv, d["ps_prior"],
-                                           ps_initial=d["ps0"], Niter=2, seed=1, solver=solver)
+                                           ps_initial=d["ps0"], Niter=2, seed=1, solver="auto")
+    with pytest.raises(ValueError):                                       # and the structured solve refuses it
+        pspec.gibbs_sample_with_fg_batched(d["vis"], d["flags"], d["fgmodes"], ninv, d["ps_prior"],
+                                           ps_initial=d["ps0"], Niter=2, seed=1, solver="flat")
     ps0 = np.broadcast_to(d["ps0"], (3, 64)).copy()
     ps0[2, 10] = np.nan                                    # baseline 2: NaN bandpower
     with pytest.raises(FloatingPointError, match="baseline 2"):
