@@ -1056,6 +1056,9 @@ extern "C" int hpx_plan_set_solver(hpx_plan* p, int mode) {
     HPX_HIP(hipMemset(p->lr_L, 0, nb * ns * lds_ * 2 * sizeof(double)));
     HPX_HIP(hipMemset(p->lr_Yre, 0, nb * ns * p->TP * sizeof(double)));
     HPX_HIP(hipMemset(p->lr_Yim, 0, nb * ns * p->TP * sizeof(double)));
+    HPX_TRY(dev_alloc(p, &p->lr_Bre, nb * p->NP * ns));
+    HPX_TRY(dev_alloc(p, &p->lr_Bim, nb * p->NP * ns));
+    HPX_TRY(hpx_lowrank_prepare(p, 0));
   }
   p->solver = mode;
   return HPX_OK;

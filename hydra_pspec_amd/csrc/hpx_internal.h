@@ -59,7 +59,7 @@ struct hpx_plan {
   // HPX_SOLVER_LOWRANK: flagged channels per baseline, the small Schur system and its solution
   int lr_fmax, lr_npad;
   int32_t *lr_flist, *lr_fcount;
-  double *lr_c, *lr_L, *lr_Wre, *lr_Wim, *lr_Yre, *lr_Yim;
+  double *lr_c, *lr_L, *lr_Wre, *lr_Wim, *lr_Yre, *lr_Yim, *lr_Bre, *lr_Bim;
   int64_t bytes;
   // factor / solution
   double *L;               // [nbl][ld/16 panels][npad][re16|im16]  (HPX_LIDX)
@@ -227,6 +227,7 @@ int hpx_launch_factor(int nbl, int npad, int ld, double* L, double* Wre, double*
                       int32_t* info, int iter_tag, const hpx_gen_batch* gen, hipStream_t st);
 // structured solve for flat noise with flags (hpx_lowrank.hip): writes X = [z; f]
 int hpx_launch_solve_lowrank(hpx_plan* p, int iter_tag, hipStream_t st);
+int hpx_lowrank_prepare(hpx_plan* p, hipStream_t st);
 // structured solve for flat noise without flags (hpx_flat.hip): writes X = [z; f]
 int hpx_launch_solve_flat(hpx_plan* p, int iter_tag, hipStream_t st);
 size_t hpx_flat_lds_bytes(const hpx_plan* p);
