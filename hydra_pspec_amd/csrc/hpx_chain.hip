@@ -1058,6 +1058,8 @@ extern "C" int hpx_plan_set_solver(hpx_plan* p, int mode) {
     HPX_HIP(hipMemset(p->lr_Yim, 0, nb * ns * p->TP * sizeof(double)));
     HPX_TRY(dev_alloc(p, &p->lr_Bre, nb * p->NP * ns));
     HPX_TRY(dev_alloc(p, &p->lr_Bim, nb * p->NP * ns));
+    HPX_TRY(dev_alloc(p, &p->lr_Tre, nb * p->NP * ns));
+    HPX_TRY(dev_alloc(p, &p->lr_Tim, nb * p->NP * ns));
     HPX_TRY(hpx_lowrank_prepare(p, 0));
   }
   p->solver = mode;

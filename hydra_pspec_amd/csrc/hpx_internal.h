@@ -59,7 +59,7 @@ struct hpx_plan {
   // HPX_SOLVER_LOWRANK: flagged channels per baseline, the small Schur system and its solution
   int lr_fmax, lr_npad;
   int32_t *lr_flist, *lr_fcount;
-  double *lr_c, *lr_L, *lr_Wre, *lr_Wim, *lr_Yre, *lr_Yim, *lr_Bre, *lr_Bim;
+  double *lr_c, *lr_L, *lr_Wre, *lr_Wim, *lr_Yre, *lr_Yim, *lr_Bre, *lr_Bim, *lr_Tre, *lr_Tim;
   int64_t bytes;
   // factor / solution
   double *L;               // [nbl][ld/16 panels][npad][re16|im16]  (HPX_LIDX)

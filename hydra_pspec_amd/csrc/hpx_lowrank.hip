@@ -33,6 +33,7 @@ struct LrArgs {
   const int32_t *flist, *fcount;     // [nbl][fmax] flagged channels, [nbl] their number
   const double* cval;                // [nbl] inverse noise variance of the unflagged channels
   const double *bre, *bim;           // [nbl][NP][npadS] the border [G | sqrt(c) Vf | 0], planar
+  const double *tre, *tim;           // [nbl][npadS][NP] its transpose
   double* Ls;                        // [nbl] small system in the factor layout (npadS, ldS)
   const double *Yre, *Yim;           // [nbl][npadS][TP] its solution
   double *Xre, *Xim;
@@ -58,7 +59,8 @@ __device__ __forceinline__ void border(const LrArgs& A, const double* __restrict
 
 // The border does not change along the chain: it is laid out once, planar, [NP][npadS] per baseline
 // (unit stride along the border index for both MFMA operands of k_lr_schur).
-__global__ void k_lr_border(const LrArgs A, double* __restrict__ bre, double* __restrict__ bim) {
+__global__ void k_lr_border(const LrArgs A, double* __restrict__ bre, double* __restrict__ bim,
+                            double* __restrict__ tre, double* __restrict__ tim) {
   const int b = blockIdx.y, N = A.N, NP = A.NP, npadS = A.npadS;
   const double* rre = A.rre + (long)b * NP * A.ncol;
   const double* rim = A.rim + (long)b * NP * A.ncol;
@@ -71,6 +73,8 @@ __global__ void k_lr_border(const LrArgs A, double* __restrict__ bre, double* __
     if (k < N) border(A, rre, rim, fl, fcnt, sc, k, col, vr, vi);
     bre[(long)b * NP * npadS + e] = vr;
     bim[(long)b * NP * npadS + e] = vi;
+    tre[(long)b * NP * npadS + (long)col * NP + k] = vr;      // transposed copy [npadS][NP] for k_lr_back
+    tim[(long)b * NP * npadS + (long)col * NP + k] = vi;
   }
 }
 
@@ -226,8 +230,8 @@ __global__ __launch_bounds__(256) void k_lr_back(const LrArgs A) {
   const double* rim = A.rim + (long)b * NP * ncol;
   const double c0 = A.cval[b];
   const int fcnt = A.fcount[b];
-  const double* bre = A.bre + (long)b * NP * A.npadS;
-  const double* bim = A.bim + (long)b * NP * A.npadS;
+  const double* tre = A.tre + (long)b * NP * A.npadS;
+  const double* tim = A.tim + (long)b * NP * A.npadS;
   for (int k = tid; k < NP; k += 256) {
     const double v = (k < N) ? ia[k] : 0.0;
     iav[k] = v;
@@ -257,8 +261,8 @@ __global__ __launch_bounds__(256) void k_lr_back(const LrArgs A) {
       }
       for (int ms = 0; ms < nms; ++ms) {
         const int m = 4 * ms + g;
-        const double a_r = -bre[(long)(k0 + li) * A.npadS + m];      // A[k = k0 + li][m] = -Bd[k][m]
-        const double a_i = -bim[(long)(k0 + li) * A.npadS + m];
+        const double a_r = -tre[(long)m * NP + k0 + li];      // A[k = k0 + li][m] = -Bd[k][m] (unit stride in k)
+        const double a_i = -tim[(long)m * NP + k0 + li];
         const double f_r = yre[(long)m * TP + t], f_i = yim[(long)m * TP + t];   // B[m][t] = Y[m][t]
         zr = mfma64(a_r, f_r, zr);
         zr = mfma64(-a_i, f_i, zr);
@@ -289,7 +293,7 @@ static void lr_args(hpx_plan* p, LrArgs& A) {
   A.hre = p->Hre; A.him = p->Him; A.p4re = p->P4re; A.p4im = p->P4im;
   A.fopre = p->Fopre; A.fopim = p->Fopim;
   A.flist = p->lr_flist; A.fcount = p->lr_fcount; A.cval = p->lr_c; A.Ls = p->lr_L;
-  A.bre = p->lr_Bre; A.bim = p->lr_Bim; A.Yre = p->lr_Yre; A.Yim = p->lr_Yim;
+  A.bre = p->lr_Bre; A.bim = p->lr_Bim; A.tre = p->lr_Tre; A.tim = p->lr_Tim; A.Yre = p->lr_Yre; A.Yim = p->lr_Yim;
   A.Xre = p->Xre; A.Xim = p->Xim;
   A.N = p->N; A.M = p->M; A.NP = p->NP; A.TP = p->TP; A.ncol = p->ncolR; A.npad = p->npad;
   A.has_omega = p->has_omega; A.fmax = p->lr_fmax; A.npadS = p->lr_npad; A.ldS = p->lr_npad + p->TP;
@@ -300,7 +304,7 @@ static void lr_args(hpx_plan* p, LrArgs& A) {
 int hpx_lowrank_prepare(hpx_plan* p, hipStream_t st) {
   LrArgs A;
   lr_args(p, A);
-  hipLaunchKernelGGL(k_lr_border, dim3(64, p->nbl), dim3(256), 0, st, A, p->lr_Bre, p->lr_Bim);
+  hipLaunchKernelGGL(k_lr_border, dim3(64, p->nbl), dim3(256), 0, st, A, p->lr_Bre, p->lr_Bim, p->lr_Tre, p->lr_Tim);
   HPX_HIP(hipGetLastError());
   HPX_HIP(hipStreamSynchronize(st));
   return HPX_OK;
