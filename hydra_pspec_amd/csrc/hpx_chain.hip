@@ -782,8 +782,21 @@ __global__ void k_inv_test(const int alpha, const double lgam, const double* __r
   if (threadIdx.x == 0) out[i] = v;
 }
 
+// Plan-owned device buffer.  A pointer that is already set is released first, so that the
+// setters (set_static / set_rng / set_solver) can be called again on the same plan without
+// the plan growing.
 template <typename Tp>
 int dev_alloc(hpx_plan* p, Tp** ptr, size_t count) {
+  if (*ptr) {
+    for (size_t i = 0; i < p->allocs.size(); ++i)
+      if (p->allocs[i].first == (void*)*ptr) {
+        (void)hipFree(*ptr);
+        p->bytes -= (int64_t)p->allocs[i].second;
+        p->allocs.erase(p->allocs.begin() + i);
+        break;
+      }
+    *ptr = nullptr;
+  }
   void* q = nullptr;
   const size_t bytes = count * sizeof(Tp);
   hipError_t e = hipMalloc(&q, bytes ? bytes : 8);
@@ -791,7 +804,7 @@ int dev_alloc(hpx_plan* p, Tp** ptr, size_t count) {
     hpx_set_error("hipMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(e));
     return HPX_EHIP;
   }
-  p->allocs.push_back(q);
+  p->allocs.push_back(std::make_pair(q, bytes));
   p->bytes += (int64_t)bytes;
   *ptr = (Tp*)q;
   return HPX_OK;
@@ -855,7 +868,7 @@ extern "C" int hpx_plan_create(hpx_plan** out, int nbl, int T, int N, int M) {
 
 extern "C" int hpx_plan_destroy(hpx_plan* p) {
   if (!p) return HPX_OK;
-  for (void* q : p->allocs) (void)hipFree(q);
+  for (auto& q : p->allocs) (void)hipFree(q.first);
   for (hipEvent_t ev : p->events) (void)hipEventDestroy(ev);
   delete p;
   return HPX_OK;
@@ -1041,7 +1054,6 @@ extern "C" int hpx_plan_set_solver(hpx_plan* p, int mode) {
     p->lr_fmax = fmax;
     p->lr_npad = ceil16(p->M + fmax);
     const size_t nb = nbl, ns = p->lr_npad, lds_ = ns + p->TP, nblkS = (ns + HPX_NB - 1) / HPX_NB;
-    p->lr_flist = nullptr; p->lr_fcount = nullptr; p->lr_c = nullptr; p->lr_L = nullptr;
     HPX_TRY(dev_alloc(p, &p->lr_flist, nb * fmax));
     HPX_TRY(dev_alloc(p, &p->lr_fcount, nb));
     HPX_TRY(dev_alloc(p, &p->lr_c, nb));
@@ -1172,6 +1184,7 @@ static int post_solve(hpx_plan* p, int it_abs, const IterOut& O, hipStream_t st)
 
 static int finish_run(hpx_plan* p, int niter, double* ps_last, hipStream_t st) {
   const int nbl = p->nbl;
+  p->have_ps = 1;
   if (ps_last)
     HPX_HIP(hipMemcpyAsync(ps_last, p->ps_cur, (size_t)nbl * p->N * sizeof(double),
                            hipMemcpyDeviceToDevice, st));
@@ -1203,6 +1216,7 @@ extern "C" int hpx_gibbs_run(hpx_plan* p, const double* ps0, int iter0, int nite
   HPX_REQUIRE(p && p->have_static, "hpx_gibbs_run: plan has no static inputs");
   HPX_REQUIRE(ps_out && lnpost_out && niter > 0 && iter0 >= 0, "hpx_gibbs_run: bad argument");
   HPX_REQUIRE(p->uni && iter0 + niter <= p->niter_tab, "hpx_gibbs_run: random tables too short");
+  HPX_REQUIRE(ps0 || p->have_ps, "hpx_gibbs_run: no starting bandpowers (ps0 is NULL on a plan that has not run yet)");
   if (thin < 1) thin = 1;
   hipStream_t st = (hipStream_t)stream;
   const int nbl = p->nbl, N = p->N, M = p->M, T = p->T, TP = p->TP;

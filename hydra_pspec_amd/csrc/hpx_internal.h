@@ -55,6 +55,7 @@ struct hpx_plan {
   int nblk;     // number of block columns
   int ngrid, nxrows, niter_tab;
   int fg_shared, prior_shared, has_omega, any_flags, have_static, profiling;
+  int have_ps;  // the chain state (ps_cur, ia) holds bandpowers: a run may continue without ps0
   int solver;   // HPX_SOLVER_DENSE / HPX_SOLVER_FLAT / HPX_SOLVER_LOWRANK (hpx_plan_set_solver)
   // HPX_SOLVER_LOWRANK: flagged channels per baseline, the small Schur system and its solution
   int lr_fmax, lr_npad;
@@ -95,7 +96,7 @@ struct hpx_plan {
   int ev_used;
   float stage_ms[HPX_NSTAGE];
   double lgam_T;           // lgamma(T)
-  std::vector<void*> allocs;
+  std::vector<std::pair<void*, size_t>> allocs;   // (device pointer, bytes)
 };
 
 // ---- augmented-system generator ------------------------------------------------

@@ -89,7 +89,9 @@ int hpx_plan_set_rng(hpx_plan* p, const double* uniforms, const double* igy, int
 /* Run `niter` Gibbs iterations for all baselines, starting at table row
  * `iter0` (pspec.py:606-623; one iteration = pspec.py:377-490).
  *   ps0       (nbl,N)       bandpowers defining the initial covariance
- *                           S = F^H diag(ps0/N^2) F
+ *                           S = F^H diag(ps0/N^2) F; NULL continues from the
+ *                           state the plan's previous run left (-1 if there
+ *                           is none)
  *   ps_forced (nbl,niter,N) optional (NULL): teacher forcing -- iteration i+1
  *                           uses ps_forced[:,i] instead of its own draw
  *   ps_out    (nbl,niter,N) f64   always

@@ -423,3 +423,33 @@ def test_lowrank_solver_matches_dense(shape, frac):
     assert np.max(np.abs(b["signal_cr"] - a["signal_cr"])) < 1e-6 * np.max(np.abs(a["signal_cr"]))
     assert np.max(np.abs(b["fg_amps"] - a["fg_amps"])) < 1e-8 * np.max(np.abs(a["fg_amps"]))
     assert np.allclose(b["ln_post"], a["ln_post"], rtol=1e-6)
+
+
+def test_plan_setters_replace_their_buffers():
+    """Calling hpx_plan_set_solver / hpx_plan_set_rng again on a plan replaces the buffers they own:
+    the plan does not grow, and the chain that follows is unchanged."""
+    import torch
+    from hydra_pspec_amd import hpx, pspec, synthetic
+    d = synthetic.make_baselines(64, 8, 6, k0=2, nbl=3, flag_frac=0.1, dense=False)
+    gb = pspec.GibbsBatch(d["vis"], d["flags"], d["fgmodes"], d["ninv_diag"], d["ps_prior"], 3, seed=4,
+                          solver="lowrank")
+    ps0 = np.broadcast_to(d["ps0"], (3, 64)).copy()
+    first = gb.run(3, ps0=ps0)["signal_ps"].clone()
+    size = gb.plan.bytes()
+    L = hpx.lib()
+    for _ in range(3):
+        hpx.check(L.hpx_plan_set_solver(gb.plan.handle, hpx.SOLVER_LOWRANK))
+        u = torch.rand(3, 64, dtype=torch.float64, device="cuda")
+        hpx.check(L.hpx_plan_set_rng(gb.plan.handle, hpx.ptr(u), hpx.ptr(u), 3))
+    assert gb.plan.bytes() == size
+    gb.close()
+    again = pspec.GibbsBatch(d["vis"], d["flags"], d["fgmodes"], d["ninv_diag"], d["ps_prior"], 3, seed=4,
+                             solver="lowrank")
+    # a plan that has never run has no state to continue from: the C entry point says so
+    o_ps = torch.empty((3, 1, 64), dtype=torch.float64, device="cuda")
+    o_ln = torch.empty((3, 1), dtype=torch.float64, device="cuda")
+    rc = L.hpx_gibbs_run(again.plan.handle, None, 0, 1, None, hpx.ptr(o_ps), hpx.ptr(o_ln), None, None, None, 1,
+                         None, hpx.stream_ptr(torch))
+    assert rc == hpx.HPX_EINVAL and "ps0" in hpx.last_error()
+    assert torch.equal(again.run(3, ps0=ps0)["signal_ps"], first)
+    again.close()
