@@ -615,16 +615,23 @@ __global__ __launch_bounds__(256) void k_fft_resid(const ResArgs A) {
   if (tid == 0) A.lnpart[(long)b * HPX_NPART + blockIdx.x] = total;
 }
 
-// betam_k = sum_t |SK[k][t]|^2 (SK = F (w s), in the Z scratch with leading dim ncol)
-__global__ void k_betam(const double* __restrict__ Kre, const double* __restrict__ Kim,
-                        double* __restrict__ betam, const int N, const int T, const int NP,
-                        const int ncol) {
-  const int b = blockIdx.y;
-  for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < N; k += gridDim.x * blockDim.x) {
+// betam_k = sum_t |SK[k][t]|^2 (SK = F (w s), in the Z scratch with leading dim ncol).
+// Sixteen lanes share a row (consecutive t: one 128-byte segment per load) and reduce by shuffles;
+// a thread per row would touch 64 different cache lines with every load.
+__global__ __launch_bounds__(256) void k_betam(const double* __restrict__ Kre, const double* __restrict__ Kim,
+                                               double* __restrict__ betam, const int N, const int T,
+                                               const int NP, const int ncol) {
+  const int b = blockIdx.y, c = threadIdx.x & 15, r = threadIdx.x >> 4;
+  for (int k0 = blockIdx.x * 16; k0 < N; k0 += gridDim.x * 16) {
+    const int k = k0 + r;
     double s = 0.0;
-    const long o = ((long)b * NP + k) * ncol;
-    for (int t = 0; t < T; ++t) s += Kre[o + t] * Kre[o + t] + Kim[o + t] * Kim[o + t];
-    betam[(long)b * N + k] = s;
+    if (k < N) {
+      const long o = ((long)b * NP + k) * ncol;
+      for (int t = c; t < T; t += 16) s += Kre[o + t] * Kre[o + t] + Kim[o + t] * Kim[o + t];
+    }
+#pragma unroll
+    for (int m = 8; m >= 1; m >>= 1) s += __shfl_xor(s, m, 16);
+    if (c == 0 && k < N) betam[(long)b * N + k] = s;
   }
 }
 
@@ -1068,8 +1075,9 @@ extern "C" int hpx_plan_set_solver(hpx_plan* p, int mode) {
     HPX_HIP(hipMemset(p->lr_L, 0, nb * ns * lds_ * 2 * sizeof(double)));
     HPX_HIP(hipMemset(p->lr_Yre, 0, nb * ns * p->TP * sizeof(double)));
     HPX_HIP(hipMemset(p->lr_Yim, 0, nb * ns * p->TP * sizeof(double)));
-    HPX_TRY(dev_alloc(p, &p->lr_Bre, nb * p->NP * ns));
-    HPX_TRY(dev_alloc(p, &p->lr_Bim, nb * p->NP * ns));
+    HPX_REQUIRE(hpx_lowrank_lds_bytes(p) <= 160 * 1024, "hpx_plan_set_solver: Ntimes / flag count too large for the low-rank solver");
+    HPX_TRY(dev_alloc(p, &p->lr_Bre, nb * p->NP * (ns + p->TP)));     // [Bd | r1]
+    HPX_TRY(dev_alloc(p, &p->lr_Bim, nb * p->NP * (ns + p->TP)));
     HPX_TRY(dev_alloc(p, &p->lr_Tre, nb * p->NP * ns));
     HPX_TRY(dev_alloc(p, &p->lr_Tim, nb * p->NP * ns));
     HPX_TRY(hpx_lowrank_prepare(p, 0));
@@ -1158,7 +1166,7 @@ static int post_solve(hpx_plan* p, int it_abs, const IterOut& O, hipStream_t st)
     HPX_TRY(hpx_launch_dft(nbl, NP, TP, p->Fopre, p->Fopim, 0, p->Gre, p->Gim, (long)NP * TP, TP,
                            nullptr, 0, p->Zre, p->Zim, (long)NP * p->ncolR, p->ncolR, 1.0, st,
                            N == NP));
-    hipLaunchKernelGGL(k_betam, dim3(4, nbl), dim3(256), 0, st, p->Zre, p->Zim, p->betam, N, T, NP,
+    hipLaunchKernelGGL(k_betam, dim3(16, nbl), dim3(256), 0, st, p->Zre, p->Zim, p->betam, N, T, NP,
                        p->ncolR);
     HPX_HIP(hipGetLastError());
   }

@@ -20,10 +20,17 @@
 // driver's default noise model (Ninv = I / 100 when no noise covariance is given,
 // run-hydra-pspec.py:436-438) together with data flags is exactly this case.
 //
-// k_lr_schur forms S and Rf on the f64 MFMA (one workgroup per baseline, tiles over waves) and
-// writes them in the factor layout; the small dense system goes through the batched Cholesky /
-// back substitution of hpx_factor.hip; k_lr_back forms z.  X = [z; f] comes out in the layout
-// k_backsolve produces, everything downstream is shared with the other solvers.
+// k_lr_schur forms S and Rf on the f64 MFMA and writes them in the factor layout; the small dense
+// system goes through the batched Cholesky / back substitution of hpx_factor.hip; k_lr_back forms
+// z.  X = [z; f] comes out in the layout k_backsolve produces, everything downstream is shared
+// with the other solvers.
+//
+// k_lr_schur streams the operand matrix Xc = [Bd | r1] (N x (npadS + TP), the border laid out once
+// per plan, the r1 columns refreshed every iteration by k_lr_r1) through LDS in chunks of 8
+// channels with global_load_lds (no VGPR staging, two buffers), and every wave keeps up to 11
+// output tiles in accumulators: a baseline's ~90 tiles are spread over the waves of 1-3
+// workgroups, so the 3 MB operand is read once per workgroup and iteration instead of once per
+// tile block (nine times at the C5 shape, which made the register-blocked version HBM-bound).
 #include "hpx_internal.h"
 
 namespace {
@@ -32,12 +39,12 @@ struct LrArgs {
   const double *ia, *cre, *rre, *rim, *p2re, *p2im, *hre, *him, *p4re, *p4im, *fopre, *fopim;
   const int32_t *flist, *fcount;     // [nbl][fmax] flagged channels, [nbl] their number
   const double* cval;                // [nbl] inverse noise variance of the unflagged channels
-  const double *bre, *bim;           // [nbl][NP][npadS] the border [G | sqrt(c) Vf | 0], planar
+  const double *bre, *bim;           // [nbl][NP][npadX] Xc = [G | sqrt(c) Vf | 0 | r1], planar, npadX = npadS + TP
   const double *tre, *tim;           // [nbl][npadS][NP] its transpose
   double* Ls;                        // [nbl] small system in the factor layout (npadS, ldS)
   const double *Yre, *Yim;           // [nbl][npadS][TP] its solution
   double *Xre, *Xim;
-  int N, M, NP, TP, ncol, npad, has_omega, fmax, npadS, ldS;
+  int N, M, NP, TP, ncol, npad, has_omega, fmax, npadS, ldS, npadX, nbl;
   double isn;
 };
 
@@ -57,11 +64,11 @@ __device__ __forceinline__ void border(const LrArgs& A, const double* __restrict
   }
 }
 
-// The border does not change along the chain: it is laid out once, planar, [NP][npadS] per baseline
-// (unit stride along the border index for both MFMA operands of k_lr_schur).
+// The border does not change along the chain: it is laid out once, planar, [NP][npadX] per baseline
+// (columns npadS.. are the r1 block k_lr_r1 rewrites every iteration), plus a transposed copy.
 __global__ void k_lr_border(const LrArgs A, double* __restrict__ bre, double* __restrict__ bim,
                             double* __restrict__ tre, double* __restrict__ tim) {
-  const int b = blockIdx.y, N = A.N, NP = A.NP, npadS = A.npadS;
+  const int b = blockIdx.y, N = A.N, NP = A.NP, npadS = A.npadS, npadX = A.npadX;
   const double* rre = A.rre + (long)b * NP * A.ncol;
   const double* rim = A.rim + (long)b * NP * A.ncol;
   const int* fl = A.flist + (long)b * A.fmax;
@@ -71,170 +78,188 @@ __global__ void k_lr_border(const LrArgs A, double* __restrict__ bre, double* __
     const int k = (int)(e / npadS), col = (int)(e % npadS);
     double vr = 0.0, vi = 0.0;
     if (k < N) border(A, rre, rim, fl, fcnt, sc, k, col, vr, vi);
-    bre[(long)b * NP * npadS + e] = vr;
-    bim[(long)b * NP * npadS + e] = vi;
+    bre[(long)b * NP * npadX + (long)k * npadX + col] = vr;
+    bim[(long)b * NP * npadX + (long)k * npadX + col] = vi;
     tre[(long)b * NP * npadS + (long)col * NP + k] = vr;      // transposed copy [npadS][NP] for k_lr_back
     tim[(long)b * NP * npadS + (long)col * NP + k] = vi;
   }
 }
 
-constexpr int LR_RT = 2, LR_CT = 3;    // row / column tiles per work item of k_lr_schur
-
-// S = E - Bd^H Dinv Bd (lower tiles) and Rf = [P4; 0] - Bd^H Dinv r1, written in the factor
-// layout.  A work item is a 2 x 3 block of 16 x 16 output tiles accumulated over all channels
-// by one wave (5 operand tiles per k-step for 24 MFMAs), operands of the next k-step in flight
-// while the current one is multiplied.
-__global__ __launch_bounds__(256, 2) void k_lr_schur(const LrArgs A) {
-  extern __shared__ double lds[];
-  const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const int li = lane & 15, g = lane >> 4;
-  const int N = A.N, M = A.M, NP = A.NP, TP = A.TP, ncol = A.ncol, TT = TP >> 4;
-  const int npadS = A.npadS, mt = npadS >> 4;
-  double* dinv = lds;
-  double* iav = dinv + NP;
+// r1 = Q + diag(1/a) P2 into columns npadS.. of Xc (rows >= N stay zero)
+__global__ void k_lr_r1(const LrArgs A, double* __restrict__ bre, double* __restrict__ bim) {
+  const int b = blockIdx.y, N = A.N, NP = A.NP, TP = A.TP, npadX = A.npadX;
+  const double* rre = A.rre + (long)b * NP * A.ncol;
+  const double* rim = A.rim + (long)b * NP * A.ncol;
   const double* ia = A.ia + (long)b * N;
-  const double* rre = A.rre + (long)b * NP * ncol;
-  const double* rim = A.rim + (long)b * NP * ncol;
-  const double* bre = A.bre + (long)b * NP * npadS;
-  const double* bim = A.bim + (long)b * NP * npadS;
-  const double c0 = A.cval[b];
-  for (int k = tid; k < NP; k += 256) {
-    const double v = (k < N) ? ia[k] : 0.0;
-    iav[k] = v;
-    dinv[k] = (k < N) ? 1.0 / fma(v, v, c0) : 0.0;
+  double* ore = bre + (long)b * NP * npadX + A.npadS;
+  double* oim = bim + (long)b * NP * npadX + A.npadS;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < (long)NP * TP; e += (long)gridDim.x * blockDim.x) {
+    const int k = (int)(e / TP), t = (int)(e % TP);
+    double vr = 0.0, vi = 0.0;
+    if (k < N) {
+      vr = rre[(long)k * A.ncol + t];
+      vi = rim[(long)k * A.ncol + t];
+      if (A.has_omega) {
+        const double a = ia[k];
+        vr = fma(a, A.p2re[(long)k * TP + t], vr);
+        vi = fma(a, A.p2im[(long)k * TP + t], vi);
+      }
+    }
+    ore[(long)k * npadX + t] = vr;
+    oim[(long)k * npadX + t] = vi;
+  }
+}
+
+constexpr int LR_KC = 8;               // channels per staged chunk (two MFMA k-steps)
+
+static __device__ __forceinline__ void lr_glds16(const double* src, double* dst) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                   (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+}
+
+// S = E - Bd^H Dinv Bd (lower tiles) and Rf = [P4; 0] - Bd^H Dinv r1, written in the factor layout.
+// Output tiles in row-major order (row ri: S tiles 0..ri, then the TT tiles of Rf) are dealt out
+// evenly to the 4 nwg waves of a baseline's workgroups, at most TPW each.  Per chunk: wait for
+// the own global_load_lds of this chunk, barrier (everybody's pieces have landed, everybody is
+// done with the other buffer), issue the next chunk into the other buffer, multiply.  A tile is
+// acc[m][c] += sum_k conj(Xc[k][m]) dinv_k Xc[k][c]: both operands come from the staged rows.
+template <int TPW>
+__global__ __launch_bounds__(256, 2) void k_lr_schur(const LrArgs A, const int nwg) {
+  extern __shared__ double lds[];
+  // the workgroups of a baseline share an XCD (and its L2)
+  const int id = blockIdx.x, xcd = id & 7, slot = id >> 3;
+  const int b = (slot / nwg) * 8 + xcd, wg = slot % nwg;
+  if (b >= A.nbl) return;
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int li = lane & 15, g = lane >> 4;
+  const int N = A.N, M = A.M, NP = A.NP, TP = A.TP, TT = TP >> 4;
+  const int npadS = A.npadS, npadX = A.npadX, mt = npadS >> 4;
+  double* dinv = lds;
+  double* stage = lds + NP;
+  const int bufd = 2 * LR_KC * npadX;                 // doubles per buffer: [re | im][8][npadX]
+  {
+    const double* ia = A.ia + (long)b * N;
+    const double c0 = A.cval[b];
+    for (int k = tid; k < NP; k += 256) {
+      const double v = (k < N) ? ia[k] : 0.0;
+      dinv[k] = (k < N) ? 1.0 / fma(v, v, c0) : 0.0;
+    }
   }
   __syncthreads();
-  double* L = A.Ls + (long)b * npadS * A.ldS * 2;
-  const int nks = NP >> 2;                             // NP is a multiple of 16: nks is a multiple of 4
-  int item = 0;
-  for (int r0 = 0; r0 < mt; r0 += LR_RT) {
-    const int nrt = min(LR_RT, mt - r0);
-    const int rlast = r0 + nrt - 1;
-    const int ncc = rlast + 1 + TT;                   // S tiles 0..rlast, then the Rf tiles
-    for (int cb = 0; cb < ncc; cb += LR_CT, ++item) {
-      if ((item & 3) != wave) continue;
-      const int nct = min(LR_CT, ncc - cb);
-      d4 ar[LR_RT][LR_CT], ai[LR_RT][LR_CT];
+  // this wave's tiles
+  const int ntile = mt * (mt + 1) / 2 + mt * TT, nwv = 4 * nwg, q = wg * 4 + wave;
+  const int base = ntile / nwv, extra = ntile % nwv;
+  const int cnt = base + (q < extra ? 1 : 0), j0 = q * base + min(q, extra);
+  int tri[TPW], tcx[TPW];
+  {
+    int ri = 0, start = 0;
+    while (ri < mt - 1 && j0 >= start + ri + 1 + TT) { start += ri + 1 + TT; ++ri; }
+    int pos = j0 - start;
 #pragma unroll
-      for (int t = 0; t < LR_RT; ++t)
+    for (int j = 0; j < TPW; ++j) {
+      const bool live = j < cnt;
+      tri[j] = live ? ri : 0;
+      tcx[j] = live ? (pos <= ri ? pos : mt + (pos - ri - 1)) : 0;
+      if (live && ++pos == ri + 1 + TT) { pos = 0; ++ri; }
+    }
+  }
+  d4 ar[TPW], ai[TPW];
 #pragma unroll
-        for (int q = 0; q < LR_CT; ++q) {
-          ar[t][q] = (d4){0., 0., 0., 0.};
-          ai[t][q] = (d4){0., 0., 0., 0.};
-        }
-      double a0r[LR_RT], a0i[LR_RT], a1r[LR_RT], a1i[LR_RT];
-      double b0r[LR_CT], b0i[LR_CT], b1r[LR_CT], b1i[LR_CT], d0, d1;
-#define HPX_LR_LOAD(ar_, ai_, br_, bi_, dk_, ks_)                                              \
-  {                                                                                            \
-    const int k_ = 4 * (ks_) + g;                        /* rows >= N of the border are zero */ \
-    const long ro_ = (long)k_ * npadS;                                                         \
-    dk_ = dinv[k_];                                                                            \
-    _Pragma("unroll") for (int t = 0; t < LR_RT; ++t) {                                        \
-      const int rt_ = min(r0 + t, mt - 1);                                                     \
-      ar_[t] = bre[ro_ + 16 * rt_ + li];                                                       \
-      ai_[t] = bim[ro_ + 16 * rt_ + li];                                                       \
-    }                                                                                          \
-    _Pragma("unroll") for (int q = 0; q < LR_CT; ++q) {                                        \
-      const int cc_ = min(cb + q, ncc - 1);                                                    \
-      if (cc_ <= rlast) {                                                                      \
-        br_[q] = bre[ro_ + 16 * cc_ + li];                                                     \
-        bi_[q] = bim[ro_ + 16 * cc_ + li];                                                     \
-      } else {                                                                                 \
-        const int kc_ = min(k_, N - 1);                                                        \
-        const int t_ = ((cc_ - rlast - 1) << 4) + li;                                          \
-        double x_ = rre[(long)kc_ * ncol + t_], y_ = rim[(long)kc_ * ncol + t_];               \
-        if (A.has_omega) {                                                                     \
-          x_ = fma(iav[k_], A.p2re[(long)kc_ * TP + t_], x_);                                  \
-          y_ = fma(iav[k_], A.p2im[(long)kc_ * TP + t_], y_);                                  \
-        }                                                                                      \
-        br_[q] = x_;                                                                           \
-        bi_[q] = y_;                                                                           \
-      }                                                                                        \
-    }                                                                                          \
+  for (int j = 0; j < TPW; ++j) {
+    ar[j] = (d4){0., 0., 0., 0.};
+    ai[j] = (d4){0., 0., 0., 0.};
   }
-#define HPX_LR_MMA(ar_, ai_, br_, bi_, dk_)                                                    \
-  _Pragma("unroll") for (int q = 0; q < LR_CT; ++q) {                                          \
-    const double x_ = dk_ * br_[q], y_ = dk_ * bi_[q];       /* B = Dinv_k (border | r1) */     \
-    _Pragma("unroll") for (int t = 0; t < LR_RT; ++t) {      /* A = conj(border) */             \
-      ar[t][q] = mfma64(ar_[t], x_, ar[t][q]);                                                 \
-      ar[t][q] = mfma64(ai_[t], y_, ar[t][q]);                                                 \
-      ai[t][q] = mfma64(ar_[t], y_, ai[t][q]);                                                 \
-      ai[t][q] = mfma64(-ai_[t], x_, ai[t][q]);                                                \
-    }                                                                                          \
+  const double* bre = A.bre + (long)b * NP * npadX;
+  const double* bim = A.bim + (long)b * NP * npadX;
+  const int np = npadX >> 4;                          // 1 KB pieces per plane and chunk
+#define HPX_LR_STAGE(chunk, bufi)                                                       \
+  for (int p_ = wave; p_ < 2 * np; p_ += 4) {                                            \
+    const int pl_ = p_ >= np ? 1 : 0, ix_ = p_ - pl_ * np;                               \
+    lr_glds16((pl_ ? bim : bre) + (long)(chunk) * LR_KC * npadX + ix_ * 128 + 2 * lane,  \
+              stage + (bufi) * bufd + pl_ * LR_KC * npadX + ix_ * 128);                  \
   }
-      HPX_LR_LOAD(a0r, a0i, b0r, b0i, d0, 0)
-      for (int ks = 0; ks < nks; ks += 2) {
-        HPX_LR_LOAD(a1r, a1i, b1r, b1i, d1, ks + 1)
-        __builtin_amdgcn_sched_barrier(0);
-        HPX_LR_MMA(a0r, a0i, b0r, b0i, d0)
-        __builtin_amdgcn_sched_barrier(0);
-        HPX_LR_LOAD(a0r, a0i, b0r, b0i, d0, min(ks + 2, nks - 1))
-        __builtin_amdgcn_sched_barrier(0);
-        HPX_LR_MMA(a1r, a1i, b1r, b1i, d1)
-        __builtin_amdgcn_sched_barrier(0);
+  const int nch = NP / LR_KC;
+  const int lanepart = g * npadX + li;
+  typedef __attribute__((address_space(3))) double lds_f64;
+  HPX_LR_STAGE(0, 0)
+  for (int ch = 0; ch < nch; ++ch) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (ch + 1 < nch) { HPX_LR_STAGE(ch + 1, (ch + 1) & 1) }
+    const lds_f64* Bc = (const lds_f64*)(stage + (ch & 1) * bufd + lanepart);
+    const lds_f64* dv = (const lds_f64*)(dinv + ch * LR_KC + g);
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const double dk = dv[4 * s];
+      const lds_f64* Bs = Bc + s * 4 * npadX;
+#pragma unroll
+      for (int j = 0; j < TPW; ++j) {
+        const double a_r = Bs[16 * tri[j]], a_i = Bs[LR_KC * npadX + 16 * tri[j]];
+        const double b_r = Bs[16 * tcx[j]], b_i = Bs[LR_KC * npadX + 16 * tcx[j]];
+        const double x_r = dk * a_r, x_i = dk * a_i;
+        ar[j] = mfma64(x_r, b_r, ar[j]);
+        ar[j] = mfma64(x_i, b_i, ar[j]);
+        ai[j] = mfma64(x_r, b_i, ai[j]);
+        ai[j] = mfma64(-x_i, b_r, ai[j]);
       }
-#undef HPX_LR_LOAD
-#undef HPX_LR_MMA
-      // lane (li, g), register v holds row m = 16 (r0 + t) + g + 4v, column 16 cc + li
+    }
+  }
+#undef HPX_LR_STAGE
+  // lane (li, g), register v holds row m = 16 ri + g + 4v of the output, column 16 cx + li
+  double* L = A.Ls + (long)b * npadS * A.ldS * 2;
 #pragma unroll
-      for (int t = 0; t < LR_RT; ++t) {
-        if (t >= nrt) break;
-        const int ri = r0 + t;
+  for (int j = 0; j < TPW; ++j) {
+    const int ri = tri[j], cx = tcx[j];
 #pragma unroll
-        for (int q = 0; q < LR_CT; ++q) {
-          if (q >= nct) break;
-          const int cc = cb + q;
-          if (cc <= rlast && cc > ri) continue;        // above the diagonal: not needed
-#pragma unroll
-          for (int v = 0; v < 4; ++v) {
-            const int m = 16 * ri + HPX_ACC_ROW(g, v);
-            if (cc <= rlast) {                         // S = E - acc
-              const int mc = 16 * cc + li;
-              double e_r = 0.0, e_i = 0.0;
-              if (m < M && mc < M) {
-                e_r = A.hre[(long)b * M * M + m * M + mc];
-                e_i = A.him[(long)b * M * M + m * M + mc];
-              } else if (m == mc) {
-                e_r = 1.0;
-              }
-              const long o = HPX_LIDX(m, mc, npadS);
-              L[o] = e_r - ar[t][q][v];
-              L[o + 16] = e_i - ai[t][q][v];
-            } else {                                   // row npadS + t' of the factor buffer = conj(Rf[m][t'])
-              const int tc = ((cc - rlast - 1) << 4) + li;
-              double e_r = 0.0, e_i = 0.0;
-              if (m < M) {
-                e_r = A.p4re[(long)b * M * TP + m * TP + tc];
-                e_i = A.p4im[(long)b * M * TP + m * TP + tc];
-              }
-              const long o = HPX_LIDX(npadS + tc, m, npadS);
-              L[o] = e_r - ar[t][q][v];
-              L[o + 16] = -(e_i - ai[t][q][v]);
-            }
-          }
+    for (int v = 0; v < 4; ++v) {
+      if (j >= cnt) continue;                      // (no break: the loop must unroll, acc stays in registers)
+      const int m = 16 * ri + HPX_ACC_ROW(g, v);
+      if (cx < mt) {                               // S = E - acc
+        const int mc = 16 * cx + li;
+        double e_r = 0.0, e_i = 0.0;
+        if (m < M && mc < M) {
+          e_r = A.hre[(long)b * M * M + m * M + mc];
+          e_i = A.him[(long)b * M * M + m * M + mc];
+        } else if (m == mc) {
+          e_r = 1.0;
         }
+        const long o = HPX_LIDX(m, mc, npadS);
+        L[o] = e_r - ar[j][v];
+        L[o + 16] = e_i - ai[j][v];
+      } else {                                     // row npadS + t of the factor buffer = conj(Rf[m][t])
+        const int tc = ((cx - mt) << 4) + li;
+        double e_r = 0.0, e_i = 0.0;
+        if (m < M) {
+          e_r = A.p4re[(long)b * M * TP + m * TP + tc];
+          e_i = A.p4im[(long)b * M * TP + m * TP + tc];
+        }
+        const long o = HPX_LIDX(npadS + tc, m, npadS);
+        L[o] = e_r - ar[j][v];
+        L[o + 16] = -(e_i - ai[j][v]);
       }
     }
   }
 }
 
+// z = Dinv (r1 - Bd [f; y]) for 16 channels x TTG t-tiles at a time per wave: the border tile is
+// fetched once for all the t-tiles of a group, operands of the next k-step are in flight while
+// the current one is multiplied; r1 comes from the columns k_lr_r1 wrote.
+template <int TTG>
 __global__ __launch_bounds__(256) void k_lr_back(const LrArgs A) {
   extern __shared__ double lds[];
   const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int li = lane & 15, g = lane >> 4;
-  const int N = A.N, M = A.M, NP = A.NP, TP = A.TP, ncol = A.ncol, TT = TP >> 4;
+  const int N = A.N, M = A.M, NP = A.NP, TP = A.TP, TT = TP >> 4, npadX = A.npadX;
   double* dinv = lds;
-  double* iav = dinv + NP;
   const double* ia = A.ia + (long)b * N;
-  const double* rre = A.rre + (long)b * NP * ncol;
-  const double* rim = A.rim + (long)b * NP * ncol;
   const double c0 = A.cval[b];
   const int fcnt = A.fcount[b];
   const double* tre = A.tre + (long)b * NP * A.npadS;
   const double* tim = A.tim + (long)b * NP * A.npadS;
+  const double* xre = A.bre + (long)b * NP * npadX + A.npadS;     // r1[k][t] at xre[k * npadX + t]
+  const double* xim = A.bim + (long)b * NP * npadX + A.npadS;
   for (int k = tid; k < NP; k += 256) {
     const double v = (k < N) ? ia[k] : 0.0;
-    iav[k] = v;
     dinv[k] = (k < N) ? 1.0 / fma(v, v, c0) : 0.0;
   }
   __syncthreads();
@@ -242,39 +267,67 @@ __global__ __launch_bounds__(256) void k_lr_back(const LrArgs A) {
   const double* yim = A.Yim + (long)b * A.npadS * TP;
   double* Xre = A.Xre + (long)b * A.npad * TP;
   double* Xim = A.Xim + (long)b * A.npad * TP;
-  const int nms = (M + fcnt + 3) >> 2;                // k-steps over the live border columns
+  const int nms = (M + fcnt + 3) >> 2;                // k-steps over the live border columns (>= 1)
   for (int kt = wave; kt < (NP >> 4); kt += 4) {
     const int k0 = kt << 4;
-    for (int tt = 0; tt < TT; ++tt) {
-      const int t = (tt << 4) + li;
-      d4 zr, zi;
+    for (int tg = 0; tg < TT; tg += TTG) {
+      d4 zr[TTG], zi[TTG];
 #pragma unroll
-      for (int v = 0; v < 4; ++v) {                   // r1[k][t], k = k0 + g + 4v
-        const int k = min(k0 + HPX_ACC_ROW(g, v), N - 1);
-        double r_r = rre[(long)k * ncol + t], r_i = rim[(long)k * ncol + t];
-        if (A.has_omega) {
-          r_r = fma(iav[k], A.p2re[(long)k * TP + t], r_r);
-          r_i = fma(iav[k], A.p2im[(long)k * TP + t], r_i);
+      for (int q = 0; q < TTG; ++q) {
+        const int t = (min(tg + q, TT - 1) << 4) + li;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {                 // r1[k][t], k = k0 + g + 4v (rows >= N are zero)
+          const long o = (long)(k0 + HPX_ACC_ROW(g, v)) * npadX + t;
+          zr[q][v] = xre[o];
+          zi[q][v] = xim[o];
         }
-        zr[v] = r_r;
-        zi[v] = r_i;
       }
-      for (int ms = 0; ms < nms; ++ms) {
-        const int m = 4 * ms + g;
-        const double a_r = -tre[(long)m * NP + k0 + li];      // A[k = k0 + li][m] = -Bd[k][m] (unit stride in k)
-        const double a_i = -tim[(long)m * NP + k0 + li];
-        const double f_r = yre[(long)m * TP + t], f_i = yim[(long)m * TP + t];   // B[m][t] = Y[m][t]
-        zr = mfma64(a_r, f_r, zr);
-        zr = mfma64(-a_i, f_i, zr);
-        zi = mfma64(a_r, f_i, zi);
-        zi = mfma64(a_i, f_r, zi);
+      double a0r, a0i, a1r, a1i, f0r[TTG], f0i[TTG], f1r[TTG], f1i[TTG];
+#define HPX_LB_LOAD(ar_, ai_, fr_, fi_, ms_)                                                   \
+  {                                                                                            \
+    const int m_ = 4 * (ms_) + g;                                                              \
+    ar_ = tre[(long)m_ * NP + k0 + li];              /* A[k = k0 + li][m] = Bd[k][m], unit stride in k */ \
+    ai_ = tim[(long)m_ * NP + k0 + li];                                                        \
+    _Pragma("unroll") for (int q = 0; q < TTG; ++q) {                                          \
+      const int t_ = (min(tg + q, TT - 1) << 4) + li;                                          \
+      fr_[q] = yre[(long)m_ * TP + t_];              /* B[m][t] = Y[m][t] */                    \
+      fi_[q] = yim[(long)m_ * TP + t_];                                                        \
+    }                                                                                          \
+  }
+#define HPX_LB_MMA(ar_, ai_, fr_, fi_)                                                         \
+  {                                                                                            \
+    const double nr_ = -ar_, ni_ = -ai_;                                                       \
+    _Pragma("unroll") for (int q = 0; q < TTG; ++q) {                                          \
+      zr[q] = mfma64(nr_, fr_[q], zr[q]);                                                      \
+      zr[q] = mfma64(ai_, fi_[q], zr[q]);                                                      \
+      zi[q] = mfma64(nr_, fi_[q], zi[q]);                                                      \
+      zi[q] = mfma64(ni_, fr_[q], zi[q]);                                                      \
+    }                                                                                          \
+  }
+      HPX_LB_LOAD(a0r, a0i, f0r, f0i, 0)
+      for (int ms = 0; ms < nms; ms += 2) {
+        HPX_LB_LOAD(a1r, a1i, f1r, f1i, min(ms + 1, nms - 1))
+        __builtin_amdgcn_sched_barrier(0);
+        HPX_LB_MMA(a0r, a0i, f0r, f0i)
+        __builtin_amdgcn_sched_barrier(0);
+        HPX_LB_LOAD(a0r, a0i, f0r, f0i, min(ms + 2, nms - 1))
+        __builtin_amdgcn_sched_barrier(0);
+        if (ms + 1 < nms) HPX_LB_MMA(a1r, a1i, f1r, f1i)
+        __builtin_amdgcn_sched_barrier(0);
       }
+#undef HPX_LB_LOAD
+#undef HPX_LB_MMA
 #pragma unroll
-      for (int v = 0; v < 4; ++v) {
-        const int k = k0 + HPX_ACC_ROW(g, v);
-        if (k < N) {
-          Xre[(long)k * TP + t] = zr[v] * dinv[k];
-          Xim[(long)k * TP + t] = zi[v] * dinv[k];
+      for (int q = 0; q < TTG; ++q) {
+        if (tg + q >= TT) continue;
+        const int t = ((tg + q) << 4) + li;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          const int k = k0 + HPX_ACC_ROW(g, v);
+          if (k < N) {
+            Xre[(long)k * TP + t] = zr[q][v] * dinv[k];
+            Xim[(long)k * TP + t] = zi[q][v] * dinv[k];
+          }
         }
       }
     }
@@ -297,6 +350,7 @@ static void lr_args(hpx_plan* p, LrArgs& A) {
   A.Xre = p->Xre; A.Xim = p->Xim;
   A.N = p->N; A.M = p->M; A.NP = p->NP; A.TP = p->TP; A.ncol = p->ncolR; A.npad = p->npad;
   A.has_omega = p->has_omega; A.fmax = p->lr_fmax; A.npadS = p->lr_npad; A.ldS = p->lr_npad + p->TP;
+  A.npadX = p->lr_npad + p->TP; A.nbl = p->nbl;
   A.isn = 1.0 / sqrt((double)p->N);
 }
 
@@ -310,17 +364,41 @@ int hpx_lowrank_prepare(hpx_plan* p, hipStream_t st) {
   return HPX_OK;
 }
 
+template <int TPW>
+static int launch_schur(hpx_plan* p, const LrArgs& A, int nwg, size_t lds, hipStream_t st) {
+  static hpx_lds_limit limit;      // per instantiation
+  HPX_TRY(limit.ensure(reinterpret_cast<const void*>(&k_lr_schur<TPW>), lds));
+  const int grid = ((p->nbl + 7) / 8) * 8 * nwg;
+  hipLaunchKernelGGL((k_lr_schur<TPW>), dim3(grid), dim3(256), lds, st, A, nwg);
+  HPX_HIP(hipGetLastError());
+  return HPX_OK;
+}
+
+// LDS bytes of k_lr_schur: 1/(c + N/ps) of every channel + two staging buffers
+size_t hpx_lowrank_lds_bytes(const hpx_plan* p) {
+  return ((size_t)p->NP + (size_t)2 * 2 * LR_KC * (p->lr_npad + p->TP)) * sizeof(double);
+}
+
 int hpx_launch_solve_lowrank(hpx_plan* p, int iter_tag, hipStream_t st) {
   LrArgs A;
   lr_args(p, A);
-  const size_t lds = (size_t)2 * p->NP * sizeof(double);
-  hipLaunchKernelGGL(k_lr_schur, dim3(p->nbl), dim3(256), lds, st, A);
+  hipLaunchKernelGGL(k_lr_r1, dim3(32, p->nbl), dim3(256), 0, st, A, p->lr_Bre, p->lr_Bim);
   HPX_HIP(hipGetLastError());
+  // output tiles per baseline over the waves of nwg workgroups, at most 11 per wave
+  const int mt = p->lr_npad >> 4, TT = p->TP >> 4, ntile = mt * (mt + 1) / 2 + mt * TT;
+  const int nwg = (ntile + 43) / 44, per = (ntile + 4 * nwg - 1) / (4 * nwg);
+  const size_t lds_s = hpx_lowrank_lds_bytes(p);
+  if (per <= 3) HPX_TRY(launch_schur<3>(p, A, nwg, lds_s, st));
+  else if (per <= 6) HPX_TRY(launch_schur<6>(p, A, nwg, lds_s, st));
+  else if (per <= 8) HPX_TRY(launch_schur<8>(p, A, nwg, lds_s, st));
+  else HPX_TRY(launch_schur<11>(p, A, nwg, lds_s, st));
   HPX_TRY(hpx_launch_factor(p->nbl, p->lr_npad, p->lr_npad + p->TP, p->lr_L, p->lr_Wre, p->lr_Wim, p->info,
                             iter_tag, nullptr, st));
   HPX_TRY(hpx_launch_backsolve(p->nbl, p->lr_npad, p->TP, p->lr_npad + p->TP, p->lr_L, p->lr_Wre, p->lr_Wim,
                                p->lr_Yre, p->lr_Yim, st));
-  hipLaunchKernelGGL(k_lr_back, dim3(p->nbl), dim3(256), lds, st, A);
+  const size_t lds = (size_t)p->NP * sizeof(double);
+  if (TT >= 2) hipLaunchKernelGGL(k_lr_back<2>, dim3(p->nbl), dim3(256), lds, st, A);
+  else hipLaunchKernelGGL(k_lr_back<1>, dim3(p->nbl), dim3(256), lds, st, A);
   HPX_HIP(hipGetLastError());
   return HPX_OK;
 }
