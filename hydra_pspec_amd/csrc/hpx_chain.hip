@@ -319,6 +319,7 @@ struct ResArgs {
   double *cr_out, *fg_out, *chisq_out;  // already offset to the slot; may be NULL
   long cr_bstride, fg_bstride, chisq_bstride;
   int N, M, T, NP, TP, npad, fg_shared, any_flags;
+  int nbl, npart;                       // fused kernel: batch size, column groups per baseline
 };
 
 __global__ __launch_bounds__(256) void k_resid(const ResArgs A) {
@@ -417,7 +418,12 @@ __global__ __launch_bounds__(256) void k_fft_resid(const ResArgs A) {
   extern __shared__ double fl[];
   __shared__ double red[4];
   const int N = A.N, M = A.M, T = A.T, TP = A.TP, tcs = A.tcs, TC = 1 << tcs, logN = A.logN;
-  const int b = blockIdx.y, c0 = blockIdx.x * TC, tid = threadIdx.x, h = N >> 1;
+  // column groups of one baseline on one XCD (they share cache lines of X, D and the outputs);
+  // workgroup ids go round-robin over the 8 XCDs
+  const int b = ((int)(blockIdx.x >> 3) / A.npart) * 8 + (int)(blockIdx.x & 7);
+  if (b >= A.nbl) return;
+  const int cg = (int)(blockIdx.x >> 3) % A.npart;
+  const int c0 = cg * TC, tid = threadIdx.x, h = N >> 1;
   double* fre = fl;
   double* fim = fl + ((long)N << tcs);
   double* tw = fim + ((long)N << tcs);              // N doubles
@@ -434,7 +440,7 @@ __global__ __launch_bounds__(256) void k_fft_resid(const ResArgs A) {
     lfr[e] = xre[(long)(N + m) * TP + c0 + tc];
     lfi[e] = xim[(long)(N + m) * TP + c0 + tc];
   }
-  double* bp = A.bpart + ((long)b * HPX_NPART + blockIdx.x) * N;
+  double* bp = A.bpart + ((long)b * HPX_NPART + cg) * N;
   for (int e = tid; e < (N << tcs); e += 256) {      // N * TC is a multiple of 256
     const int k = e >> tcs, tc = e & (TC - 1);
     const double zr = xre[(long)k * TP + c0 + tc], zi = xim[(long)k * TP + c0 + tc];
@@ -612,7 +618,7 @@ __global__ __launch_bounds__(256) void k_fft_resid(const ResArgs A) {
     }
   }
   const double total = block_sum(acc, red);
-  if (tid == 0) A.lnpart[(long)b * HPX_NPART + blockIdx.x] = total;
+  if (tid == 0) A.lnpart[(long)b * HPX_NPART + cg] = total;
 }
 
 // betam_k = sum_t |SK[k][t]|^2 (SK = F (w s), in the Z scratch with leading dim ncol).
@@ -1136,7 +1142,7 @@ static int post_solve(hpx_plan* p, int it_abs, const IterOut& O, hipStream_t st)
   R.cr_out = O.cr_out; R.fg_out = (M > 0) ? O.fg_out : nullptr; R.chisq_out = O.chisq_out;
   R.N = N; R.M = M; R.T = T; R.NP = NP; R.TP = TP; R.npad = p->npad;
   R.fg_shared = p->fg_shared; R.any_flags = p->any_flags;
-  R.twre = p->Fopre; R.twim = p->Fopim; R.isn = isn; R.logN = 0; R.tcs = 0;
+  R.twre = p->Fopre; R.twim = p->Fopim; R.isn = isn; R.logN = 0; R.tcs = 0; R.nbl = nbl; R.npart = 1;
   // time columns per block of the fused kernel: 64 KiB of LDS for the signal, as k_fft
   int npart = 1, TC = 4096 / NP;
   if (TC > 16) TC = 16;
@@ -1150,7 +1156,8 @@ static int post_solve(hpx_plan* p, int it_abs, const IterOut& O, hipStream_t st)
     const size_t lds = ((size_t)N * TC * 2 + N + (size_t)2 * M * TC + (size_t)2 * M * (256 / TC)) * sizeof(double);
     static hpx_lds_limit limit;
     HPX_TRY(limit.ensure(reinterpret_cast<const void*>(&k_fft_resid), lds));
-    hipLaunchKernelGGL(k_fft_resid, dim3(npart, nbl), dim3(256), lds, st, R);
+    R.nbl = nbl; R.npart = npart;
+    hipLaunchKernelGGL(k_fft_resid, dim3(((nbl + 7) / 8) * 8 * npart), dim3(256), lds, st, R);
     HPX_HIP(hipGetLastError());
     HPX_TRY(mark(p, st));
   } else {

@@ -96,13 +96,19 @@ __global__ __launch_bounds__(256) void k_fft(const double* __restrict__ Wre,
                                              double* __restrict__ outre,
                                              double* __restrict__ outim, const long out_bstride,
                                              const int out_ld, const int N, const int logN,
-                                             const int ncol, const int tcs, const double scale) {
+                                             const int ncol, const int tcs, const double scale,
+                                             const int nbl, const int ncg) {
   extern __shared__ double fl[];
   const int TC = 1 << tcs;
   double* fre = fl;
   double* fim = fl + ((long)N << tcs);
   double* tw = fim + ((long)N << tcs);         // cos(2 pi j / N), then -sin(2 pi j / N), j < N/2
-  const int b = blockIdx.y, c0 = blockIdx.x * TC, tid = threadIdx.x;
+  // The column groups of one baseline read and write interleaved pieces of the same cache lines
+  // (TC consecutive doubles of every row): they go to ONE XCD, whose L2 then merges them.
+  // (Workgroup ids are dealt round-robin to the 8 XCDs.)
+  const int b = ((int)(blockIdx.x >> 3) / ncg) * 8 + (int)(blockIdx.x & 7);
+  if (b >= nbl) return;
+  const int c0 = ((int)(blockIdx.x >> 3) % ncg) * TC, tid = threadIdx.x;
   const double* ir = inre + (long)b * in_bstride;
   const double* ii = inim + (long)b * in_bstride;
   const double* rsb = rs ? rs + (long)b * rs_n : nullptr;
@@ -225,13 +231,14 @@ int hpx_launch_dft(int nbl, int NP, int ncol, const double* Wre, const double* W
     static hpx_lds_limit lim_fwd, lim_inv;
     HPX_TRY(lim_fwd.ensure(reinterpret_cast<const void*>(&k_fft<1>), lds));
     HPX_TRY(lim_inv.ensure(reinterpret_cast<const void*>(&k_fft<-1>), lds));
-    dim3 grid((ncol + TC - 1) / TC, nbl);
+    const int ncg = (ncol + TC - 1) / TC;
+    dim3 grid(((nbl + 7) / 8) * 8 * ncg);
     if (conjW)
       hipLaunchKernelGGL(k_fft<1>, grid, dim3(256), lds, st, Wre, Wim, inre, inim, in_bstride, in_ld,
-                         rs, rs_n, outre, outim, out_bstride, out_ld, NP, logN, ncol, tcs, scale);
+                         rs, rs_n, outre, outim, out_bstride, out_ld, NP, logN, ncol, tcs, scale, nbl, ncg);
     else
       hipLaunchKernelGGL(k_fft<-1>, grid, dim3(256), lds, st, Wre, Wim, inre, inim, in_bstride, in_ld,
-                         rs, rs_n, outre, outim, out_bstride, out_ld, NP, logN, ncol, tcs, scale);
+                         rs, rs_n, outre, outim, out_bstride, out_ld, NP, logN, ncol, tcs, scale, nbl, ncg);
     HPX_HIP(hipGetLastError());
     return HPX_OK;
   }
