@@ -3,7 +3,7 @@
 
 Run in the build container only (needs /root/reference):
 
-    python tests/golden/make_golden.py [--only small,steps,chain_synth,chain_testdata]
+    python tests/golden/make_golden.py [--only small,steps,chain_synth,chain_testdata,chain_fullsize]
 
 The reference is imported unmodified; its two I/O-only dependencies that are
 absent here (pyuvdata, astropy -- used by file loaders, never by the Gibbs path)
@@ -296,6 +296,29 @@ def gen_chain_testdata(hp):
     print("chain_testdata.npz", len(out), "arrays")
 
 
+def gen_chain_fullsize(hp):
+    """The reference itself at BASELINE.json's full channel counts: the C3 shape (32, 512, 12) without
+    and with 15 % flags, and the C5 shape (32, 1024, 12) with 15 % flags; a few iterations each
+    (1.7 s / 12 s per iteration here).  Inputs are stored with the outputs."""
+    from hydra_pspec_amd import synthetic
+    out = {}
+    cases = (("c3", 512, 0.0, 40, 4), ("c3f", 512, 0.15, 41, 4), ("c5f", 1024, 0.15, 42, 3))
+    for tag, N, frac, k0, niter in cases:
+        T, M = 32, 12
+        d = synthetic.make_baselines(N, T, M, k0=k0, flag_frac=frac)
+        vis, fl = d["vis"][0], d["flags"][0]
+        r = run_chain(hp, vis, fl, d["S_initial"], d["fgmodes"], d["Ninv"], d["ps_prior"], niter, d["seed"])
+        cr, S_last, ps, fg, chi, lp, _ = r
+        out[f"{tag}_vis"], out[f"{tag}_flags"] = vis, fl
+        out[f"{tag}_fgmodes"], out[f"{tag}_ninv_diag"] = d["fgmodes"], np.diag(d["Ninv"]).real.copy()
+        out[f"{tag}_prior"], out[f"{tag}_ps0"], out[f"{tag}_seed"] = d["ps_prior"], d["ps0"], np.array(d["seed"])
+        out[f"{tag}_ps"], out[f"{tag}_lnpost"] = ps, lp
+        out[f"{tag}_cr_last"], out[f"{tag}_fg"], out[f"{tag}_chisq_last"] = cr[-1], fg, chi[-1]
+        print("fullsize", tag, "lnpost", lp)
+    np.savez_compressed(HERE / "chain_fullsize.npz", **out)
+    print("chain_fullsize.npz", len(out), "arrays")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="small,steps,chain_synth,chain_testdata")
@@ -310,6 +333,8 @@ def main():
         gen_chain_synth(hp)
     if "chain_testdata" in todo:
         gen_chain_testdata(hp)
+    if "chain_fullsize" in todo:
+        gen_chain_fullsize(hp)
 
 
 if __name__ == "__main__":

@@ -88,3 +88,35 @@ def test_large_N_global_operand_path():
     print(f"N=2048: signal_cr {ds:.2e}, fg_amps {df:.2e} vs dense solve")
     assert ds < 1e-6 and df < 1e-6
     assert np.all(out["signal_ps"][b, 0] > 0)
+
+
+@pytest.mark.parametrize("tag", ["c3", "c3f", "c5f"])
+@pytest.mark.parametrize("solver", ["dense", "auto"])
+def test_reference_chain_at_full_size(golden, tag, solver):
+    """Against the REFERENCE's own output at BASELINE.json's channel counts (tests/golden/chain_fullsize.npz,
+    produced by running the reference: C3 shape without / with 15 % flags, C5 shape with 15 % flags).
+    Teacher-forced on the reference's bandpowers, every iteration: P(k) rtol 1e-6; free-running over the
+    same few iterations as well (the reference's CG stop, rtol 1e-8, is the only difference in the maths)."""
+    from hydra_pspec_amd import pspec
+    g = golden("chain_fullsize")
+    vis, fl = g[f"{tag}_vis"][None], g[f"{tag}_flags"][None]
+    ref_ps, ref_ln = g[f"{tag}_ps"], g[f"{tag}_lnpost"]
+    niter = len(ref_ps)
+    kw = dict(ps_initial=g[f"{tag}_ps0"], Niter=niter, seed=int(g[f"{tag}_seed"]), solver=solver,
+              keep=("signal_cr", "fg_amps", "chisq"))
+    args = (vis, fl, g[f"{tag}_fgmodes"], g[f"{tag}_ninv_diag"][None], g[f"{tag}_prior"])
+    forced = pspec.gibbs_sample_with_fg_batched(*args, ps_forced=ref_ps[None], **kw)
+    free = pspec.gibbs_sample_with_fg_batched(*args, **kw)
+    live = ref_ps > 1e-9 * np.median(ref_ps)
+    for name, out in (("teacher-forced", forced), ("free-running", free)):
+        dev = np.abs(out["signal_ps"][0] / ref_ps - 1)[live]
+        print(f"{tag} {solver} {name}: P(k) max rel dev vs reference {dev.max():.2e}")
+        assert dev.max() < 1e-6
+        assert np.allclose(out["ln_post"][0], ref_ln, rtol=2e-5)
+    fg_ref, cr_ref = g[f"{tag}_fg"], g[f"{tag}_cr_last"]
+    assert np.max(np.abs(forced["fg_amps"][0] - fg_ref)) < 1e-6 * np.max(np.abs(fg_ref))
+    assert np.max(np.abs(forced["signal_cr"][0, -1] - cr_ref)) < 1e-6 * np.max(np.abs(cr_ref))
+    # chi^2 is built from the residual d - model, ~1e-4 of the foreground-dominated solution: the reference's
+    # CG stop leaves ~1e-4 relative noise in it (same norm-wise gate as tests/test_gpu_chain.py)
+    chi_ref = g[f"{tag}_chisq_last"]
+    assert np.max(np.abs(forced["chisq"][0, -1] - chi_ref)) < 2e-3 * np.max(np.abs(chi_ref))

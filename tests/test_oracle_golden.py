@@ -183,3 +183,15 @@ def test_oqe(golden, s):
         assert relerr(oqe_ref.q(V, s, Rm, b.real), g[f"F11_{s}_q"]) < TIGHT
     assert relerr(oqe_ref.Sig_QEN(Rm, Cn, 0.37), g[f"F11_{s}_SigN"]) < TIGHT
     assert relerr(oqe_ref.Sig_QESN(Rm, Cn, Rm, 0.37), g[f"F11_{s}_SigSN"]) < TIGHT
+
+
+def test_chain_fullsize_c3_prefix(golden):
+    """The oracle against the REFERENCE's own chain at BASELINE.json's channel count (C3 shape
+    (32, 512, 12), unflagged): first two iterations, same seed, same CG solver."""
+    g = golden("chain_fullsize")
+    N = g["c3_vis"].shape[1]
+    S0 = R.covariance_from_pspec(g["c3_ps0"] / N ** 2, R.fourier_operator(N))
+    res = R.gibbs_sample_with_fg(g["c3_vis"], g["c3_flags"], S0, g["c3_fgmodes"], np.diag(g["c3_ninv_diag"]),
+                                 g["c3_prior"], Niter=2, seed=int(g["c3_seed"]))
+    assert np.max(np.abs(res[2] / g["c3_ps"][:2] - 1)) < 1e-7
+    assert np.allclose(res[5], g["c3_lnpost"][:2], rtol=1e-8)
