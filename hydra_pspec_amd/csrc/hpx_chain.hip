@@ -1012,8 +1012,8 @@ extern "C" int hpx_assemble_K(hpx_plan* p, const double* ps, double* k_out, void
 
 extern "C" int hpx_plan_set_solver(hpx_plan* p, int mode) {
   HPX_REQUIRE(p && p->have_static, "hpx_plan_set_solver: plan has no static inputs");
-  HPX_REQUIRE(mode == HPX_SOLVER_DENSE || mode == HPX_SOLVER_FLAT || mode == HPX_SOLVER_LOWRANK,
-              "hpx_plan_set_solver: unknown mode");
+  HPX_REQUIRE(mode == HPX_SOLVER_DENSE || mode == HPX_SOLVER_FLAT || mode == HPX_SOLVER_LOWRANK ||
+              mode == HPX_SOLVER_LOWRANK_DIRECT, "hpx_plan_set_solver: unknown mode");
   if (mode == HPX_SOLVER_FLAT) {
     HPX_REQUIRE(!p->any_flags, "hpx_plan_set_solver: the flat-noise solver needs unflagged data");
     HPX_REQUIRE(p->M <= 16 && p->TP <= 256, "hpx_plan_set_solver: the flat-noise solver needs M <= 16, T <= 256");
@@ -1028,7 +1028,7 @@ extern "C" int hpx_plan_set_solver(hpx_plan* p, int mode) {
           return HPX_EINVAL;
         }
   }
-  if (mode == HPX_SOLVER_LOWRANK) {
+  if (mode == HPX_SOLVER_LOWRANK || mode == HPX_SOLVER_LOWRANK_DIRECT) {
     HPX_REQUIRE(p->TP <= 256, "hpx_plan_set_solver: the low-rank solver needs T <= 256");
     const int nbl = p->nbl, N = p->N;
     std::vector<double> ni((size_t)nbl * N);
@@ -1081,14 +1081,33 @@ extern "C" int hpx_plan_set_solver(hpx_plan* p, int mode) {
     HPX_HIP(hipMemset(p->lr_L, 0, nb * ns * lds_ * 2 * sizeof(double)));
     HPX_HIP(hipMemset(p->lr_Yre, 0, nb * ns * p->TP * sizeof(double)));
     HPX_HIP(hipMemset(p->lr_Yim, 0, nb * ns * p->TP * sizeof(double)));
-    HPX_REQUIRE(hpx_lowrank_lds_bytes(p) <= 160 * 1024, "hpx_plan_set_solver: Ntimes / flag count too large for the low-rank solver");
-    HPX_TRY(dev_alloc(p, &p->lr_Bre, nb * p->NP * (ns + p->TP)));     // [Bd | r1]
-    HPX_TRY(dev_alloc(p, &p->lr_Bim, nb * p->NP * (ns + p->TP)));
-    HPX_TRY(dev_alloc(p, &p->lr_Tre, nb * p->NP * ns));
-    HPX_TRY(dev_alloc(p, &p->lr_Tim, nb * p->NP * ns));
+    // FFT form when the channel count has an FFT and the foreground block fits one MFMA tile
+    p->lr_fft = (mode == HPX_SOLVER_LOWRANK && hpx_dft_use_fft && p->N == p->NP && (N & (N - 1)) == 0 &&
+                 N >= 32 && N <= 4096 && p->M <= 16 && hpx_flat_lds_bytes(p) <= 160 * 1024) ? 1 : 0;
+    if (p->lr_fft) {
+      p->lr_cp = ceil16(1 + p->M);
+      const size_t xw = (size_t)p->lr_cp + p->TP;
+      std::vector<int32_t> finv((size_t)nbl * N, -1);
+      for (int b = 0; b < nbl; ++b)
+        for (int j = 0; j < cnt[b]; ++j) finv[(size_t)b * N + list[(size_t)b * fmax + j]] = j;
+      HPX_TRY(dev_alloc(p, &p->lr_finv, nb * N));
+      HPX_HIP(hipMemcpy(p->lr_finv, finv.data(), finv.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+      HPX_TRY(dev_alloc(p, &p->lr_Ire, nb * p->NP * xw));
+      HPX_TRY(dev_alloc(p, &p->lr_Iim, nb * p->NP * xw));
+      HPX_TRY(dev_alloc(p, &p->lr_Ore, nb * p->NP * xw));
+      HPX_TRY(dev_alloc(p, &p->lr_Oim, nb * p->NP * xw));
+      HPX_TRY(dev_alloc(p, &p->lr_Sre, nb * 16 * (16 + p->TP)));
+      HPX_TRY(dev_alloc(p, &p->lr_Sim, nb * 16 * (16 + p->TP)));
+    } else {
+      HPX_REQUIRE(hpx_lowrank_lds_bytes(p) <= 160 * 1024, "hpx_plan_set_solver: Ntimes / flag count too large for the low-rank solver");
+      HPX_TRY(dev_alloc(p, &p->lr_Bre, nb * p->NP * (ns + p->TP)));     // [Bd | r1]
+      HPX_TRY(dev_alloc(p, &p->lr_Bim, nb * p->NP * (ns + p->TP)));
+      HPX_TRY(dev_alloc(p, &p->lr_Tre, nb * p->NP * ns));
+      HPX_TRY(dev_alloc(p, &p->lr_Tim, nb * p->NP * ns));
+    }
     HPX_TRY(hpx_lowrank_prepare(p, 0));
   }
-  p->solver = mode;
+  p->solver = (mode == HPX_SOLVER_LOWRANK_DIRECT) ? HPX_SOLVER_LOWRANK : mode;
   return HPX_OK;
 }
 
@@ -1131,6 +1150,9 @@ struct IterOut {
   long cr_bstride, fg_bstride, chisq_bstride;
 };
 
+#ifndef HPX_FUSE_TC
+#define HPX_FUSE_TC 8      // fewest time columns per block for which the fused transform + residual kernel is used
+#endif
 static int post_solve(hpx_plan* p, int it_abs, const IterOut& O, hipStream_t st) {
   const int nbl = p->nbl, N = p->N, M = p->M, T = p->T, NP = p->NP, TP = p->TP;
   const double isn = 1.0 / sqrt((double)N);
@@ -1147,7 +1169,7 @@ static int post_solve(hpx_plan* p, int it_abs, const IterOut& O, hipStream_t st)
   int npart = 1, TC = 4096 / NP;
   if (TC > 16) TC = 16;
   const bool pow2 = N == NP && (N & (N - 1)) == 0 && N >= 32 && N <= 4096;
-  if (pow2 && hpx_dft_use_fft && TC >= 8 && TP / TC <= HPX_NPART) {   // fewer columns per block: two kernels win
+  if (pow2 && hpx_dft_use_fft && TC >= HPX_FUSE_TC && TP / TC <= HPX_NPART) {   // fewer columns per block: two kernels win
     while ((1 << R.logN) < N) ++R.logN;
     while ((1 << R.tcs) < TC) ++R.tcs;
     npart = TP / TC;

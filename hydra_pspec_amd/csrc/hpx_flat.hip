@@ -34,23 +34,19 @@ struct FlatArgs {
   int N, M, NP, TP, ncol, npad, has_omega, iter_tag;
 };
 
-__global__ __launch_bounds__(256) void k_solve_flat(const FlatArgs A) {
-  extern __shared__ double lds[];
-  const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+// S = H - G^H Dinv G (16 x 16, identity padding beyond M) and Rf = P4 - G^H Dinv r1 (16 x TP) of
+// baseline b into the LDS matrix sre/sim (row length SW = 16 + TP: [S | Rf]).  Also fills dinv
+// and iav.  Shared by the flat-noise solver and by the FFT form of the low-rank solver, whose
+// Schur complement has these as its foreground block.
+__device__ __forceinline__ void flat_blocks(const FlatArgs& A, const int b, double* dinv, double* iav,
+                                            double* slab, double* sre, double* sim, const double c0) {
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int li = lane & 15, g = lane >> 4;
   const int N = A.N, M = A.M, NP = A.NP, TP = A.TP, ncol = A.ncol, TT = TP >> 4;
-  const int SW = 16 + TP;                         // row length of the augmented M x M system
-  double* dinv = lds;                             // [NP]
-  double* iav = dinv + NP;                        // [NP]
-  double* slab = iav + NP;                        // [1 + FT_MAX][2][4][64]
-  double* sre = slab + (1 + FT_MAX) * 2 * 256;    // [16][SW]
-  double* sim = sre + 16 * SW;
-  __shared__ int bad_s;
+  const int SW = 16 + TP;
   const double* ia = A.ia + (long)b * N;
   const double* rre = A.rre + (long)b * NP * ncol;
   const double* rim = A.rim + (long)b * NP * ncol;
-  const double c0 = A.cre[(long)b * N];
-  if (tid == 0) bad_s = 0;
   for (int k = tid; k < NP; k += 256) {
     const double v = (k < N) ? ia[k] : 0.0;
     iav[k] = v;
@@ -186,6 +182,25 @@ __global__ __launch_bounds__(256) void k_solve_flat(const FlatArgs A) {
     __syncthreads();
   }
 
+}
+
+__global__ __launch_bounds__(256) void k_solve_flat(const FlatArgs A) {
+  extern __shared__ double lds[];
+  const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int li = lane & 15, g = lane >> 4;
+  const int N = A.N, M = A.M, NP = A.NP, TP = A.TP, ncol = A.ncol, TT = TP >> 4;
+  const int SW = 16 + TP;                         // row length of the augmented M x M system
+  double* dinv = lds;                             // [NP]
+  double* iav = dinv + NP;                        // [NP]
+  double* slab = iav + NP;                        // [1 + FT_MAX][2][4][64]
+  double* sre = slab + (1 + FT_MAX) * 2 * 256;    // [16][SW]
+  double* sim = sre + 16 * SW;
+  __shared__ int bad_s;
+  const double* rre = A.rre + (long)b * NP * ncol;
+  const double* rim = A.rim + (long)b * NP * ncol;
+  if (tid == 0) bad_s = 0;
+  flat_blocks(A, b, dinv, iav, slab, sre, sim, A.cre[(long)b * N]);
+
   // ---- f = S^-1 Rf: Gauss-Jordan on the augmented 16 x (16 + TP) system (S Hermitian
   // positive definite: no pivoting)
   double* prow_r = slab;                           // scaled pivot row / pivot column of a step
@@ -275,19 +290,53 @@ __global__ __launch_bounds__(256) void k_solve_flat(const FlatArgs A) {
   if (tid == 0 && bad_s && A.info) atomicCAS(&A.info[b], 0, A.iter_tag);
 }
 
+// The blocks alone, to global memory: out[b][16][16 + TP] planar (low-rank solver, FFT form).
+__global__ __launch_bounds__(256) void k_flat_blocks(const FlatArgs A, const double* __restrict__ cval,
+                                                     double* __restrict__ ore, double* __restrict__ oim) {
+  extern __shared__ double lds[];
+  const int b = blockIdx.x, NP = A.NP, SW = 16 + A.TP;
+  double* dinv = lds;
+  double* iav = dinv + NP;
+  double* slab = iav + NP;
+  double* sre = slab + (1 + FT_MAX) * 2 * 256;
+  double* sim = sre + 16 * SW;
+  flat_blocks(A, b, dinv, iav, slab, sre, sim, cval[b]);
+  for (int e = threadIdx.x; e < 16 * SW; e += 256) {
+    ore[(long)b * 16 * SW + e] = sre[e];
+    oim[(long)b * 16 * SW + e] = sim[e];
+  }
+}
+
 }  // namespace
 
 size_t hpx_flat_lds_bytes(const hpx_plan* p) {
   return ((size_t)2 * p->NP + (size_t)(1 + FT_MAX) * 512 + (size_t)2 * 16 * (16 + p->TP)) * sizeof(double);
 }
 
-int hpx_launch_solve_flat(hpx_plan* p, int iter_tag, hipStream_t st) {
-  FlatArgs A;
+static void flat_args(hpx_plan* p, FlatArgs& A, int iter_tag) {
   A.ia = p->ia; A.cre = p->Cre; A.rre = p->Rre; A.rim = p->Rim; A.p2re = p->P2re; A.p2im = p->P2im;
   A.hre = p->Hre; A.him = p->Him; A.p4re = p->P4re; A.p4im = p->P4im;
   A.Xre = p->Xre; A.Xim = p->Xim; A.info = p->info;
   A.N = p->N; A.M = p->M; A.NP = p->NP; A.TP = p->TP; A.ncol = p->ncolR; A.npad = p->npad;
   A.has_omega = p->has_omega; A.iter_tag = iter_tag;
+}
+
+// foreground blocks of the Schur complement, [nbl][16][16 + TP] planar, with the per-baseline
+// noise level cval[b] (low-rank solver, FFT form; needs M <= 16)
+int hpx_launch_flat_blocks(hpx_plan* p, const double* cval, double* ore, double* oim, hipStream_t st) {
+  FlatArgs A;
+  flat_args(p, A, 0);
+  const size_t lds = hpx_flat_lds_bytes(p);
+  static hpx_lds_limit limit;
+  HPX_TRY(limit.ensure(reinterpret_cast<const void*>(&k_flat_blocks), lds));
+  hipLaunchKernelGGL(k_flat_blocks, dim3(p->nbl), dim3(256), lds, st, A, cval, ore, oim);
+  HPX_HIP(hipGetLastError());
+  return HPX_OK;
+}
+
+int hpx_launch_solve_flat(hpx_plan* p, int iter_tag, hipStream_t st) {
+  FlatArgs A;
+  flat_args(p, A, iter_tag);
   const size_t lds = hpx_flat_lds_bytes(p);
   static hpx_lds_limit limit;
   HPX_TRY(limit.ensure(reinterpret_cast<const void*>(&k_solve_flat), lds));

@@ -61,6 +61,11 @@ struct hpx_plan {
   int lr_fmax, lr_npad;
   int32_t *lr_flist, *lr_fcount;
   double *lr_c, *lr_L, *lr_Wre, *lr_Wim, *lr_Yre, *lr_Yim, *lr_Bre, *lr_Bim, *lr_Tre, *lr_Tim;
+  // FFT form of the low-rank solver (hpx_lowrank.hip): transform input / output, foreground
+  // blocks, channel -> flagged index
+  int lr_fft, lr_cp;
+  double *lr_Ire, *lr_Iim, *lr_Ore, *lr_Oim, *lr_Sre, *lr_Sim;
+  int32_t* lr_finv;
   int64_t bytes;
   // factor / solution
   double *L;               // [nbl][ld/16 panels][npad][re16|im16]  (HPX_LIDX)
@@ -229,6 +234,7 @@ int hpx_launch_factor(int nbl, int npad, int ld, double* L, double* Wre, double*
 // structured solve for flat noise with flags (hpx_lowrank.hip): writes X = [z; f]
 int hpx_launch_solve_lowrank(hpx_plan* p, int iter_tag, hipStream_t st);
 size_t hpx_lowrank_lds_bytes(const hpx_plan* p);
+int hpx_launch_flat_blocks(hpx_plan* p, const double* cval, double* ore, double* oim, hipStream_t st);
 int hpx_lowrank_prepare(hpx_plan* p, hipStream_t st);
 // structured solve for flat noise without flags (hpx_flat.hip): writes X = [z; f]
 int hpx_launch_solve_flat(hpx_plan* p, int iter_tag, hipStream_t st);

@@ -31,6 +31,17 @@
 // output tiles in accumulators: a baseline's ~90 tiles are spread over the waves of 1-3
 // workgroups, so the 3 MB operand is read once per workgroup and iteration instead of once per
 // tile block (nine times at the C5 shape, which made the register-blocked version HBM-bound).
+//
+// FFT form (power-of-two N, M <= 16; hpx_plan.lr_fft).  The columns of Vf are columns of the Fourier
+// operator, so every product with Vf is a DFT evaluated at (or scattered from) the flagged channels
+// and the border never has to be laid out:
+//     (Vf^H Dinv Vf)[i][j] = dhat[(x_j - x_i + N/2) mod N] / N,   dhat = Fop^T dinv      (1 transform)
+//     (G^H Dinv Vf)[m][j]  = (Fop^T (dinv . conj G_m))[x_j] / sqrt N                     (M transforms)
+//     (Vf^H Dinv r1)[j][t] = (conj(Fop)^T (dinv . r1_t))[x_j] / sqrt N                   (T transforms)
+//     (Vf y)[k][t]         = (Fop^T w_t)[k] / sqrt N,  w_t[x_j] = y_j[t], zero elsewhere  (T transforms)
+// i.e. 1 + M + 2T length-N transforms, an f x f gather, the M x M / M x T foreground blocks the
+// flat-noise solver already forms (hpx_flat.hip), and the same small Cholesky: O(N log N (M + T))
+// instead of O(N (M + f)(M + f + T)).
 #include "hpx_internal.h"
 
 namespace {
@@ -45,6 +56,13 @@ struct LrArgs {
   const double *Yre, *Yim;           // [nbl][npadS][TP] its solution
   double *Xre, *Xim;
   int N, M, NP, TP, ncol, npad, has_omega, fmax, npadS, ldS, npadX, nbl;
+  // FFT form: transform input / output [nbl][NP][XW] planar (columns [0, CP): dinv, dinv conj(G);
+  // columns [CP, CP + TP): dinv r1, later the scattered y), the foreground blocks [nbl][16][16 + TP],
+  // channel -> index in the flagged list (or -1)
+  double *ire, *iim;
+  const double *ore, *oim, *sre, *sim;
+  const int32_t* finv;
+  int CP, XW;
   double isn;
 };
 
@@ -339,6 +357,196 @@ __global__ __launch_bounds__(256) void k_lr_back(const LrArgs A) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// FFT form
+__global__ void k_lrf_cols(const LrArgs A) {
+  const int b = blockIdx.y, N = A.N, NP = A.NP, TP = A.TP, M = A.M, CP = A.CP, XW = A.XW;
+  const double* rre = A.rre + (long)b * NP * A.ncol;
+  const double* rim = A.rim + (long)b * NP * A.ncol;
+  const double* ia = A.ia + (long)b * N;
+  const double c0 = A.cval[b];
+  double* ire = A.ire + (long)b * NP * XW;
+  double* iim = A.iim + (long)b * NP * XW;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < (long)NP * XW; e += (long)gridDim.x * blockDim.x) {
+    const int k = (int)(e / XW), c = (int)(e % XW);
+    double vr = 0.0, vi = 0.0;
+    if (k < N) {
+      const double a = ia[k], d = 1.0 / fma(a, a, c0);
+      if (c == 0) {
+        vr = d;
+      } else if (c <= M) {                            // dinv conj(G[k][c-1])
+        vr = d * rre[(long)k * A.ncol + TP + c - 1];
+        vi = -d * rim[(long)k * A.ncol + TP + c - 1];
+      } else if (c >= CP) {                           // dinv r1[k][t]
+        const int t = c - CP;
+        double x = rre[(long)k * A.ncol + t], y = rim[(long)k * A.ncol + t];
+        if (A.has_omega) {
+          x = fma(a, A.p2re[(long)k * TP + t], x);
+          y = fma(a, A.p2im[(long)k * TP + t], y);
+        }
+        vr = d * x;
+        vi = d * y;
+      }
+    }
+    ire[e] = vr;
+    iim[e] = vi;
+  }
+}
+
+// S and Rf in the factor layout from the transforms (ore/oim) and the foreground blocks (sre/sim)
+__global__ __launch_bounds__(256) void k_lrf_gather(const LrArgs A) {
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int N = A.N, M = A.M, NP = A.NP, TP = A.TP, npadS = A.npadS, XW = A.XW, CP = A.CP, SW = 16 + TP;
+  const int* fl = A.flist + (long)b * A.fmax;
+  const int fcnt = A.fcount[b];
+  const double c0 = A.cval[b];
+  const double sc = sqrt(c0) * A.isn, cn = c0 * A.isn * A.isn;      // sqrt(c / N), c / N
+  const double* ore = A.ore + (long)b * NP * XW;
+  const double* oim = A.oim + (long)b * NP * XW;
+  const double* sre = A.sre + (long)b * 16 * SW;
+  const double* sim = A.sim + (long)b * 16 * SW;
+  double* L = A.Ls + (long)b * npadS * A.ldS * 2;
+  const int h = N / 2;
+  for (int e = tid; e < npadS * npadS; e += 256) {
+    const int r = e / npadS, c = e - r * npadS;
+    if (c > r) continue;
+    double vr = (r == c) ? 1.0 : 0.0, vi = 0.0;              // identity padding
+    if (r < M) {                                              // foreground block (c <= r < M)
+      vr = sre[r * SW + c];
+      vi = sim[r * SW + c];
+    } else if (r - M < fcnt) {
+      const int xi = fl[r - M];
+      if (c < M) {                                            // conj of -(G^H Dinv sqrt(c) Vf)[c][i]
+        vr = -sc * ore[(long)xi * XW + 1 + c];
+        vi = sc * oim[(long)xi * XW + 1 + c];
+      } else {                                                // delta - c (Vf^H Dinv Vf)[i][j]
+        const int xj = fl[c - M];
+        int x = xj - xi + h;
+        x += (x < 0) ? N : 0;
+        x -= (x >= N) ? N : 0;
+        vr -= cn * ore[(long)x * XW];
+        vi = -cn * oim[(long)x * XW];
+      }
+    }
+    const long o = HPX_LIDX(r, c, npadS);
+    L[o] = vr;
+    L[o + 16] = vi;
+  }
+  for (int e = tid; e < npadS * TP; e += 256) {               // row npadS + t = conj(Rf[m][t])
+    const int m = e / TP, t = e - m * TP;
+    double vr = 0.0, vi = 0.0;
+    if (m < M) {
+      vr = sre[m * SW + 16 + t];
+      vi = sim[m * SW + 16 + t];
+    } else if (m - M < fcnt) {                                // -(sqrt(c) Vf^H Dinv r1)[i][t]
+      const int xi = fl[m - M];
+      vr = -sc * ore[(long)xi * XW + CP + t];
+      vi = -sc * oim[(long)xi * XW + CP + t];
+    }
+    const long o = HPX_LIDX(npadS + t, m, npadS);
+    L[o] = vr;
+    L[o + 16] = -vi;
+  }
+}
+
+// w[x][t] = y_j[t] at the flagged channels x = x_j, zero elsewhere (input of the last transform)
+__global__ void k_lrf_fill(const LrArgs A) {
+  const int b = blockIdx.y, N = A.N, NP = A.NP, TP = A.TP, M = A.M, CP = A.CP, XW = A.XW;
+  const int32_t* finv = A.finv + (long)b * N;
+  const double* yre = A.Yre + (long)b * A.npadS * TP;
+  const double* yim = A.Yim + (long)b * A.npadS * TP;
+  double* ire = A.ire + (long)b * NP * XW + CP;
+  double* iim = A.iim + (long)b * NP * XW + CP;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < (long)NP * TP; e += (long)gridDim.x * blockDim.x) {
+    const int k = (int)(e / TP), t = (int)(e % TP);
+    const int j = (k < N) ? finv[k] : -1;
+    ire[(long)k * XW + t] = (j >= 0) ? yre[(long)(M + j) * TP + t] : 0.0;
+    iim[(long)k * XW + t] = (j >= 0) ? yim[(long)(M + j) * TP + t] : 0.0;
+  }
+}
+
+// z = Dinv (r1 - G f - sqrt(c/N) What), X = [z; f; 0]
+__global__ __launch_bounds__(256) void k_lrf_back(const LrArgs A) {
+  extern __shared__ double lds[];
+  const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int li = lane & 15, g = lane >> 4;
+  const int N = A.N, M = A.M, NP = A.NP, TP = A.TP, ncol = A.ncol, TT = TP >> 4, XW = A.XW, CP = A.CP;
+  double* dinv = lds;
+  double* iav = dinv + NP;
+  double* fre = iav + NP;                          // f[m][t], 16 x TP
+  double* fim = fre + 16 * TP;
+  const double* ia = A.ia + (long)b * N;
+  const double* rre = A.rre + (long)b * NP * ncol;
+  const double* rim = A.rim + (long)b * NP * ncol;
+  const double c0 = A.cval[b];
+  const double sc = sqrt(c0) * A.isn;
+  const double* wre = A.ore + (long)b * NP * XW + CP;
+  const double* wim = A.oim + (long)b * NP * XW + CP;
+  const double* yre = A.Yre + (long)b * A.npadS * TP;
+  const double* yim = A.Yim + (long)b * A.npadS * TP;
+  for (int k = tid; k < NP; k += 256) {
+    const double v = (k < N) ? ia[k] : 0.0;
+    iav[k] = v;
+    dinv[k] = (k < N) ? 1.0 / fma(v, v, c0) : 0.0;
+  }
+  for (int e = tid; e < 16 * TP; e += 256) {
+    const int m = e / TP;
+    fre[e] = (m < M) ? yre[e] : 0.0;
+    fim[e] = (m < M) ? yim[e] : 0.0;
+  }
+  __syncthreads();
+  double* Xre = A.Xre + (long)b * A.npad * TP;
+  double* Xim = A.Xim + (long)b * A.npad * TP;
+  for (int kt = wave; kt < (NP >> 4); kt += 4) {
+    const int k0 = kt << 4;
+    double ga_r[4], ga_i[4];                       // A[k = k0 + li][m = 4 ks + g] = -G[k][m]
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const long o = (long)min(k0 + li, N - 1) * ncol + TP + 4 * ks + g;
+      const bool live = 4 * ks + g < M;
+      ga_r[ks] = live ? -rre[o] : 0.0;
+      ga_i[ks] = live ? -rim[o] : 0.0;
+    }
+    for (int tt = 0; tt < TT; ++tt) {
+      const int t = (tt << 4) + li;
+      d4 zr, zi;
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {                // r1[k][t] - sqrt(c/N) What[k][t], k = k0 + g + 4v
+        const int kk = k0 + HPX_ACC_ROW(g, v), k = min(kk, N - 1);
+        double r_r = rre[(long)k * ncol + t], r_i = rim[(long)k * ncol + t];
+        if (A.has_omega) {
+          r_r = fma(iav[k], A.p2re[(long)k * TP + t], r_r);
+          r_i = fma(iav[k], A.p2im[(long)k * TP + t], r_i);
+        }
+        zr[v] = fma(-sc, wre[(long)kk * XW + t], r_r);
+        zi[v] = fma(-sc, wim[(long)kk * XW + t], r_i);
+      }
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {             // B[m = 4 ks + g][t] = f[m][t]
+        const int m = 4 * ks + g;
+        const double f_r = fre[m * TP + t], f_i = fim[m * TP + t];
+        zr = mfma64(ga_r[ks], f_r, zr);
+        zr = mfma64(-ga_i[ks], f_i, zr);
+        zi = mfma64(ga_r[ks], f_i, zi);
+        zi = mfma64(ga_i[ks], f_r, zi);
+      }
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const int k = k0 + HPX_ACC_ROW(g, v);
+        if (k < N) {
+          Xre[(long)k * TP + t] = zr[v] * dinv[k];
+          Xim[(long)k * TP + t] = zi[v] * dinv[k];
+        }
+      }
+    }
+  }
+  for (int e = tid; e < (A.npad - N) * TP; e += 256) {
+    const int m = e / TP, t = e - m * TP;
+    Xre[(long)(N + m) * TP + t] = (m < M) ? fre[m * TP + t] : 0.0;
+    Xim[(long)(N + m) * TP + t] = (m < M) ? fim[m * TP + t] : 0.0;
+  }
+}
+
 }  // namespace
 
 static void lr_args(hpx_plan* p, LrArgs& A) {
@@ -351,11 +559,14 @@ static void lr_args(hpx_plan* p, LrArgs& A) {
   A.N = p->N; A.M = p->M; A.NP = p->NP; A.TP = p->TP; A.ncol = p->ncolR; A.npad = p->npad;
   A.has_omega = p->has_omega; A.fmax = p->lr_fmax; A.npadS = p->lr_npad; A.ldS = p->lr_npad + p->TP;
   A.npadX = p->lr_npad + p->TP; A.nbl = p->nbl;
+  A.ire = p->lr_Ire; A.iim = p->lr_Iim; A.ore = p->lr_Ore; A.oim = p->lr_Oim; A.sre = p->lr_Sre; A.sim = p->lr_Sim;
+  A.finv = p->lr_finv; A.CP = p->lr_cp; A.XW = p->lr_cp + p->TP;
   A.isn = 1.0 / sqrt((double)p->N);
 }
 
 // the iteration-invariant border of every baseline (after hpx_plan_set_solver filled the lists)
 int hpx_lowrank_prepare(hpx_plan* p, hipStream_t st) {
+  if (p->lr_fft) return HPX_OK;                       // the FFT form never lays the border out
   LrArgs A;
   lr_args(p, A);
   hipLaunchKernelGGL(k_lr_border, dim3(64, p->nbl), dim3(256), 0, st, A, p->lr_Bre, p->lr_Bim, p->lr_Tre, p->lr_Tim);
@@ -379,9 +590,38 @@ size_t hpx_lowrank_lds_bytes(const hpx_plan* p) {
   return ((size_t)p->NP + (size_t)2 * 2 * LR_KC * (p->lr_npad + p->TP)) * sizeof(double);
 }
 
+static int solve_lowrank_fft(hpx_plan* p, const LrArgs& A, int iter_tag, hipStream_t st) {
+  const int NP = p->NP, TP = p->TP, CP = p->lr_cp, XW = CP + TP;
+  const long bs = (long)NP * XW;
+  hipLaunchKernelGGL(k_lrf_cols, dim3(32, p->nbl), dim3(256), 0, st, A);
+  HPX_HIP(hipGetLastError());
+  HPX_TRY(hpx_launch_flat_blocks(p, p->lr_c, p->lr_Sre, p->lr_Sim, st));
+  HPX_TRY(hpx_launch_dft(p->nbl, NP, CP, p->Fopre, p->Fopim, 0, p->lr_Ire, p->lr_Iim, bs, XW, nullptr, 0,
+                         p->lr_Ore, p->lr_Oim, bs, XW, 1.0, st, 1));
+  HPX_TRY(hpx_launch_dft(p->nbl, NP, TP, p->Fopre, p->Fopim, 1, p->lr_Ire + CP, p->lr_Iim + CP, bs, XW, nullptr, 0,
+                         p->lr_Ore + CP, p->lr_Oim + CP, bs, XW, 1.0, st, 1));
+  hipLaunchKernelGGL(k_lrf_gather, dim3(p->nbl), dim3(256), 0, st, A);
+  HPX_HIP(hipGetLastError());
+  HPX_TRY(hpx_launch_factor(p->nbl, p->lr_npad, p->lr_npad + TP, p->lr_L, p->lr_Wre, p->lr_Wim, p->info,
+                            iter_tag, nullptr, st));
+  HPX_TRY(hpx_launch_backsolve(p->nbl, p->lr_npad, TP, p->lr_npad + TP, p->lr_L, p->lr_Wre, p->lr_Wim,
+                               p->lr_Yre, p->lr_Yim, st));
+  hipLaunchKernelGGL(k_lrf_fill, dim3(32, p->nbl), dim3(256), 0, st, A);
+  HPX_HIP(hipGetLastError());
+  HPX_TRY(hpx_launch_dft(p->nbl, NP, TP, p->Fopre, p->Fopim, 0, p->lr_Ire + CP, p->lr_Iim + CP, bs, XW, nullptr, 0,
+                         p->lr_Ore + CP, p->lr_Oim + CP, bs, XW, 1.0, st, 1));
+  const size_t lds = ((size_t)2 * NP + (size_t)2 * 16 * TP) * sizeof(double);
+  static hpx_lds_limit limit;
+  HPX_TRY(limit.ensure(reinterpret_cast<const void*>(&k_lrf_back), lds));
+  hipLaunchKernelGGL(k_lrf_back, dim3(p->nbl), dim3(256), lds, st, A);
+  HPX_HIP(hipGetLastError());
+  return HPX_OK;
+}
+
 int hpx_launch_solve_lowrank(hpx_plan* p, int iter_tag, hipStream_t st) {
   LrArgs A;
   lr_args(p, A);
+  if (p->lr_fft) return solve_lowrank_fft(p, A, iter_tag, st);
   hipLaunchKernelGGL(k_lr_r1, dim3(32, p->nbl), dim3(256), 0, st, A, p->lr_Bre, p->lr_Bim);
   HPX_HIP(hipGetLastError());
   // output tiles per baseline over the waves of nwg workgroups, at most 11 per wave

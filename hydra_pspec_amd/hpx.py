@@ -15,7 +15,7 @@ _LIB_PATH = Path(__file__).resolve().parent / "libhpx.so"
 
 HPX_OK, HPX_EINVAL, HPX_EHIP, HPX_ENOTPD = 0, -1, -2, -3
 NSTAGE = 6
-SOLVER_DENSE, SOLVER_FLAT, SOLVER_LOWRANK = 0, 1, 2
+SOLVER_DENSE, SOLVER_FLAT, SOLVER_LOWRANK, SOLVER_LOWRANK_DIRECT = 0, 1, 2, 3
 STAGES = ("assemble", "factor", "backsolve", "transform", "residual", "draw")
 
 _vp, _i, _i64 = C.c_void_p, C.c_int, C.c_int64

@@ -202,7 +202,13 @@ class GibbsBatch:
             # solve (diagonal + border system): hpx_flat.hip without flags, hpx_lowrank.hip with
             # flags (border widened by one column per flagged channel); everything else the dense
             # Cholesky.  "flat" / "lowrank" insist on the structured solve, "dense" forbids it.
-            assert solver in ("auto", "dense", "flat", "lowrank"), "solver must be auto, dense, flat or lowrank"
+            assert solver in ("auto", "dense", "flat", "lowrank", "lowrank-direct"), \
+                "solver must be auto, dense, flat, lowrank or lowrank-direct"
+            # "lowrank-direct": the low-rank solve with the border laid out explicitly (MFMA form) even
+            # where the FFT form applies (power-of-two Nfreqs, Nmodes <= 16); same results, for A/B
+            direct = solver == "lowrank-direct"
+            if direct:
+                solver = "lowrank"
             self.solver = "dense"
             if solver != "dense":
                 use = d_flags.bool()
@@ -220,8 +226,9 @@ class GibbsBatch:
                                      + ("no flags, Nmodes <= 16" if solver == "flat"
                                         else "flags with Nmodes + max flagged channels <= 240"))
             if self.solver != "dense":
-                hpx.check(L.hpx_plan_set_solver(self.plan.handle, hpx.SOLVER_FLAT if self.solver == "flat"
-                                                else hpx.SOLVER_LOWRANK), "hpx_plan_set_solver")
+                mode = hpx.SOLVER_FLAT if self.solver == "flat" else \
+                    (hpx.SOLVER_LOWRANK_DIRECT if direct else hpx.SOLVER_LOWRANK)
+                hpx.check(L.hpx_plan_set_solver(self.plan.handle, mode), "hpx_plan_set_solver")
         self.iter_done = 0
 
     def close(self):

@@ -135,6 +135,7 @@ int hpx_plan_info(hpx_plan* p, int32_t* info_host);
  * complement (hpx_lowrank.hip; the small dense system reuses the batched Cholesky);
  * -1 unless every baseline qualifies and M + max f <= 240, T <= 256. */
 #define HPX_SOLVER_LOWRANK 2
+#define HPX_SOLVER_LOWRANK_DIRECT 3   /* as 2, but always the explicit-border (MFMA) form, never the FFT form */
 int hpx_plan_set_solver(hpx_plan* p, int mode);
 
 /* time (ms) spent in each stage of the last hpx_gibbs_run, measured with HIP

@@ -416,8 +416,12 @@ def test_lowrank_solver_matches_dense(shape, frac):
     a = pspec.gibbs_sample_with_fg_batched(d["vis"], d["flags"], F, d["ninv_diag"], prior, solver="dense", **kw)
     b = pspec.gibbs_sample_with_fg_batched(d["vis"], d["flags"], F, d["ninv_diag"], prior, solver="lowrank", **kw)
     c = pspec.gibbs_sample_with_fg_batched(d["vis"], d["flags"], F, d["ninv_diag"], prior, **kw)
+    e = pspec.gibbs_sample_with_fg_batched(d["vis"], d["flags"], F, d["ninv_diag"], prior, solver="lowrank-direct", **kw)
     assert np.isfinite(a["signal_ps"]).all()
     assert np.array_equal(b["signal_ps"], c["signal_ps"])            # "auto" picks it
+    # explicit-border (MFMA) form against the FFT form (the same thing where N is not a power of two)
+    assert np.max(np.abs(e["signal_ps"][live_all := a["signal_ps"] > 1e-9] / a["signal_ps"][live_all] - 1)) < 1e-6
+    assert np.max(np.abs(e["signal_cr"] - a["signal_cr"])) < 1e-6 * np.max(np.abs(a["signal_cr"]))
     live = a["signal_ps"] > 1e-9
     assert np.max(np.abs(b["signal_ps"][live] / a["signal_ps"][live] - 1)) < 1e-6
     assert np.max(np.abs(b["signal_cr"] - a["signal_cr"])) < 1e-6 * np.max(np.abs(a["signal_cr"]))
