@@ -1094,6 +1094,9 @@ extern "C" int hpx_plan_set_solver(hpx_plan* p, int mode) {
       HPX_HIP(hipMemcpy(p->lr_finv, finv.data(), finv.size() * sizeof(int32_t), hipMemcpyHostToDevice));
       HPX_TRY(dev_alloc(p, &p->lr_Ire, nb * p->NP * xw));
       HPX_TRY(dev_alloc(p, &p->lr_Iim, nb * p->NP * xw));
+      // columns 1 + M .. lr_cp - 1 of the transform input are never written: zero them once
+      HPX_HIP(hipMemset(p->lr_Ire, 0, nb * p->NP * xw * sizeof(double)));
+      HPX_HIP(hipMemset(p->lr_Iim, 0, nb * p->NP * xw * sizeof(double)));
       HPX_TRY(dev_alloc(p, &p->lr_Ore, nb * p->NP * xw));
       HPX_TRY(dev_alloc(p, &p->lr_Oim, nb * p->NP * xw));
       HPX_TRY(dev_alloc(p, &p->lr_Sre, nb * 16 * (16 + p->TP)));

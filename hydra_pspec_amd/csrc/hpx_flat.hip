@@ -32,6 +32,10 @@ struct FlatArgs {
   double *Xre, *Xim;
   int32_t* info;
   int N, M, NP, TP, ncol, npad, has_omega, iter_tag;
+  // low-rank solver, FFT form: the operands of the contraction are also the input of its
+  // transforms, [nbl][NP][CP + TP] planar = [dinv | dinv conj(G) | 0 | dinv r1]  (NULL: not written)
+  double *xin_re, *xin_im;
+  int CP;
 };
 
 // S = H - G^H Dinv G (16 x 16, identity padding beyond M) and Rf = P4 - G^H Dinv r1 (16 x TP) of
@@ -43,10 +47,12 @@ __device__ __forceinline__ void flat_blocks(const FlatArgs& A, const int b, doub
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int li = lane & 15, g = lane >> 4;
   const int N = A.N, M = A.M, NP = A.NP, TP = A.TP, ncol = A.ncol, TT = TP >> 4;
-  const int SW = 16 + TP;
+  const int SW = 16 + TP, XW = A.CP + TP;
   const double* ia = A.ia + (long)b * N;
   const double* rre = A.rre + (long)b * NP * ncol;
   const double* rim = A.rim + (long)b * NP * ncol;
+  double* xin_r = A.xin_re ? A.xin_re + (long)b * NP * XW : nullptr;
+  double* xin_i = A.xin_re ? A.xin_im + (long)b * NP * XW : nullptr;
   for (int k = tid; k < NP; k += 256) {
     const double v = (k < N) ? ia[k] : 0.0;
     iav[k] = v;
@@ -89,11 +95,16 @@ __device__ __forceinline__ void flat_blocks(const FlatArgs& A, const int b, doub
       }                                                                                    \
     }                                                                                      \
   }
-#define HPX_FL_MMA(gr_, gi_, dk_, br_, bi_)                                                \
+#define HPX_FL_MMA(gr_, gi_, dk_, br_, bi_, ks_)                                           \
   {                                                                                        \
+    const long xo_ = (long)(4 * (ks_) + g) * XW;                                           \
     const double a_r = gr_, a_i = -gi_;      /* A[m = li][k] = conj(G[k][m]) */            \
     if (with_s) {                            /* B[k][m' = li] = Dinv_k G[k][m'] */         \
       const double b_r = dk_ * gr_, b_i = dk_ * gi_;                                       \
+      if (xin_r) {                                                                         \
+        if (li < M) { xin_r[xo_ + 1 + li] = b_r; xin_i[xo_ + 1 + li] = -b_i; }             \
+        if (li == 0) { xin_r[xo_] = dk_; xin_i[xo_] = 0.0; }                               \
+      }                                                                                    \
       ar[0] = mfma64(a_r, b_r, ar[0]);                                                     \
       ar[0] = mfma64(-a_i, b_i, ar[0]);                                                    \
       ai[0] = mfma64(a_r, b_i, ai[0]);                                                     \
@@ -102,6 +113,10 @@ __device__ __forceinline__ void flat_blocks(const FlatArgs& A, const int b, doub
     _Pragma("unroll") for (int q = 0; q < FT_MAX; ++q) {                                   \
       if (q < nt) {                          /* B[k][t] = Dinv_k r1[k][t] */               \
         const double b_r = dk_ * br_[q], b_i = dk_ * bi_[q];                               \
+        if (xin_r) {                                                                       \
+          xin_r[xo_ + A.CP + ((tb + q) << 4) + li] = b_r;                                  \
+          xin_i[xo_ + A.CP + ((tb + q) << 4) + li] = b_i;                                  \
+        }                                                                                  \
         ar[1 + q] = mfma64(a_r, b_r, ar[1 + q]);                                           \
         ar[1 + q] = mfma64(-a_i, b_i, ar[1 + q]);                                          \
         ai[1 + q] = mfma64(a_r, b_i, ai[1 + q]);                                           \
@@ -117,16 +132,16 @@ __device__ __forceinline__ void flat_blocks(const FlatArgs& A, const int b, doub
       for (int i = 0; i + 1 < nmy; i += 2) {
         HPX_FL_LOAD(gr1, gi1, dk1, br1, bi1, ks + 4)
         __builtin_amdgcn_sched_barrier(0);
-        HPX_FL_MMA(gr0, gi0, dk0, br0, bi0)
+        HPX_FL_MMA(gr0, gi0, dk0, br0, bi0, ks)
         __builtin_amdgcn_sched_barrier(0);
         const int nx = min(ks + 8, kslast);
         HPX_FL_LOAD(gr0, gi0, dk0, br0, bi0, nx)
         __builtin_amdgcn_sched_barrier(0);
-        HPX_FL_MMA(gr1, gi1, dk1, br1, bi1)
+        HPX_FL_MMA(gr1, gi1, dk1, br1, bi1, ks + 4)
         __builtin_amdgcn_sched_barrier(0);
         ks += 8;
       }
-      if (nmy & 1) HPX_FL_MMA(gr0, gi0, dk0, br0, bi0)
+      if (nmy & 1) HPX_FL_MMA(gr0, gi0, dk0, br0, bi0, ks)
     }
 #undef HPX_FL_LOAD
 #undef HPX_FL_MMA
@@ -319,13 +334,16 @@ static void flat_args(hpx_plan* p, FlatArgs& A, int iter_tag) {
   A.Xre = p->Xre; A.Xim = p->Xim; A.info = p->info;
   A.N = p->N; A.M = p->M; A.NP = p->NP; A.TP = p->TP; A.ncol = p->ncolR; A.npad = p->npad;
   A.has_omega = p->has_omega; A.iter_tag = iter_tag;
+  A.xin_re = nullptr; A.xin_im = nullptr; A.CP = 0;
 }
 
 // foreground blocks of the Schur complement, [nbl][16][16 + TP] planar, with the per-baseline
 // noise level cval[b] (low-rank solver, FFT form; needs M <= 16)
-int hpx_launch_flat_blocks(hpx_plan* p, const double* cval, double* ore, double* oim, hipStream_t st) {
+int hpx_launch_flat_blocks(hpx_plan* p, const double* cval, double* ore, double* oim, double* xin_re,
+                           double* xin_im, int cp, hipStream_t st) {
   FlatArgs A;
   flat_args(p, A, 0);
+  A.xin_re = xin_re; A.xin_im = xin_im; A.CP = cp;
   const size_t lds = hpx_flat_lds_bytes(p);
   static hpx_lds_limit limit;
   HPX_TRY(limit.ensure(reinterpret_cast<const void*>(&k_flat_blocks), lds));

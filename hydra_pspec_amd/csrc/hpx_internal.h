@@ -234,7 +234,8 @@ int hpx_launch_factor(int nbl, int npad, int ld, double* L, double* Wre, double*
 // structured solve for flat noise with flags (hpx_lowrank.hip): writes X = [z; f]
 int hpx_launch_solve_lowrank(hpx_plan* p, int iter_tag, hipStream_t st);
 size_t hpx_lowrank_lds_bytes(const hpx_plan* p);
-int hpx_launch_flat_blocks(hpx_plan* p, const double* cval, double* ore, double* oim, hipStream_t st);
+int hpx_launch_flat_blocks(hpx_plan* p, const double* cval, double* ore, double* oim, double* xin_re,
+                           double* xin_im, int cp, hipStream_t st);
 int hpx_lowrank_prepare(hpx_plan* p, hipStream_t st);
 // structured solve for flat noise without flags (hpx_flat.hip): writes X = [z; f]
 int hpx_launch_solve_flat(hpx_plan* p, int iter_tag, hipStream_t st);

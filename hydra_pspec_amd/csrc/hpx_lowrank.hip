@@ -359,42 +359,12 @@ __global__ __launch_bounds__(256) void k_lr_back(const LrArgs A) {
 
 // ---------------------------------------------------------------------------------------------
 // FFT form
-__global__ void k_lrf_cols(const LrArgs A) {
-  const int b = blockIdx.y, N = A.N, NP = A.NP, TP = A.TP, M = A.M, CP = A.CP, XW = A.XW;
-  const double* rre = A.rre + (long)b * NP * A.ncol;
-  const double* rim = A.rim + (long)b * NP * A.ncol;
-  const double* ia = A.ia + (long)b * N;
-  const double c0 = A.cval[b];
-  double* ire = A.ire + (long)b * NP * XW;
-  double* iim = A.iim + (long)b * NP * XW;
-  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < (long)NP * XW; e += (long)gridDim.x * blockDim.x) {
-    const int k = (int)(e / XW), c = (int)(e % XW);
-    double vr = 0.0, vi = 0.0;
-    if (k < N) {
-      const double a = ia[k], d = 1.0 / fma(a, a, c0);
-      if (c == 0) {
-        vr = d;
-      } else if (c <= M) {                            // dinv conj(G[k][c-1])
-        vr = d * rre[(long)k * A.ncol + TP + c - 1];
-        vi = -d * rim[(long)k * A.ncol + TP + c - 1];
-      } else if (c >= CP) {                           // dinv r1[k][t]
-        const int t = c - CP;
-        double x = rre[(long)k * A.ncol + t], y = rim[(long)k * A.ncol + t];
-        if (A.has_omega) {
-          x = fma(a, A.p2re[(long)k * TP + t], x);
-          y = fma(a, A.p2im[(long)k * TP + t], y);
-        }
-        vr = d * x;
-        vi = d * y;
-      }
-    }
-    ire[e] = vr;
-    iim[e] = vi;
-  }
-}
-
-// S and Rf in the factor layout from the transforms (ore/oim) and the foreground blocks (sre/sim)
+// S and Rf in the factor layout from the transforms (ore/oim) and the foreground blocks (sre/sim).
+// Elements are visited in storage order (16 consecutive rows of a panel, then the column): a
+// wave's stores are 128-byte runs.  dhat (column 0 of the transform output, stride XW in memory)
+// is staged in LDS once: every entry of the f x f block is a lookup in it.
 __global__ __launch_bounds__(256) void k_lrf_gather(const LrArgs A) {
+  extern __shared__ double lds[];
   const int b = blockIdx.x, tid = threadIdx.x;
   const int N = A.N, M = A.M, NP = A.NP, TP = A.TP, npadS = A.npadS, XW = A.XW, CP = A.CP, SW = 16 + TP;
   const int* fl = A.flist + (long)b * A.fmax;
@@ -406,26 +376,34 @@ __global__ __launch_bounds__(256) void k_lrf_gather(const LrArgs A) {
   const double* sre = A.sre + (long)b * 16 * SW;
   const double* sim = A.sim + (long)b * 16 * SW;
   double* L = A.Ls + (long)b * npadS * A.ldS * 2;
+  double* dhr = lds;                                // [N]
+  double* dhi = dhr + N;
+  int* xf = reinterpret_cast<int*>(dhi + N);        // [npadS] channel of border column M + i (or -1)
+  for (int x = tid; x < N; x += 256) {
+    dhr[x] = ore[(long)x * XW];
+    dhi[x] = oim[(long)x * XW];
+  }
+  for (int m = tid; m < npadS; m += 256) xf[m] = (m >= M && m - M < fcnt) ? fl[m - M] : -1;
+  __syncthreads();
   const int h = N / 2;
   for (int e = tid; e < npadS * npadS; e += 256) {
-    const int r = e / npadS, c = e - r * npadS;
+    const int rr = e & 15, q = e >> 4, c = q % npadS, r = ((q / npadS) << 4) + rr;
     if (c > r) continue;
     double vr = (r == c) ? 1.0 : 0.0, vi = 0.0;              // identity padding
     if (r < M) {                                              // foreground block (c <= r < M)
       vr = sre[r * SW + c];
       vi = sim[r * SW + c];
-    } else if (r - M < fcnt) {
-      const int xi = fl[r - M];
+    } else if (xf[r] >= 0) {
+      const int xi = xf[r];
       if (c < M) {                                            // conj of -(G^H Dinv sqrt(c) Vf)[c][i]
         vr = -sc * ore[(long)xi * XW + 1 + c];
         vi = sc * oim[(long)xi * XW + 1 + c];
       } else {                                                // delta - c (Vf^H Dinv Vf)[i][j]
-        const int xj = fl[c - M];
-        int x = xj - xi + h;
+        int x = xf[c] - xi + h;
         x += (x < 0) ? N : 0;
         x -= (x >= N) ? N : 0;
-        vr -= cn * ore[(long)x * XW];
-        vi = -cn * oim[(long)x * XW];
+        vr -= cn * dhr[x];
+        vi = -cn * dhi[x];
       }
     }
     const long o = HPX_LIDX(r, c, npadS);
@@ -433,15 +411,14 @@ __global__ __launch_bounds__(256) void k_lrf_gather(const LrArgs A) {
     L[o + 16] = vi;
   }
   for (int e = tid; e < npadS * TP; e += 256) {               // row npadS + t = conj(Rf[m][t])
-    const int m = e / TP, t = e - m * TP;
+    const int tt = e & 15, q = e >> 4, m = q % npadS, t = ((q / npadS) << 4) + tt;
     double vr = 0.0, vi = 0.0;
     if (m < M) {
       vr = sre[m * SW + 16 + t];
       vi = sim[m * SW + 16 + t];
-    } else if (m - M < fcnt) {                                // -(sqrt(c) Vf^H Dinv r1)[i][t]
-      const int xi = fl[m - M];
-      vr = -sc * ore[(long)xi * XW + CP + t];
-      vi = -sc * oim[(long)xi * XW + CP + t];
+    } else if (xf[m] >= 0) {                                  // -(sqrt(c) Vf^H Dinv r1)[i][t]
+      vr = -sc * ore[(long)xf[m] * XW + CP + t];
+      vi = -sc * oim[(long)xf[m] * XW + CP + t];
     }
     const long o = HPX_LIDX(npadS + t, m, npadS);
     L[o] = vr;
@@ -593,14 +570,16 @@ size_t hpx_lowrank_lds_bytes(const hpx_plan* p) {
 static int solve_lowrank_fft(hpx_plan* p, const LrArgs& A, int iter_tag, hipStream_t st) {
   const int NP = p->NP, TP = p->TP, CP = p->lr_cp, XW = CP + TP;
   const long bs = (long)NP * XW;
-  hipLaunchKernelGGL(k_lrf_cols, dim3(32, p->nbl), dim3(256), 0, st, A);
-  HPX_HIP(hipGetLastError());
-  HPX_TRY(hpx_launch_flat_blocks(p, p->lr_c, p->lr_Sre, p->lr_Sim, st));
+  // foreground blocks; the same pass writes the transform input [dinv | dinv conj(G) | dinv r1]
+  HPX_TRY(hpx_launch_flat_blocks(p, p->lr_c, p->lr_Sre, p->lr_Sim, p->lr_Ire, p->lr_Iim, CP, st));
   HPX_TRY(hpx_launch_dft(p->nbl, NP, CP, p->Fopre, p->Fopim, 0, p->lr_Ire, p->lr_Iim, bs, XW, nullptr, 0,
                          p->lr_Ore, p->lr_Oim, bs, XW, 1.0, st, 1));
   HPX_TRY(hpx_launch_dft(p->nbl, NP, TP, p->Fopre, p->Fopim, 1, p->lr_Ire + CP, p->lr_Iim + CP, bs, XW, nullptr, 0,
                          p->lr_Ore + CP, p->lr_Oim + CP, bs, XW, 1.0, st, 1));
-  hipLaunchKernelGGL(k_lrf_gather, dim3(p->nbl), dim3(256), 0, st, A);
+  const size_t lds_g = (size_t)2 * p->N * sizeof(double) + (size_t)p->lr_npad * sizeof(int);
+  static hpx_lds_limit limit_g;
+  HPX_TRY(limit_g.ensure(reinterpret_cast<const void*>(&k_lrf_gather), lds_g));
+  hipLaunchKernelGGL(k_lrf_gather, dim3(p->nbl), dim3(256), lds_g, st, A);
   HPX_HIP(hipGetLastError());
   HPX_TRY(hpx_launch_factor(p->nbl, p->lr_npad, p->lr_npad + TP, p->lr_L, p->lr_Wre, p->lr_Wim, p->info,
                             iter_tag, nullptr, st));
