@@ -441,15 +441,33 @@ __global__ __launch_bounds__(256) void k_fft_resid(const ResArgs A) {
     lfi[e] = xim[(long)(N + m) * TP + c0 + tc];
   }
   double* bp = A.bpart + ((long)b * HPX_NPART + cg) * N;
-  for (int e = tid; e < (N << tcs); e += 256) {      // N * TC is a multiple of 256
-    const int k = e >> tcs, tc = e & (TC - 1);
-    const double zr = xre[(long)k * TP + c0 + tc], zi = xim[(long)k * TP + c0 + tc];
-    const double sg = (k & 1) ? -1.0 : 1.0;
-    fre[e] = zr * sg;
-    fim[e] = zi * sg;
-    double v = zr * zr + zi * zi;                    // sum over this block's time columns
-    for (int o = TC >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    if (tc == 0) bp[k] = v;
+  // loads in batches of 16 per thread, all in flight before the first use (one element at a time
+  // every iteration waits out a memory round trip); N * TC is a multiple of 256
+  {
+    constexpr int UB = 16;
+    const int total = N << tcs;
+    for (int e0 = tid; e0 < total; e0 += 256 * UB) {
+      double zr[UB], zi[UB];
+#pragma unroll
+      for (int u = 0; u < UB; ++u) {
+        const int e = min(e0 + 256 * u, total - 1), k = e >> tcs, tc = e & (TC - 1);
+        zr[u] = xre[(long)k * TP + c0 + tc];
+        zi[u] = xim[(long)k * TP + c0 + tc];
+      }
+#pragma unroll
+      for (int u = 0; u < UB; ++u) {
+        const int e = e0 + 256 * u;
+        if (e < total) {                                  // uniform over the workgroup
+          const int k = e >> tcs, tc = e & (TC - 1);
+          const double sg = (k & 1) ? -1.0 : 1.0;
+          fre[e] = zr[u] * sg;
+          fim[e] = zi[u] * sg;
+          double v = zr[u] * zr[u] + zi[u] * zi[u];       // sum over this block's time columns
+          for (int o = TC >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+          if (tc == 0) bp[k] = v;
+        }
+      }
+    }
   }
   int s = 0;
   for (; s + 3 <= logN; s += 3) {

@@ -42,6 +42,7 @@ struct FlatArgs {
 // baseline b into the LDS matrix sre/sim (row length SW = 16 + TP: [S | Rf]).  Also fills dinv
 // and iav.  Shared by the flat-noise solver and by the FFT form of the low-rank solver, whose
 // Schur complement has these as its foreground block.
+template <bool XIN>
 __device__ __forceinline__ void flat_blocks(const FlatArgs& A, const int b, double* dinv, double* iav,
                                             double* slab, double* sre, double* sim, const double c0) {
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -51,8 +52,8 @@ __device__ __forceinline__ void flat_blocks(const FlatArgs& A, const int b, doub
   const double* ia = A.ia + (long)b * N;
   const double* rre = A.rre + (long)b * NP * ncol;
   const double* rim = A.rim + (long)b * NP * ncol;
-  double* xin_r = A.xin_re ? A.xin_re + (long)b * NP * XW : nullptr;
-  double* xin_i = A.xin_re ? A.xin_im + (long)b * NP * XW : nullptr;
+  double* xin_r = XIN ? A.xin_re + (long)b * NP * XW : nullptr;      // XIN: also write the transform input
+  double* xin_i = XIN ? A.xin_im + (long)b * NP * XW : nullptr;
   for (int k = tid; k < NP; k += 256) {
     const double v = (k < N) ? ia[k] : 0.0;
     iav[k] = v;
@@ -101,7 +102,7 @@ __device__ __forceinline__ void flat_blocks(const FlatArgs& A, const int b, doub
     const double a_r = gr_, a_i = -gi_;      /* A[m = li][k] = conj(G[k][m]) */            \
     if (with_s) {                            /* B[k][m' = li] = Dinv_k G[k][m'] */         \
       const double b_r = dk_ * gr_, b_i = dk_ * gi_;                                       \
-      if (xin_r) {                                                                         \
+      if (XIN) {                                                                           \
         if (li < M) { xin_r[xo_ + 1 + li] = b_r; xin_i[xo_ + 1 + li] = -b_i; }             \
         if (li == 0) { xin_r[xo_] = dk_; xin_i[xo_] = 0.0; }                               \
       }                                                                                    \
@@ -113,7 +114,7 @@ __device__ __forceinline__ void flat_blocks(const FlatArgs& A, const int b, doub
     _Pragma("unroll") for (int q = 0; q < FT_MAX; ++q) {                                   \
       if (q < nt) {                          /* B[k][t] = Dinv_k r1[k][t] */               \
         const double b_r = dk_ * br_[q], b_i = dk_ * bi_[q];                               \
-        if (xin_r) {                                                                       \
+        if (XIN) {                                                                         \
           xin_r[xo_ + A.CP + ((tb + q) << 4) + li] = b_r;                                  \
           xin_i[xo_ + A.CP + ((tb + q) << 4) + li] = b_i;                                  \
         }                                                                                  \
@@ -214,7 +215,7 @@ __global__ __launch_bounds__(256) void k_solve_flat(const FlatArgs A) {
   const double* rre = A.rre + (long)b * NP * ncol;
   const double* rim = A.rim + (long)b * NP * ncol;
   if (tid == 0) bad_s = 0;
-  flat_blocks(A, b, dinv, iav, slab, sre, sim, A.cre[(long)b * N]);
+  flat_blocks<false>(A, b, dinv, iav, slab, sre, sim, A.cre[(long)b * N]);
 
   // ---- f = S^-1 Rf: Gauss-Jordan on the augmented 16 x (16 + TP) system (S Hermitian
   // positive definite: no pivoting)
@@ -315,7 +316,7 @@ __global__ __launch_bounds__(256) void k_flat_blocks(const FlatArgs A, const dou
   double* slab = iav + NP;
   double* sre = slab + (1 + FT_MAX) * 2 * 256;
   double* sim = sre + 16 * SW;
-  flat_blocks(A, b, dinv, iav, slab, sre, sim, cval[b]);
+  flat_blocks<true>(A, b, dinv, iav, slab, sre, sim, cval[b]);
   for (int e = threadIdx.x; e < 16 * SW; e += 256) {
     ore[(long)b * 16 * SW + e] = sre[e];
     oim[(long)b * 16 * SW + e] = sim[e];

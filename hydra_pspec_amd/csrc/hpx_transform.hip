@@ -86,6 +86,9 @@ __global__ __launch_bounds__(256, 2) void k_dft(const double* Wre, const double*
 // plain one with sign flips on both sides (N % 4 == 0):
 //   (F v)[k] = (-1)^k sum_x (-1)^x v[x] e^{-2 pi i k x / N},   F^H likewise with e^{+...}.
 // Twiddles e^{-2 pi i j / N} are row N/2+1 of the operator itself (numpy's exp on the host).
+#ifndef HPX_FFT_DIAG
+#define HPX_FFT_DIAG 0     // timing-only ablations (wrong results): 1 no passes, 2 no stores, 4 no loads
+#endif
 template <int SIGN>
 __global__ __launch_bounds__(256) void k_fft(const double* __restrict__ Wre,
                                              const double* __restrict__ Wim,
@@ -117,19 +120,43 @@ __global__ __launch_bounds__(256) void k_fft(const double* __restrict__ Wre,
     tw[j] = Wre[(long)(h + 1) * N + h + j];
     tw[h + j] = Wim[(long)(h + 1) * N + h + j];
   }
-  for (int e = tid; e < (N << tcs); e += 256) {
-    const int k = e >> tcs, tc = e & (TC - 1);
-    double vr = 0.0, vi = 0.0;
-    if (c0 + tc < ncol) {
-      double sc = (k & 1) ? -1.0 : 1.0;
-      if (rsb) sc = (k < rs_n) ? sc * rsb[k] : 0.0;
-      vr = ir[(long)k * in_ld + c0 + tc] * sc;
-      vi = ii[(long)k * in_ld + c0 + tc] * sc;
+  // Loads in batches of 16 per thread, all issued before the first LDS write: one element at a
+  // time the loop waits out a full memory round trip per iteration (16 of them at N = 1024),
+  // which was two thirds of the kernel's time.
+#ifndef HPX_FFT_UB
+#define HPX_FFT_UB 16
+#endif
+  constexpr int UB = HPX_FFT_UB;
+  const int total = N << tcs;
+  for (int e0 = tid; e0 < total; e0 += 256 * UB) {
+    double vr[UB], vi[UB], sc[UB];
+#pragma unroll
+    for (int u = 0; u < UB; ++u) {
+      const int e = min(e0 + 256 * u, total - 1);      // clamped: in-bounds, unused beyond the end
+      const int k = e >> tcs, tc = min(e & (TC - 1), ncol - 1 - c0);
+      vr[u] = (HPX_FFT_DIAG & 4) ? 0.0 : ir[(long)k * in_ld + c0 + tc];
+      vi[u] = (HPX_FFT_DIAG & 4) ? 0.0 : ii[(long)k * in_ld + c0 + tc];
+      sc[u] = (k & 1) ? -1.0 : 1.0;
     }
-    fre[e] = vr;
-    fim[e] = vi;
+#pragma unroll
+    for (int u = 0; u < UB; ++u) {
+      const int e = e0 + 256 * u;
+      if (e < total) {
+        const bool live = c0 + (e & (TC - 1)) < ncol;
+        fre[e] = live ? vr[u] * sc[u] : 0.0;
+        fim[e] = live ? vi[u] * sc[u] : 0.0;
+      }
+    }
   }
-  int s = 0;
+  if (rsb) {                         // optional row scaling (no caller on the hot path uses it)
+    for (int e = tid; e < total; e += 256) {
+      const int k = e >> tcs;
+      const double r = (k < rs_n) ? rsb[k] : 0.0;
+      fre[e] *= r;
+      fim[e] *= r;
+    }
+  }
+  int s = (HPX_FFT_DIAG & 1) ? logN : 0;
   for (; s + 3 <= logN; s += 3) {
     __syncthreads();
     fft_pass<3, SIGN>(fre, fim, tw, N, h, logN, s, tcs, tid);
@@ -147,6 +174,7 @@ __global__ __launch_bounds__(256) void k_fft(const double* __restrict__ Wre,
   for (int e = tid; e < (N << tcs); e += 256) {
     const int pidx = e >> tcs, tc = e & (TC - 1);
     if (c0 + tc >= ncol) continue;
+    if ((HPX_FFT_DIAG & 2) && fre[e] != 12345.678) continue;
     const int x = (int)(__brev((unsigned)pidx) >> (32 - logN));
     const double sc = (x & 1) ? -scale : scale;
     orr[(long)x * out_ld + c0 + tc] = fre[e] * sc;
