@@ -133,7 +133,10 @@ int hpx_plan_info(hpx_plan* p, int32_t* info_host);
  * flags): C = c I - c Vf Vf^H with one column of Vf per flagged channel, so the system is
  * diagonal plus a border of width M + f and is solved exactly through the (M+f) x (M+f) Schur
  * complement (hpx_lowrank.hip; the small dense system reuses the batched Cholesky);
- * -1 unless every baseline qualifies and M + max f <= 240, T <= 256. */
+ * -1 unless every baseline qualifies and M + max f <= 240, T <= 256.  For power-of-two N and
+ * M <= 16 the products with Vf are taken as length-N transforms evaluated at the flagged
+ * channels (the border is never formed, O(N log N (M + T)) per iteration); otherwise the border is
+ * laid out once per plan and contracted on the MFMA. */
 #define HPX_SOLVER_LOWRANK 2
 #define HPX_SOLVER_LOWRANK_DIRECT 3   /* as 2, but always the explicit-border (MFMA) form, never the FFT form */
 int hpx_plan_set_solver(hpx_plan* p, int mode);

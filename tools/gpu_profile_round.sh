@@ -14,6 +14,12 @@ cd /tmp
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python3 $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline > $O/kt.log 2>&1
 cd $R
 cp $(ls $O/kt/*/*kernel_stats.csv | head -1) $O/${TAG}_kernel_stats_c3.csv 2>/dev/null; echo "kernel stats done"
+# the structured (flagged, flat-noise) path at C5: per-kernel times of solver=auto
+cd /tmp
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt5 -- python3 $R/bench.py --config C5 --solver auto --steps 10 --warmup 2 --no-cpu-baseline > $O/kt5.log 2>&1
+cd $R
+cp $(ls $O/kt5/*/*kernel_stats.csv | head -1) $O/${TAG}_kernel_stats_c5_auto.csv 2>/dev/null
+grep -o '{"metric.*' $O/kt5.log > $O/${TAG}_bench_c5_auto_under_rocprof.json; echo "C5 auto kernel stats done"
 i=0
 for set in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
   i=$((i+1))
