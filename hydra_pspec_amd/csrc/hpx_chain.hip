@@ -664,13 +664,24 @@ __global__ __launch_bounds__(256) void k_betam(const double* __restrict__ Kre, c
 // Q = exp(-z) sum_{k<a} z^k / k!  (= scipy.special.gammaincc(a, z) = invgamma.cdf
 // of pspec.py:51 at x = beta/z).  Forward sum for z < a, scaled Horner form
 // around the leading term for z >= a (no overflow, all terms positive).
-__device__ double igamc_int(const int a, const double z, const double lgam_a) {
+#define HPX_RK_MAX 512
+// rk[k] = 1 / k (LDS table, k < a <= HPX_RK_MAX, else NULL): the forward sum multiplies by it instead of dividing --
+// an fp64 division is ~10 dependent vector instructions, and the 1000-point CDF grids of the
+// prior channels made that loop the bulk of k_draw (one more rounding per term: ~a ulp in Q).
+__device__ double igamc_int(const int a, const double z, const double lgam_a, const double* rk) {
   if (!(z > 0.0)) return 1.0;
   if (z < (double)a) {
     double t = 1.0, s = 1.0;
-    for (int k = 1; k < a; ++k) {
-      t *= z / (double)k;
-      s += t;
+    if (rk) {
+      for (int k = 1; k < a; ++k) {
+        t *= z * rk[k];
+        s += t;
+      }
+    } else {                                   // shape beyond the table (Ntimes > HPX_RK_MAX)
+      for (int k = 1; k < a; ++k) {
+        t *= z / (double)k;
+        s += t;
+      }
     }
     return exp(-z) * s;
   }
@@ -684,11 +695,11 @@ __device__ double igamc_int(const int a, const double z, const double lgam_a) {
 // cdfs: LDS array of ngrid doubles.  Returns the sample to every thread.
 __device__ double inversion_draw(const int alpha, const double lgam, const double beta,
                                  const double u, const double* __restrict__ xg, const int ngrid,
-                                 double* cdfs, double* red, int* redi) {
+                                 double* cdfs, double* red, int* redi, const double* rk) {
   const int tid = threadIdx.x;
   double mn = INFINITY;
   for (int i = tid; i < ngrid; i += 256) {
-    const double c = igamc_int(alpha, beta / xg[i], lgam);
+    const double c = igamc_int(alpha, beta / xg[i], lgam, rk);
     cdfs[i] = c;
     mn = fmin(mn, c);
   }
@@ -750,7 +761,10 @@ __global__ __launch_bounds__(256) void k_draw(const DrawArgs A) {
   __shared__ double red[4];
   __shared__ int redi[4];
   __shared__ int pcount;
+  __shared__ double rk_s[HPX_RK_MAX];
   const int b = blockIdx.x, tid = threadIdx.x, N = A.N;
+  for (int k = tid; k < HPX_RK_MAX; k += 256) rk_s[k] = 1.0 / (double)(k > 0 ? k : 1);
+  const double* rk = (A.T <= HPX_RK_MAX) ? rk_s : nullptr;
   // beta_k = N sum_t |z_kt|^2 and the chi^2 total from the partial sums of the residual kernel
   // (one slot per block of a baseline there), added in slot order
   double* beta = A.beta + (long)b * N;
@@ -784,7 +798,7 @@ __global__ __launch_bounds__(256) void k_draw(const DrawArgs A) {
   for (int i = 0; i < np; ++i) {
     const int k = plist[i], row = pmap[k];
     const double v = inversion_draw(A.T, A.lgam_T, beta[k], A.uni[k], A.xgrid + (long)row * A.ngrid,
-                                    A.ngrid, dyn, red, redi);
+                                    A.ngrid, dyn, red, redi, rk);
     if (tid == 0) ps_out[k] = v;
     __syncthreads();
   }
@@ -807,9 +821,12 @@ __global__ void k_inv_test(const int alpha, const double lgam, const double* __r
   extern __shared__ double dyn[];
   __shared__ double red[4];
   __shared__ int redi[4];
+  __shared__ double rk_s[HPX_RK_MAX];
   const int i = blockIdx.x;
+  for (int k = threadIdx.x; k < HPX_RK_MAX; k += 256) rk_s[k] = 1.0 / (double)(k > 0 ? k : 1);
+  __syncthreads();
   const double v = inversion_draw(alpha, lgam, beta[i], u[i], xgrid + (long)i * ngrid, ngrid, dyn,
-                                  red, redi);
+                                  red, redi, alpha <= HPX_RK_MAX ? rk_s : nullptr);
   if (threadIdx.x == 0) out[i] = v;
 }
 
