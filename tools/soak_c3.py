@@ -1,12 +1,17 @@
-"""BASELINE config C3 at its full length: 1024 baselines x (32, 512, 12), 2000 iterations, dense path.
+"""BASELINE configs at full length: C3 = 1024 baselines x (32, 512, 12), 2000 iterations (default), or
+C5 = 1024 x (32, 1024, 12) with 15 % flags (`soak_c3.py <solver> C5 [niter]`).
 Checks that the chains stay finite and recover the injected spectrum; prints the sustained rate."""
 import sys, time
 import numpy as np
 sys.path.insert(0, '.')
 import torch
 from hydra_pspec_amd import pspec, synthetic
-nbl, T, N, M, niter = 1024, 32, 512, 12, 2000
-d = synthetic.make_baselines(N, T, M, nbl=nbl, dense=False)
+nbl, T, N, M, niter, frac = 1024, 32, 512, 12, 2000, 0.0
+if len(sys.argv) > 2 and sys.argv[2] == "C5":
+    N, frac = 1024, 0.15
+if len(sys.argv) > 3:
+    niter = int(sys.argv[3])
+d = synthetic.make_baselines(N, T, M, nbl=nbl, flag_frac=frac, dense=False)
 gb = pspec.GibbsBatch(d["vis"], d["flags"], d["fgmodes"], d["ninv_diag"], d["ps_prior"], niter, seed=d["seed"],
                       solver=sys.argv[1] if len(sys.argv) > 1 else "dense")
 ps0 = np.broadcast_to(d["ps0"], (nbl, N)).copy()
