@@ -457,3 +457,23 @@ def test_plan_setters_replace_their_buffers():
     assert rc == hpx.HPX_EINVAL and "ps0" in hpx.last_error()
     assert torch.equal(again.run(3, ps0=ps0)["signal_ps"], first)
     again.close()
+
+
+@pytest.mark.parametrize("solver", ["lowrank", "lowrank-direct"])
+def test_lowrank_mixed_batch_with_an_unflagged_baseline(solver):
+    """A batch in which one baseline has no flagged channel at all (its border is the foreground
+    block alone) next to flagged ones, through both forms of the low-rank solver."""
+    from hydra_pspec_amd import pspec, synthetic
+    nbl, T, N, M = 3, 8, 64, 6
+    d = synthetic.make_baselines(N, T, M, k0=21, nbl=nbl, flag_frac=0.1, dense=False)
+    d["flags"][1, :] = True                                    # baseline 1: nothing flagged
+    kw = dict(ps_initial=d["ps0"], Niter=4, seed=d["seed"], keep=("signal_cr", "fg_amps"))
+    a = pspec.gibbs_sample_with_fg_batched(d["vis"], d["flags"], d["fgmodes"], d["ninv_diag"], d["ps_prior"],
+                                           solver="dense", **kw)
+    b = pspec.gibbs_sample_with_fg_batched(d["vis"], d["flags"], d["fgmodes"], d["ninv_diag"], d["ps_prior"],
+                                           solver=solver, **kw)
+    live = a["signal_ps"] > 1e-9
+    assert np.isfinite(b["signal_ps"]).all()
+    assert np.max(np.abs(b["signal_ps"][live] / a["signal_ps"][live] - 1)) < 1e-6
+    assert np.max(np.abs(b["signal_cr"] - a["signal_cr"])) < 1e-6 * np.max(np.abs(a["signal_cr"]))
+    assert np.max(np.abs(b["fg_amps"] - a["fg_amps"])) < 1e-8 * np.max(np.abs(a["fg_amps"]))
