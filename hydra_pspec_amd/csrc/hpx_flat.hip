@@ -25,7 +25,16 @@
 
 namespace {
 
-constexpr int FT_MAX = 3;          // t-tiles per pass of the first contraction
+#ifndef HPX_FLAT_DIAG
+#define HPX_FLAT_DIAG 0            // timing-only ablations (wrong results): 1 no Gauss-Jordan, 2 no back product, 4 no contraction
+#endif
+#ifndef HPX_FT_MAX
+#define HPX_FT_MAX 2
+#endif
+#ifndef HPX_FLAT_WGS
+#define HPX_FLAT_WGS 1              // workgroups per CU the register budget is set for
+#endif
+constexpr int FT_MAX = HPX_FT_MAX; // t-tiles per pass of the first contraction
 
 struct FlatArgs {
   const double *ia, *cre, *rre, *rim, *p2re, *p2im, *hre, *him, *p4re, *p4im;
@@ -72,39 +81,46 @@ __device__ __forceinline__ void flat_blocks(const FlatArgs& A, const int b, doub
       ar[q] = (d4){0., 0., 0., 0.};
       ai[q] = (d4){0., 0., 0., 0.};
     }
-    // operands of the next k-step are in flight while the current one is multiplied
-    double gr0, gi0, gr1, gi1, dk0, dk1, br0[FT_MAX], bi0[FT_MAX], br1[FT_MAX], bi1[FT_MAX];
-#define HPX_FL_LOAD(gr_, gi_, dk_, br_, bi_, ks_)                                          \
+    // This wave's k-steps (ks = wave + 4 i) in chunks of KCH: the operands of the next chunk are in
+    // flight while the current one is multiplied (one k-step is 12 MFMAs, a third of a memory round
+    // trip: a chunk of one left every step waiting).  Loads are unconditional (clamped indices; P2
+    // is zero without omega): a load under a runtime condition makes hipcc branch around it and
+    // drain the queue.  Steps past the end carry Dinv = 0.
+    constexpr int KCH = 2;
+    const int nmy = (nks > wave) ? (nks - wave + 3) / 4 : 0;
+    const int nchk = (nmy + KCH - 1) / KCH;
+    double gr[2][KCH], gi[2][KCH], dk[2][KCH], br[2][KCH][FT_MAX], bi[2][KCH][FT_MAX];
+    int kq[2][KCH];                                   // channel 4 ks + g of the step, or -1
+#define HPX_FL_LOAD(S, creq_)                                                              \
   {                                                                                        \
-    const int k_ = 4 * (ks_) + g;                                                          \
-    const int kc_ = min(k_, N - 1);          /* padded channels: Dinv = 0, finite operand */ \
-    const long ro_ = (long)kc_ * ncol;                                                     \
-    gr_ = rre[ro_ + TP + li];                                                              \
-    gi_ = rim[ro_ + TP + li];                                                              \
-    dk_ = dinv[k_];                                                                        \
-    const double ik_ = iav[k_];                                                            \
-    _Pragma("unroll") for (int q = 0; q < FT_MAX; ++q) {                                   \
-      if (q < nt) {                                                                        \
-        const int t_ = ((tb + q) << 4) + li;                                               \
-        double x_ = rre[ro_ + t_], y_ = rim[ro_ + t_];                                     \
-        if (A.has_omega) {                                                                 \
-          x_ = fma(ik_, A.p2re[(long)kc_ * TP + t_], x_);                                  \
-          y_ = fma(ik_, A.p2im[(long)kc_ * TP + t_], y_);                                  \
-        }                                                                                  \
-        br_[q] = x_;                                                                       \
-        bi_[q] = y_;                                                                       \
+    const int cl_ = min((creq_), nchk - 1);                                                \
+    _Pragma("unroll") for (int u = 0; u < KCH; ++u) {                                      \
+      const int i_ = KCH * cl_ + u;                                                        \
+      const bool ok_ = ((creq_) < nchk) && (i_ < nmy);                                     \
+      const int k_ = 4 * (wave + 4 * min(i_, nmy - 1)) + g;                                \
+      const int kc_ = min(k_, N - 1);        /* padded channels: Dinv = 0, finite operand */ \
+      const long ro_ = (long)kc_ * ncol;                                                   \
+      gr[S][u] = rre[ro_ + TP + li];                                                       \
+      gi[S][u] = rim[ro_ + TP + li];                                                       \
+      dk[S][u] = ok_ ? dinv[k_] : 0.0;                                                     \
+      kq[S][u] = ok_ ? k_ : -1;                                                            \
+      const double ik_ = iav[k_];                                                          \
+      _Pragma("unroll") for (int q = 0; q < FT_MAX; ++q) {                                 \
+        const int t_ = ((tb + min(q, nt - 1)) << 4) + li;                                  \
+        br[S][u][q] = fma(ik_, A.p2re[(long)kc_ * TP + t_], rre[ro_ + t_]);                \
+        bi[S][u][q] = fma(ik_, A.p2im[(long)kc_ * TP + t_], rim[ro_ + t_]);                \
       }                                                                                    \
     }                                                                                      \
   }
-#define HPX_FL_MMA(gr_, gi_, dk_, br_, bi_, ks_)                                           \
-  {                                                                                        \
-    const long xo_ = (long)(4 * (ks_) + g) * XW;                                           \
-    const double a_r = gr_, a_i = -gi_;      /* A[m = li][k] = conj(G[k][m]) */            \
+#define HPX_FL_MMA(S)                                                                      \
+  _Pragma("unroll") for (int u = 0; u < KCH; ++u) {                                        \
+    const long xo_ = (long)max(kq[S][u], 0) * XW;                                          \
+    const double a_r = gr[S][u], a_i = -gi[S][u];   /* A[m = li][k] = conj(G[k][m]) */     \
     if (with_s) {                            /* B[k][m' = li] = Dinv_k G[k][m'] */         \
-      const double b_r = dk_ * gr_, b_i = dk_ * gi_;                                       \
-      if (XIN) {                                                                           \
+      const double b_r = dk[S][u] * gr[S][u], b_i = dk[S][u] * gi[S][u];                   \
+      if (XIN && kq[S][u] >= 0) {                                                          \
         if (li < M) { xin_r[xo_ + 1 + li] = b_r; xin_i[xo_ + 1 + li] = -b_i; }             \
-        if (li == 0) { xin_r[xo_] = dk_; xin_i[xo_] = 0.0; }                               \
+        if (li == 0) { xin_r[xo_] = dk[S][u]; xin_i[xo_] = 0.0; }                          \
       }                                                                                    \
       ar[0] = mfma64(a_r, b_r, ar[0]);                                                     \
       ar[0] = mfma64(-a_i, b_i, ar[0]);                                                    \
@@ -113,8 +129,8 @@ __device__ __forceinline__ void flat_blocks(const FlatArgs& A, const int b, doub
     }                                                                                      \
     _Pragma("unroll") for (int q = 0; q < FT_MAX; ++q) {                                   \
       if (q < nt) {                          /* B[k][t] = Dinv_k r1[k][t] */               \
-        const double b_r = dk_ * br_[q], b_i = dk_ * bi_[q];                               \
-        if (XIN) {                                                                         \
+        const double b_r = dk[S][u] * br[S][u][q], b_i = dk[S][u] * bi[S][u][q];           \
+        if (XIN && kq[S][u] >= 0) {                                                        \
           xin_r[xo_ + A.CP + ((tb + q) << 4) + li] = b_r;                                  \
           xin_i[xo_ + A.CP + ((tb + q) << 4) + li] = b_i;                                  \
         }                                                                                  \
@@ -125,24 +141,18 @@ __device__ __forceinline__ void flat_blocks(const FlatArgs& A, const int b, doub
       }                                                                                    \
     }                                                                                      \
   }
-    const int nmy = (nks > wave) ? (nks - wave + 3) / 4 : 0;
-    if (nmy > 0) {
-      int ks = wave;
-      const int kslast = wave + 4 * (nmy - 1);
-      HPX_FL_LOAD(gr0, gi0, dk0, br0, bi0, ks)
-      for (int i = 0; i + 1 < nmy; i += 2) {
-        HPX_FL_LOAD(gr1, gi1, dk1, br1, bi1, ks + 4)
+    if (nmy > 0 && !(HPX_FLAT_DIAG & 4)) {
+      HPX_FL_LOAD(0, 0)
+      for (int c = 0; c < nchk; c += 2) {
+        HPX_FL_LOAD(1, c + 1)
         __builtin_amdgcn_sched_barrier(0);
-        HPX_FL_MMA(gr0, gi0, dk0, br0, bi0, ks)
+        HPX_FL_MMA(0)
         __builtin_amdgcn_sched_barrier(0);
-        const int nx = min(ks + 8, kslast);
-        HPX_FL_LOAD(gr0, gi0, dk0, br0, bi0, nx)
+        HPX_FL_LOAD(0, c + 2)
         __builtin_amdgcn_sched_barrier(0);
-        HPX_FL_MMA(gr1, gi1, dk1, br1, bi1, ks + 4)
+        HPX_FL_MMA(1)
         __builtin_amdgcn_sched_barrier(0);
-        ks += 8;
       }
-      if (nmy & 1) HPX_FL_MMA(gr0, gi0, dk0, br0, bi0, ks)
     }
 #undef HPX_FL_LOAD
 #undef HPX_FL_MMA
@@ -200,7 +210,7 @@ __device__ __forceinline__ void flat_blocks(const FlatArgs& A, const int b, doub
 
 }
 
-__global__ __launch_bounds__(256) void k_solve_flat(const FlatArgs A) {
+__global__ __launch_bounds__(256, HPX_FLAT_WGS) void k_solve_flat(const FlatArgs A) {
   extern __shared__ double lds[];
   const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int li = lane & 15, g = lane >> 4;
@@ -223,7 +233,7 @@ __global__ __launch_bounds__(256) void k_solve_flat(const FlatArgs A) {
   double* prow_i = prow_r + SW;
   double* pcol_r = prow_i + SW;
   double* pcol_i = pcol_r + 16;
-  for (int k = 0; k < 16; ++k) {
+  for (int k = (HPX_FLAT_DIAG & 1) ? 16 : 0; k < 16; ++k) {
     const double piv = sre[k * SW + k];
     if (tid == 0 && !(piv > 0.0)) bad_s = 1;
     const double rinv = 1.0 / piv;
@@ -254,7 +264,7 @@ __global__ __launch_bounds__(256) void k_solve_flat(const FlatArgs A) {
   // ---- z = Dinv (r1 - G f), written with f and the zero padding as X = [z; f; 0]
   double* Xre = A.Xre + (long)b * A.npad * TP;
   double* Xim = A.Xim + (long)b * A.npad * TP;
-  for (int kt = wave; kt < (NP >> 4); kt += 4) {
+  for (int kt = (HPX_FLAT_DIAG & 2) ? (NP >> 4) : wave; kt < (NP >> 4); kt += 4) {
     const int k0 = kt << 4;
     // A[k = k0 + li][m = 4 ks + g] = -G[k][m]
     double ga_r[4], ga_i[4];
@@ -307,7 +317,7 @@ __global__ __launch_bounds__(256) void k_solve_flat(const FlatArgs A) {
 }
 
 // The blocks alone, to global memory: out[b][16][16 + TP] planar (low-rank solver, FFT form).
-__global__ __launch_bounds__(256) void k_flat_blocks(const FlatArgs A, const double* __restrict__ cval,
+__global__ __launch_bounds__(256, HPX_FLAT_WGS) void k_flat_blocks(const FlatArgs A, const double* __restrict__ cval,
                                                      double* __restrict__ ore, double* __restrict__ oim) {
   extern __shared__ double lds[];
   const int b = blockIdx.x, NP = A.NP, SW = 16 + A.TP;
