@@ -271,39 +271,47 @@ __global__ __launch_bounds__(256, HPX_FLAT_WGS) void k_solve_flat(const FlatArgs
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       const long o = (long)min(k0 + li, N - 1) * ncol + TP + 4 * ks + g;
-      const bool live = 4 * ks + g < M;
-      ga_r[ks] = live ? -rre[o] : 0.0;
-      ga_i[ks] = live ? -rim[o] : 0.0;
+      ga_r[ks] = -rre[o];                          // columns M .. 15 of G are zero padding (k_prep)
+      ga_i[ks] = -rim[o];
     }
-    for (int tt = 0; tt < TT; ++tt) {
-      const int t = (tt << 4) + li;
-      d4 zr, zi;
+    // two t-tiles at a time: all loads of the pair are issued before the first use, and none sits
+    // under a runtime condition (P2 is zero without omega)
+    for (int tt = 0; tt < TT; tt += 2) {
+      d4 zr[2], zi[2];
 #pragma unroll
-      for (int v = 0; v < 4; ++v) {               // start from r1[k][t], k = k0 + g + 4v
-        const int k = min(k0 + HPX_ACC_ROW(g, v), N - 1);
-        double r_r = rre[(long)k * ncol + t], r_i = rim[(long)k * ncol + t];
-        if (A.has_omega) {
-          r_r = fma(iav[k], A.p2re[(long)k * TP + t], r_r);
-          r_i = fma(iav[k], A.p2im[(long)k * TP + t], r_i);
+      for (int q = 0; q < 2; ++q) {
+        const int t = (min(tt + q, TT - 1) << 4) + li;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {             // start from r1[k][t], k = k0 + g + 4v
+          const int k = min(k0 + HPX_ACC_ROW(g, v), N - 1);
+          zr[q][v] = fma(iav[k], A.p2re[(long)k * TP + t], rre[(long)k * ncol + t]);
+          zi[q][v] = fma(iav[k], A.p2im[(long)k * TP + t], rim[(long)k * ncol + t]);
         }
-        zr[v] = r_r;
-        zi[v] = r_i;
       }
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {            // B[m = 4 ks + g][t] = f[m][t]
-        const int m = 4 * ks + g;
-        const double f_r = sre[m * SW + 16 + t], f_i = sim[m * SW + 16 + t];
-        zr = mfma64(ga_r[ks], f_r, zr);
-        zr = mfma64(-ga_i[ks], f_i, zr);
-        zi = mfma64(ga_r[ks], f_i, zi);
-        zi = mfma64(ga_i[ks], f_r, zi);
+      for (int q = 0; q < 2; ++q) {
+        const int t = (min(tt + q, TT - 1) << 4) + li;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {          // B[m = 4 ks + g][t] = f[m][t]
+          const int m = 4 * ks + g;
+          const double f_r = sre[m * SW + 16 + t], f_i = sim[m * SW + 16 + t];
+          zr[q] = mfma64(ga_r[ks], f_r, zr[q]);
+          zr[q] = mfma64(-ga_i[ks], f_i, zr[q]);
+          zi[q] = mfma64(ga_r[ks], f_i, zi[q]);
+          zi[q] = mfma64(ga_i[ks], f_r, zi[q]);
+        }
       }
 #pragma unroll
-      for (int v = 0; v < 4; ++v) {
-        const int k = k0 + HPX_ACC_ROW(g, v);
-        if (k < N) {
-          Xre[(long)k * TP + t] = zr[v] * dinv[k];
-          Xim[(long)k * TP + t] = zi[v] * dinv[k];
+      for (int q = 0; q < 2; ++q) {
+        if (tt + q >= TT) continue;
+        const int t = ((tt + q) << 4) + li;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          const int k = k0 + HPX_ACC_ROW(g, v);
+          if (k < N) {
+            Xre[(long)k * TP + t] = zr[q][v] * dinv[k];
+            Xim[(long)k * TP + t] = zi[q][v] * dinv[k];
+          }
         }
       }
     }
