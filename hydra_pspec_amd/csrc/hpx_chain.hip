@@ -516,9 +516,11 @@ __global__ __launch_bounds__(256) void k_fft_resid(const ResArgs A) {
   {                                                                                   \
     const int x0_ = (xt_) << 4;                                                       \
     _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {                                \
-      const int m = 4 * ks + g;                                                       \
-      nfr[ks] = (m < M) ? fmr[(long)(x0_ + li) * M + m] : 0.0;                        \
-      nfi[ks] = (m < M) ? fmi[(long)(x0_ + li) * M + m] : 0.0;                        \
+      const int m = 4 * ks + g;                  /* unconditional (clamped) load, then the  */ \
+      const long fo_ = (long)(x0_ + li) * M + min(m, M - 1);      /* select: no branch      */ \
+      const double fr_ = fmr[fo_], fi_ = fmi[fo_];                                    \
+      nfr[ks] = (m < M) ? fr_ : 0.0;                                                  \
+      nfi[ks] = (m < M) ? fi_ : 0.0;                                                  \
     }                                                                                 \
     _Pragma("unroll") for (int v = 0; v < 4; ++v) {                                   \
       const int x_ = x0_ + HPX_ACC_ROW(g, v);                                         \
