@@ -191,3 +191,29 @@ def test_assemble_K(T, Tn, N, M, frac):
         pad = got[n:npad, :]
         assert np.array_equal(pad[:, n:npad], np.eye(npad - n)) and not pad[:, :n].any()
     gb.close()
+
+
+def test_zpotrs_size_sweep(T):
+    """Every order 1..70 and a few around the 16 / 32 block boundaries further up, with 1..40 right-hand
+    sides: exercises the 16-wide last block column, single-tile groups, 2+2 / 3 groupings and the
+    k-sliced / unsliced forms of the back substitution."""
+    from hydra_pspec_amd import hpx
+    rng = np.random.default_rng(99)
+    sizes = list(range(1, 71)) + [95, 96, 97, 111, 112, 113, 127, 128, 129, 160, 161, 255, 256, 257]
+    worst = 0.0
+    for i, n in enumerate(sizes):
+        nrhs = [1, 2, 15, 16, 17, 31, 32, 33, 40][i % 9]
+        nb = 1 + i % 3
+        A = _hpd(rng, nb, n, cond=1e3)
+        A = 0.5 * (A + np.conj(np.swapaxes(A, 1, 2)))
+        B = rng.standard_normal((nb, n, nrhs)) + 1j * rng.standard_normal((nb, n, nrhs))
+        dA, dB = _dev(T, A, T.complex128), _dev(T, B, T.complex128)
+        dX = T.zeros_like(dB)
+        info = T.zeros(nb, dtype=T.int32, device="cuda")
+        hpx.check(hpx.lib().hpx_zpotrs_batched(nb, n, nrhs, hpx.ptr(dA), hpx.ptr(dB), hpx.ptr(dX),
+                                               hpx.ptr(info), None))
+        assert not info.cpu().numpy().any(), (n, nrhs)
+        err = relerr(dX.cpu().numpy(), np.linalg.solve(A, B))
+        worst = max(worst, err)
+        assert err < 1e-10, (n, nrhs, err)
+    print(f"size sweep: worst relative error {worst:.2e} over {len(sizes)} orders")
