@@ -24,7 +24,6 @@ __device__ __forceinline__ void dft_tile(const double* __restrict__ Wre,
     ai[c] = (d4){0., 0., 0., 0.};
   }
   const int nks = NP >> 2;
-#pragma unroll 2
   for (int ks = 0; ks < nks; ++ks) {
     const int k = 4 * ks + g;
     const double wr = Wre[(long)k * NP + x0 + li];
