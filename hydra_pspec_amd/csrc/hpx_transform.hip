@@ -7,7 +7,7 @@
 namespace {
 
 // One wave: one 16-row x-tile, CTN 16-column tiles.  Grid (x-tile groups of 4, nbl).
-template <int CTN>
+template <int CTN, bool RS>
 __device__ __forceinline__ void dft_tile(const double* __restrict__ Wre,
                                          const double* __restrict__ Wim, const double wsign,
                                          const double* __restrict__ inre,
@@ -23,22 +23,43 @@ __device__ __forceinline__ void dft_tile(const double* __restrict__ Wre,
     ar[c] = (d4){0., 0., 0., 0.};
     ai[c] = (d4){0., 0., 0., 0.};
   }
+  // k-steps in pairs with two operand register sets: the loads of the next step are in flight
+  // while the current one is multiplied (nks = NP / 4 is a multiple of 4)
   const int nks = NP >> 2;
-  for (int ks = 0; ks < nks; ++ks) {
-    const int k = 4 * ks + g;
-    const double wr = Wre[(long)k * NP + x0 + li];
-    const double wi = wsign * Wim[(long)k * NP + x0 + li];
-    const double sc = rs ? (k < rs_n ? rs[k] : 0.0) : 1.0;
-#pragma unroll
-    for (int c = 0; c < CTN; ++c) {
-      const long o = (long)k * in_ld + c0 + 16 * c + li;
-      const double br = inre[o] * sc, bi = inim[o] * sc;
-      ar[c] = mfma64(wr, br, ar[c]);
-      ar[c] = mfma64(-wi, bi, ar[c]);
-      ai[c] = mfma64(wr, bi, ai[c]);
-      ai[c] = mfma64(wi, br, ai[c]);
-    }
+  double w0r, w0i, w1r, w1i, s0, s1, b0r[CTN], b0i[CTN], b1r[CTN], b1i[CTN];
+#define HPX_DFT_LOAD(wr_, wi_, sc_, br_, bi_, ks_)                                  \
+  {                                                                                 \
+    const int k_ = 4 * (ks_) + g;                                                   \
+    wr_ = Wre[(long)k_ * NP + x0 + li];                                             \
+    wi_ = wsign * Wim[(long)k_ * NP + x0 + li];                                     \
+    sc_ = RS ? rs[min(k_, rs_n - 1)] * (k_ < rs_n ? 1.0 : 0.0) : 1.0;               \
+    _Pragma("unroll") for (int c = 0; c < CTN; ++c) {                               \
+      const long o_ = (long)k_ * in_ld + c0 + 16 * c + li;                          \
+      br_[c] = inre[o_];                                                            \
+      bi_[c] = inim[o_];                                                            \
+    }                                                                               \
   }
+#define HPX_DFT_MMA(wr_, wi_, sc_, br_, bi_)                                        \
+  _Pragma("unroll") for (int c = 0; c < CTN; ++c) {                                 \
+    const double br = br_[c] * sc_, bi = bi_[c] * sc_;                              \
+    ar[c] = mfma64(wr_, br, ar[c]);                                                 \
+    ar[c] = mfma64(-wi_, bi, ar[c]);                                                \
+    ai[c] = mfma64(wr_, bi, ai[c]);                                                 \
+    ai[c] = mfma64(wi_, br, ai[c]);                                                 \
+  }
+  HPX_DFT_LOAD(w0r, w0i, s0, b0r, b0i, 0)
+  for (int ks = 0; ks < nks; ks += 2) {
+    HPX_DFT_LOAD(w1r, w1i, s1, b1r, b1i, ks + 1)
+    __builtin_amdgcn_sched_barrier(0);
+    HPX_DFT_MMA(w0r, w0i, s0, b0r, b0i)
+    __builtin_amdgcn_sched_barrier(0);
+    HPX_DFT_LOAD(w0r, w0i, s0, b0r, b0i, min(ks + 2, nks - 1))     // branch-free: re-read at the end
+    __builtin_amdgcn_sched_barrier(0);
+    HPX_DFT_MMA(w1r, w1i, s1, b1r, b1i)
+    __builtin_amdgcn_sched_barrier(0);
+  }
+#undef HPX_DFT_LOAD
+#undef HPX_DFT_MMA
 #pragma unroll
   for (int c = 0; c < CTN; ++c)
 #pragma unroll
@@ -72,12 +93,17 @@ __global__ __launch_bounds__(256, 2) void k_dft(const double* Wre, const double*
   double* oi = outim + (long)b * out_bstride;
   const double* rsb = rs ? rs + (long)b * rs_n : nullptr;
   int c0 = 0;
-  for (; c0 + 32 <= ncol; c0 += 32)
-    dft_tile<2>(Wre, Wim, wsign, ir, ii, in_ld, rsb, rs_n, orr, oi, out_ld, NP, xt * 16, c0, scale,
-                lane);
-  if (c0 < ncol)
-    dft_tile<1>(Wre, Wim, wsign, ir, ii, in_ld, rsb, rs_n, orr, oi, out_ld, NP, xt * 16, c0, scale,
-                lane);
+  if (rsb) {                                   // optional row scaling: its own instantiation
+    for (; c0 + 32 <= ncol; c0 += 32)
+      dft_tile<2, true>(Wre, Wim, wsign, ir, ii, in_ld, rsb, rs_n, orr, oi, out_ld, NP, xt * 16, c0, scale, lane);
+    if (c0 < ncol)
+      dft_tile<1, true>(Wre, Wim, wsign, ir, ii, in_ld, rsb, rs_n, orr, oi, out_ld, NP, xt * 16, c0, scale, lane);
+  } else {
+    for (; c0 + 32 <= ncol; c0 += 32)
+      dft_tile<2, false>(Wre, Wim, wsign, ir, ii, in_ld, rsb, rs_n, orr, oi, out_ld, NP, xt * 16, c0, scale, lane);
+    if (c0 < ncol)
+      dft_tile<1, false>(Wre, Wim, wsign, ir, ii, in_ld, rsb, rs_n, orr, oi, out_ld, NP, xt * 16, c0, scale, lane);
+  }
 }
 
 // Power-of-two N: in-place radix-2 decimation-in-frequency FFT in LDS, TC columns per
