@@ -272,7 +272,8 @@ def test_build_matrices_and_gcr_vs_reference(golden, tag):
     assert relerr(smp[0], xs[0]) < RTOL and relerr(smp[3], xs[1]) < RTOL
 
 
-@pytest.mark.parametrize("shape", [(3, 8, 64, 6), (2, 32, 512, 12), (2, 203, 120, 12), (2, 5, 30, 0)])
+@pytest.mark.parametrize("shape", [(3, 8, 64, 6), (2, 32, 512, 12), (2, 203, 120, 12), (2, 5, 30, 0), (2, 40, 64, 6),
+                                   (2, 70, 128, 16)])
 def test_flat_noise_solver_matches_dense(shape):
     """Unflagged baselines with flat Ninv: the structured (diagonal + rank-M border) solve of
     hpx_flat.hip against the dense Cholesky path on the same inputs -- same chains to rounding."""
@@ -401,7 +402,8 @@ def test_non_positive_definite_system_is_reported(solver):
 
 
 @pytest.mark.parametrize("shape,frac", [((3, 8, 64, 6), 0.1), ((2, 32, 512, 12), 0.15), ((2, 6, 30, 5), 0.2),
-                                        ((2, 16, 96, 20), 0.05)])
+                                        ((2, 16, 96, 20), 0.05), ((2, 40, 64, 6), 0.1), ((2, 70, 128, 16), 0.1),
+                                        ((2, 203, 120, 12), 0.1)])
 def test_lowrank_solver_matches_dense(shape, frac):
     """Flagged baselines with one noise variance over their unflagged channels: the structured solve of
     hpx_lowrank.hip (diagonal + border of width Nmodes + flagged channels) against the dense Cholesky
