@@ -543,6 +543,7 @@ __global__ __launch_bounds__(256) void k_fft_resid(const ResArgs A) {
       d4 mr = {0., 0., 0., 0.}, mi = {0., 0., 0., 0.};
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {                // A[channel x0 + li][m = 4 ks + g] = F[x][m]
+        if (4 * ks >= M) break;                       // k-steps made of padding only (M <= 12: one in four)
         mr = mfma64(cfr[ks], bfr[ks], mr);
         mr = mfma64(-cfi[ks], bfi[ks], mr);
         mi = mfma64(cfr[ks], bfi[ks], mi);
