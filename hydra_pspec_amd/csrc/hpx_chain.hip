@@ -642,6 +642,147 @@ __global__ __launch_bounds__(256) void k_fft_resid(const ResArgs A) {
   if (tid == 0) A.lnpart[(long)b * HPX_NPART + cg] = total;
 }
 
+// The same for channel counts without an in-LDS FFT (N not a power of two, e.g. the 120 channels of
+// the reference's test data) and small enough for the dense transform to be cheap (NP <= 256): s = U z
+// as a contraction with conj(Fop) on the MFMA, tile by tile (16 channels x 16 times), and each tile
+// goes straight on to the model term, residual, chi^2 and outputs from its accumulators -- s is not
+// written to and read back from HBM, and one launch replaces k_dft + k_resid.  Wave w of block j owns
+// the channel tile 4 j + w and sweeps the time tiles; it also forms sum_t |z|^2 of its own channels.
+__global__ __launch_bounds__(256) void k_dft_resid(const ResArgs A) {
+  __shared__ double red[4];
+  const int b = blockIdx.y, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, g = lane >> 4;
+  const int N = A.N, M = A.M, T = A.T, TP = A.TP, NP = A.NP, TT = TP >> 4;
+  const double* xre = A.Xre + (long)b * A.npad * TP;
+  const double* xim = A.Xim + (long)b * A.npad * TP;
+  const double* dre = A.Dre + (long)b * NP * TP;
+  const double* dim_ = A.Dim + (long)b * NP * TP;
+  const double* fmr = A.Fre + (A.fg_shared ? 0 : (long)b * N * M);
+  const double* fmi = A.Fim + (A.fg_shared ? 0 : (long)b * N * M);
+  const double* ninv = A.ninv + (long)b * N;
+  const uint8_t* fl8 = A.flags + (long)b * N;
+  const int xt = blockIdx.x * 4 + wave, x0 = xt << 4;
+  double acc = 0.0;
+  if (x0 < NP) {
+    // A operand of the model term, F[x0 + li][m = 4 ks + g]: the same for every time tile
+    double cfr[4], cfi[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const int m = 4 * ks + g;
+      const long fo = (long)min(x0 + li, N - 1) * (M > 0 ? M : 1) + min(m, (M > 0 ? M : 1) - 1);
+      const double fr = (M > 0) ? fmr[fo] : 0.0, fi = (M > 0) ? fmi[fo] : 0.0;
+      const bool ok = (m < M) && (x0 + li < N);
+      cfr[ks] = ok ? fr : 0.0;
+      cfi[ks] = ok ? fi : 0.0;
+    }
+    double cnv[4], cw[4], zz[4];
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const int x = min(x0 + HPX_ACC_ROW(g, v), N - 1);
+      cnv[v] = ninv[x];
+      cw[v] = fl8[x] ? 1.0 : 0.0;
+      zz[v] = 0.0;
+    }
+    const int nks = NP >> 2;                       // a multiple of 4
+    for (int tt = 0; tt < TT; ++tt) {
+      const int t = (tt << 4) + li;
+      // s^[x][t] = sum_k conj(Fop)[x][k] z[k][t]: A[x0 + li][k = 4 ks + g], B[k][t]; two operand sets
+      d4 sr = {0., 0., 0., 0.}, si = {0., 0., 0., 0.};
+      double w0r, w0i, w1r, w1i, b0r, b0i, b1r, b1i;
+#define HPX_DR_LOAD(wr_, wi_, br_, bi_, ks_)                          \
+  {                                                                   \
+    const int k_ = 4 * (ks_) + g;                                     \
+    wr_ = A.twre[(long)k_ * NP + x0 + li];                            \
+    wi_ = A.twim[(long)k_ * NP + x0 + li];                            \
+    br_ = xre[(long)k_ * TP + t];                                     \
+    bi_ = xim[(long)k_ * TP + t];                                     \
+  }
+#define HPX_DR_MMA(wr_, wi_, br_, bi_)    /* conj(W) z */             \
+  {                                                                   \
+    sr = mfma64(wr_, br_, sr);                                        \
+    sr = mfma64(wi_, bi_, sr);                                        \
+    si = mfma64(wr_, bi_, si);                                        \
+    si = mfma64(-wi_, br_, si);                                       \
+  }
+      HPX_DR_LOAD(w0r, w0i, b0r, b0i, 0)
+      for (int ks = 0; ks < nks; ks += 2) {
+        HPX_DR_LOAD(w1r, w1i, b1r, b1i, ks + 1)
+        __builtin_amdgcn_sched_barrier(0);
+        HPX_DR_MMA(w0r, w0i, b0r, b0i)
+        __builtin_amdgcn_sched_barrier(0);
+        HPX_DR_LOAD(w0r, w0i, b0r, b0i, min(ks + 2, nks - 1))
+        __builtin_amdgcn_sched_barrier(0);
+        HPX_DR_MMA(w1r, w1i, b1r, b1i)
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#undef HPX_DR_LOAD
+#undef HPX_DR_MMA
+      // model term F f: B[m = 4 ks + g][t] = f[m][t] (rows N + m of X)
+      d4 mr = {0., 0., 0., 0.}, mi = {0., 0., 0., 0.};
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        if (4 * ks >= M) break;
+        const int m = min(4 * ks + g, M - 1);
+        const double fr = xre[(long)(N + m) * TP + t], fi = xim[(long)(N + m) * TP + t];
+        const double br = (4 * ks + g < M) ? fr : 0.0, bi = (4 * ks + g < M) ? fi : 0.0;
+        mr = mfma64(cfr[ks], br, mr);
+        mr = mfma64(-cfi[ks], bi, mr);
+        mi = mfma64(cfr[ks], bi, mi);
+        mi = mfma64(cfi[ks], br, mi);
+      }
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const int x = x0 + HPX_ACC_ROW(g, v);
+        const long o = (long)min(x, NP - 1) * TP + t;
+        const double zr = xre[o], zi = xim[o];             // this channel's z (rows < N of X)
+        if (x < N) zz[v] += zr * zr + zi * zi;
+        if (x >= N) continue;
+        if (t >= T) {
+          if (A.any_flags) { A.Gre[(long)b * NP * TP + o] = 0.0; A.Gim[(long)b * NP * TP + o] = 0.0; }
+          continue;
+        }
+        const double s_r = sr[v] * A.isn, s_i = si[v] * A.isn;
+        const double rr = dre[o] - (s_r + mr[v]), ri = dim_[o] - (s_i + mi[v]);
+        const double w = cw[v];
+        const double c2 = (rr * rr + ri * ri) * cnv[v];
+        acc += w * c2;
+        if (A.any_flags) {
+          A.Gre[(long)b * NP * TP + o] = w * s_r;
+          A.Gim[(long)b * NP * TP + o] = w * s_i;
+        }
+        if (A.cr_out) {
+          double* q = A.cr_out + (long)b * A.cr_bstride + ((long)t * N + x) * 2;
+          q[0] = s_r;
+          q[1] = s_i;
+        }
+        if (A.chisq_out) A.chisq_out[(long)b * A.chisq_bstride + (long)t * N + x] = c2;
+      }
+    }
+    // sum_t |z_xt|^2 of the tile's channels: over the 16 lanes of a row group, then slot 0 of the
+    // partial-sum table (the other slots of these channels are zero: every channel has one owner)
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      double s = zz[v];
+      s += __shfl_xor(s, 8, 16);
+      s += __shfl_xor(s, 4, 16);
+      s += __shfl_xor(s, 2, 16);
+      s += __shfl_xor(s, 1, 16);
+      const int x = x0 + HPX_ACC_ROW(g, v);
+      if (li == 0 && x < N)
+        for (int j = 0; j < A.npart; ++j) A.bpart[((long)b * HPX_NPART + j) * N + x] = (j == 0) ? s : 0.0;
+    }
+  }
+  if (A.fg_out && blockIdx.x == 0) {
+    for (int e = tid; e < T * M; e += 256) {
+      const int t = e / M, m = e % M;
+      double* q = A.fg_out + (long)b * A.fg_bstride + (long)e * 2;
+      q[0] = xre[(long)(N + m) * TP + t];
+      q[1] = xim[(long)(N + m) * TP + t];
+    }
+  }
+  const double total = block_sum(acc, red);
+  if (tid == 0) A.lnpart[(long)b * HPX_NPART + blockIdx.x] = total;
+}
+
 // betam_k = sum_t |SK[k][t]|^2 (SK = F (w s), in the Z scratch with leading dim ncol).
 // Sixteen lanes share a row (consecutive t: one 128-byte segment per load) and reduce by shuffles;
 // a thread per row would touch 64 different cache lines with every load.
@@ -1186,6 +1327,9 @@ struct IterOut {
   long cr_bstride, fg_bstride, chisq_bstride;
 };
 
+#ifndef HPX_DFT_RESID
+#define HPX_DFT_RESID 1       // small N without an FFT: dense transform + residual in one kernel
+#endif
 #ifndef HPX_FUSE_TC
 #define HPX_FUSE_TC 8      // fewest time columns per block for which the fused transform + residual kernel is used
 #endif
@@ -1216,6 +1360,14 @@ static int post_solve(hpx_plan* p, int it_abs, const IterOut& O, hipStream_t st)
     HPX_TRY(limit.ensure(reinterpret_cast<const void*>(&k_fft_resid), lds));
     R.nbl = nbl; R.npart = npart;
     hipLaunchKernelGGL(k_fft_resid, dim3(((nbl + 7) / 8) * 8 * npart), dim3(256), lds, st, R);
+    HPX_HIP(hipGetLastError());
+    HPX_TRY(mark(p, st));
+  } else if (HPX_DFT_RESID && NP <= 256 && M <= 16 && hpx_dft_use_fft) {
+    // small N without an in-LDS FFT: dense transform fused with the residual (k_dft_resid), booked
+    // under "transform"
+    npart = (NP / 16 + 3) / 4;
+    R.nbl = nbl; R.npart = npart;
+    hipLaunchKernelGGL(k_dft_resid, dim3(npart, nbl), dim3(256), 0, st, R);
     HPX_HIP(hipGetLastError());
     HPX_TRY(mark(p, st));
   } else {
