@@ -479,3 +479,36 @@ def test_lowrank_mixed_batch_with_an_unflagged_baseline(solver):
     assert np.max(np.abs(b["signal_ps"][live] / a["signal_ps"][live] - 1)) < 1e-6
     assert np.max(np.abs(b["signal_cr"] - a["signal_cr"])) < 1e-6 * np.max(np.abs(a["signal_cr"]))
     assert np.max(np.abs(b["fg_amps"] - a["fg_amps"])) < 1e-8 * np.max(np.abs(a["fg_amps"]))
+
+
+def test_solver_agreement_random_shapes():
+    """Seeded sweep of small random shapes (odd and power-of-two channel counts, 0..8 modes, with and
+    without flags): wherever a structured solver applies it must reproduce the dense Cholesky path."""
+    from hydra_pspec_amd import pspec, synthetic
+    rng = np.random.default_rng(2024)
+    checked = {"flat": 0, "lowrank": 0}
+    for case in range(24):
+        nbl = int(rng.integers(1, 4))
+        T = int(rng.integers(2, 41))
+        N = int(rng.choice([8, 12, 16, 24, 32, 40, 64, 72, 96, 128]))
+        M = int(rng.integers(1, min(9, N // 2)))          # the DPSS modes of the recipe need M < N / 2
+        frac = float(rng.choice([0.0, 0.1, 0.25]))
+        d = synthetic.make_baselines(N, T, M, k0=100 + case, nbl=nbl, flag_frac=frac, dense=False)
+        if frac > 0:
+            assert not d["flags"].all()
+        prior = d["ps_prior"] if N >= 64 else np.zeros((2, N))
+        kw = dict(ps_initial=d["ps0"], Niter=3, seed=d["seed"], keep=("signal_cr", "fg_amps"))
+        args = (d["vis"], d["flags"], d["fgmodes"], d["ninv_diag"], prior)
+        a = pspec.gibbs_sample_with_fg_batched(*args, solver="dense", **kw)
+        forms = ["flat"] if frac == 0 else ["lowrank", "lowrank-direct"]
+        for solver in forms:
+            b = pspec.gibbs_sample_with_fg_batched(*args, solver=solver, **kw)
+            live = a["signal_ps"] > 1e-9 * np.median(a["signal_ps"])
+            tag = (case, nbl, T, N, M, frac, solver)
+            assert np.isfinite(b["signal_ps"]).all(), tag
+            assert np.max(np.abs(b["signal_ps"][live] / a["signal_ps"][live] - 1)) < 1e-6, tag
+            assert np.max(np.abs(b["signal_cr"] - a["signal_cr"])) < 1e-6 * np.max(np.abs(a["signal_cr"])), tag
+            if M > 0:
+                assert np.max(np.abs(b["fg_amps"] - a["fg_amps"])) < 1e-7 * np.max(np.abs(a["fg_amps"])), tag
+            checked["flat" if solver == "flat" else "lowrank"] += 1
+    assert checked["flat"] >= 4 and checked["lowrank"] >= 8
