@@ -145,9 +145,10 @@ int hpx_plan_set_solver(hpx_plan* p, int mode);
  * events on the run's stream; host array of HPX_NSTAGE floats
  * [assemble, factor, backsolve, transform, residual, draw]; needs
  * hpx_plan_set_profiling(p,1) before the run (adds event records only).
- * For power-of-two N <= 512 the back transform and the residual are one kernel,
- * booked under "transform" ("residual" then only holds the masked transform of
- * flagged data); HPX_SOLVER_FLAT books its solve under "factor". */
+ * For power-of-two N <= 512, and for N <= 256 without an FFT, the back transform and
+ * the residual are one kernel, booked under "transform" ("residual" then only holds
+ * the masked transform of flagged data); the structured solvers book their whole
+ * solve under "factor". */
 #define HPX_NSTAGE 6
 int hpx_plan_set_profiling(hpx_plan* p, int on);
 int hpx_plan_stage_ms(hpx_plan* p, float* ms_host);
