@@ -12,6 +12,8 @@ BASELINE.json / SURVEY 8d): 1024 synthetic baselines per GPU of shape
 N > 1 ranks each own a contiguous block of 1024 more baselines (C4 at N = 8):
 independent chains, no collective on the data path ("weak" scaling); rank 0
 reports (total baselines x K) / (max over ranks of the K-step wall time).
+Without a launcher (`WORLD_SIZE` unset) `--gpus N` makes this process a launcher
+that starts the N ranks itself and never touches a GPU.
 Inputs are resident in HBM when the timed region starts.
 
 Extra objects on the JSON line: ``roofline`` for the dominant kernel (k_factor:
@@ -114,8 +116,184 @@ def cpu_baseline_multiproc(N, T, M, flag_frac, niter=8, max_procs=16):
     if not secs:
         return None
     return dict(value=len(secs) * niter / max(secs), unit="baseline*iter/s", processes=len(secs), blas_threads=1,
-                sample=f"{len(secs)} processes x 1 baseline x {niter} iterations, slowest {max(secs):.1f} s, "
-                       f"wall incl. start-up {wall:.1f} s")
+                sample=f"{len(secs)} of {os.cpu_count()} cores: {len(secs)} processes x 1 baseline x {niter} iterations, "
+                       f"slowest {max(secs):.1f} s, wall incl. start-up {wall:.1f} s (capped at {max_procs} processes "
+                       "to bound memory and the run time of the default bench)")
+
+
+def flops_flat(N, M, T):
+    """Structured solve without flags (k_solve_flat): two MFMA contractions over the channels and the
+    back product, DESIGN.md section 4."""
+    return 8.0 * N * M * (M + 2 * T)
+
+
+def bytes_flat(N, M, T):
+    """k_solve_flat per unit: reads the invariant blocks Q (N x T) and G (N x M), writes X ((N+M) x T); c128."""
+    return 16.0 * N * (T + M) + 16.0 * (N + M) * T
+
+
+def bytes_fft_resid(N, M, T):
+    """k_fft_resid per unit: reads the solution z and the data d (N x T c128 each), writes the per-block
+    partial sums of |z|^2 (N doubles per block of 8-16 time columns)."""
+    return 2 * 16.0 * N * T + 8.0 * N * max(1, T // max(1, min(16, 4096 // N)))
+
+
+def flops_lowrank(N, M, T, f):
+    """Low-rank solve, FFT form: transforms of the border + the (M+f) Cholesky
+    and its two triangular solves."""
+    n = M + f
+    return 5.0 * N * np.log2(N) * (1 + M + 2 * T) + 4.0 / 3.0 * n ** 3 + 8.0 * n * n * T + 8.0 * N * M * (M + 2 * T)
+
+
+def roofline_for(solver, stage, nbl, N, M, T, fmax, K, traffic, peak_meas):
+    """Roofline object of the dominant kernel (stage) of the solver that actually ran.  Durations are
+    the HIP-event stage times of the timed region (hpx_plan_stage_ms), averaged per launch."""
+    if solver == "dense":
+        ms = stage["factor"] / K
+        fl = flops_factor(N, M, T)
+        ach = nbl * fl / (ms * 1e-3) / 1e12
+        return {"kernel": "k_factor (batched complex Cholesky + forward solve, FP64 MFMA)", "bound": "mfma",
+                "achieved": ach, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": ach / FP64_MFMA_PEAK_TFLOPS, "traffic": traffic,
+                "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; see profiles/pmc_traffic.json "
+                                  "for the calibration of FETCH_SIZE on this kernel's load shape" if traffic else None,
+                "peak_measured": peak_meas, "avg_launch_ms": ms, "flops_per_unit": fl, "units_per_launch": nbl}
+    # structured solvers: which stage dominates decides the kernel that is priced
+    solve_ms, post_ms = stage["factor"] / K, stage["transform"] / K
+    if solver == "flat":
+        if post_ms >= solve_ms:
+            by = bytes_fft_resid(N, M, T)
+            ach = nbl * by / (post_ms * 1e-3) / 1e9
+            return {"kernel": "k_fft_resid (back transform + model + residual + chi^2 + |z|^2 sums, one pass)",
+                    "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                    "traffic": None, "avg_launch_ms": post_ms, "bytes_per_unit": by, "units_per_launch": nbl}
+        by = bytes_flat(N, M, T)
+        ach = nbl * by / (solve_ms * 1e-3) / 1e9
+        return {"kernel": "k_solve_flat (diagonal + rank-M border system through its Schur complement)",
+                "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                "traffic": None, "avg_launch_ms": solve_ms, "bytes_per_unit": by, "flops_per_unit": flops_flat(N, M, T),
+                "units_per_launch": nbl}
+    fl = flops_lowrank(N, M, T, fmax)
+    ach = nbl * fl / (solve_ms * 1e-3) / 1e12
+    return {"kernel": "low-rank solve (k_flat_blocks, 3 x k_fft, k_lrf_gather, k_factor/k_backsolve of order M+f, "
+                      "k_lrf_fill, k_lrf_back): the 'factor' stage as a whole",
+            "bound": "mfma", "achieved": ach, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": ach / FP64_MFMA_PEAK_TFLOPS, "traffic": None, "peak_measured": peak_meas,
+            "avg_launch_ms": solve_ms, "flops_per_unit": fl, "units_per_launch": nbl,
+            "note": "a chain of short HBM/latency-bound kernels; the flop model is the solver's own "
+                    "(transforms + order-(M+f) Cholesky), not the dense factorisation's"}
+
+
+def whole_step_for(solver, value_per_gpu, N, M, T, fmax):
+    """Whole-iteration flop/byte model of the solver that ran (dense: SURVEY 8(d) F_alg / B_alg)."""
+    if solver == "dense":
+        fl, by = flops_unit(N, M, T), bytes_unit(N, M, T)
+    else:
+        post_fl = 2 * T * 5 * N * np.log2(N) + 8.0 * N * M * T
+        post_by = 3 * 16.0 * T * N + 8.0 * N
+        if solver == "flat":
+            fl, by = flops_flat(N, M, T) + post_fl, bytes_flat(N, M, T) + post_by
+        else:
+            fl = flops_lowrank(N, M, T, fmax) + post_fl
+            by = bytes_flat(N, M, T) + post_by + 2 * 16.0 * N * (1 + M + 2 * T) * 3
+    return {"flops_per_unit": fl, "bytes_per_unit": by, "tflops": value_per_gpu * fl / 1e12,
+            "frac_mfma": value_per_gpu * fl / 1e12 / FP64_MFMA_PEAK_TFLOPS,
+            "frac_hbm": value_per_gpu * by / 1e9 / HBM_PEAK_GBS}
+
+
+def spawn_ranks(args, argv):
+    """`python bench.py --gpus N` without a launcher: start N ranks of this script, one per GPU,
+    and relay rank 0's JSON line.  The parent never imports torch, never loads libhpx and never
+    touches a GPU (a process that has initialised HIP must not fork/exec GPU children); the
+    children are plain `python bench.py ...` runs with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in
+    their environment, exactly what `torch.distributed.run` would have set.  Mirrors the
+    reference's one-rank-per-block layout (run-hydra-pspec.py:268-287, :476-490)."""
+    import socket
+    import subprocess
+    import tempfile
+    n = args.gpus
+    with socket.socket() as s:          # a free rendezvous port on the loopback interface
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    out0 = tempfile.TemporaryFile(mode="w+")
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, str(Path(__file__).resolve())] + argv, env=env,
+                                      stdout=out0 if r == 0 else subprocess.DEVNULL, stderr=None))
+    # wait for all ranks; if one fails the others would sit in a barrier for ever: end them
+    codes = [None] * n
+    deadline = time.time() + float(os.environ.get("HPX_BENCH_SPAWN_TIMEOUT", "3000"))
+    while any(c is None for c in codes):
+        for r, pr in enumerate(procs):
+            if codes[r] is None:
+                codes[r] = pr.poll()
+        failed = any(c not in (None, 0) for c in codes) or time.time() > deadline
+        if failed:
+            for r, pr in enumerate(procs):     # exactly the children started above
+                if codes[r] is None:
+                    pr.terminate()
+            for r, pr in enumerate(procs):
+                if codes[r] is None:
+                    try:
+                        codes[r] = pr.wait(timeout=20)
+                    except subprocess.TimeoutExpired:
+                        pr.kill()
+                        codes[r] = pr.wait()
+            break
+        time.sleep(0.05)
+    out0.seek(0)
+    sys.stdout.write(out0.read())
+    sys.stdout.flush()
+    bad = [(r, c) for r, c in enumerate(codes) if c != 0]
+    if bad:
+        print(f"bench.py: ranks failed (rank, exit code): {bad}", file=sys.stderr)
+        return 1
+    return 0
+
+
+def init_ranks(args):
+    """(rank, world, local_rank, dist-or-None, backend).  Refuses a launcher whose world size
+    disagrees with --gpus."""
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher set WORLD_SIZE={world}")
+    return rank, world, local_rank
+
+
+def dry_run(args):
+    """Rank plumbing without a GPU (tests/test_bench_spawn.py): every rank joins a gloo group,
+    computes its block of baselines exactly as the real run does, takes part in the barrier and the
+    max-over-ranks reduction, and rank 0 prints what every rank owns."""
+    import torch
+    import torch.distributed as dist
+    from hydra_pspec_amd.sharding import split_counts
+    rank, world, local_rank = init_ranks(args)
+    if os.environ.get("HPX_BENCH_DRYRUN_FAIL_RANK") == str(rank):     # test hook: a rank that dies early
+        sys.exit(3)
+    nbl_gpu = args.nbl or CONFIGS[args.config][0]
+    counts = split_counts(nbl_gpu * world, world)
+    k0 = sum(counts[:rank])
+    blocks = [(k0, k0 + counts[rank])]
+    t = torch.tensor([0.001 * (rank + 1)], dtype=torch.float64)
+    if world > 1:
+        dist.init_process_group("gloo")
+        dist.barrier()
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        got = [None] * world
+        dist.all_gather_object(got, (rank, local_rank, k0, k0 + counts[rank], os.getpid()))
+        blocks = [(g[2], g[3]) for g in sorted(got)]
+        pids = [g[4] for g in sorted(got)]
+        dist.barrier()
+        dist.destroy_process_group()
+    else:
+        pids = [os.getpid()]
+    if rank == 0:
+        print(json.dumps({"dry_run": True, "n_gpus": world, "blocks": blocks, "pids": pids,
+                          "baselines_total": int(sum(counts)), "max_time": float(t.item())}))
 
 
 def main():
@@ -129,11 +307,17 @@ def main():
     ap.add_argument("--solver", default="dense", choices=["dense", "auto"],
                     help="dense (default): the general batched-Cholesky path the metric is about; auto: let "
                          "unflagged flat-noise batches take the structured solve (reported separately anyway)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="rank plumbing only (gloo, no GPU): print the blocks of baselines the ranks would own")
     args = ap.parse_args()
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # `python bench.py --gpus N` on its own: this process becomes a launcher and nothing else
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args, sys.argv[1:]))
+    if args.dry_run:
+        return dry_run(args)
+
+    rank, world, local_rank = init_ranks(args)
     import torch
     assert torch.cuda.is_available(), "bench.py needs a GPU"
     # rehearsal knobs (one-GPU box): HPX_BENCH_DEVICE pins every rank to one device and
@@ -163,6 +347,7 @@ def main():
     gb = pspec.GibbsBatch(d["vis"], d["flags"], d["fgmodes"], d["ninv_diag"], d["ps_prior"],
                           W + K, seed=d["seed"], solver=args.solver)
     ps0 = np.broadcast_to(d["ps0"], (nbl, N)).copy()
+    fmax = int((~np.asarray(d["flags"]).astype(bool)).sum(axis=1).max())
 
     def barrier():
         torch.cuda.synchronize()
@@ -186,6 +371,28 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
 
+    # SURVEY 8(d)'s inclusive variant of the metric: the same K steps again, this time with the
+    # random tables uploaded from host memory and P(k) / ln-posterior downloaded inside the clock
+    gb.plan.set_profiling(False)
+    uni_h, igy_h = pspec.draw_tables(T, N, W + K, d["seed"])
+    ps_host = torch.empty((nbl, K, N), dtype=torch.float64, pin_memory=True)
+    ln_host = torch.empty((nbl, K), dtype=torch.float64, pin_memory=True)
+    gb.iter_done = W
+    barrier()
+    t1 = time.perf_counter()
+    gb.set_tables(uni_h, igy_h)
+    o2 = gb.run(K, ps0=(first["ps_last"] if W > 0 else ps0))
+    ps_host.copy_(o2["signal_ps"], non_blocking=True)
+    ln_host.copy_(o2["ln_post"], non_blocking=True)
+    torch.cuda.synchronize()
+    dt_incl = time.perf_counter() - t1
+    same_chain = bool(torch.equal(o2["signal_ps"], out["signal_ps"]))
+    if dist is not None:
+        tt = torch.tensor([dt_incl], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt_incl = float(tt.item())
+    del o2
+
     # the same batch through solver="auto" (outside the timed region): unflagged flat-noise inputs
     # such as C3's then take the O(N M (M+T)) structured solve instead of the dense factorisation
     flat_extra = None
@@ -201,10 +408,13 @@ def main():
             torch.cuda.synchronize()
             dtf = time.perf_counter() - t1
             dev = float((fo["signal_ps"] / out["signal_ps"] - 1).abs().max().item())
+            fstage = gf.plan.stage_ms()
             flat_extra = {"value": nbl * K / dtf, "unit": "baseline*iter/s", "ms_per_step": dtf / K * 1e3,
-                          "stage_ms_per_step": {k: v / K for k, v in gf.plan.stage_ms().items()},
+                          "stage_ms_per_step": {k: v / K for k, v in fstage.items()},
                           "pk_max_rel_dev_vs_dense": dev,
                           "solver": gf.solver,
+                          "roofline": roofline_for(gf.solver, fstage, nbl, N, M, T, fmax, K, None, None),
+                          "whole_step": whole_step_for(gf.solver, nbl * K / dtf, N, M, T, fmax),
                           "note": "solver='auto' on the same batch: one Ninv value over the unflagged channels -> "
                                   "diagonal + border system solved through its Schur complement (hpx_flat.hip "
                                   "without flags, hpx_lowrank.hip with flags); not the headline value, which stays "
@@ -214,17 +424,18 @@ def main():
     if rank == 0:
         total_units = sum(counts) * K
         value = total_units / dt
-        fac_ms = stage["factor"] / K                        # average k_factor launch (HIP events)
-        fac_tflops = nbl * flops_factor(N, M, T) / (fac_ms * 1e-3) / 1e12
         traffic = None
-        try:   # HBM bytes per k_factor launch from the committed PMC passes (profiles/), same workload
-            pm = json.load(open(REPO / "profiles" / "pmc_traffic.json"))[args.config]["k_factor"]
-            traffic = pm["bytes_per_launch"] * nbl / pm["baselines"]
-        except Exception:
-            pass
+        if gb.solver == "dense":
+            try:   # HBM bytes per k_factor launch from the committed PMC passes (profiles/), same workload
+                pm = json.load(open(REPO / "profiles" / "pmc_traffic.json"))[args.config]["k_factor"]
+                traffic = pm["bytes_per_launch"] * nbl / pm["baselines"]
+            except Exception:
+                pass
         peak_meas = np.zeros(1)
         import ctypes
         hpx.check(hpx.lib().hpx_mfma_f64_peak(20000, peak_meas.ctypes.data_as(ctypes.c_void_p)))
+        roof = roofline_for(gb.solver, stage, nbl, N, M, T, fmax, K, traffic, float(peak_meas[0]))
+        roof["whole_step"] = whole_step_for(gb.solver, value / world, N, M, T, fmax)
         res = {
             "metric": "baseline x Gibbs-iter/sec at Nfreq=512; P(k) rtol vs CPU ref",
             "value": value, "unit": "baseline*iter/s", "n_gpus": world, "steps": K, "warmup": W,
@@ -235,20 +446,12 @@ def main():
                                    "7-bin prior, fp64",
                        "baselines_total": int(sum(counts)), "sharding": "contiguous blocks by baseline index, "
                        "no collective"},
-            "roofline": {"kernel": "k_factor (batched complex Cholesky + forward solve, FP64 MFMA)",
-                         "bound": "mfma", "achieved": fac_tflops, "peak": FP64_MFMA_PEAK_TFLOPS,
-                         "unit": "TFLOP/s", "frac": fac_tflops / FP64_MFMA_PEAK_TFLOPS, "traffic": traffic,
-                         "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, (2*FETCH+WRITE)*1024 "
-                                           "(profiles/r01_pmc_c3.txt)" if traffic else None,
-                         "peak_measured": float(peak_meas[0]),
-                         "avg_launch_ms": fac_ms, "flops_per_unit": flops_factor(N, M, T),
-                         "units_per_launch": nbl,
-                         "whole_step": {"flops_per_unit": flops_unit(N, M, T),
-                                        "bytes_per_unit": bytes_unit(N, M, T),
-                                        "tflops": value / world * flops_unit(N, M, T) / 1e12,
-                                        "frac_mfma": value / world * flops_unit(N, M, T) / 1e12
-                                        / FP64_MFMA_PEAK_TFLOPS,
-                                        "frac_hbm": value / world * bytes_unit(N, M, T) / 1e9 / HBM_PEAK_GBS}},
+            "value_incl_transfers": total_units / dt_incl,
+            "incl_transfers_note": f"the same {K} steps with the (Niter, Nfreq) random tables uploaded from host memory "
+                                   f"and P(k) + ln-posterior ({(ps_host.numel() + ln_host.numel()) * 8 / 1e6:.0f} MB per GPU) "
+                                   "copied to pinned host memory inside the clock (SURVEY 8d); same chain bit for bit: "
+                                   f"{same_chain}",
+            "roofline": roof,
             "stage_ms_per_step": {k: v / K for k, v in stage.items()},
         }
         res["config"]["solver"] = gb.solver
@@ -264,11 +467,14 @@ def main():
                           sample=mp["sample"], single_process=one)
             else:
                 cb = dict(one, multi_process=mp)
+            cb["note"] = ("the port drops the reference's per-iteration multiprocess.Pool fork and is ~1.7x faster "
+                          "than the reference itself per iteration (0.93 vs 1.60 s at (32, 512, 12) on the build "
+                          "container): a conservative baseline")
             res["cpu_baseline"] = cb
             # P(k) deviation of the GPU chain from the CPU chain on the same baselines/seed
             chk = pspec.gibbs_sample_with_fg_batched(dd["vis"], dd["flags"], dd["fgmodes"], dd["ninv_diag"],
                                                      dd["ps_prior"], ps_initial=dd["ps0"],
-                                                     Niter=ref_ps.shape[1], seed=dd["seed"])
+                                                     Niter=ref_ps.shape[1], seed=dd["seed"], solver=args.solver)
             res["pk_max_rel_dev_vs_cpu"] = float(np.max(np.abs(chk["signal_ps"] / ref_ps - 1)))
             res["speedup_vs_cpu_baseline"] = value / cb["value"]
         print(json.dumps(res))

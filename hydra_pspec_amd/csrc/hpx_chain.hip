@@ -1058,6 +1058,7 @@ extern "C" int hpx_plan_create(hpx_plan** out, int nbl, int T, int N, int M) {
   if (e == hipSuccess) e = hipMemset(p->P2re, 0, ssz * sizeof(double));
   if (e == hipSuccess) e = hipMemset(p->P2im, 0, ssz * sizeof(double));
   if (e == hipSuccess) e = hipMemset(p->info, 0, nb * sizeof(int32_t));
+  if (e == hipSuccess) e = hipDeviceSynchronize();   // null-stream memsets vs. the caller's (non-blocking) streams
   if (e != hipSuccess) {
     hpx_set_error("hpx_plan_create: memset failed: %s", hipGetErrorString(e));
     hpx_plan_destroy(p);
@@ -1148,13 +1149,19 @@ extern "C" int hpx_plan_set_static(hpx_plan* p, const double* vis, const uint8_t
   return HPX_OK;
 }
 
-extern "C" int hpx_plan_set_rng(hpx_plan* p, const double* uniforms, const double* igy, int niter) {
+extern "C" int hpx_plan_set_rng(hpx_plan* p, const double* uniforms, const double* igy, int niter,
+                                void* stream) {
   HPX_REQUIRE(p && uniforms && igy && niter > 0, "hpx_plan_set_rng: bad argument");
+  hipStream_t st = (hipStream_t)stream;
   const size_t cnt = (size_t)niter * p->N;
-  HPX_TRY(dev_alloc(p, &p->uni, cnt));
-  HPX_TRY(dev_alloc(p, &p->igy, cnt));
-  HPX_HIP(hipMemcpy(p->uni, uniforms, cnt * sizeof(double), hipMemcpyDeviceToDevice));
-  HPX_HIP(hipMemcpy(p->igy, igy, cnt * sizeof(double), hipMemcpyDeviceToDevice));
+  if (niter != p->niter_tab || !p->uni || !p->igy) {   // same length: the tables are refreshed in place
+    HPX_TRY(dev_alloc(p, &p->uni, cnt));
+    HPX_TRY(dev_alloc(p, &p->igy, cnt));
+  }
+  // on the caller's stream, and complete on return: the caller may release its tensors at once
+  HPX_HIP(hipMemcpyAsync(p->uni, uniforms, cnt * sizeof(double), hipMemcpyDeviceToDevice, st));
+  HPX_HIP(hipMemcpyAsync(p->igy, igy, cnt * sizeof(double), hipMemcpyDeviceToDevice, st));
+  HPX_HIP(hipStreamSynchronize(st));
   p->niter_tab = niter;
   return HPX_OK;
 }
@@ -1252,8 +1259,20 @@ extern "C" int hpx_plan_set_solver(hpx_plan* p, int mode) {
       for (int k = 0; k < N; ++k)
         if (!fl[(size_t)b * N + k]) list[(size_t)b * fmax + j++] = k;
     }
-    p->lr_fmax = fmax;
-    p->lr_npad = ceil16(p->M + fmax);
+    // decide the form and check its LDS need BEFORE anything is allocated on the plan
+    const int use_fft = (mode == HPX_SOLVER_LOWRANK && hpx_dft_use_fft && p->N == p->NP && (N & (N - 1)) == 0 &&
+                         N >= 32 && N <= 4096 && p->M <= 16 && hpx_flat_lds_bytes(p) <= 160 * 1024) ? 1 : 0;
+    {
+      const int old_fmax = p->lr_fmax, old_npad = p->lr_npad;
+      p->lr_fmax = fmax;
+      p->lr_npad = ceil16(p->M + fmax);
+      if (!use_fft && hpx_lowrank_lds_bytes(p) > 160 * 1024) {
+        p->lr_fmax = old_fmax;
+        p->lr_npad = old_npad;
+        hpx_set_error("hpx_plan_set_solver: Ntimes / flag count too large for the low-rank solver");
+        return HPX_EINVAL;
+      }
+    }
     const size_t nb = nbl, ns = p->lr_npad, lds_ = ns + p->TP, nblkS = (ns + HPX_NB - 1) / HPX_NB;
     HPX_TRY(dev_alloc(p, &p->lr_flist, nb * fmax));
     HPX_TRY(dev_alloc(p, &p->lr_fcount, nb));
@@ -1270,8 +1289,7 @@ extern "C" int hpx_plan_set_solver(hpx_plan* p, int mode) {
     HPX_HIP(hipMemset(p->lr_Yre, 0, nb * ns * p->TP * sizeof(double)));
     HPX_HIP(hipMemset(p->lr_Yim, 0, nb * ns * p->TP * sizeof(double)));
     // FFT form when the channel count has an FFT and the foreground block fits one MFMA tile
-    p->lr_fft = (mode == HPX_SOLVER_LOWRANK && hpx_dft_use_fft && p->N == p->NP && (N & (N - 1)) == 0 &&
-                 N >= 32 && N <= 4096 && p->M <= 16 && hpx_flat_lds_bytes(p) <= 160 * 1024) ? 1 : 0;
+    p->lr_fft = use_fft;
     if (p->lr_fft) {
       p->lr_cp = ceil16(1 + p->M);
       const size_t xw = (size_t)p->lr_cp + p->TP;
@@ -1290,7 +1308,6 @@ extern "C" int hpx_plan_set_solver(hpx_plan* p, int mode) {
       HPX_TRY(dev_alloc(p, &p->lr_Sre, nb * 16 * (16 + p->TP)));
       HPX_TRY(dev_alloc(p, &p->lr_Sim, nb * 16 * (16 + p->TP)));
     } else {
-      HPX_REQUIRE(hpx_lowrank_lds_bytes(p) <= 160 * 1024, "hpx_plan_set_solver: Ntimes / flag count too large for the low-rank solver");
       HPX_TRY(dev_alloc(p, &p->lr_Bre, nb * p->NP * (ns + p->TP)));     // [Bd | r1]
       HPX_TRY(dev_alloc(p, &p->lr_Bim, nb * p->NP * (ns + p->TP)));
       HPX_TRY(dev_alloc(p, &p->lr_Tre, nb * p->NP * ns));

@@ -194,10 +194,7 @@ class GibbsBatch:
                 hpx.ptr(d_fg) if M > 0 else None, int(fg_shared), hpx.ptr(d_pmap), hpx.ptr(d_xgrid),
                 int(len(xgrid)), int(prior_shared), NGRID, hpx.ptr(d_omega), hpx.ptr(d_fop),
                 int(self.any_flags), hpx.stream_ptr(torch)), "hpx_plan_set_static")
-            d_uni = hpx.to_dev(torch, uni, f64, self.device)
-            d_igy = hpx.to_dev(torch, igy, f64, self.device)
-            hpx.check(L.hpx_plan_set_rng(self.plan.handle, hpx.ptr(d_uni), hpx.ptr(d_igy),
-                                         self.Niter), "hpx_plan_set_rng")
+            self.set_tables(uni, igy)
             # "auto": baselines whose unflagged channels share one noise variance take a structured
             # solve (diagonal + border system): hpx_flat.hip without flags, hpx_lowrank.hip with
             # flags (border widened by one column per flagged channel); everything else the dense
@@ -228,11 +225,29 @@ class GibbsBatch:
             if self.solver != "dense":
                 mode = hpx.SOLVER_FLAT if self.solver == "flat" else \
                     (hpx.SOLVER_LOWRANK_DIRECT if direct else hpx.SOLVER_LOWRANK)
-                hpx.check(L.hpx_plan_set_solver(self.plan.handle, mode), "hpx_plan_set_solver")
+                rc = L.hpx_plan_set_solver(self.plan.handle, mode)
+                if rc == hpx.HPX_EINVAL and solver == "auto":
+                    # the C side has the last word on what a structured solver can hold (LDS of the
+                    # border form, transform sizes): "auto" then stays on the dense factorisation
+                    self.solver = "dense"
+                else:
+                    hpx.check(rc, "hpx_plan_set_solver")
         self.iter_done = 0
 
     def close(self):
         self.plan.close()
+
+    def set_tables(self, uni, igy):
+        """(Re)load the bandpower draw's random tables, each (Niter, Nfreqs): uniforms and
+        ``1/gammainccinv(Ntimes-1, U)`` (:func:`draw_tables`).  Host arrays are uploaded on the
+        current stream; the call returns when the plan owns a copy."""
+        torch = self.torch
+        assert tuple(uni.shape) == (self.Niter, self.N) and tuple(igy.shape) == (self.Niter, self.N)
+        with torch.cuda.device(self.device):
+            d_uni = hpx.to_dev(torch, uni, torch.float64, self.device)
+            d_igy = hpx.to_dev(torch, igy, torch.float64, self.device)
+            hpx.check(hpx.lib().hpx_plan_set_rng(self.plan.handle, hpx.ptr(d_uni), hpx.ptr(d_igy),
+                                                 self.Niter, hpx.stream_ptr(torch)), "hpx_plan_set_rng")
 
     def run(self, niter, ps0=None, ps_forced=None, keep=("ps", "ln_post"), thin=1, shp0=None):
         """Advance every chain by ``niter`` iterations.
@@ -323,6 +338,16 @@ class GibbsBatch:
             return out
 
 
+def make_batch(vis, flags, fgmodes, Ninv, ps_prior, Niter, seed=None, map_estimate=False, device=None,
+               solver="auto"):
+    """A :class:`GibbsBatch` from the inverse noise covariance in any form the path accepts:
+    diagonals ``(Nfreqs,)`` / ``(Nbl,Nfreqs)`` or matrices ``(Nfreqs,Nfreqs)`` / ``(Nbl,Nfreqs,Nfreqs)``
+    (reference run-hydra-pspec.py:427-438 passes ``inv(noise_cov)``)."""
+    nbl, T, N = tuple(vis.shape)
+    return GibbsBatch(vis, flags, fgmodes, _ninv_diag(Ninv, nbl, T, N), ps_prior, Niter, seed=seed,
+                      map_estimate=map_estimate, device=device, solver=solver)
+
+
 def gibbs_sample_with_fg_batched(vis, flags, fgmodes, Ninv, ps_prior, S_initial=None,
                                  ps_initial=None, Niter=100, seed=None, map_estimate=False,
                                  keep=("ps", "ln_post"), thin=1, ps_forced=None, device=None,
@@ -360,9 +385,8 @@ def gibbs_sample_with_fg_batched(vis, flags, fgmodes, Ninv, ps_prior, S_initial=
         ps_initial, resid = pspec_from_covariance(S0)
         if np.any(resid > FOURIER_FORM_TOL):     # general covariance: first iteration via Sh'
             shp0 = np.ascontiguousarray(np.broadcast_to(sqrt_cov_delay_basis(S0), (nbl, N, N)))
-    ninv = _ninv_diag(Ninv, nbl, T, N)
-    gb = GibbsBatch(vis, flags, fgmodes, ninv, ps_prior, Niter, seed=seed,
-                    map_estimate=map_estimate, device=device, solver=solver)
+    gb = make_batch(vis, flags, fgmodes, Ninv, ps_prior, Niter, seed=seed, map_estimate=map_estimate,
+                    device=device, solver=solver)
     try:
         if shp0 is not None:
             assert iter0 == 0, "a general S_initial cannot be combined with iter0 > 0"

@@ -83,8 +83,9 @@ int hpx_plan_set_static(hpx_plan* p, const double* vis, const uint8_t* flags,
  *   uniforms (niter,N) f64   U
  *   igy      (niter,N) f64   1/gammainccinv(T-1, U)  (= invgamma.ppf(U, a=T-1))
  * Both shared by all baselines of the plan (the reference driver passes the same
- * seed for every baseline, run-hydra-pspec.py:547). */
-int hpx_plan_set_rng(hpx_plan* p, const double* uniforms, const double* igy, int niter);
+ * seed for every baseline, run-hydra-pspec.py:547).  Copied on `stream`; complete on return. */
+int hpx_plan_set_rng(hpx_plan* p, const double* uniforms, const double* igy, int niter,
+                     void* stream);
 
 /* Run `niter` Gibbs iterations for all baselines, starting at table row
  * `iter0` (pspec.py:606-623; one iteration = pspec.py:377-490).

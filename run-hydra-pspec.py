@@ -67,7 +67,8 @@ def build_parser():
     p.add_argument("--clobber", action="store_true")
     p.add_argument("--write_Niter", type=int, default=100)
     p.add_argument("--resume", action="store_true",
-                   help="continue interrupted chains from the dps-eor.npy found in the output tree")
+                   help="continue chains from the checkpoints in the output tree (written every --write_Niter "
+                        "iterations); the earlier run's args.json must name the same inputs and seed")
     p.add_argument("--outputs", type=str, default="all",
                    help="'all' (the six reference files) or 'ps' (dps-eor.npy and ln-post.npy only)")
     return p
@@ -170,6 +171,7 @@ def main(argv=None):
     ps0 = np.empty((nbl, N))
     S_general = None
     ninv = np.empty((nbl, N))
+    ninv_dense = None        # (nbl,N,N) once any baseline has a non-diagonal inverse noise covariance
     fg = None
     flags_any = np.empty((nbl, N), bool)
     for b, ap in enumerate(antpairs):
@@ -196,9 +198,22 @@ def main(argv=None):
         else:
             ps0[b] = default_ps0 if default_ps0 is not None else float(N)   # sigcov0 = eye(N) (:425)
         if args.noise_cov:
-            ninv[b] = np.diag(np.linalg.inv(load_aux(args.noise_cov, args.noise_cov_file, bl))).real
+            # the reference hands the FULL inverse to the sampler (run-hydra-pspec.py:436); a matrix
+            # with off-diagonal terms is never reduced to its diagonal here
+            Ni_b = np.linalg.inv(load_aux(args.noise_cov, args.noise_cov_file, bl))
+            ninv[b] = np.diag(Ni_b).real
+            if np.any(Ni_b - np.diag(np.diag(Ni_b)) != 0):
+                if ninv_dense is None:
+                    ninv_dense = np.zeros((nbl, N, N), dtype=complex)
+                    for bb in range(b):
+                        ninv_dense[bb] = np.diag(ninv[bb])
+                ninv_dense[b] = Ni_b
+            elif ninv_dense is not None:
+                ninv_dense[b] = np.diag(ninv[b])
         else:
             ninv[b] = default_ninv[b] if default_ninv is not None else 1.0 / 10.0 ** 2   # :438
+            if ninv_dense is not None:
+                ninv_dense[b] = np.diag(ninv[b])
         if args.fgmodes:
             # default file name of scripts/calc-vis-cov-matrices.py (reference :444-449)
             default_name = f"evecs-{freq_str}.npy" if freq_str else "fgmodes.npy"
@@ -223,6 +238,11 @@ def main(argv=None):
     else:
         dirname = f"results-seed-{args.seed}-Niter-{args.Niter}"
     results = out_dir / dirname
+    # --resume needs the earlier run's arguments before this run overwrites args.json
+    old_args = None
+    if args.resume and (results / "args.json").exists():
+        with open(results / "args.json") as f:
+            old_args = json.load(f)
     if rank == 0:
         if results.exists() and not args.clobber and not args.resume and world == 1:
             # keep earlier results: move them aside under their modification time (reference :343-345,
@@ -232,68 +252,106 @@ def main(argv=None):
             mtime = datetime.fromtimestamp(os.path.getmtime(results)).isoformat()
             shutil.move(str(results), str(results.with_name(f"{results.name}-{mtime}")))
         results.mkdir(parents=True, exist_ok=True)
-        with open(results / "args.json", "w") as f:
-            json.dump(vars(args), f, indent=2)
 
     # ---- sampling -----------------------------------------------------------------------
     import torch
     torch.cuda.set_device(local_rank)
-    keep = ("signal_cr", "fg_amps", "chisq") if args.outputs == "all" else ()
+    all_out = args.outputs == "all"
+    keep = ("signal_cr", "fg_amps", "chisq") if all_out else ()
     t0 = time.perf_counter()
     if S_general is not None and np.any(np.abs(S_general).sum(axis=(1, 2)) == 0):
         raise SystemExit("mixing Fourier-form and general sigcov0 across baselines is not supported")
-    # --resume: continue from the checkpoints in the output tree (all baselines of the rank must
-    # have been interrupted at the same iteration)
-    iter0, previous = 0, None
-    if args.resume:
+    Niter = 1 if args.map_estimate else int(args.Niter)
+    chunk = max(1, int(args.write_Niter))
+    names = {"signal_ps": "dps-eor.npy", "ln_post": "ln-post.npy"}
+    if all_out:
+        names.update(signal_cr="gcr-eor.npy", fg_amps="fg-amps.npy", chisq="chisq.npy")
+
+    # --resume: continue from the checkpoints in the output tree.  They must come from the same
+    # inputs and seed (args.json); baselines caught mid-write at different iterations are rolled
+    # back to the earliest one (the chain is deterministic, nothing is lost but time).
+    iter0, hist = 0, None
+    if args.resume and not args.map_estimate and S_general is None:
+        if old_args is None:
+            raise SystemExit(f"--resume: no args.json of an earlier run in {results}")
+        run_only = {"Niter", "resume", "clobber", "verbose", "write_Niter", "Nproc", "config", "outputs"}
+        diff = sorted(k for k in vars(args) if k not in run_only and old_args.get(k) != getattr(args, k))
+        if diff:
+            raise SystemExit("--resume: the earlier run in " + str(results) + " used different "
+                             + ", ".join(f"{k} ({old_args.get(k)!r} != {getattr(args, k)!r})" for k in diff)
+                             + ": refusing to splice two different chains")
         previous = []
         for ap in antpairs:
             bdir = results / f"{ap[0]}-{ap[1]}"
-            names = ("dps-eor.npy", "ln-post.npy") + (("gcr-eor.npy", "fg-amps.npy", "chisq.npy")
-                                                       if args.outputs == "all" else ())
-            if not all((bdir / n).exists() for n in names):
+            if not all((bdir / n).exists() for n in names.values()):
                 previous = None
                 break
-            previous.append({n: np.load(bdir / n) for n in names})
+            previous.append({k: np.load(bdir / n) for k, n in names.items()})
         if previous:
-            ks = {len(pv["dps-eor.npy"]) for pv in previous}
-            if len(ks) == 1 and 0 < next(iter(ks)) < args.Niter and S_general is None:
-                iter0 = next(iter(ks))
-                ps0 = np.stack([pv["dps-eor.npy"][-1] for pv in previous])
-            else:
-                previous = None
-    out = pspec.gibbs_sample_with_fg_batched(
-        vis, flags_any, fg, ninv, ps_prior,
-        S_initial=S_general, ps_initial=None if S_general is not None else ps0,
-        Niter=args.Niter, seed=args.seed, map_estimate=args.map_estimate, keep=keep, iter0=iter0)
-    if iter0:
-        key = {"signal_ps": "dps-eor.npy", "ln_post": "ln-post.npy", "signal_cr": "gcr-eor.npy",
-               "fg_amps": "fg-amps.npy", "chisq": "chisq.npy"}
-        for name, fn in key.items():
-            if name in out:
-                out[name] = np.concatenate([np.stack([pv[fn] for pv in previous]), out[name]], axis=1)
-    t_process = time.perf_counter() - t0
+            k_done = min(len(pv["signal_ps"]) for pv in previous)
+            if any(len(pv[k]) < k_done for pv in previous for k in names):
+                k_done = min(len(pv[k]) for pv in previous for k in names)
+            if 0 < k_done < Niter:
+                iter0 = k_done
+                hist = {k: [np.stack([pv[k][:k_done] for pv in previous])] for k in names}
+                ps0 = hist["signal_ps"][0][:, -1].copy()
+    if rank == 0:
+        with open(results / "args.json", "w") as f:
+            json.dump(vars(args), f, indent=2)
+    if hist is None:
+        hist = {k: [] for k in names}
 
-    write_times, ant_strs = [], []
+    Ninv_arg = ninv if ninv_dense is None else ninv_dense
+    gb = pspec.make_batch(vis, flags_any, fg, Ninv_arg, ps_prior, Niter, seed=args.seed,
+                          map_estimate=args.map_estimate)
     fop = utils.fourier_operator(N)
-    for b, ap in enumerate(antpairs):
-        bdir = results / f"{ap[0]}-{ap[1]}"
-        bdir.mkdir(parents=True, exist_ok=True)
-        tw = time.perf_counter()
-        np.save(bdir / "dps-eor.npy", out["signal_ps"][b])
-        np.save(bdir / "ln-post.npy", out["ln_post"][b])
-        if args.outputs == "all":
-            S_last = pspec.covariance_from_pspec(out["signal_ps"][b, -1] / N ** 2, fop)
-            niter = out["signal_ps"].shape[1]
-            # the reference writes rows [:Niter] of the current (N,N) covariance when the last
-            # write is a periodic one, the full matrix otherwise (pspec.py:625-651)
-            cov = S_last[:niter] if niter % args.write_Niter == 0 else S_last
-            np.save(bdir / "gcr-eor.npy", out["signal_cr"][b])
-            np.save(bdir / "cov-eor.npy", cov)
-            np.save(bdir / "fg-amps.npy", out["fg_amps"][b])
-            np.save(bdir / "chisq.npy", out["chisq"][b])
-        write_times.append(time.perf_counter() - tw)
-        ant_strs.append(f"{ap[0]}_{ap[1]}")
+    write_times, ant_strs = [0.0] * nbl, [f"{ap[0]}_{ap[1]}" for ap in antpairs]
+
+    def write_all(done, periodic):
+        """The per-baseline files with everything sampled so far (reference pspec.py:625-653:
+        every write_Niter iterations and at the end).  Each file is replaced atomically, so a crash
+        leaves either the previous checkpoint or the new one, never a torn file."""
+        full = {k: (v[0] if len(v) == 1 else np.concatenate(v, axis=1)) for k, v in hist.items()}
+        for k in full:
+            hist[k] = [full[k]]
+        for b, ap in enumerate(antpairs):
+            bdir = results / f"{ap[0]}-{ap[1]}"
+            bdir.mkdir(parents=True, exist_ok=True)
+            tw = time.perf_counter()
+            arrays = {names[k]: full[k][b] for k in names}
+            if all_out:
+                S_last = pspec.covariance_from_pspec(full["signal_ps"][b, -1] / N ** 2, fop)
+                # rows [:done] of the current (N,N) covariance on a periodic write, the full matrix
+                # on the final one (the reference's slicing quirk, pspec.py:630 vs :648)
+                arrays["cov-eor.npy"] = S_last[:done] if periodic else S_last
+            for fn, arr in arrays.items():
+                tmp = bdir / (fn + ".tmp.npy")
+                np.save(tmp, arr)
+                os.replace(tmp, bdir / fn)
+            write_times[b] += time.perf_counter() - tw
+
+    done = gb.iter_done = iter0
+    t_process = 0.0
+    try:
+        while done < Niter:
+            n = min(chunk - done % chunk, Niter - done)
+            tp = time.perf_counter()
+            if done == 0 and S_general is not None:
+                shp0 = np.stack([pspec.sqrt_cov_delay_basis(S_general[b]) for b in range(nbl)])
+                out = gb.run(n, shp0=shp0, keep=keep)
+            else:
+                out = gb.run(n, ps0=ps0 if done == iter0 else None, keep=keep)
+            for k in names:
+                hist[k].append(out[k].cpu().numpy())
+            t_process += time.perf_counter() - tp
+            done += n
+            if done % chunk == 0 or done == Niter:
+                write_all(done, periodic=(done % chunk == 0))
+            if args.verbose and rank == 0:
+                print(f"iteration {done}/{Niter}: {nbl * n / (time.perf_counter() - tp):.1f} baseline*iter/s", flush=True)
+    finally:
+        gb.close()
+    _ = t0
 
     if rank == 0:
         total = time.perf_counter() - t_start

@@ -157,3 +157,37 @@ def test_driver_output_naming_and_no_clobber(tmp_path):
     assert len([p for p in tmp_path.iterdir() if p.name.startswith(res.name)]) == 2
     assert drv.main(common + ["--dirname", "run", "--map_estimate"]) == 0
     assert (tmp_path / "run-map-estimate" / "0-1" / "dps-eor.npy").exists()
+
+
+@pytest.mark.gpu
+def test_driver_periodic_checkpoints_and_resume_guard(tmp_path, monkeypatch):
+    """--write_Niter checkpoints are on disk while the run is still going (reference pspec.py:625-636),
+    an interrupted run continues from them to the chain of an uninterrupted one, and --resume refuses
+    an output tree written with another seed."""
+    from hydra_pspec_amd import pspec
+    drv = _driver()
+    common = ["--synthetic", "2,8,32", "--Nfgmodes", "4", "--ps_prior_lo", "0.1", "--ps_prior_hi", "2",
+              "--out_dir", str(tmp_path), "--write_Niter", "2"]
+    assert drv.main(common + ["--seed", "5", "--Niter", "6", "--dirname", "full"]) == 0
+    # crash after the second chunk: the third gb.run raises
+    real_run, calls = pspec.GibbsBatch.run, []
+
+    def dying_run(self, niter, **kw):
+        calls.append(niter)
+        if len(calls) == 3:
+            raise RuntimeError("simulated crash")
+        return real_run(self, niter, **kw)
+    monkeypatch.setattr(pspec.GibbsBatch, "run", dying_run)
+    with pytest.raises(RuntimeError, match="simulated crash"):
+        drv.main(common + ["--seed", "5", "--Niter", "6", "--dirname", "part"])
+    monkeypatch.setattr(pspec.GibbsBatch, "run", real_run)
+    assert calls == [2, 2, 2]
+    for k in (1, 2):
+        assert np.load(tmp_path / "part" / f"0-{k}" / "dps-eor.npy").shape == (4, 32)
+        assert np.load(tmp_path / "part" / f"0-{k}" / "cov-eor.npy").shape == (4, 32)     # rows [:done], periodic write
+    with pytest.raises(SystemExit, match="seed"):
+        drv.main(common + ["--seed", "6", "--Niter", "6", "--dirname", "part", "--resume"])
+    assert drv.main(common + ["--seed", "5", "--Niter", "6", "--dirname", "part", "--resume"]) == 0
+    for k in (1, 2):
+        for f in ("dps-eor.npy", "gcr-eor.npy", "ln-post.npy", "chisq.npy", "fg-amps.npy", "cov-eor.npy"):
+            assert np.array_equal(np.load(tmp_path / "part" / f"0-{k}" / f), np.load(tmp_path / "full" / f"0-{k}" / f)), f

@@ -446,7 +446,7 @@ def test_plan_setters_replace_their_buffers():
     for _ in range(3):
         hpx.check(L.hpx_plan_set_solver(gb.plan.handle, hpx.SOLVER_LOWRANK))
         u = torch.rand(3, 64, dtype=torch.float64, device="cuda")
-        hpx.check(L.hpx_plan_set_rng(gb.plan.handle, hpx.ptr(u), hpx.ptr(u), 3))
+        hpx.check(L.hpx_plan_set_rng(gb.plan.handle, hpx.ptr(u), hpx.ptr(u), 3, None))
     assert gb.plan.bytes() == size
     gb.close()
     again = pspec.GibbsBatch(d["vis"], d["flags"], d["fgmodes"], d["ninv_diag"], d["ps_prior"], 3, seed=4,
