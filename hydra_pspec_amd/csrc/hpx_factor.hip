@@ -30,6 +30,18 @@
 #define HPX_RT3 1
 #endif
 #define HPX_INL __forceinline__
+// Complex products as THREE real MFMAs (Gauss / "3M"): with p = pr + i pi, b = br + i bi,
+//   conj(p) b = (S1 + S2) + i (S1 - S2 - S3),  S1 = pr br, S2 = pi bi, S3 = (pr + pi)(br - bi),
+// so a tile keeps three accumulators (A1 = Kre/2 - S1, A2 = Kre/2 - S2, A3 = Kim + S3;
+// re = A1 + A2, im = A1 - A2 + A3) and a k-step costs 3 MFMAs and one fp64 add per operand
+// instead of 4 MFMAs.  Norm-wise as accurate as the four-product form (the imaginary part
+// carries an error of a few ulp of |p||b| rather than of |Im|; Higham, "Stability of a method
+// for multiplying complex matrices with three real matrix multiplications", 1992), which is
+// what a Cholesky factorisation's backward error bound needs.  HPX_3M=0 builds the 4-product
+// kernels (A/B measurements).
+#ifndef HPX_3M
+#define HPX_3M 1
+#endif
 #ifndef HPX_WGS
 #define HPX_WGS 2          // workgroups per CU the register budget is set for
 #endif
@@ -98,6 +110,55 @@ struct gen_signal {             // the part of hpx_gen the diagonal block needs 
   int rmin;
 };
 
+#if HPX_3M
+// Tail of a tile group in the three-product form: turn the accumulators into the tiles, multiply by
+// W = conj(Ljj^-1) (LDS) and store.
+template <int CT, int RT>
+__device__ HPX_INL void trsm_store_3m(d4 (&a1)[RT][CT], d4 (&a2)[RT][CT], d4 (&a3)[RT][CT],
+                                      double* __restrict__ Lre, double* __restrict__ Lim, const int npad,
+                                      const int c0, const int r0, const int rstride, const double* Wre,
+                                      const double* Wim, const int lane) {
+  const int li = lane & 15, g = lane >> 4;
+  // the tiles themselves, in place: a1 <- re, a2 <- im, a3 <- re + im;  then X^T = W acc^T again
+  // as three real products per complex one: X1 = wr re, X2 = wi im, X3 = (wr + wi)(re + im);
+  // Re X = X1 - X2, Im X = X3 - X1 - X2.  Each 16-column result is stored as soon as it is done.
+#pragma unroll
+  for (int t = 0; t < RT; ++t)
+#pragma unroll
+    for (int ci = 0; ci < CT; ++ci) {
+      const d4 re_ = a1[t][ci] + a2[t][ci];
+      const d4 im_ = a1[t][ci] - a2[t][ci] + a3[t][ci];
+      a1[t][ci] = re_;
+      a2[t][ci] = im_;
+      a3[t][ci] = re_ + im_;
+    }
+#pragma unroll
+  for (int t = 0; t < RT; ++t) {
+#pragma unroll
+    for (int ci = 0; ci < CT; ++ci) {
+      d4 x1 = {0., 0., 0., 0.}, x2 = {0., 0., 0., 0.}, x3 = {0., 0., 0., 0.};
+#pragma unroll
+      for (int cj = 0; cj <= ci; ++cj)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          const int kq = 16 * cj + HPX_ACC_ROW(g, v);
+          const double wr = Wre[(16 * ci + li) * WLD + kq];
+          const double wi = Wim[(16 * ci + li) * WLD + kq];
+          x1 = mfma64(wr, a1[t][cj][v], x1);
+          x2 = mfma64(wi, a2[t][cj][v], x2);
+          x3 = mfma64(wr + wi, a3[t][cj][v], x3);
+        }
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const long off = HPX_LIDX(r0 + t * rstride + li, c0 + 16 * ci + HPX_ACC_ROW(g, v), npad);
+        Lre[off] = x1[v] - x2[v];
+        Lim[off] = x3[v] - x1[v] - x2[v];
+      }
+    }
+  }
+}
+#endif
+
 // RT off-diagonal 16-row tiles (rows r0 + i*rstride) of block column (c0, CT*16 wide),
 // processed together so that the panel operand conj(L[c][k]) is fetched once per k-step
 // for all of them (the panel rows are the re-read-heavy operand: without this reuse every
@@ -110,7 +171,11 @@ __device__ HPX_INL void offdiag_group(double* __restrict__ Lre, double* __restri
                                               const hpx_gen& G, long long* st_) {
   const int li = lane & 15, g = lane >> 4;
   HPX_T0();
+#if HPX_3M
+  d4 a1[RT][CT], a2[RT][CT], a3[RT][CT];
+#else
   d4 ar[RT][CT], ai[RT][CT];
+#endif
   // acc^T[c][r] -= conj(L[c][k]) * L[r][k].  c0 is a multiple of 32, so the k range is a
   // whole number of chunk pairs; operands of the next chunk are fetched into the other
   // register buffer while the current one feeds the MFMAs (explicit double buffering:
@@ -136,6 +201,22 @@ __device__ HPX_INL void offdiag_group(double* __restrict__ Lre, double* __restri
       pi_[ci][s] = HPX_LDA((base_im), s * kstep + aoff + ci * ptile);            \
     }                                                                            \
   }
+#if HPX_3M
+#define HPX_MMA_CHUNK(br_, bi_, pr_, pi_)                                        \
+  _Pragma("unroll") for (int s = 0; s < KC; ++s) {                               \
+    double bd_[RT];                                                              \
+    _Pragma("unroll") for (int t = 0; t < RT; ++t) bd_[t] = br_[t][s] - bi_[t][s]; \
+    _Pragma("unroll") for (int ci = 0; ci < CT; ++ci) {                          \
+      const double npr = -pr_[ci][s], npi = -pi_[ci][s];                         \
+      const double psm = pr_[ci][s] + pi_[ci][s];                                \
+      _Pragma("unroll") for (int t = 0; t < RT; ++t) {                           \
+        a1[t][ci] = mfma64(npr, br_[t][s], a1[t][ci]);                           \
+        a2[t][ci] = mfma64(npi, bi_[t][s], a2[t][ci]);                           \
+        a3[t][ci] = mfma64(psm, bd_[t], a3[t][ci]);                              \
+      }                                                                          \
+    }                                                                            \
+  }
+#else
 #define HPX_MMA_CHUNK(br_, bi_, pr_, pi_)                                        \
   _Pragma("unroll") for (int s = 0; s < KC; ++s)                                 \
     _Pragma("unroll") for (int ci = 0; ci < CT; ++ci) {                          \
@@ -147,6 +228,7 @@ __device__ HPX_INL void offdiag_group(double* __restrict__ Lre, double* __restri
         ai[t][ci] = mfma64(pi_[ci][s], br_[t][s], ai[t][ci]);                    \
       }                                                                          \
     }
+#endif
   // the first chunk's operands are requested before the accumulators are initialised, so
   // that the two load latencies overlap
   if (nch > 0) {
@@ -162,15 +244,28 @@ __device__ HPX_INL void offdiag_group(double* __restrict__ Lre, double* __restri
         for (int v = 0; v < 4; ++v) {
           double vr, vi;
           hpx_gen_signal(G, r0 + t * rstride + li, c0 + 16 * ci + HPX_ACC_ROW(g, v), vr, vi);
+#if HPX_3M
+          a1[t][ci][v] = 0.5 * vr;
+          a2[t][ci][v] = 0.5 * vr;
+          a3[t][ci][v] = vi;
+#else
           ar[t][ci][v] = vr;
           ai[t][ci][v] = vi;
+#endif
         }
       } else {
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
           const long off = HPX_LIDX(r0 + t * rstride + li, c0 + 16 * ci + HPX_ACC_ROW(g, v), npad);
+#if HPX_3M
+          const double vr = Lre[off];
+          a1[t][ci][v] = 0.5 * vr;
+          a2[t][ci][v] = 0.5 * vr;
+          a3[t][ci][v] = Lim[off];
+#else
           ar[t][ci][v] = Lre[off];
           ai[t][ci][v] = Lim[off];
+#endif
         }
       }
     }
@@ -201,6 +296,9 @@ __device__ HPX_INL void offdiag_group(double* __restrict__ Lre, double* __restri
 #undef HPX_MMA_CHUNK
   HPX_TICK(5);
   // X^T = W * acc^T,  W = conj(Ljj^-1) lower triangular (LDS), acc^T as B operand
+#if HPX_3M
+  trsm_store_3m<CT, RT>(a1, a2, a3, Lre, Lim, npad, c0, r0, rstride, Wre, Wim, lane);
+#else
 #pragma unroll
   for (int t = 0; t < RT; ++t) {
     d4 xr[CT], xi[CT];
@@ -230,8 +328,153 @@ __device__ HPX_INL void offdiag_group(double* __restrict__ Lre, double* __restri
         Lim[off] = xi[ci][v];
       }
   }
+#endif
   HPX_TICK(6);
 }
+
+// Measured round 2 (C3, 1024 baselines; tools/build_variant.sh + tools/stamps.py): fusing the next
+// diagonal block's update into the pass cuts k_factor's FETCH_SIZE by 12 % and the separate partial
+// phase from 8.9 % to 1.8 % of a wave's cycles, but the closing barrier and the per-group fixed costs
+// take it back (4.69 ms fused vs 4.58); dealing groups by equal COUNT per wave is worse still (5.21):
+// both stay available as build switches, off by default.
+#ifndef HPX_FUSE_DIAG
+#define HPX_FUSE_DIAG 0
+#endif
+#ifndef HPX_BALANCED
+#define HPX_BALANCED 0
+#endif
+#if HPX_3M && HPX_FUSE_DIAG
+// The two row tiles directly below block column (c0, 32 wide) -- rows c1 = c0 + 32 .. c1 + 31, i.e.
+// the rows of the NEXT diagonal block -- together with that block's own update over the same
+// columns k < c0:  D_next^T[c][r] -= sum_k conj(L[c1 + c][k]) L[c1 + r][k]  needs exactly the two
+// row-tile operands this pass streams anyway.  One wave takes both tiles and keeps, besides
+// their 2 x 2 tile accumulators, the three lower tiles of D_next (tile 0 = (0,0), 1 = (0,1),
+// 2 = (1,1) as in diag_tile); the sums are parked in sh.part for diag_panel of the next block
+// column, which then only adds the last 32 columns.  Saves re-reading 1 KiB x c0 per block column
+// from HBM (4.5 MB per baseline at N = 512) and the separate diag_partial_next phase.
+template <bool GEN>
+__device__ HPX_INL void offdiag_diag_group(double* __restrict__ Lre, double* __restrict__ Lim,
+                                           lds_FactorShared* __restrict__ shp, const int npad,
+                                           const int c0, const double* Wre, const double* Wim,
+                                           const int lane, const hpx_gen& G, long long* st_) {
+  constexpr int CT = 2, RT = 2;
+  const int li = lane & 15, g = lane >> 4;
+  const int r0 = c0 + 32;
+  HPX_T0();
+  d4 a1[RT][CT], a2[RT][CT], a3[RT][CT];
+  d4 q1[3], q2[3], q3[3];
+  const int nch = c0 >> 2;                     // k-steps (c0 is a multiple of 32: even)
+  const double* pre = Lre + (long)g * 32;
+  const double* pim = Lim + (long)g * 32;
+  const long kstep = 128;
+  const long ptile = (long)npad * 32;
+  const long boff = (long)(r0 >> 4) * ptile + li;
+  const long aoff = (long)(c0 >> 4) * ptile + li;
+  double b0r[RT], b0i[RT], b1r[RT], b1i[RT], p0r[CT], p0i[CT], p1r[CT], p1i[CT];
+#define HPX_FD_LOAD(br_, bi_, pr_, pi_, base_re, base_im)                        \
+  _Pragma("unroll") for (int t = 0; t < RT; ++t) {                               \
+    br_[t] = HPX_LD((base_re), boff + t * ptile);                                \
+    bi_[t] = HPX_LD((base_im), boff + t * ptile);                                \
+  }                                                                              \
+  _Pragma("unroll") for (int ci = 0; ci < CT; ++ci) {                            \
+    pr_[ci] = HPX_LDA((base_re), aoff + ci * ptile);                             \
+    pi_[ci] = HPX_LDA((base_im), aoff + ci * ptile);                             \
+  }
+#define HPX_FD_MMA(br_, bi_, pr_, pi_)                                           \
+  {                                                                              \
+    double bd_[RT], bs_[RT];                                                     \
+    _Pragma("unroll") for (int t = 0; t < RT; ++t) {                             \
+      bd_[t] = br_[t] - bi_[t];                                                  \
+      bs_[t] = br_[t] + bi_[t];                                                  \
+    }                                                                            \
+    _Pragma("unroll") for (int ci = 0; ci < CT; ++ci) {                          \
+      const double npr = -pr_[ci], npi = -pi_[ci];                               \
+      const double psm = pr_[ci] + pi_[ci];                                      \
+      _Pragma("unroll") for (int t = 0; t < RT; ++t) {                           \
+        a1[t][ci] = mfma64(npr, br_[t], a1[t][ci]);                              \
+        a2[t][ci] = mfma64(npi, bi_[t], a2[t][ci]);                              \
+        a3[t][ci] = mfma64(psm, bd_[t], a3[t][ci]);                              \
+      }                                                                          \
+    }                                                                            \
+    /* next diagonal block: (c-tile, r-tile) = (0,0), (0,1), (1,1) */            \
+    q1[0] = mfma64(-br_[0], br_[0], q1[0]);                                      \
+    q2[0] = mfma64(-bi_[0], bi_[0], q2[0]);                                      \
+    q3[0] = mfma64(bs_[0], bd_[0], q3[0]);                                       \
+    q1[1] = mfma64(-br_[0], br_[1], q1[1]);                                      \
+    q2[1] = mfma64(-bi_[0], bi_[1], q2[1]);                                      \
+    q3[1] = mfma64(bs_[0], bd_[1], q3[1]);                                       \
+    q1[2] = mfma64(-br_[1], br_[1], q1[2]);                                      \
+    q2[2] = mfma64(-bi_[1], bi_[1], q2[2]);                                      \
+    q3[2] = mfma64(bs_[1], bd_[1], q3[2]);                                       \
+  }
+  if (nch > 0) {
+    HPX_FD_LOAD(b0r, b0i, p0r, p0i, pre, pim)
+  }
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int t = 0; t < 3; ++t) {
+    q1[t] = (d4){0., 0., 0., 0.};
+    q2[t] = (d4){0., 0., 0., 0.};
+    q3[t] = (d4){0., 0., 0., 0.};
+  }
+#pragma unroll
+  for (int t = 0; t < RT; ++t)
+#pragma unroll
+    for (int ci = 0; ci < CT; ++ci) {
+      if (GEN && r0 + 16 * t < G.rmin) {
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          double vr, vi;
+          hpx_gen_signal(G, r0 + 16 * t + li, c0 + 16 * ci + HPX_ACC_ROW(g, v), vr, vi);
+          a1[t][ci][v] = 0.5 * vr;
+          a2[t][ci][v] = 0.5 * vr;
+          a3[t][ci][v] = vi;
+        }
+      } else {
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          const long off = HPX_LIDX(r0 + 16 * t + li, c0 + 16 * ci + HPX_ACC_ROW(g, v), npad);
+          const double vr = Lre[off];
+          a1[t][ci][v] = 0.5 * vr;
+          a2[t][ci][v] = 0.5 * vr;
+          a3[t][ci][v] = Lim[off];
+        }
+      }
+    }
+  HPX_TICK(4);
+  if (nch > 0) {
+    for (int ch = 0; ch < nch; ch += 2) {
+      const double* qre = pre + kstep;
+      const double* qim = pim + kstep;
+      HPX_FD_LOAD(b1r, b1i, p1r, p1i, qre, qim)
+      __builtin_amdgcn_sched_barrier(0);
+      HPX_FD_MMA(b0r, b0i, p0r, p0i)
+      __builtin_amdgcn_sched_barrier(0);
+      const long adv = (ch + 2 < nch) ? 2 * kstep : 0;     // branch-free tail (see offdiag_group)
+      pre += adv;
+      pim += adv;
+      HPX_FD_LOAD(b0r, b0i, p0r, p0i, pre, pim)
+      __builtin_amdgcn_sched_barrier(0);
+      HPX_FD_MMA(b1r, b1i, p1r, p1i)
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+#undef HPX_FD_LOAD
+#undef HPX_FD_MMA
+  HPX_TICK(5);
+  // park the next diagonal block's sums (what diag_partial_next would have produced)
+#pragma unroll
+  for (int t = 0; t < 3; ++t)
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      shp->part[t][0][v][lane] = q1[t][v] + q2[t][v];
+      shp->part[t][1][v][lane] = q1[t][v] - q2[t][v] + q3[t][v];
+    }
+  HPX_TICK(1);
+  trsm_store_3m<CT, RT>(a1, a2, a3, Lre, Lim, npad, c0, r0, 16, Wre, Wim, lane);
+  HPX_TICK(6);
+}
+#endif
 
 template <bool GEN>
 __device__ HPX_OUTLINE void offdiag_narrow(double* Lre, double* Lim, const int npad, const int c0,
@@ -291,6 +534,18 @@ __device__ __forceinline__ void diag_tile(const glb_f64* __restrict__ Lre,
       yi[buf][u] = pBi[o_];                                    \
     }                                                          \
   }
+#if HPX_3M
+  d4 q1 = {0., 0., 0., 0.}, q2 = {0., 0., 0., 0.}, q3 = {0., 0., 0., 0.};   // -S1, -S2, S3 (see HPX_3M)
+#define HPX_DT_MUL(buf)                                        \
+  _Pragma("unroll") for (int u = 0; u < 4; ++u) {              \
+    const double cr_ = xr[buf][u], ci_ = xi[buf][u];           \
+    const double rr_ = (TILE == 1) ? yr[buf][u] : cr_;         \
+    const double ri_ = (TILE == 1) ? yi[buf][u] : ci_;         \
+    q1 = mfma64(-cr_, rr_, q1);                                \
+    q2 = mfma64(-ci_, ri_, q2);                                \
+    q3 = mfma64(cr_ + ci_, rr_ - ri_, q3);                     \
+  }
+#else
 #define HPX_DT_MUL(buf)                                        \
   _Pragma("unroll") for (int u = 0; u < 4; ++u) {              \
     const double cr_ = xr[buf][u], ci_ = xi[buf][u];           \
@@ -301,6 +556,7 @@ __device__ __forceinline__ void diag_tile(const glb_f64* __restrict__ Lre,
     ai = mfma64(-cr_, ri_, ai);                                \
     ai = mfma64(ci_, rr_, ai);                                 \
   }
+#endif
   HPX_DT_LOAD(0, 0);
   for (int ch = 0; ch < nch; ch += 2) {
     HPX_DT_LOAD(1, ch + 1);
@@ -315,6 +571,10 @@ __device__ __forceinline__ void diag_tile(const glb_f64* __restrict__ Lre,
   }
 #undef HPX_DT_LOAD
 #undef HPX_DT_MUL
+#if HPX_3M
+  ar += q1 + q2;
+  ai += q1 - q2 + q3;
+#endif
 }
 
 // Tile `t` of the diagonal block at c1, summed over the columns k < kend that are final already.
@@ -633,12 +893,66 @@ __global__ __launch_bounds__(256, HPX_WGS) void k_factor(double* __restrict__ L_
     bad |= diag_panel<GEN, GLDS>((glb_f64*)Lre, (glb_f64*)Lim, (glb_f64*)(Wgre + jb * 1024),
                                  (glb_f64*)(Wgim + jb * 1024), (lds_FactorShared*)&sh, npad, c0, wj, tid,
                                  GS, st_);
-    // tiles below the diagonal block (incl. the right-hand-side rows): wave w owns tiles
-    // rt0 + w + 4 i and works through them in groups
-    int rt = ((c0 + wj) >> 4) + ((wave + rot0 + jb * HPX_ROT) & 3);
+    // tiles below the diagonal block (incl. the right-hand-side rows)
+    const int pos = (wave + rot0 + jb * HPX_ROT) & 3;
+    int rt = ((c0 + wj) >> 4) + pos;
     if (wj == 32) {
-      // this wave's tiles in groups of 3 (2 + 2 rather than 3 + 1: a single-tile pass costs
-      // nearly as much as a three-tile one, its k-loop is bound by load latency)
+      const int c1 = c0 + 32;
+#if HPX_3M && HPX_FUSE_DIAG
+      const bool fuse = c0 > 0 && npad - c1 >= 32;
+#else
+      const bool fuse = false;
+#endif
+#if HPX_BALANCED
+      // The pass is cut into 4 m groups of up to three consecutive row tiles, every wave takes m
+      // of them (group i goes to the wave at position i & 3): a group's time is set by the length
+      // of its k-loop far more than by its tile count (the loop is bound by load latency), so equal
+      // group COUNTS per wave are what keeps the waves level at the closing barrier.  With the
+      // fused group (the two tiles of the next diagonal block's rows plus that block's update,
+      // offdiag_diag_group) as group 0.
+      {
+        const int t0 = (c1 >> 4) + (fuse ? 2 : 0);          // first tile dealt in plain groups
+        const int rem = nrt - t0;
+        const int ng = fuse ? 1 : 0;                          // groups that are not plain
+        const int m = ((rem + 2) / 3 + ng + 3) >> 2;          // groups per wave
+        const int np = 4 * m - ng;                            // plain groups
+        const int sz = rem / np, extra = rem - sz * np;       // the first `extra` of them hold sz + 1 tiles
+        for (int gi = pos; gi < 4 * m; gi += 4) {
+#if HPX_3M && HPX_FUSE_DIAG
+          if (fuse && gi == 0) {
+            offdiag_diag_group<GEN>(Lre, Lim, (lds_FactorShared*)&sh, npad, c0, sh.Yre, sh.Yim, lane, G, st_);
+            continue;
+          }
+#endif
+          const int n = gi - ng;
+          const int first = t0 + n * sz + min(n, extra), cnt = sz + (n < extra ? 1 : 0);
+          if (cnt == 3) offdiag_group<2, 3, GEN>(Lre, Lim, npad, c0, first << 4, 16, sh.Yre, sh.Yim, lane, G, st_);
+          else if (cnt == 2) offdiag_group<2, 2, GEN>(Lre, Lim, npad, c0, first << 4, 16, sh.Yre, sh.Yim, lane, G, st_);
+          else if (cnt == 1) offdiag_group<2, 1, GEN>(Lre, Lim, npad, c0, first << 4, 16, sh.Yre, sh.Yim, lane, G, st_);
+        }
+      }
+#else
+      if (fuse) {
+        // The wave at position 3 takes the two tiles of the next diagonal block's rows together
+        // with that block's update (offdiag_diag_group: 7 tile accumulators); meanwhile each of
+        // the other three takes up to three of the next nine tiles (stride 3 tiles), so that the
+        // cyclic deal of the rest, in which position 3 gets the fewest, starts about level.
+#if HPX_3M && HPX_FUSE_DIAG
+        const int base = (c1 >> 4) + 2, rem = nrt - base;
+        if (pos == 3) {
+          offdiag_diag_group<GEN>(Lre, Lim, (lds_FactorShared*)&sh, npad, c0, sh.Yre, sh.Yim, lane, G, st_);
+        } else {
+          const int n1 = (rem > pos) ? min(3, (rem - pos + 2) / 3) : 0;
+          const int r1 = (base + pos) << 4;
+          if (n1 == 3) offdiag_group<2, 3, GEN>(Lre, Lim, npad, c0, r1, 48, sh.Yre, sh.Yim, lane, G, st_);
+          else if (n1 == 2) offdiag_group<2, 2, GEN>(Lre, Lim, npad, c0, r1, 48, sh.Yre, sh.Yim, lane, G, st_);
+          else if (n1 == 1) offdiag_group<2, 1, GEN>(Lre, Lim, npad, c0, r1, 48, sh.Yre, sh.Yim, lane, G, st_);
+        }
+        rt = base + 9 + pos;
+#endif
+      }
+      // this wave's (remaining) tiles rt + 4 i in groups of 3 (2 + 2 rather than 3 + 1: a single-tile
+      // pass costs nearly as much as a three-tile one, its k-loop is bound by load latency)
       int cnt = (nrt - rt + 3) >> 2;
       while (cnt > 0) {
 #if HPX_RT3
@@ -658,11 +972,11 @@ __global__ __launch_bounds__(256, HPX_WGS) void k_factor(double* __restrict__ L_
           cnt -= 1;
         }
       }
-      // early part of the next diagonal block (columns < c0): its tiles go to the waves that
-      // got the fewest off-diagonal tiles in this pass
-      const int c1 = c0 + 32;
-      if (c0 > 0 && c1 < npad) {
-        const int t = 3 - ((wave + rot0 + jb * HPX_ROT) & 3);
+#endif
+      // early part of the next diagonal block (columns < c0) where the fused group did not form it:
+      // its tiles go to the waves that got the fewest off-diagonal tiles in this pass
+      if (!fuse && c0 > 0 && c1 < npad) {
+        const int t = 3 - pos;
         if (t < ((npad - c1 >= 32) ? 3 : 1)) {
           HPX_T0();
           diag_partial_next((const glb_f64*)Lre, (const glb_f64*)Lim, (lds_FactorShared*)&sh, npad, c1, c0,

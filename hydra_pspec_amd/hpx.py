@@ -11,7 +11,8 @@ from pathlib import Path
 import numpy as np
 
 _LIB = None
-_LIB_PATH = Path(__file__).resolve().parent / "libhpx.so"
+# HPX_LIB_PATH: another build of the same library (A/B measurements of kernel variants, tools/build_variant.sh)
+_LIB_PATH = Path(os.environ.get("HPX_LIB_PATH") or Path(__file__).resolve().parent / "libhpx.so")
 
 HPX_OK, HPX_EINVAL, HPX_EHIP, HPX_ENOTPD = 0, -1, -2, -3
 NSTAGE = 6

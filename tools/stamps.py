@@ -1,0 +1,24 @@
+"""In-kernel stamp shares of k_factor (diagnostic build only: tools/build_variant.sh stamp HPX_STAMP=1,
+run with HPX_LIB_PATH=hydra_pspec_amd/variants/libhpx_stamp.so).  Prints mean cycles per phase per wave."""
+import ctypes as C, os, sys
+import numpy as np
+sys.path.insert(0, '.')
+import torch  # noqa
+from hydra_pspec_amd import hpx, pspec, synthetic
+N, T, M, nbl = 512, 32, 12, int(os.environ.get("NBL", "1024"))
+d = synthetic.make_baselines(N, T, M, nbl=nbl, dense=False)
+gb = pspec.GibbsBatch(d["vis"], d["flags"], d["fgmodes"], d["ninv_diag"], d["ps_prior"], 3, seed=1, solver="dense")
+ps0 = np.broadcast_to(d["ps0"], (nbl, N)).copy()
+gb.run(3, ps0=ps0)
+L = C.CDLL(str(hpx._LIB_PATH))
+n = nbl * 4 * 8
+buf = (C.c_longlong * n)()
+assert L.hpx_debug_stamps(buf, n) == 0
+a = np.frombuffer(buf, dtype=np.int64).reshape(nbl, 4, 8).astype(float)
+names = ["diag last32+combine", "next-diag partial/park", "potf2 loop", "final scale", "tile init(gen)", "k-loop",
+         "X mult+store", "end barrier"]
+tot = a.sum(axis=2)
+print("cycles per wave (mean over %d WGs), total %.0f = %.3f ms at 2.4 GHz" % (nbl, tot.mean(), tot.mean() / 2.4e6))
+for i, nm in enumerate(names):
+    print("  %-24s %10.0f  %5.1f%%   per-wave-id: %s" % (nm, a[:, :, i].mean(), 100 * a[:, :, i].mean() / tot.mean(),
+                                                       np.round(a[:, :, i].mean(axis=0)).astype(int)))
