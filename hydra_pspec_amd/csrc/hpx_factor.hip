@@ -19,6 +19,7 @@
 //        computed TRANSPOSED so that the accumulator tile is directly the
 //        B operand of the multiplication by conj(Ljj^-1): no data movement.
 #include "hpx_internal.h"
+#include <stdlib.h>
 
 // Timing-only ablation builds (wrong results; never shipped): HPX_DIAG bit 0 = no B-operand
 // loads in the k-loop, bit 1 = no panel (A) loads, bit 2 = skip the in-LDS Cholesky steps,
@@ -1148,7 +1149,7 @@ __device__ __forceinline__ void back_block(const double* __restrict__ Lre,
   __syncthreads();
 }
 
-__global__ __launch_bounds__(256, 3) void k_backsolve(const double* __restrict__ L_all,
+__global__ __launch_bounds__(256, 3) void k_backsolve_v1(const double* __restrict__ L_all,
                                                       const double* __restrict__ Wre_all,
                                                       const double* __restrict__ Wim_all,
                                                       double* __restrict__ Xre_all,
@@ -1181,6 +1182,197 @@ __global__ __launch_bounds__(256, 3) void k_backsolve(const double* __restrict__
         back_block<1>(Lre, Lim, Wgre + jb * 1024, Wgim + jb * 1024, Xre, Xim, sh, npad, TP, ld, c0,
                       tt, ksl, nsl, wave, lane);
     }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Backward substitution, second form (round 2): every element of L is fetched by exactly one wave
+// and the solution X by one super-block pass instead of one pass per block column.
+//
+// The block columns are taken four at a time (a "super-block" of 128 columns); wave w owns block
+// column 4 J + w and BOTH t-tiles of a pair (two accumulator sets against one L operand), and runs
+// over all rows below the super-block on its own (phase A: no k-split, nothing to reduce, no LDS).
+// Inside the super-block (phase B) the four block columns are finished from the last to the first:
+// the owner multiplies by its inverse diagonal block and stores its 32 rows of X, and after a
+// barrier the waves to its left add those rows' contribution (two 16-row chunks).  Against the
+// first form (k_backsolve_v1: one pass over the rows below per 32-wide block column, t-tiles on
+// different waves) this reads X n/128 instead of n/32 times and never streams a tile of L through
+// two waves.  Complex products are three real MFMAs each (HPX_3M, see the top of this file):
+// A1 = Zr/2 - S1, A2 = Zr/2 - S2, A3 = Zi + S3 with S1 = lr xr, S2 = lm xi, S3 = (lr + lm)(xr - xi).
+template <int CT, int NT>
+__device__ __forceinline__ void bs_accumulate(d4 (&a1)[2][2], d4 (&a2)[2][2], d4 (&a3)[2][2],
+                                              const double* __restrict__ Lre, const double* __restrict__ Lim,
+                                              const double* __restrict__ Xre, const double* __restrict__ Xim,
+                                              const int npad, const int TP, const int c0, const int t0,
+                                              const int rbeg, const int nch, const int lane) {
+  if (nch <= 0) return;
+  const int li = lane & 15, g = lane >> 4;
+  double lr0[CT][4], lm0[CT][4], lr1[CT][4], lm1[CT][4];
+  double xr0[NT][4], xi0[NT][4], xr1[NT][4], xi1[NT][4];
+#define HPX_BS_LOAD(lr, lm, xr_, xi_, ch_)                                               \
+  {                                                                                      \
+    const int rb_ = rbeg + ((ch_) << 4);                                                 \
+    _Pragma("unroll") for (int ci = 0; ci < CT; ++ci) {                                  \
+      const long off = HPX_LIDX(rb_ + 4 * g, c0 + 16 * ci + li, npad);                   \
+      const double2 q0 = *reinterpret_cast<const double2*>(Lre + off);                   \
+      const double2 q1 = *reinterpret_cast<const double2*>(Lre + off + 2);               \
+      const double2 q2 = *reinterpret_cast<const double2*>(Lim + off);                   \
+      const double2 q3 = *reinterpret_cast<const double2*>(Lim + off + 2);               \
+      lr[ci][0] = q0.x; lr[ci][1] = q0.y; lr[ci][2] = q1.x; lr[ci][3] = q1.y;            \
+      lm[ci][0] = q2.x; lm[ci][1] = q2.y; lm[ci][2] = q3.x; lm[ci][3] = q3.y;            \
+    }                                                                                    \
+    _Pragma("unroll") for (int tt = 0; tt < NT; ++tt)                                    \
+      _Pragma("unroll") for (int s = 0; s < 4; ++s) {                                    \
+        const long xo = (long)(rb_ + 4 * g + s) * TP + t0 + 16 * tt + li;                \
+        xr_[tt][s] = Xre[xo];                                                            \
+        xi_[tt][s] = Xim[xo];                                                            \
+      }                                                                                  \
+  }
+#define HPX_BS_MMA(lr, lm, xr_, xi_)                                                     \
+  _Pragma("unroll") for (int s = 0; s < 4; ++s) {                                        \
+    double xd_[NT];                                                                      \
+    _Pragma("unroll") for (int tt = 0; tt < NT; ++tt) xd_[tt] = xr_[tt][s] - xi_[tt][s]; \
+    _Pragma("unroll") for (int ci = 0; ci < CT; ++ci) {                                  \
+      const double nlr = -lr[ci][s], nlm = -lm[ci][s], lsm = lr[ci][s] + lm[ci][s];      \
+      _Pragma("unroll") for (int tt = 0; tt < NT; ++tt) {                                \
+        a1[tt][ci] = mfma64(nlr, xr_[tt][s], a1[tt][ci]);                                \
+        a2[tt][ci] = mfma64(nlm, xi_[tt][s], a2[tt][ci]);                                \
+        a3[tt][ci] = mfma64(lsm, xd_[tt], a3[tt][ci]);                                   \
+      }                                                                                  \
+    }                                                                                    \
+  }
+  HPX_BS_LOAD(lr0, lm0, xr0, xi0, 0)
+  for (int ch = 0; ch + 1 < nch; ch += 2) {
+    HPX_BS_LOAD(lr1, lm1, xr1, xi1, ch + 1)
+    __builtin_amdgcn_sched_barrier(0);
+    HPX_BS_MMA(lr0, lm0, xr0, xi0)
+    __builtin_amdgcn_sched_barrier(0);
+    const int nx = min(ch + 2, nch - 1);                 // branch-free: a harmless re-read at the end
+    HPX_BS_LOAD(lr0, lm0, xr0, xi0, nx)
+    __builtin_amdgcn_sched_barrier(0);
+    HPX_BS_MMA(lr1, lm1, xr1, xi1)
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  if (nch & 1) HPX_BS_MMA(lr0, lm0, xr0, xi0)            // the odd chunk sits in set 0
+#undef HPX_BS_LOAD
+#undef HPX_BS_MMA
+}
+
+template <int CT, int NT>
+__device__ __forceinline__ void bs_init(d4 (&a1)[2][2], d4 (&a2)[2][2], d4 (&a3)[2][2],
+                                        const double* __restrict__ Lre, const double* __restrict__ Lim,
+                                        const int npad, const int c0, const int t0, const int lane) {
+  const int li = lane & 15, g = lane >> 4;
+#pragma unroll
+  for (int tt = 0; tt < NT; ++tt)
+#pragma unroll
+    for (int ci = 0; ci < CT; ++ci)
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {      // Z[c][t] = conj(Laug[npad + t][c])
+        const long off = HPX_LIDX(npad + t0 + 16 * tt + li, c0 + 16 * ci + HPX_ACC_ROW(g, v), npad);
+        const double zr = Lre[off];
+        a1[tt][ci][v] = 0.5 * zr;
+        a2[tt][ci][v] = 0.5 * zr;
+        a3[tt][ci][v] = -Lim[off];
+      }
+}
+
+// X[c][t] = sum_{c' >= c in the block} conj(Linv[c'][c]) Y[c'][t], stored to X
+template <int CT, int NT>
+__device__ __forceinline__ void bs_finish(d4 (&a1)[2][2], d4 (&a2)[2][2], d4 (&a3)[2][2],
+                                          const double* __restrict__ Wgre, const double* __restrict__ Wgim,
+                                          double* __restrict__ Xre, double* __restrict__ Xim, const int TP,
+                                          const int c0, const int t0, const int lane) {
+  const int li = lane & 15, g = lane >> 4;
+#pragma unroll
+  for (int tt = 0; tt < NT; ++tt) {
+    d4 yr[CT], yi[CT];
+#pragma unroll
+    for (int ci = 0; ci < CT; ++ci) {
+      yr[ci] = a1[tt][ci] + a2[tt][ci];
+      yi[ci] = a1[tt][ci] - a2[tt][ci] + a3[tt][ci];
+    }
+#pragma unroll
+    for (int ci = 0; ci < CT; ++ci) {
+      d4 xr = {0., 0., 0., 0.}, xi = {0., 0., 0., 0.};
+#pragma unroll
+      for (int cj = ci; cj < CT; ++cj)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          const int kq = 16 * cj + HPX_ACC_ROW(g, v);
+          const double wr = Wgre[kq * 32 + 16 * ci + li], wi = Wgim[kq * 32 + 16 * ci + li];
+          xr = mfma64(wr, yr[cj][v], xr);
+          xr = mfma64(wi, yi[cj][v], xr);
+          xi = mfma64(wr, yi[cj][v], xi);
+          xi = mfma64(-wi, yr[cj][v], xi);
+        }
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const long xo = (long)(c0 + 16 * ci + HPX_ACC_ROW(g, v)) * TP + t0 + 16 * tt + li;
+        Xre[xo] = xr[v];
+        Xim[xo] = xi[v];
+      }
+    }
+  }
+}
+
+template <int NT>
+__device__ __forceinline__ void bs_pair(const double* __restrict__ Lre, const double* __restrict__ Lim,
+                                        const double* __restrict__ Wgre_all, const double* __restrict__ Wgim_all,
+                                        double* __restrict__ Xre, double* __restrict__ Xim, const int npad,
+                                        const int TP, const int t0, const int wave, const int lane) {
+  const int nblk = (npad + HPX_NB - 1) / HPX_NB, nsb = (nblk + 3) >> 2;
+  d4 a1[2][2], a2[2][2], a3[2][2];
+  for (int J = nsb - 1; J >= 0; --J) {
+    const int jb = 4 * J + wave;
+    const bool have = jb < nblk;
+    const int c0 = jb * HPX_NB;
+    const int ct = have ? (min(HPX_NB, npad - c0) >> 4) : 0;      // 16-column tiles of this wave's block
+    // phase A: rows below the super-block
+    const int rbeg = min(npad, 128 * (J + 1));
+    if (ct == 2) {
+      bs_init<2, NT>(a1, a2, a3, Lre, Lim, npad, c0, t0, lane);
+      bs_accumulate<2, NT>(a1, a2, a3, Lre, Lim, Xre, Xim, npad, TP, c0, t0, rbeg, (npad - rbeg) >> 4, lane);
+    } else if (ct == 1) {
+      bs_init<1, NT>(a1, a2, a3, Lre, Lim, npad, c0, t0, lane);
+      bs_accumulate<1, NT>(a1, a2, a3, Lre, Lim, Xre, Xim, npad, TP, c0, t0, rbeg, (npad - rbeg) >> 4, lane);
+    }
+    // phase B: the super-block's own block columns, last to first
+    for (int w = 3; w >= 0; --w) {
+      const int jw = 4 * J + w;
+      if (jw >= nblk) continue;                                    // uniform over the workgroup
+      if (wave == w) {
+        if (ct == 2) bs_finish<2, NT>(a1, a2, a3, Wgre_all + (long)jw * 1024, Wgim_all + (long)jw * 1024, Xre, Xim, TP, c0, t0, lane);
+        else bs_finish<1, NT>(a1, a2, a3, Wgre_all + (long)jw * 1024, Wgim_all + (long)jw * 1024, Xre, Xim, TP, c0, t0, lane);
+      }
+      __syncthreads();                                             // X rows of block jw are in memory
+      if (wave < w) {                                              // (the waves to the left always hold 32-wide blocks)
+        const int rw = jw * HPX_NB, nchw = min(HPX_NB, npad - rw) >> 4;
+        bs_accumulate<2, NT>(a1, a2, a3, Lre, Lim, Xre, Xim, npad, TP, c0, t0, rw, nchw, lane);
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256, 2) void k_backsolve(const double* __restrict__ L_all,
+                                                      const double* __restrict__ Wre_all,
+                                                      const double* __restrict__ Wim_all,
+                                                      double* __restrict__ Xre_all,
+                                                      double* __restrict__ Xim_all,
+                                                      const int npad, const int TP, const int ld) {
+  const int b = blockIdx.x;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const double* Lre = L_all + (long)b * npad * ld * 2;
+  const double* Lim = Lre + 16;
+  const int nblk = (npad + HPX_NB - 1) / HPX_NB;
+  const double* Wgre = Wre_all + (long)b * nblk * 1024;
+  const double* Wgim = Wim_all + (long)b * nblk * 1024;
+  double* Xre = Xre_all + (long)b * npad * TP;
+  double* Xim = Xim_all + (long)b * npad * TP;
+  const int TT = TP >> 4;
+  for (int tp = 0; tp < TT; tp += 2) {                 // pairs of t-tiles (T <= 32: one pass)
+    if (tp + 1 < TT) bs_pair<2>(Lre, Lim, Wgre, Wgim, Xre, Xim, npad, TP, tp << 4, wave, lane);
+    else bs_pair<1>(Lre, Lim, Wgre, Wgim, Xre, Xim, npad, TP, tp << 4, wave, lane);
   }
 }
 
@@ -1277,7 +1469,12 @@ int hpx_launch_factor(int nbl, int npad, int ld, double* L, double* Wre, double*
 
 int hpx_launch_backsolve(int nbl, int npad, int TP, int ld, const double* L, const double* Wre,
                          const double* Wim, double* Xre, double* Xim, hipStream_t st) {
-  hipLaunchKernelGGL(k_backsolve, dim3(nbl), dim3(256), 0, st, L, Wre, Wim, Xre, Xim, npad, TP, ld);
+  // HPX_BACKSOLVE_V1=1 (environment, read once): the first form, for A/B measurements
+  static const int use_v1 = (getenv("HPX_BACKSOLVE_V1") && atoi(getenv("HPX_BACKSOLVE_V1")) != 0) ? 1 : 0;
+  if (use_v1)
+    hipLaunchKernelGGL(k_backsolve_v1, dim3(nbl), dim3(256), 0, st, L, Wre, Wim, Xre, Xim, npad, TP, ld);
+  else
+    hipLaunchKernelGGL(k_backsolve, dim3(nbl), dim3(256), 0, st, L, Wre, Wim, Xre, Xim, npad, TP, ld);
   HPX_HIP(hipGetLastError());
   return HPX_OK;
 }
