@@ -45,10 +45,16 @@ SIGNATURES = {
     "hpx_dft_batched": (_i, [_i, _i, _i, _vp, _vp, _vp, _i, _vp]),
     "hpx_invgamma_inversion": (_i, [_i, _i, _vp, _vp, _vp, _i, _vp, _vp]),
     "hpx_dpss_project": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
-    "hpx_oqe_fisher": (_i, [_i, _i, _vp, _vp, _i, _vp]),
-    "hpx_oqe_qh": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp]),
+    "hpx_dpss_workspace_bytes": (_i64, [_i, _i, _i, _i]),
+    "hpx_dpss_project_grouped": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _vp]),
+    "hpx_oqe_workspace_bytes": (_i64, [_i, _i, _i]),
+    "hpx_oqe_fisher": (_i, [_i, _i, _vp, _vp, _i, _vp, _i64, _vp]),
+    "hpx_oqe_qh": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _i64, _vp]),
+    "hpx_oqe_sandwich_diag": (_i, [_i, _i, _vp, _vp, _i, _vp, _vp, _i64, _vp]),
+    "hpx_oqe_mopt": (_i, [_i, _i, _vp, _vp, _vp]),
+    "hpx_lincomb": (_i, [_i64, C.c_double, _vp, C.c_double, _vp, _vp, _vp]),
     "hpx_fgmodes_eig": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp]),
-    "hpx_oqe_qauto": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp]),
+    "hpx_oqe_qauto": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _i64, _vp]),
     "hpx_mfma_probe": (_i, [_vp, _vp, _vp]),
     "hpx_mfma_f64_peak": (_i, [_i, _vp]),
 }

@@ -8,8 +8,10 @@ The two expensive pieces run on the GPU: the Fisher matrices ``F`` / ``Ft``
 (O(s^5) / O(s^4) trace loops in the reference, here two s x s x s contractions:
 ``X = M R M^H``, ``Wm = conj(M) R M^T``, ``F_ab = conj(Wm_ba) X_ab / 2``,
 ``Ft_ab = |X_ab|^2 / 2`` -- valid for any ``R``) and the cross-estimator ``q_h``
-(``q_t = conj(FFT(R x1))_t FFT(R x2)_t / 2``).  The remaining helpers are s x s
-glue on the host.
+(``q_t = conj(FFT(R x1))_t FFT(R x2)_t / 2``), both as dense MFMA products with the DFT matrix;
+the normalisations (``M_Finv``, ``M_Fhalf`` on the batched Cholesky solver, ``M_opt``) and the
+noise terms (``bias``, ``Sig_QEN``, ``Sig_QESN``: diagonals of ``M (R C R') M^H``) run on the
+device as well.
 """
 import numpy as np
 import scipy.linalg
@@ -28,17 +30,25 @@ def Q(tau, s):                      # oqe.py:13-20 (computed, not cached on disk
     return np.outer(v.conj(), v)
 
 
-def _fisher(R, variant):
+def _dev():
     torch = hpx.require_gpu()
+    return torch, torch.device("cuda", torch.cuda.current_device())
+
+
+def _c128(torch, dev, x):
+    return hpx.to_dev(torch, np.ascontiguousarray(np.asarray(x, dtype=complex)), torch.complex128, dev)
+
+
+def _fisher(R, variant):
+    torch, dev = _dev()
     R = np.asarray(R, dtype=complex)
     batched = R.ndim == 3
     Rb = R if batched else R[None]
     nb, s, _ = Rb.shape
-    dev = torch.device("cuda", torch.cuda.current_device())
-    d_R = hpx.to_dev(torch, Rb, torch.complex128, dev)
+    d_R = _c128(torch, dev, Rb)
     d_F = torch.zeros_like(d_R)
-    hpx.check(hpx.lib().hpx_oqe_fisher(nb, s, hpx.ptr(d_R), hpx.ptr(d_F), variant, hpx.stream_ptr(torch)),
-              "hpx_oqe_fisher")
+    hpx.check(hpx.lib().hpx_oqe_fisher(nb, s, hpx.ptr(d_R), hpx.ptr(d_F), variant, None, 0,
+                                       hpx.stream_ptr(torch)), "hpx_oqe_fisher")
     out = d_F.cpu().numpy()
     return out if batched else out[0]
 
@@ -55,24 +65,99 @@ def Ft(s, R):
     return _fisher(R, 1)
 
 
-def M_Fhalf(Fm):                    # oqe.py:69-70
-    return np.linalg.inv(scipy.linalg.sqrtm(Fm))
+def _device_inverse(torch, dev, d_A):
+    """inv(A) for a Hermitian positive-definite (1,s,s) device matrix through the batched Cholesky
+    solver (identity right-hand side); None if a pivot is not positive."""
+    s = d_A.shape[-1]
+    d_eye = torch.eye(s, dtype=torch.complex128, device=dev)[None].contiguous()
+    d_inv = torch.empty_like(d_A)
+    info = torch.zeros(1, dtype=torch.int32, device=dev)
+    hpx.check(hpx.lib().hpx_zpotrs_batched(1, s, s, hpx.ptr(d_A), hpx.ptr(d_eye), hpx.ptr(d_inv),
+                                           hpx.ptr(info), hpx.stream_ptr(torch)), "hpx_zpotrs_batched")
+    return d_inv if int(info.item()) == 0 else None
 
 
-def M_Finv(Fm):                     # oqe.py:73-74
+def _is_hpd_candidate(Fm):
+    Fm = np.asarray(Fm)
+    return Fm.ndim == 2 and np.allclose(Fm, Fm.conj().T, rtol=1e-13, atol=0) and np.all(np.diag(Fm).real > 0)
+
+
+def M_Finv(Fm):
+    """``inv(F)`` (oqe.py:73-74).  A Hermitian Fisher matrix (any Hermitian weighting ``R`` gives one)
+    is inverted on the GPU by the batched Cholesky solver; other matrices fall back to LAPACK."""
+    if _is_hpd_candidate(Fm):
+        torch, dev = _dev()
+        d_inv = _device_inverse(torch, dev, _c128(torch, dev, np.asarray(Fm)[None]))
+        if d_inv is not None:
+            out = d_inv[0].cpu().numpy()
+            return out.real.copy() if np.isrealobj(Fm) else out
     return np.linalg.inv(Fm)
 
 
-def M_opt(Fm):                      # oqe.py:77-84
-    M = np.diag(np.divide(1, np.diag(Fm)))
-    W = M @ Fm
-    for row in range(M.shape[0]):
-        M[row] = np.divide(M[row], np.sum(W[row]))
-    return M
+def M_Fhalf(Fm, tol=1e-15, maxit=60):
+    """``inv(sqrtm(F))`` (oqe.py:69-70).  For a Hermitian positive-definite ``F`` the principal inverse
+    square root is the limit of the Denman-Beavers iteration ``Y <- (Y + Z^-1)/2, Z <- (Z + Y^-1)/2``
+    from ``Y = F, Z = I`` (``Z -> F^-1/2``); the inverses run on the GPU's batched Cholesky solver and
+    the averages in ``hpx_lincomb``.  Other matrices fall back to scipy's ``sqrtm``."""
+    if _is_hpd_candidate(Fm):
+        torch, dev = _dev()
+        s = np.shape(Fm)[0]
+        L = hpx.lib()
+        st = hpx.stream_ptr(torch)
+        Y = _c128(torch, dev, np.asarray(Fm)[None])
+        scale = float(np.trace(np.asarray(Fm)).real) / s          # F / scale has unit-order eigenvalues
+        Y = (Y / scale).contiguous()
+        Z = torch.eye(s, dtype=torch.complex128, device=dev)[None].contiguous()
+        ok = True
+        for _ in range(maxit):
+            Yi, Zi = _device_inverse(torch, dev, Y), _device_inverse(torch, dev, Z)
+            if Yi is None or Zi is None:
+                ok = False
+                break
+            Yn, Zn = torch.empty_like(Y), torch.empty_like(Z)
+            n = 2 * s * s
+            hpx.check(L.hpx_lincomb(n, 0.5, hpx.ptr(Y), 0.5, hpx.ptr(Zi), hpx.ptr(Yn), st), "hpx_lincomb")
+            hpx.check(L.hpx_lincomb(n, 0.5, hpx.ptr(Z), 0.5, hpx.ptr(Yi), hpx.ptr(Zn), st), "hpx_lincomb")
+            delta = float((Zn - Z).abs().max() / Zn.abs().max())
+            Y, Z = Yn, Zn
+            if delta < tol:
+                break
+        if ok:
+            out = (Z[0] / np.sqrt(scale)).cpu().numpy()
+            return out.real.copy() if np.isrealobj(Fm) else out
+    return np.linalg.inv(scipy.linalg.sqrtm(Fm))
+
+
+def M_opt(Fm):
+    """oqe.py:77-84: ``diag(1/F_aa)`` with row ``a`` divided by ``sum_b (M F)_ab`` (HIP kernel)."""
+    torch, dev = _dev()
+    Fm = np.asarray(Fm)
+    d_F = _c128(torch, dev, Fm[None])
+    d_M = torch.empty_like(d_F)
+    hpx.check(hpx.lib().hpx_oqe_mopt(1, Fm.shape[0], hpx.ptr(d_F), hpx.ptr(d_M), hpx.stream_ptr(torch)),
+              "hpx_oqe_mopt")
+    out = d_M[0].cpu().numpy()
+    return out.real.copy() if np.isrealobj(Fm) else out
+
+
+def _sandwich_diag(R, Cm, conj_right):
+    """diag(M (R C R') M^H), R' = conj(R) or R, on the device (three dense products + a row dot)."""
+    torch, dev = _dev()
+    s = np.shape(R)[0]
+    d_R, d_C = _c128(torch, dev, np.asarray(R)[None]), _c128(torch, dev, np.asarray(Cm)[None])
+    d_o = torch.empty((1, s), dtype=torch.complex128, device=dev)
+    hpx.check(hpx.lib().hpx_oqe_sandwich_diag(1, s, hpx.ptr(d_R), hpx.ptr(d_C), int(conj_right), hpx.ptr(d_o),
+                                              None, 0, hpx.stream_ptr(torch)), "hpx_oqe_sandwich_diag")
+    return d_o[0].cpu().numpy()
+
+
+def bias_all(s, R, C_noise_total):
+    """The noise bias for every delay at once: ``1/2 diag(M (R C conj R) M^H)``."""
+    return 0.5 * _sandwich_diag(R, C_noise_total, True)
 
 
 def bias(tau, s, R, C_noise_total):  # oqe.py:23-24
-    return 0.5 * np.trace(C_noise_total @ R.conj() @ Q(tau, s) @ R)
+    return bias_all(s, R, C_noise_total)[tau]
 
 
 def _q_auto(V, s, R):
@@ -84,7 +169,7 @@ def _q_auto(V, s, R):
     d_R = hpx.to_dev(torch, np.asarray(R, dtype=complex)[None], torch.complex128, dev)
     d_V = hpx.to_dev(torch, V[None], torch.complex128, dev)
     d_q = torch.zeros((1, len(V), s), dtype=torch.complex128, device=dev)
-    hpx.check(hpx.lib().hpx_oqe_qauto(1, len(V), s, hpx.ptr(d_R), hpx.ptr(d_V), hpx.ptr(d_q),
+    hpx.check(hpx.lib().hpx_oqe_qauto(1, len(V), s, hpx.ptr(d_R), hpx.ptr(d_V), hpx.ptr(d_q), None, 0,
                                       hpx.stream_ptr(torch)), "hpx_oqe_qauto")
     return d_q[0].cpu().numpy()
 
@@ -103,7 +188,7 @@ def q_h(V, s, R, taper=None):
     d_R = hpx.to_dev(torch, np.asarray(R, dtype=complex)[None], torch.complex128, dev)
     d_V = hpx.to_dev(torch, V[None, :2 * npair], torch.complex128, dev)
     d_q = torch.zeros((1, npair, s), dtype=torch.complex128, device=dev)
-    hpx.check(hpx.lib().hpx_oqe_qh(1, npair, s, hpx.ptr(d_R), hpx.ptr(d_V), hpx.ptr(d_q),
+    hpx.check(hpx.lib().hpx_oqe_qh(1, npair, s, hpx.ptr(d_R), hpx.ptr(d_V), hpx.ptr(d_q), None, 0,
                                    hpx.stream_ptr(torch)), "hpx_oqe_qh")
     return d_q[0].cpu().numpy()
 
@@ -141,19 +226,13 @@ def getqs(Vis, R):                  # oqe.py:130-144
 
 
 def Sig_QEN(R, C_noise, norm):      # oqe.py:161-173
-    s = len(R)
-    out = np.zeros(s, dtype=complex)
-    for i in range(s):
-        E = R @ Q(i, s) @ R * norm
-        out[i] = 0.5 * np.trace(E @ C_noise @ E @ C_noise)
-    return out
+    """``E_i = norm R Q_i R`` is rank one (``u_i v_i^T``), so ``1/2 tr(E C E C) = 1/2 norm^2 n_i^2`` with
+    ``n = diag(M (R C R) M^H)`` (device)."""
+    n = _sandwich_diag(R, C_noise, False)
+    return 0.5 * norm ** 2 * n * n
 
 
 def Sig_QESN(R, C_noise, C_S, norm):  # oqe.py:177-186
-    s = len(R)
-    out = np.zeros(s, dtype=complex)
-    for i in range(s):
-        E = R @ Q(i, s) @ R * norm
-        out[i] = 0.5 * np.trace((E @ C_noise @ E @ C_noise) + (E @ C_S @ E @ C_noise)
-                                + (E @ C_noise @ E @ C_S))
-    return out
+    n = _sandwich_diag(R, C_noise, False)
+    sg = _sandwich_diag(R, C_S, False)
+    return 0.5 * norm ** 2 * (n * n + 2.0 * sg * n)

@@ -194,18 +194,49 @@ int hpx_invgamma_inversion(int n, int alpha, const double* beta, const double* u
 /* DPSS weighted fit in closed form (hydra_pspec/dpss.py:7-94): for each of nb
  * spectra d (nb,N) c128 with weights tw (nb,N) f64 (= taper*w), basis
  * modes (nm,N) f64 and inverse covariance icov (N,N) c128 (Hermitian part is
- * used), returns amps (nb, 2*nm) f64 interleaved (re,im). */
+ * used), returns amps (nb, 2*nm) f64 interleaved (re,im).  nm <= 32. */
 int hpx_dpss_project(int nb, int N, int nm, const double* d, const double* tw,
                      const double* modes, const double* icov, double* amps,
                      void* stream);
+/* The (baseline x time) batch: `ngroups` groups of `per` spectra that share their weights
+ * (d (ngroups*per, N) c128, tw (ngroups, N)).  Per group the weighted normal matrix
+ * A = Mw^H icov Mw, its inverse and the projector P = Mw^H icov diag(tw) are formed once (dense
+ * product on the f64 MFMA); per spectrum the tall-skinny projection P d and the nm x nm multiply run
+ * in one MFMA kernel that reads the visibility cube once.  `work`: device workspace of at least
+ * hpx_dpss_workspace_bytes(...) bytes -- the call is then fully asynchronous on `stream` and
+ * allocates nothing; NULL: allocated and released inside the call (which then synchronises and
+ * reports a non-positive-definite normal matrix as HPX_ENOTPD).  reuse_projector != 0: the per-group
+ * stage is skipped and the projector the previous call left in the SAME caller workspace is used
+ * (new data, unchanged weights: tw / modes / icov may then be NULL). */
+int64_t hpx_dpss_workspace_bytes(int ngroups, int per, int N, int nm);
+int hpx_dpss_project_grouped(int ngroups, int per, int N, int nm, const double* d,
+                             const double* tw, const double* modes, const double* icov,
+                             double* amps, void* work, int64_t work_bytes, int reuse_projector,
+                             void* stream);
 
-/* OQE (hydra_pspec/oqe.py): Fisher matrix F_ab = 1/2 tr(R* Q_a R Q_b)
- * (oqe.py:43-50) and Ft (oqe.py:53-66) for nb weightings R (nb,s,s) c128,
- * variant 0 = F, 1 = Ft; q_h (oqe.py:104-114) for V (nb,2P,s) -> (nb,P,s). */
+/* OQE (hydra_pspec/oqe.py).  Every O(s^3) piece is a dense product with the DFT matrix
+ * M[a][j] = exp(-2 pi i a j / s) (oqe.py:7-10) or the weighting R on the f64 MFMA; Q_tau is rank
+ * one, so the trace formulas collapse (hpx_extra.hip).  `work` / `work_bytes`: device workspace of at
+ * least hpx_oqe_workspace_bytes(nb, s, nvis) bytes -- the call then allocates nothing and does not
+ * synchronise; NULL: allocated and released inside the call (which then synchronises).
+ *   hpx_oqe_fisher: F_ab = 1/2 tr(R* Q_a R Q_b) (oqe.py:43-50, variant 0) or Ft (oqe.py:53-66,
+ *     variant 1) for nb weightings R (nb,s,s) c128 -> (nb,s,s) c128.
+ *   hpx_oqe_qh: q_h (oqe.py:104-114) for V (nb,2P,s) -> (nb,P,s). */
+int64_t hpx_oqe_workspace_bytes(int nb, int s, int nvis);
 int hpx_oqe_fisher(int nb, int s, const double* R, double* F_out, int variant,
-                   void* stream);
+                   void* work, int64_t work_bytes, void* stream);
 int hpx_oqe_qh(int nb, int npair, int s, const double* R, const double* V,
-               double* q_out, void* stream);
+               double* q_out, void* work, int64_t work_bytes, void* stream);
+/* diag(M (R C R') M^H) (nb,s) c128 with R' = conj(R) (conj_right != 0) or R: the quantity behind
+ * oqe.bias (R C conj R; oqe.py:23-24) and Sig_QEN / Sig_QESN (R C R; oqe.py:161-186). */
+int hpx_oqe_sandwich_diag(int nb, int s, const double* R, const double* C, int conj_right,
+                          double* out, void* work, int64_t work_bytes, void* stream);
+/* M_opt (oqe.py:77-84): diag(1/F_aa) with row a divided by sum_b (M F)_ab; (nb,s,s) c128 -> same. */
+int hpx_oqe_mopt(int nb, int s, const double* F, double* M_out, void* stream);
+/* out = a x + b y over n doubles (the averaging step of the inverse-square-root iteration behind
+ * oqe.M_Fhalf, whose inverses run on hpx_zpotrs_batched). */
+int hpx_lincomb(int64_t n, double a, const double* x, double b, const double* y, double* out,
+                void* stream);
 
 /* Foreground modes from the data: for each baseline the `nmodes` leading
  * eigenvectors (unit norm, largest component real positive, eigenvalues descending) of the
@@ -221,7 +252,7 @@ int hpx_fgmodes_eig(int nb, int T, int N, int nmodes, const double* vis, double*
  * R (nb,s,s) c128, q_out (nb,nvis,s) c128.  Replaces the double loop of oqe.q / oqe.qhat
  * (oqe.py:27-30, :88-101); the caller subtracts bias[tau]. */
 int hpx_oqe_qauto(int nb, int nvis, int s, const double* R, const double* V, double* q_out,
-                  void* stream);
+                  void* work, int64_t work_bytes, void* stream);
 
 /* Empirical lane map of v_mfma_f64_16x16x4_f64 (diagnostic used by the tests):
  * computes D = A(16x4) * B(4x16) and writes, for lane l and register v, the

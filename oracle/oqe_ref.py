@@ -112,3 +112,26 @@ def getqs(Vis, R):                  # oqe.py:130-144 (prints dropped)
     s = len(Vis[0])
     Fm = F(s, R)
     return q_h(Vis, s, R), Fm, M_opt(Fm), M_Finv(Fm)
+
+
+# ---- closed forms (Q_tau is rank one): what the device computes, usable at sizes where the loops above
+# cannot run; tests/test_oracle_golden.py pins them to the loop forms at small s.
+def _M(s):
+    return np.fft.fft(np.eye(s))         # row tau = m(tau, s)
+
+
+def F_closed(s, R):
+    Mm = _M(s)
+    X = Mm @ R @ Mm.conj().T
+    Wm = Mm.conj() @ R @ Mm.T
+    return 0.5 * Wm.T.conj() * X
+
+
+def Ft_closed(s, R):
+    Mm = _M(s)
+    return 0.5 * np.abs(Mm @ R @ Mm.conj().T) ** 2
+
+
+def q_h_closed(V, s, R):
+    Y = np.fft.fft(np.asarray(V) @ R.T, axis=-1)          # rows: FFT(R x)
+    return 0.5 * Y[0::2].conj() * Y[1::2]

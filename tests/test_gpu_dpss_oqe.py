@@ -95,3 +95,70 @@ def test_sample_S_and_covariance_api(golden):
         pspec.sample_S()
     assert relerr(pspec.covariance_from_pspec(g["F2_ps"], utils.fourier_operator(8)), g["F2_cov"]) < 1e-13
     assert relerr(pspec.sprior(g["F4_s"], 2, 10.0), g["F5_prior"]) < 1e-12
+
+
+@pytest.mark.parametrize("s", [8, 16])
+def test_oqe_normalisations_on_device(golden, s):
+    """M_Fhalf (Denman-Beavers on the batched Cholesky solver), M_Finv, M_opt against the reference's
+    own outputs (oqe.py:69-84)."""
+    from hydra_pspec_amd import oqe
+    g = golden("small")
+    Fm = g[f"F11_{s}_F"]
+    assert relerr(oqe.M_Fhalf(Fm), g[f"F11_{s}_MFhalf"]) < 1e-9
+    assert relerr(oqe.M_Finv(Fm), g[f"F11_{s}_MFinv"]) < 1e-9
+    assert relerr(oqe.M_opt(Fm), g[f"F11_{s}_Mopt"]) < 1e-11
+    # a non-Hermitian matrix takes the LAPACK fallback and still matches numpy
+    A = Fm + 0.1 * np.triu(np.ones((s, s)), 1)
+    assert relerr(oqe.M_Finv(A), np.linalg.inv(A)) < 1e-12
+
+
+def test_oqe_at_bench_size_vs_closed_form():
+    """s = 512 (the bench shape; the reference's O(s^5) loops cannot run there): the device Fisher
+    matrices, q_h and the noise terms against the numpy closed forms of the oracle."""
+    from hydra_pspec_amd import oqe
+    from oracle import oqe_ref
+    s, nb = 512, 2
+    rng = np.random.default_rng(5)
+    a = (rng.standard_normal((nb, s, s)) + 1j * rng.standard_normal((nb, s, s))) / np.sqrt(s)
+    R = a @ a.conj().transpose(0, 2, 1) + np.eye(s)
+    Fd = oqe.F(s, R)
+    Ftd = oqe.Ft(s, R)
+    for b in range(nb):
+        assert relerr(Fd[b], oqe_ref.F_closed(s, R[b])) < 1e-11
+        assert relerr(Ftd[b], oqe_ref.Ft_closed(s, R[b])) < 1e-11
+    V = rng.standard_normal((6, s)) + 1j * rng.standard_normal((6, s))
+    assert relerr(oqe.q_h(V, s, R[0]), oqe_ref.q_h_closed(V, s, R[0])) < 1e-11
+    Cn = np.diag(rng.uniform(0.5, 1.5, s)).astype(complex)
+    Mm = np.fft.fft(np.eye(s))
+    ref_bias = 0.5 * np.diagonal(Mm @ (R[0] @ Cn @ R[0].conj()) @ Mm.conj().T)
+    assert relerr(oqe.bias_all(s, R[0], Cn), ref_bias) < 1e-11
+    n = np.diagonal(Mm @ (R[0] @ Cn @ R[0]) @ Mm.conj().T)
+    assert relerr(oqe.Sig_QEN(R[0], Cn, 0.5), 0.5 * 0.25 * n * n) < 1e-11
+
+
+def test_dpss_grouped_at_bench_size_vs_closed_form():
+    """The (baseline x time) cube at the bench shape (N = 512, 12 modes, weights shared by the 32
+    times of a baseline): a sample of spectra against the CPU closed form; groups of one spectrum
+    (hpx_dpss_project) give the same amplitudes."""
+    from hydra_pspec_amd import dpss
+    from oracle import dpss_ref
+    rng = np.random.default_rng(8)
+    ng, per, N, nm = 6, 32, 512, 12
+    freqs = np.linspace(100., 200., N)
+    x = np.arange(N)
+    cov = np.exp(-0.5 * ((x[:, None] - x[None, :]) / 3.0) ** 2) + 0.5 * np.eye(N)     # smooth + white
+    d = rng.standard_normal((ng, per, N)) + 1j * rng.standard_normal((ng, per, N))
+    w = (rng.uniform(size=(ng, N)) > 0.15).astype(float)
+    modes, amps = dpss.dpss_fit_modes_batched(d, w, freqs, cov, nmodes=nm, alpha=6.0)
+    assert amps.shape == (ng, per, 2 * nm)
+    for gi, t in ((0, 0), (2, 17), (5, 31)):
+        _, cf = dpss_ref.dpss_fit_closed_form(d[gi, t], w[gi], freqs, cov, nmodes=nm, alpha=6.0)
+        assert np.max(np.abs(amps[gi, t] - cf)) < 1e-9 * np.max(np.abs(cf))
+    _, single = dpss.dpss_fit_modes_batched(d[2, :3], np.broadcast_to(w[2], (3, N)).copy(), freqs, cov,
+                                            nmodes=nm, alpha=6.0)
+    assert np.max(np.abs(single - amps[2, :3])) < 1e-11 * np.max(np.abs(single))
+    # more than 16 modes: two mode tiles
+    _, a20 = dpss.dpss_fit_modes_batched(d[1, :5], w[1], freqs, cov, nmodes=20, alpha=11.0)
+    for t in (0, 4):
+        _, cf = dpss_ref.dpss_fit_closed_form(d[1, t], w[1], freqs, cov, nmodes=20, alpha=11.0)
+        assert np.max(np.abs(a20[t] - cf)) < 1e-8 * np.max(np.abs(cf))

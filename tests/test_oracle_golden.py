@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 
 from oracle import pspec_ref as R, dpss_ref, oqe_ref
-from conftest import relerr
+from conftest import relerr, GOLDEN
 
 TIGHT = 1e-12
 
@@ -195,3 +195,18 @@ def test_chain_fullsize_c3_prefix(golden):
                                  g["c3_prior"], Niter=2, seed=int(g["c3_seed"]))
     assert np.max(np.abs(res[2] / g["c3_ps"][:2] - 1)) < 1e-7
     assert np.allclose(res[5], g["c3_lnpost"][:2], rtol=1e-8)
+
+
+def test_oqe_closed_forms_equal_the_loop_forms():
+    """oracle/oqe_ref.py's closed forms (used by the GPU tests at s = 512) against its restatement of the
+    reference's trace loops and against the reference's own outputs."""
+    from oracle import oqe_ref
+    g = dict(np.load(GOLDEN / "small.npz"))
+    for s in (8, 16):
+        for key, fkey, ftkey in (("R", "F", "Ft"), ("Rg", "Fg", "Ftg")):
+            R = g[f"F11_{s}_{key}"]
+            assert relerr(oqe_ref.F_closed(s, R), g[f"F11_{s}_{fkey}"]) < 1e-12
+            assert relerr(oqe_ref.Ft_closed(s, R), g[f"F11_{s}_{ftkey}"]) < 1e-12
+        V = g[f"F11_{s}_V"]
+        assert relerr(oqe_ref.q_h_closed(V, s, g[f"F11_{s}_R"]), g[f"F11_{s}_qh"]) < 1e-12
+        assert relerr(oqe_ref.q_h_closed(V, s, g[f"F11_{s}_Rg"]), g[f"F11_{s}_qhg"]) < 1e-12
