@@ -194,6 +194,86 @@ __global__ void k_fg_planar(const double* __restrict__ fg, double* __restrict__ 
   }
 }
 
+// ---- dense (Hermitian, non-diagonal) inverse noise covariance -----------------------------------
+// (nbl|1, N, N) c128 row-major -> planar [b][NP][NP] zero padded; herm != 0: out[k][x] = conj(in[x][k])
+__global__ void k_dense_planar(const double* __restrict__ m, const int shared, double* __restrict__ re,
+                               double* __restrict__ im, const int N, const int NP) {
+  const int b = blockIdx.y;
+  const long tot = (long)NP * NP;
+  const double* src = m + (shared ? 0 : (long)b * N * N * 2);
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < tot; e += (long)gridDim.x * blockDim.x) {
+    const int k = (int)(e / NP), x = (int)(e % NP);
+    double vr = 0.0, vi = 0.0;
+    if (k < N && x < N) {
+      vr = src[((long)k * N + x) * 2];
+      vi = src[((long)k * N + x) * 2 + 1];
+    }
+    re[(long)b * tot + e] = vr;
+    im[(long)b * tot + e] = vi;
+  }
+}
+// planar [b][NP][NP]: out[k][x] = conj(in[x][k])
+__global__ void k_conj_transpose(const double* __restrict__ ire, const double* __restrict__ iim,
+                                 double* __restrict__ ore, double* __restrict__ oim, const int NP) {
+  const int b = blockIdx.y;
+  const long tot = (long)NP * NP;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < tot; e += (long)gridDim.x * blockDim.x) {
+    const int k = (int)(e / NP), x = (int)(e % NP);
+    ore[(long)b * tot + e] = ire[(long)b * tot + (long)x * NP + k];
+    oim[(long)b * tot + e] = -iim[(long)b * tot + (long)x * NP + k];
+  }
+}
+// the real diagonal of the planar matrices -> (nbl, N)
+__global__ void k_take_diag(const double* __restrict__ re, double* __restrict__ dg, const int N, const int NP) {
+  const int b = blockIdx.y;
+  for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < N; k += gridDim.x * blockDim.x)
+    dg[(long)b * N + k] = re[(long)b * NP * NP + (long)k * NP + k];
+}
+// Z[b][j][t] += A[b][j][t] for t < TP (both with leading dimension ld_z / ld_a)
+__global__ void k_add_block(double* __restrict__ zre, double* __restrict__ zim, const long z_bs, const int ld_z,
+                            const double* __restrict__ are, const double* __restrict__ aim, const long a_bs,
+                            const int ld_a, const int NP, const int TP) {
+  const int b = blockIdx.y;
+  const long tot = (long)NP * TP;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < tot; e += (long)gridDim.x * blockDim.x) {
+    const int j = (int)(e / TP), t = (int)(e % TP);
+    zre[(long)b * z_bs + (long)j * ld_z + t] += are[(long)b * a_bs + (long)j * ld_a + t];
+    zim[(long)b * z_bs + (long)j * ld_z + t] += aim[(long)b * a_bs + (long)j * ld_a + t];
+  }
+}
+// omega_b block: O[j][t] = (omk + i oml)/sqrt2, replicated per baseline (the dense product is batched)
+__global__ void k_prep_omega_b(const double* __restrict__ omega, double* __restrict__ Ore,
+                               double* __restrict__ Oim, const int T, const int N, const int NP, const int TP) {
+  const int b = blockIdx.y;
+  const long tot = (long)NP * TP;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < tot; e += (long)gridDim.x * blockDim.x) {
+    const int j = (int)(e / TP), t = (int)(e % TP);
+    double zr = 0.0, zi = 0.0;
+    if (j < N && t < T) {
+      zr = omega[((long)t * 4 + 2) * N + j] / SQRT2;
+      zi = omega[((long)t * 4 + 3) * N + j] / SQRT2;
+    }
+    Ore[(long)b * tot + e] = zr;
+    Oim[(long)b * tot + e] = zi;
+  }
+}
+// lnpart[b][0] = sum_{x,t} Re( conj(r[x][t]) v[x][t] )  (r^H Ninv r summed over the times; v = Ninv r)
+__global__ __launch_bounds__(256) void k_quadform(const double* __restrict__ rre, const double* __restrict__ rim,
+                                                  const long r_bs, const int ld_r, const double* __restrict__ vre,
+                                                  const double* __restrict__ vim, const long v_bs, const int ld_v,
+                                                  double* __restrict__ lnpart, const int N, const int T) {
+  __shared__ double red[4];
+  const int b = blockIdx.x;
+  double acc = 0.0;
+  for (int e = threadIdx.x; e < N * T; e += 256) {
+    const int x = e / T, t = e % T;
+    const long o1 = (long)b * r_bs + (long)x * ld_r + t, o2 = (long)b * v_bs + (long)x * ld_v + t;
+    acc += rre[o1] * vre[o2] + rim[o1] * vim[o2];
+  }
+  const double tot = block_sum(acc, red);
+  if (threadIdx.x == 0) lnpart[(long)b * HPX_NPART] = tot;
+}
+
 // ia = 1/a = sqrt(N / ps); bandpowers below HPX_PS_FLOOR (incl. zero) are treated as the floor:
 // the channel's signal is then pinned to ~0, which is what a -> 0 means in the unscaled system.
 #define HPX_PS_FLOOR 1e-280
@@ -320,6 +400,8 @@ struct ResArgs {
   long cr_bstride, fg_bstride, chisq_bstride;
   int N, M, T, NP, TP, npad, fg_shared, any_flags;
   int nbl, npart;                       // fused kernel: batch size, column groups per baseline
+  int resid_to_g;                       // k_resid: write the residual d - model to G (dense noise: the
+                                        // quadratic form r^H Ninv r is taken afterwards; needs !any_flags)
 };
 
 __global__ __launch_bounds__(256) void k_resid(const ResArgs A) {
@@ -365,7 +447,7 @@ __global__ __launch_bounds__(256) void k_resid(const ResArgs A) {
     if (in && (t & 15) == 0) part[x * TG + (t >> 4)] = v;
     if (!in) continue;
     if (t >= T) {
-      if (A.any_flags) { A.Gre[(long)b * A.NP * TP + o] = 0.0; A.Gim[(long)b * A.NP * TP + o] = 0.0; }
+      if (A.any_flags || A.resid_to_g) { A.Gre[(long)b * A.NP * TP + o] = 0.0; A.Gim[(long)b * A.NP * TP + o] = 0.0; }
       continue;
     }
     const double sr = sre[o], si = sim[o];
@@ -383,6 +465,9 @@ __global__ __launch_bounds__(256) void k_resid(const ResArgs A) {
     if (A.any_flags) {
       A.Gre[(long)b * A.NP * TP + o] = w * sr;
       A.Gim[(long)b * A.NP * TP + o] = w * si;
+    } else if (A.resid_to_g) {
+      A.Gre[(long)b * A.NP * TP + o] = rr;
+      A.Gim[(long)b * A.NP * TP + o] = ri;
     }
     if (A.cr_out) {
       double* q = A.cr_out + (long)b * A.cr_bstride + ((long)t * N + x) * 2;
@@ -1086,12 +1171,13 @@ extern "C" int hpx_plan_dims(const hpx_plan* p, int* npad, int* tpad, int* ld) {
   return HPX_OK;
 }
 
-extern "C" int hpx_plan_set_static(hpx_plan* p, const double* vis, const uint8_t* flags,
-                                   const double* ninv, const double* fgmodes, int fg_shared,
-                                   const int32_t* prior_map, const double* xgrid, int nxrows,
-                                   int prior_shared, int ngrid, const double* omega,
-                                   const double* fop, int any_flags, void* stream) {
-  HPX_REQUIRE(p && vis && flags && ninv && fop && prior_map, "hpx_plan_set_static: null argument");
+static int set_static_impl(hpx_plan* p, const double* vis, const uint8_t* flags,
+                           const double* ninv, const double* ninv_dense, const double* nih_dense,
+                           int noise_shared, const double* fgmodes, int fg_shared,
+                           const int32_t* prior_map, const double* xgrid, int nxrows,
+                           int prior_shared, int ngrid, const double* omega,
+                           const double* fop, int any_flags, void* stream) {
+  HPX_REQUIRE(p && vis && flags && (ninv || ninv_dense) && fop && prior_map, "hpx_plan_set_static: null argument");
   HPX_REQUIRE(p->M == 0 || fgmodes, "hpx_plan_set_static: fgmodes required when M > 0");
   HPX_REQUIRE(nxrows == 0 || (xgrid && ngrid >= 2 && ngrid <= 8192),
               "hpx_plan_set_static: bad prior grid");
@@ -1104,7 +1190,25 @@ extern "C" int hpx_plan_set_static(hpx_plan* p, const double* vis, const uint8_t
   p->ngrid = ngrid;
   p->nxrows = nxrows;
   HPX_HIP(hipMemcpyAsync(p->flags, flags, (size_t)nbl * N, hipMemcpyDeviceToDevice, st));
-  HPX_HIP(hipMemcpyAsync(p->ninv, ninv, (size_t)nbl * N * sizeof(double), hipMemcpyDeviceToDevice, st));
+  p->dense_noise = ninv_dense ? 1 : 0;
+  hpx_devbuf ones, tmp;                    // dense noise only
+  if (ninv_dense) {
+    HPX_REQUIRE(nih_dense && !any_flags,
+                "hpx_plan_set_static_dense: needs sqrtm(Ninv) and unflagged data (the reference's column-masked "
+                "Ni = Ninv diag(w) is not Hermitian, pspec.py:361)");
+    const size_t msz = (size_t)nbl * NP * NP;
+    HPX_TRY(dev_alloc(p, &p->NIre, msz)); HPX_TRY(dev_alloc(p, &p->NIim, msz));
+    HPX_TRY(dev_alloc(p, &p->CDre, msz)); HPX_TRY(dev_alloc(p, &p->CDim, msz));
+    hipLaunchKernelGGL(k_dense_planar, dim3(64, nbl), dim3(256), 0, st, ninv_dense, noise_shared, p->NIre, p->NIim, N, NP);
+    hipLaunchKernelGGL(k_take_diag, dim3(4, nbl), dim3(256), 0, st, p->NIre, p->ninv, N, NP);   // chi^2 uses Ninv.diagonal()
+    HPX_HIP(hipGetLastError());
+    HPX_TRY(ones.alloc((size_t)nbl * N));
+    std::vector<double> h1((size_t)nbl * N, 1.0);
+    HPX_HIP(hipMemcpyAsync(ones.p, h1.data(), h1.size() * sizeof(double), hipMemcpyHostToDevice, st));
+    HPX_HIP(hipStreamSynchronize(st));     // h1 goes out of scope with this block's caller frame only at return; be explicit
+  } else {
+    HPX_HIP(hipMemcpyAsync(p->ninv, ninv, (size_t)nbl * N * sizeof(double), hipMemcpyDeviceToDevice, st));
+  }
   HPX_HIP(hipMemcpyAsync(p->pmap, prior_map, (size_t)(prior_shared ? 1 : nbl) * N * sizeof(int32_t),
                          hipMemcpyDeviceToDevice, st));
   if (nxrows > 0) {
@@ -1119,17 +1223,60 @@ extern "C" int hpx_plan_set_static(hpx_plan* p, const double* vis, const uint8_t
     hipLaunchKernelGGL(k_fg_planar, dim3(256), dim3(256), 0, st, fgmodes, p->Fre, p->Fim, tot);
     HPX_HIP(hipGetLastError());
   }
-  hipLaunchKernelGGL(k_prep, dim3(128, nbl), dim3(256), 0, st, vis, flags, ninv, fgp, p->fg_shared,
-                     omega, p->Zre, p->Zim, p->Dre, p->Dim, p->ni, T, N, M, NP, TP, MP, p->ncolR);
-  HPX_HIP(hipGetLastError());
   const double isn = 1.0 / sqrt((double)N);
+  if (!ninv_dense) {
+    hipLaunchKernelGGL(k_prep, dim3(128, nbl), dim3(256), 0, st, vis, flags, ninv, fgp, p->fg_shared,
+                       omega, p->Zre, p->Zim, p->Dre, p->Dim, p->ni, T, N, M, NP, TP, MP, p->ncolR);
+    HPX_HIP(hipGetLastError());
+  } else {
+    // Z = Ninv [d | F | .] + Ninv^1/2 [omega_b | 0]: the operand block with unit weights (into R as
+    // scratch), then two dense products on the MFMA (the stored planar matrices are Hermitian:
+    // buffer[k][x] = conj(W[x][k]), hence conjW = 1)
+    const long mstr = (long)NP * NP, zstr = (long)NP * p->ncolR;
+    hipLaunchKernelGGL(k_prep, dim3(128, nbl), dim3(256), 0, st, vis, flags, ones.p, fgp, p->fg_shared,
+                       (const double*)nullptr, p->Rre, p->Rim, p->Dre, p->Dim, p->ni, T, N, M, NP, TP, MP, p->ncolR);
+    HPX_HIP(hipGetLastError());
+    HPX_TRY(hpx_launch_dft(nbl, NP, p->ncolR, p->NIre, p->NIim, 1, p->Rre, p->Rim, zstr, p->ncolR, nullptr, 0,
+                           p->Zre, p->Zim, zstr, p->ncolR, 1.0, st, 0, mstr));
+    hipLaunchKernelGGL(k_take_diag, dim3(4, nbl), dim3(256), 0, st, p->NIre, p->ni, N, NP);
+    if (omega) {
+      const size_t msz = (size_t)nbl * NP * NP, osz = (size_t)nbl * NP * TP;
+      HPX_TRY(tmp.alloc(2 * msz + 4 * osz));
+      double *hre = tmp.p, *him = hre + msz, *ore = him + msz, *oim = ore + osz, *ure = oim + osz, *uim = ure + osz;
+      hipLaunchKernelGGL(k_dense_planar, dim3(64, nbl), dim3(256), 0, st, nih_dense, noise_shared, hre, him, N, NP);
+      hipLaunchKernelGGL(k_prep_omega_b, dim3(32, nbl), dim3(256), 0, st, omega, ore, oim, T, N, NP, TP);
+      HPX_HIP(hipGetLastError());
+      HPX_TRY(hpx_launch_dft(nbl, NP, TP, hre, him, 1, ore, oim, (long)NP * TP, TP, nullptr, 0, ure, uim,
+                             (long)NP * TP, TP, 1.0, st, 0, mstr));
+      hipLaunchKernelGGL(k_add_block, dim3(32, nbl), dim3(256), 0, st, p->Zre, p->Zim, zstr, p->ncolR, ure, uim,
+                         (long)NP * TP, TP, NP, TP);
+      HPX_HIP(hipGetLastError());
+    }
+    // C = U^H Ninv U = F Ninv F^H / N = F (F Ninv)^H / N  (C is Hermitian): two transforms and a
+    // conjugate transpose; CD doubles as scratch for F Ninv
+    HPX_TRY(hpx_launch_dft(nbl, NP, NP, p->Fopre, p->Fopim, 0, p->NIre, p->NIim, mstr, NP, nullptr, 0,
+                           p->CDre, p->CDim, mstr, NP, 1.0, st, N == NP));
+    hpx_devbuf a1h;
+    HPX_TRY(a1h.alloc(2 * (size_t)nbl * NP * NP));
+    hipLaunchKernelGGL(k_conj_transpose, dim3(64, nbl), dim3(256), 0, st, p->CDre, p->CDim, a1h.p,
+                       a1h.p + (size_t)nbl * NP * NP, NP);
+    HPX_HIP(hipGetLastError());
+    HPX_TRY(hpx_launch_dft(nbl, NP, NP, p->Fopre, p->Fopim, 0, a1h.p, a1h.p + (size_t)nbl * NP * NP, mstr, NP,
+                           nullptr, 0, p->CDre, p->CDim, mstr, NP, 1.0 / (double)N, st, N == NP));
+    HPX_HIP(hipStreamSynchronize(st));     // a1h is released here
+  }
   // R = U^H Z = F Z / sqrt(N)
   HPX_TRY(hpx_launch_dft(nbl, NP, p->ncolR, p->Fopre, p->Fopim, 0, p->Zre, p->Zim,
                          (long)NP * p->ncolR, p->ncolR, nullptr, 0, p->Rre, p->Rim,
                          (long)NP * p->ncolR, p->ncolR, isn, st, N == NP));
-  hipLaunchKernelGGL(k_circ, dim3(4, nbl), dim3(256), 0, st, p->Rre, p->Rim, p->Cre, p->Cim, N, NP,
-                     p->ncolR, TP + MP);
-  HPX_HIP(hipGetLastError());
+  if (!p->dense_noise) {
+    hipLaunchKernelGGL(k_circ, dim3(4, nbl), dim3(256), 0, st, p->Rre, p->Rim, p->Cre, p->Cim, N, NP,
+                       p->ncolR, TP + MP);
+    HPX_HIP(hipGetLastError());
+  } else {
+    HPX_HIP(hipMemsetAsync(p->Cre, 0, (size_t)nbl * N * sizeof(double), st));
+    HPX_HIP(hipMemsetAsync(p->Cim, 0, (size_t)nbl * N * sizeof(double), st));
+  }
   if (M > 0) {
     hipLaunchKernelGGL(k_small, dim3(nbl), dim3(256), 0, st, fgp, p->fg_shared, p->Zre, p->Zim,
                        p->Hre, p->Him, p->P4re, p->P4im, N, M, NP, TP, MP, p->ncolR);
@@ -1146,7 +1293,28 @@ extern "C" int hpx_plan_set_static(hpx_plan* p, const double* vis, const uint8_t
   }
   HPX_HIP(hipStreamSynchronize(st));
   p->have_static = 1;
+  if (p->dense_noise) p->solver = HPX_SOLVER_DENSE;
   return HPX_OK;
+}
+
+extern "C" int hpx_plan_set_static(hpx_plan* p, const double* vis, const uint8_t* flags,
+                                   const double* ninv, const double* fgmodes, int fg_shared,
+                                   const int32_t* prior_map, const double* xgrid, int nxrows,
+                                   int prior_shared, int ngrid, const double* omega,
+                                   const double* fop, int any_flags, void* stream) {
+  HPX_REQUIRE(ninv, "hpx_plan_set_static: null argument");
+  return set_static_impl(p, vis, flags, ninv, nullptr, nullptr, 0, fgmodes, fg_shared, prior_map, xgrid, nxrows,
+                         prior_shared, ngrid, omega, fop, any_flags, stream);
+}
+
+extern "C" int hpx_plan_set_static_dense(hpx_plan* p, const double* vis, const uint8_t* flags,
+                                         const double* ninv_dense, const double* nih_dense, int noise_shared,
+                                         const double* fgmodes, int fg_shared, const int32_t* prior_map,
+                                         const double* xgrid, int nxrows, int prior_shared, int ngrid,
+                                         const double* omega, const double* fop, int any_flags, void* stream) {
+  HPX_REQUIRE(ninv_dense && nih_dense, "hpx_plan_set_static_dense: null noise matrices");
+  return set_static_impl(p, vis, flags, nullptr, ninv_dense, nih_dense, noise_shared, fgmodes, fg_shared, prior_map,
+                         xgrid, nxrows, prior_shared, ngrid, omega, fop, any_flags, stream);
 }
 
 extern "C" int hpx_plan_set_rng(hpx_plan* p, const double* uniforms, const double* igy, int niter,
@@ -1171,6 +1339,8 @@ static hpx_gen_batch gen_of(const hpx_plan* p) {
   B.ia = p->ia; B.cre = p->Cre; B.cim = p->Cim; B.rre = p->Rre; B.rim = p->Rim;
   B.p2re = p->P2re; B.p2im = p->P2im; B.hre = p->Hre; B.him = p->Him;
   B.p4re = p->P4re; B.p4im = p->P4im;
+  B.cdre = p->dense_noise ? p->CDre : nullptr;
+  B.cdim = p->dense_noise ? p->CDim : nullptr;
   B.N = p->N; B.M = p->M; B.NP = p->NP; B.TP = p->TP; B.ncol = p->ncolR;
   B.has_omega = p->has_omega;
   B.rmin = 32 * (p->N / 32);
@@ -1209,6 +1379,8 @@ extern "C" int hpx_plan_set_solver(hpx_plan* p, int mode) {
   HPX_REQUIRE(p && p->have_static, "hpx_plan_set_solver: plan has no static inputs");
   HPX_REQUIRE(mode == HPX_SOLVER_DENSE || mode == HPX_SOLVER_FLAT || mode == HPX_SOLVER_LOWRANK ||
               mode == HPX_SOLVER_LOWRANK_DIRECT, "hpx_plan_set_solver: unknown mode");
+  HPX_REQUIRE(mode == HPX_SOLVER_DENSE || !p->dense_noise,
+              "hpx_plan_set_solver: a dense inverse noise covariance needs the dense solver");
   if (mode == HPX_SOLVER_FLAT) {
     HPX_REQUIRE(!p->any_flags, "hpx_plan_set_solver: the flat-noise solver needs unflagged data");
     HPX_REQUIRE(p->M <= 16 && p->TP <= 256, "hpx_plan_set_solver: the flat-noise solver needs M <= 16, T <= 256");
@@ -1376,11 +1548,12 @@ static int post_solve(hpx_plan* p, int it_abs, const IterOut& O, hipStream_t st)
   R.N = N; R.M = M; R.T = T; R.NP = NP; R.TP = TP; R.npad = p->npad;
   R.fg_shared = p->fg_shared; R.any_flags = p->any_flags;
   R.twre = p->Fopre; R.twim = p->Fopim; R.isn = isn; R.logN = 0; R.tcs = 0; R.nbl = nbl; R.npart = 1;
+  R.resid_to_g = p->dense_noise;
   // time columns per block of the fused kernel: 64 KiB of LDS for the signal, as k_fft
   int npart = 1, TC = 4096 / NP;
   if (TC > 16) TC = 16;
   const bool pow2 = N == NP && (N & (N - 1)) == 0 && N >= 32 && N <= 4096;
-  if (pow2 && hpx_dft_use_fft && TC >= HPX_FUSE_TC && TP / TC <= HPX_NPART) {   // fewer columns per block: two kernels win
+  if (pow2 && hpx_dft_use_fft && TC >= HPX_FUSE_TC && TP / TC <= HPX_NPART && !p->dense_noise) {   // fewer columns per block: two kernels win
     while ((1 << R.logN) < N) ++R.logN;
     while ((1 << R.tcs) < TC) ++R.tcs;
     npart = TP / TC;
@@ -1393,7 +1566,7 @@ static int post_solve(hpx_plan* p, int it_abs, const IterOut& O, hipStream_t st)
     hipLaunchKernelGGL(k_fft_resid, dim3(((nbl + 7) / 8) * 8 * npart), dim3(256), lds, st, R);
     HPX_HIP(hipGetLastError());
     HPX_TRY(mark(p, st));
-  } else if (HPX_DFT_RESID && NP <= 256 && M <= 16 && hpx_dft_use_fft) {
+  } else if (HPX_DFT_RESID && NP <= 256 && M <= 16 && hpx_dft_use_fft && !p->dense_noise) {
     // small N without an in-LDS FFT: dense transform fused with the residual (k_dft_resid), booked
     // under "transform"
     npart = (NP / 16 + 3) / 4;
@@ -1409,6 +1582,15 @@ static int post_solve(hpx_plan* p, int it_abs, const IterOut& O, hipStream_t st)
     hipLaunchKernelGGL(k_resid, dim3(nbl), dim3(256),
                        (size_t)(2 * M * TP + N * (TP / 16)) * sizeof(double), st, R);
     HPX_HIP(hipGetLastError());
+    if (p->dense_noise) {
+      // first ln-posterior term with the full matrix: sum_t r_t^H Ninv r_t  (pspec.py:472-477);
+      // k_resid left the residual in G, v = Ninv r goes to the Z scratch
+      HPX_TRY(hpx_launch_dft(nbl, NP, TP, p->NIre, p->NIim, 1, p->Gre, p->Gim, (long)NP * TP, TP, nullptr, 0,
+                             p->Zre, p->Zim, (long)NP * p->ncolR, p->ncolR, 1.0, st, 0, (long)NP * NP));
+      hipLaunchKernelGGL(k_quadform, dim3(nbl), dim3(256), 0, st, p->Gre, p->Gim, (long)NP * TP, TP, p->Zre, p->Zim,
+                         (long)NP * p->ncolR, p->ncolR, p->lnpart, N, T);
+      HPX_HIP(hipGetLastError());
+    }
   }
   if (p->any_flags) {   // |F (w s)|^2 for the masked S^-1 quadratic form (pspec.py:479-483)
     HPX_TRY(hpx_launch_dft(nbl, NP, TP, p->Fopre, p->Fopim, 0, p->Gre, p->Gim, (long)NP * TP, TP,
@@ -1497,10 +1679,18 @@ extern "C" int hpx_gibbs_run(hpx_plan* p, const double* ps0, int iter0, int nite
       HPX_TRY(mark(p, st));
     } else {
       const hpx_gen_batch gen = gen_of(p);
-      HPX_TRY(launch_assemble_edge(p, st));
-      HPX_TRY(mark(p, st));
-      HPX_TRY(hpx_launch_factor(nbl, p->npad, p->ld, p->L, p->Wre, p->Wim, p->info, iter0 + it + 1,
-                                &gen, st));
+      if (p->dense_noise) {
+        // general Hermitian C: the whole augmented matrix is laid out, then factored in place
+        HPX_TRY(launch_assemble(p, st, 0));
+        HPX_TRY(mark(p, st));
+        HPX_TRY(hpx_launch_factor(nbl, p->npad, p->ld, p->L, p->Wre, p->Wim, p->info, iter0 + it + 1,
+                                  nullptr, st));
+      } else {
+        HPX_TRY(launch_assemble_edge(p, st));
+        HPX_TRY(mark(p, st));
+        HPX_TRY(hpx_launch_factor(nbl, p->npad, p->ld, p->L, p->Wre, p->Wim, p->info, iter0 + it + 1,
+                                  &gen, st));
+      }
       HPX_TRY(mark(p, st));
       HPX_TRY(hpx_launch_backsolve(nbl, p->npad, TP, p->ld, p->L, p->Wre, p->Wim, p->Xre, p->Xim, st));
       HPX_TRY(mark(p, st));
@@ -1632,8 +1822,13 @@ extern "C" int hpx_gibbs_step_general(hpx_plan* p, const double* shp, int iter0,
   }
   const long mstr = (long)NP * NP;
   hipLaunchKernelGGL(k_mat_planar, dim3(64, nbl), dim3(256), 0, st, shp, p->SHre, p->SHim, N, NP);
-  hipLaunchKernelGGL(k_circ_matrix, dim3(64, nbl), dim3(256), 0, st, p->Cre, p->Cim, p->CMre, p->CMim,
-                     N, NP);
+  if (p->dense_noise) {
+    HPX_HIP(hipMemcpyAsync(p->CMre, p->CDre, msz * sizeof(double), hipMemcpyDeviceToDevice, st));
+    HPX_HIP(hipMemcpyAsync(p->CMim, p->CDim, msz * sizeof(double), hipMemcpyDeviceToDevice, st));
+  } else {
+    hipLaunchKernelGGL(k_circ_matrix, dim3(64, nbl), dim3(256), 0, st, p->Cre, p->Cim, p->CMre, p->CMim,
+                       N, NP);
+  }
   HPX_HIP(hipGetLastError());
   // The dense kernel computes out = W in with W[x][k] read from the planar buffer at [k][x];
   // both C and Sh' are Hermitian, so the stored row-major matrix is conj(W^T): conjW = 1.

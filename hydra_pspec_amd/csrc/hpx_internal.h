@@ -56,6 +56,11 @@ struct hpx_plan {
   int ngrid, nxrows, niter_tab;
   int fg_shared, prior_shared, has_omega, any_flags, have_static, profiling;
   int have_ps;  // the chain state (ps_cur, ia) holds bandpowers: a run may continue without ps0
+  // dense (non-diagonal, Hermitian) inverse noise covariance (hpx_plan_set_static_dense): C = U^H Ni U
+  // is a general Hermitian matrix instead of a circulant
+  int dense_noise;
+  double *NIre, *NIim;     // [nbl][NP][NP] Ninv, planar row-major (zero padded)
+  double *CDre, *CDim;     // [nbl][NP][NP] C = U^H Ninv U
   int solver;   // HPX_SOLVER_DENSE / HPX_SOLVER_FLAT / HPX_SOLVER_LOWRANK (hpx_plan_set_solver)
   // HPX_SOLVER_LOWRANK: flagged channels per baseline, the small Schur system and its solution
   int lr_fmax, lr_npad;
@@ -118,7 +123,8 @@ struct hpx_plan {
 // Pointers are per baseline (already offset), except P2 (shared).
 struct hpx_gen {
   const double *ia, *cre, *cim, *rre, *rim, *p2re, *p2im, *hre, *him, *p4re, *p4im;
-  int N, M, TP, ncol, has_omega, rmin;
+  const double *cdre, *cdim;   // dense C[r][c] (leading dimension NP) or NULL: circulant circ[r-c]
+  int N, M, NP, TP, ncol, has_omega, rmin;
 };
 __device__ __forceinline__ void hpx_gen_entry(const hpx_gen& G, const int r, const int c,
                                               const int npad, double& vr, double& vi) {
@@ -129,8 +135,13 @@ __device__ __forceinline__ void hpx_gen_entry(const hpx_gen& G, const int r, con
   if (c < N) {
     if (r < N) {
       const double ic = G.ia[c];
-      vr = G.cre[r - c] + (r == c ? ic * ic : 0.0);
-      vi = (r == c) ? 0.0 : G.cim[r - c];
+      if (G.cdre) {
+        vr = G.cdre[(long)r * G.NP + c] + (r == c ? ic * ic : 0.0);
+        vi = (r == c) ? 0.0 : G.cdim[(long)r * G.NP + c];
+      } else {
+        vr = G.cre[r - c] + (r == c ? ic * ic : 0.0);
+        vi = (r == c) ? 0.0 : G.cim[r - c];
+      }
     } else if (r < N + M) {
       const long o = (long)c * G.ncol + G.TP + (r - N);
       vr = G.rre[o];
@@ -173,6 +184,7 @@ __device__ __forceinline__ void hpx_gen_signal(const hpx_gen& G, const int r, co
 // batch-level description: per-baseline strides are implied by the plan dimensions
 struct hpx_gen_batch {
   const double *ia, *cre, *cim, *rre, *rim, *p2re, *p2im, *hre, *him, *p4re, *p4im;
+  const double *cdre, *cdim;   // dense C, [nbl][NP][NP], or NULL
   int N, M, NP, TP, ncol, has_omega, rmin;
 };
 __device__ __forceinline__ hpx_gen hpx_gen_for(const hpx_gen_batch& B, const int b) {
@@ -188,7 +200,9 @@ __device__ __forceinline__ hpx_gen hpx_gen_for(const hpx_gen_batch& B, const int
   G.him = B.him + (long)b * B.M * B.M;
   G.p4re = B.p4re + (long)b * B.M * B.TP;
   G.p4im = B.p4im + (long)b * B.M * B.TP;
-  G.N = B.N; G.M = B.M; G.TP = B.TP; G.ncol = B.ncol; G.has_omega = B.has_omega;
+  G.cdre = B.cdre ? B.cdre + (long)b * B.NP * B.NP : nullptr;
+  G.cdim = B.cdim ? B.cdim + (long)b * B.NP * B.NP : nullptr;
+  G.N = B.N; G.M = B.M; G.NP = B.NP; G.TP = B.TP; G.ncol = B.ncol; G.has_omega = B.has_omega;
   G.rmin = B.rmin;
   return G;
 }

@@ -85,6 +85,32 @@ def _prior_tables(ps_prior, N):
     return pmap, xgrid
 
 
+def sqrtm_hermitian(A):
+    """Principal square root of Hermitian positive semi-definite matrices (.., N, N) through one
+    eigendecomposition (what ``scipy.linalg.sqrtm`` returns for them; reference pspec.py:362)."""
+    A = np.asarray(A, dtype=complex)
+    lam, V = np.linalg.eigh(0.5 * (A + np.conj(np.swapaxes(A, -1, -2))))
+    return (V * np.sqrt(np.clip(lam, 0.0, None))[..., None, :]) @ np.conj(np.swapaxes(V, -1, -2))
+
+
+def _ninv_dense(Ninv, nbl, N):
+    """``Ninv`` if it is a non-diagonal (N,N) / (Nbl,N,N) matrix (then it must be Hermitian), else None."""
+    if not isinstance(Ninv, np.ndarray) and hasattr(Ninv, "detach"):
+        if Ninv.ndim < 2 or tuple(Ninv.shape[-2:]) != (N, N):
+            return None
+        Ninv = Ninv.detach().cpu().numpy()
+    Ninv = np.asarray(Ninv)
+    if Ninv.shape not in ((N, N), (nbl, N, N)):
+        return None
+    d = np.diagonal(Ninv, axis1=-2, axis2=-1)
+    if not np.any(Ninv - d[..., None] * np.eye(N) != 0):
+        return None
+    herm = np.conj(np.swapaxes(Ninv, -1, -2))
+    if not np.allclose(Ninv, herm, rtol=1e-12, atol=1e-14 * np.abs(Ninv).max()):
+        raise NotImplementedError("a non-Hermitian inverse noise covariance is not supported")
+    return np.ascontiguousarray(Ninv, dtype=complex)
+
+
 def _ninv_diag(Ninv, nbl, T, N):
     """Accept (N,), (nbl,N) diagonals or (N,N)/(nbl,N,N) dense matrices that are
     diagonal; return (nbl,N).  Dense non-diagonal inverse covariances make the
@@ -105,7 +131,8 @@ def _ninv_diag(Ninv, nbl, T, N):
         d = np.diagonal(Ninv, axis1=-2, axis2=-1)
         off = Ninv - d[..., None] * np.eye(N)
         if np.any(off != 0):
-            raise NotImplementedError("only diagonal inverse noise covariances are supported")
+            raise NotImplementedError("this entry point takes diagonal inverse noise covariances only "
+                                      "(make_batch / gibbs_sample_with_fg[_batched] accept Hermitian matrices)")
         return np.ascontiguousarray(np.broadcast_to(d.real, (nbl, N)), dtype=float)
     raise AssertionError("Ninv shape must be (Nfreqs, Nfreqs) or a diagonal (Nfreqs,)")
 
@@ -147,7 +174,9 @@ class GibbsBatch:
     """
 
     def __init__(self, vis, flags, fgmodes, ninv_diag, ps_prior, Niter, seed=None,
-                 map_estimate=False, device=None, tables=None, omega=None, solver="auto"):
+                 map_estimate=False, device=None, tables=None, omega=None, solver="auto", ninv_dense=None):
+        """``ninv_dense``: Hermitian non-diagonal inverse noise covariance(s) (N,N) or (Nbl,N,N) instead of
+        ``ninv_diag`` (:func:`make_batch` routes them here): dense solver only, unflagged data only."""
         torch = hpx.require_gpu()
         self.torch = torch
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None \
@@ -168,8 +197,16 @@ class GibbsBatch:
             fl_np = flags if isinstance(flags, np.ndarray) else flags.detach().cpu().numpy()
             d_flags = hpx.to_dev(torch, np.ascontiguousarray(fl_np).astype(np.uint8), torch.uint8,
                                  self.device)
-            d_ninv = hpx.to_dev(torch, ninv_diag, f64, self.device)
-            assert tuple(d_ninv.shape) == (nbl, N)
+            self.dense_noise = ninv_dense is not None
+            if self.dense_noise:
+                nd = np.asarray(ninv_dense, dtype=complex)
+                assert nd.shape in ((N, N), (nbl, N, N)), "Ninv shape must be (Nfreqs, Nfreqs) or (Nbl, Nfreqs, Nfreqs)"
+                d_nd = hpx.to_dev(torch, nd, c128, self.device)
+                d_nh = hpx.to_dev(torch, sqrtm_hermitian(nd), c128, self.device)
+                d_ninv = None
+            else:
+                d_ninv = hpx.to_dev(torch, ninv_diag, f64, self.device)
+                assert tuple(d_ninv.shape) == (nbl, N)
             fg_shared = len(fg_shape) == 2
             d_fg = hpx.to_dev(torch, fgmodes, c128, self.device)
             pmap, xgrid = _prior_tables(ps_prior if isinstance(ps_prior, np.ndarray)
@@ -189,11 +226,23 @@ class GibbsBatch:
             self.any_flags = bool((~fl_np.astype(bool)).any())
             self.plan = hpx.Plan(nbl, T, N, M)
             L = hpx.lib()
-            hpx.check(L.hpx_plan_set_static(
-                self.plan.handle, hpx.ptr(d_vis), hpx.ptr(d_flags), hpx.ptr(d_ninv),
-                hpx.ptr(d_fg) if M > 0 else None, int(fg_shared), hpx.ptr(d_pmap), hpx.ptr(d_xgrid),
-                int(len(xgrid)), int(prior_shared), NGRID, hpx.ptr(d_omega), hpx.ptr(d_fop),
-                int(self.any_flags), hpx.stream_ptr(torch)), "hpx_plan_set_static")
+            if self.dense_noise:
+                if self.any_flags:
+                    raise NotImplementedError(
+                        "a non-diagonal inverse noise covariance together with flagged channels is not "
+                        "supported: the reference's column-masked Ni = Ninv * flags is not Hermitian there "
+                        "(pspec.py:361 FIXME)")
+                hpx.check(L.hpx_plan_set_static_dense(
+                    self.plan.handle, hpx.ptr(d_vis), hpx.ptr(d_flags), hpx.ptr(d_nd), hpx.ptr(d_nh),
+                    int(nd.ndim == 2), hpx.ptr(d_fg) if M > 0 else None, int(fg_shared), hpx.ptr(d_pmap),
+                    hpx.ptr(d_xgrid), int(len(xgrid)), int(prior_shared), NGRID, hpx.ptr(d_omega), hpx.ptr(d_fop),
+                    0, hpx.stream_ptr(torch)), "hpx_plan_set_static_dense")
+            else:
+                hpx.check(L.hpx_plan_set_static(
+                    self.plan.handle, hpx.ptr(d_vis), hpx.ptr(d_flags), hpx.ptr(d_ninv),
+                    hpx.ptr(d_fg) if M > 0 else None, int(fg_shared), hpx.ptr(d_pmap), hpx.ptr(d_xgrid),
+                    int(len(xgrid)), int(prior_shared), NGRID, hpx.ptr(d_omega), hpx.ptr(d_fop),
+                    int(self.any_flags), hpx.stream_ptr(torch)), "hpx_plan_set_static")
             self.set_tables(uni, igy)
             # "auto": baselines whose unflagged channels share one noise variance take a structured
             # solve (diagonal + border system): hpx_flat.hip without flags, hpx_lowrank.hip with
@@ -207,6 +256,10 @@ class GibbsBatch:
             if direct:
                 solver = "lowrank"
             self.solver = "dense"
+            if self.dense_noise:
+                if solver not in ("auto", "dense"):
+                    raise ValueError("a non-diagonal inverse noise covariance needs solver='dense' (or 'auto')")
+                solver = "dense"
             if solver != "dense":
                 use = d_flags.bool()
                 ref = torch.where(use, d_ninv, torch.nan).nan_to_num(nan=-1.0).max(dim=1, keepdim=True).values
@@ -339,13 +392,19 @@ class GibbsBatch:
 
 
 def make_batch(vis, flags, fgmodes, Ninv, ps_prior, Niter, seed=None, map_estimate=False, device=None,
-               solver="auto"):
+               solver="auto", tables=None):
     """A :class:`GibbsBatch` from the inverse noise covariance in any form the path accepts:
     diagonals ``(Nfreqs,)`` / ``(Nbl,Nfreqs)`` or matrices ``(Nfreqs,Nfreqs)`` / ``(Nbl,Nfreqs,Nfreqs)``
     (reference run-hydra-pspec.py:427-438 passes ``inv(noise_cov)``)."""
     nbl, T, N = tuple(vis.shape)
+    # (a 2-D (Nbl, Nfreqs) array is a stack of diagonals unless Nbl == Nfreqs, where the matrix reading wins
+    # as in the reference, which only knows (Nfreqs, Nfreqs))
+    nd = _ninv_dense(Ninv, nbl, N) if len(np.shape(Ninv)) >= 2 else None
+    if nd is not None:
+        return GibbsBatch(vis, flags, fgmodes, None, ps_prior, Niter, seed=seed, map_estimate=map_estimate,
+                          device=device, solver=solver, ninv_dense=nd, tables=tables)
     return GibbsBatch(vis, flags, fgmodes, _ninv_diag(Ninv, nbl, T, N), ps_prior, Niter, seed=seed,
-                      map_estimate=map_estimate, device=device, solver=solver)
+                      map_estimate=map_estimate, device=device, solver=solver, tables=tables)
 
 
 def gibbs_sample_with_fg_batched(vis, flags, fgmodes, Ninv, ps_prior, S_initial=None,
@@ -665,7 +724,7 @@ def gibbs_step_fgmodes(vis, flags, signal_S, fgmodes, Ninv, ps_prior=None, f0=No
         ps_prior = np.zeros((2, N))
     ps0, resid = pspec_from_covariance(np.asarray(signal_S))
     T = vis.shape[0]
-    gb = GibbsBatch(vis[None], np.asarray(flags)[None], fgmodes, _ninv_diag(Ninv, 1, T, N), ps_prior, 1,
+    gb = make_batch(vis[None], np.asarray(flags)[None], fgmodes, Ninv, ps_prior, 1,
                     map_estimate=map_estimate, tables=draw_tables(T, N, 1, None, reseed=False))
     try:
         if resid > FOURIER_FORM_TOL:
@@ -713,8 +772,8 @@ def gibbs_sample_with_fg(vis, flags, S_initial, fgmodes, Ninv, ps_prior, Niter=1
     ps0, resid = pspec_from_covariance(np.asarray(S_initial))
     shp0 = sqrt_cov_delay_basis(np.asarray(S_initial))[None] if resid > FOURIER_FORM_TOL else None
     fop = utils.fourier_operator(Nfreqs)
-    gb = GibbsBatch(vis[None], flags[None], fgmodes, _ninv_diag(Ninv, 1, Ntimes, Nfreqs), ps_prior,
-                    Niter, seed=seed, map_estimate=map_estimate, solver=solver)
+    gb = make_batch(vis[None], flags[None], fgmodes, Ninv, ps_prior, Niter, seed=seed,
+                    map_estimate=map_estimate, solver=solver)
     signal_cr = np.zeros((Niter, Ntimes, Nfreqs), dtype=complex)
     signal_ps = np.zeros((Niter, Nfreqs))
     fg_amps = np.zeros((Niter, Ntimes, Nmodes), dtype=complex)

@@ -78,6 +78,22 @@ int hpx_plan_set_static(hpx_plan* p, const double* vis, const uint8_t* flags,
                         int prior_shared, int ngrid, const double* omega,
                         const double* fop, int any_flags, void* stream);
 
+/* The same for a dense (non-diagonal) Hermitian inverse noise covariance, what the reference driver
+ * passes for a correlated --noise_cov (run-hydra-pspec.py:427-438, pspec.py:361-369):
+ *   ninv_dense (nbl|1,N,N) c128   Ninv = inv(noise_cov), Hermitian
+ *   nih_dense  (nbl|1,N,N) c128   its principal square root sqrtm(Ninv) (pspec.py:362)
+ *   noise_shared                  != 0: one pair of matrices for all baselines
+ * C = U^H Ninv U is then a general Hermitian matrix (not a circulant): every iteration lays the
+ * whole augmented system out and factors it in place; the first ln-posterior term is the full
+ * quadratic form r^H Ninv r (pspec.py:472-477), chi^2 uses Ninv.diagonal() (pspec.py:452).
+ * Needs unflagged data (any_flags == 0): the reference's column-masked Ni = Ninv diag(w) is not
+ * Hermitian (pspec.py:361 FIXME) and is refused with HPX_EINVAL. */
+int hpx_plan_set_static_dense(hpx_plan* p, const double* vis, const uint8_t* flags,
+                              const double* ninv_dense, const double* nih_dense, int noise_shared,
+                              const double* fgmodes, int fg_shared, const int32_t* prior_map,
+                              const double* xgrid, int nxrows, int prior_shared, int ngrid,
+                              const double* omega, const double* fop, int any_flags, void* stream);
+
 /* Random tables of the bandpower draw (pspec.py:113-125): one uniform per
  * channel per iteration from the chain's global stream.
  *   uniforms (niter,N) f64   U

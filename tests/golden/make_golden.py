@@ -3,7 +3,7 @@
 
 Run in the build container only (needs /root/reference):
 
-    python tests/golden/make_golden.py [--only small,steps,chain_synth,chain_testdata,chain_fullsize]
+    python tests/golden/make_golden.py [--only small,steps,chain_synth,chain_testdata,chain_fullsize,steps_dense]
 
 The reference is imported unmodified; its two I/O-only dependencies that are
 absent here (pyuvdata, astropy -- used by file loaders, never by the Gibbs path)
@@ -234,6 +234,51 @@ def gen_steps(hp):
     print("steps.npz", len(out), "arrays")
 
 
+# --------------------------------------------------------------------------- dense noise covariance
+def dense_noise_inputs():
+    """A banded, complex Hermitian positive-definite noise covariance (neighbouring channels
+    correlated) and unflagged data: the case in which the reference's Ni = flags.T * Ninv * flags stays
+    Hermitian (pspec.py:361).  Ninv = inv(noise_cov) as the driver forms it (run-hydra-pspec.py:436)."""
+    from hydra_pspec_amd import synthetic
+    T, N, M = 8, 32, 4
+    d = synthetic.make_baselines(N, T, M, k0=333, flag_frac=0.0, prior=True)
+    sig2 = 1.0 / d["Ninv"][0, 0].real
+    i = np.arange(N)
+    band = np.zeros((N, N), dtype=complex)
+    band[i, i] = 1.0 + 0.2 * np.cos(0.3 * i)
+    band[i[:-1], i[:-1] + 1] = 0.3 * np.exp(0.4j)
+    band[i[:-1] + 1, i[:-1]] = 0.3 * np.exp(-0.4j)
+    band[i[:-2], i[:-2] + 2] = 0.1
+    band[i[:-2] + 2, i[:-2]] = 0.1
+    noise_cov = sig2 * band
+    return dict(vis=d["vis"][0], flags=d["flags"][0], S=d["S_initial"], fgmodes=d["fgmodes"],
+                Ninv=np.linalg.inv(noise_cov), prior=d["ps_prior"], noise_cov=noise_cov)
+
+
+def gen_steps_dense(hp):
+    import warnings
+    out = {}
+    inp = dense_noise_inputs()
+    for k, v in inp.items():
+        out[f"in_{k}"] = v
+    np.random.seed(4242)
+    cr, S_s, ps, fg, chi, lp = hp.pspec.gibbs_step_fgmodes(
+        vis=inp["vis"] * inp["flags"], flags=inp["flags"], signal_S=inp["S"], fgmodes=inp["fgmodes"],
+        Ninv=inp["Ninv"], ps_prior=inp["prior"], nproc=1)
+    out["step_cr"], out["step_S"], out["step_ps"], out["step_fg"] = cr, S_s, ps, fg
+    out["step_chisq"], out["step_lnpost"] = chi, np.array(lp)          # chisq is complex here (Ninv.diagonal())
+    print("dense step ps[:3]", ps[:3], "lnpost", lp)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")      # the chain driver stores the complex chi^2 into a real array
+        r = run_chain(hp, inp["vis"], inp["flags"], inp["S"], inp["fgmodes"], inp["Ninv"], inp["prior"], 6, 77)
+        pack_chain(out, "chain_", r)
+        with exact_solver():
+            r2 = run_chain(hp, inp["vis"], inp["flags"], inp["S"], inp["fgmodes"], inp["Ninv"], inp["prior"], 6, 77)
+        out["chain_exact_ps"], out["chain_exact_lnpost"] = r2[2], r2[5]
+    np.savez(HERE / "steps_dense.npz", **out)
+    print("steps_dense.npz", len(out), "arrays")
+
+
 # --------------------------------------------------------------------------- chains
 def run_chain(hp, vis, flags, S0, F, Ninv, prior, niter, seed):
     t0 = time.time()
@@ -335,6 +380,8 @@ def main():
         gen_chain_testdata(hp)
     if "chain_fullsize" in todo:
         gen_chain_fullsize(hp)
+    if "steps_dense" in todo:
+        gen_steps_dense(hp)
 
 
 if __name__ == "__main__":

@@ -191,3 +191,24 @@ def test_driver_periodic_checkpoints_and_resume_guard(tmp_path, monkeypatch):
     for k in (1, 2):
         for f in ("dps-eor.npy", "gcr-eor.npy", "ln-post.npy", "chisq.npy", "fg-amps.npy", "cov-eor.npy"):
             assert np.array_equal(np.load(tmp_path / "part" / f"0-{k}" / f), np.load(tmp_path / "full" / f"0-{k}" / f)), f
+
+
+@pytest.mark.gpu
+def test_driver_correlated_noise_cov(golden, tmp_path):
+    """--noise_cov with off-diagonal terms reaches the sampler as the full inverse (reference
+    run-hydra-pspec.py:436), never as its diagonal (run-hydra-pspec.py:199)."""
+    drv = _driver()
+    g = golden("steps_dense")
+    aux = tmp_path / "aux" / "0-1"
+    aux.mkdir(parents=True)
+    np.save(aux / "eor-cov.npy", g["in_S"])
+    np.save(aux / "fgmodes.npy", g["in_fgmodes"])
+    np.save(aux / "noise-cov.npy", g["in_noise_cov"])
+    np.savez(tmp_path / "vis.npz", vis=g["in_vis"][None], antpairs=np.array([[0, 1]]))
+    rc = drv.main(["--file_paths", str(tmp_path / "vis.npz"), "--sigcov0", str(tmp_path / "aux"), "--sigcov0_file",
+                   "eor-cov.npy", "--fgmodes", str(tmp_path / "aux"), "--fgmodes_file", "fgmodes.npy", "--Nfgmodes", "4",
+                   "--noise_cov", str(tmp_path / "aux"), "--noise_cov_file", "noise-cov.npy", "--ps_prior_lo", "0.1",
+                   "--ps_prior_hi", "2", "--seed", "77", "--Niter", "6", "--out_dir", str(tmp_path), "--dirname", "res"])
+    assert rc == 0
+    ps = np.load(tmp_path / "res" / "0-1" / "dps-eor.npy")
+    assert np.max(np.abs(ps / g["chain_ps"] - 1)) < 1e-6

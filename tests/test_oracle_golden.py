@@ -210,3 +210,18 @@ def test_oqe_closed_forms_equal_the_loop_forms():
         V = g[f"F11_{s}_V"]
         assert relerr(oqe_ref.q_h_closed(V, s, g[f"F11_{s}_R"]), g[f"F11_{s}_qh"]) < 1e-12
         assert relerr(oqe_ref.q_h_closed(V, s, g[f"F11_{s}_Rg"]), g[f"F11_{s}_qhg"]) < 1e-12
+
+
+def test_dense_noise_covariance_step_and_chain():
+    """A banded Hermitian noise covariance without flags (golden steps_dense.npz = the reference's own
+    output, run-hydra-pspec.py:427-438 / pspec.py:361-369): the oracle reproduces the reference."""
+    g = dict(np.load(GOLDEN / "steps_dense.npz"))
+    np.random.seed(4242)
+    o = R.gibbs_step_fgmodes(g["in_vis"] * g["in_flags"], g["in_flags"], g["in_S"], g["in_fgmodes"], g["in_Ninv"],
+                             g["in_prior"])
+    assert np.max(np.abs(o[2] / g["step_ps"] - 1)) < 1e-7
+    assert relerr(o[0], g["step_cr"]) < 1e-7 and relerr(o[3], g["step_fg"]) < 1e-7
+    assert o[5] == pytest.approx(float(g["step_lnpost"]), rel=1e-6)
+    r = R.gibbs_sample_with_fg(g["in_vis"], g["in_flags"], g["in_S"], g["in_fgmodes"], g["in_Ninv"], g["in_prior"],
+                               Niter=6, seed=77)
+    assert np.max(np.abs(r[2] / g["chain_ps"] - 1)) < 1e-6
