@@ -38,6 +38,9 @@ CONFIGS = {
     "C2": (64, 32, 256, 12, 0.0),
     "C3": (1024, 32, 512, 12, 0.0),
     "C5": (1024, 32, 1024, 12, 0.15),
+    # N4: time-dependent flags, one system per (baseline, time): 32 x 32 = 1024
+    # factorisations of the C3 order per iteration
+    "N4": (32, 32, 512, 12, 0.10),
 }
 FP64_MFMA_PEAK_TFLOPS = 78.6   # AMD spec (32 FLOP/clk/SIMD x 1024 SIMDs x 2.4 GHz); the local
 #                                microarch guide has no f64 row -- the measured issue peak is
@@ -462,10 +465,18 @@ def main():
     K, W = args.steps, args.warmup
 
     d = synthetic.make_baselines(N, T, M, k0=k0, nbl=nbl, flag_frac=frac, dense=False)
-    gb = pspec.GibbsBatch(d["vis"], d["flags"], d["fgmodes"], d["ninv_diag"], d["ps_prior"],
+    flags_in, ninv_in = d["flags"], d["ninv_diag"]
+    if args.config == "N4":
+        rng = np.random.default_rng(11 + k0)
+        flags_in = np.broadcast_to(d["flags"][:, None, :], (nbl, T, N)).copy()
+        flags_in &= rng.uniform(size=(nbl, T, N)) > 0.05
+        ninv_in = np.ascontiguousarray(np.broadcast_to(d["ninv_diag"][:, None, :] *
+                                                       rng.uniform(0.7, 1.3, size=(nbl, T, 1)), (nbl, T, N)))
+    gb = pspec.GibbsBatch(d["vis"], flags_in, d["fgmodes"], ninv_in, d["ps_prior"],
                           W + K, seed=d["seed"], solver=args.solver)
     ps0 = np.broadcast_to(d["ps0"], (nbl, N)).copy()
     fmax = int((~np.asarray(d["flags"]).astype(bool)).sum(axis=1).max())
+    units_per_bl = T if args.config == "N4" else 1      # factorisations per baseline and iteration
 
     def barrier():
         torch.cuda.synchronize()
@@ -514,7 +525,7 @@ def main():
     # the same batch through solver="auto" (outside the timed region): unflagged flat-noise inputs
     # such as C3's then take the O(N M (M+T)) structured solve instead of the dense factorisation
     flat_extra = None
-    if rank == 0 and world == 1 and args.solver == "dense":
+    if rank == 0 and world == 1 and args.solver == "dense" and args.config != "N4":
         gf = pspec.GibbsBatch(d["vis"], d["flags"], d["fgmodes"], d["ninv_diag"], d["ps_prior"],
                               W + K, seed=d["seed"], solver="auto")
         if gf.solver in ("flat", "lowrank"):
@@ -552,8 +563,14 @@ def main():
         peak_meas = np.zeros(1)
         import ctypes
         hpx.check(hpx.lib().hpx_mfma_f64_peak(20000, peak_meas.ctypes.data_as(ctypes.c_void_p)))
-        roof = roofline_for(gb.solver, stage, nbl, N, M, T, fmax, K, traffic, float(peak_meas[0]))
-        roof["whole_step"] = whole_step_for(gb.solver, value / world, N, M, T, fmax)
+        if args.config == "N4":      # nbl*T systems with one right-hand side each
+            roof = roofline_for("dense", stage, nbl * T, N, M, 1, fmax, K, None, float(peak_meas[0]))
+            roof["whole_step"] = whole_step_for("dense", value / world * T, N, M, 1, fmax)
+            roof["note"] = ("time-dependent flags: one (N+M)-order system per (baseline, time) and iteration; "
+                            f"units_per_launch = {nbl} baselines x {T} times")
+        else:
+            roof = roofline_for(gb.solver, stage, nbl, N, M, T, fmax, K, traffic, float(peak_meas[0]))
+            roof["whole_step"] = whole_step_for(gb.solver, value / world, N, M, T, fmax)
         res = {
             "metric": "baseline x Gibbs-iter/sec at Nfreq=512; P(k) rtol vs CPU ref",
             "value": value, "unit": "baseline*iter/s", "n_gpus": world, "steps": K, "warmup": W,
@@ -575,7 +592,11 @@ def main():
         res["config"]["solver"] = gb.solver
         if flat_extra:
             res["flat_noise_structured_solve"] = flat_extra     # (key kept from the unflagged case)
-        if world == 1 and not args.no_cpu_baseline:
+        if args.config == "N4":
+            res["config"]["workload"] += (f"; TIME-DEPENDENT flags (5 % per time on top) and noise levels: "
+                                          f"{nbl_gpu * T} factorisations per iteration")
+            res["systems_per_second"] = value * units_per_bl
+        if world == 1 and not args.no_cpu_baseline and args.config != "N4":
             one, ref_ps, dd = cpu_baseline(N, T, M, frac)
             mp = cpu_baseline_multiproc(N, T, M, frac)
             if mp and mp["value"] > one["value"]:

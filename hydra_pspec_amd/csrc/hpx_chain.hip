@@ -74,8 +74,9 @@ __global__ void k_prep(const double* __restrict__ vis, const uint8_t* __restrict
                        double* __restrict__ Zre, double* __restrict__ Zim,
                        double* __restrict__ Dre, double* __restrict__ Dim,
                        double* __restrict__ ni_out, const int T, const int N, const int M,
-                       const int NP, const int TP, const int MP, const int ncol) {
+                       const int NP, const int TP, const int MP, const int ncol, const int omega_mod) {
   const int b = blockIdx.y;
+  const int tom = omega_mod > 0 ? b % omega_mod : 0;      // per-time units: the draws of "their" time
   const long tot = (long)NP * ncol;
   const double* F = fg + (fg_shared ? 0 : (long)b * N * M * 2);
   for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < tot;
@@ -96,8 +97,8 @@ __global__ void k_prep(const double* __restrict__ vis, const uint8_t* __restrict
           zi = ni * di;
           if (omega) {
             const double nih = sqrt(ni);
-            zr += nih * (omega[((long)t * 4 + 2) * N + j] / SQRT2);
-            zi += nih * (omega[((long)t * 4 + 3) * N + j] / SQRT2);
+            zr += nih * (omega[((long)(t + tom) * 4 + 2) * N + j] / SQRT2);
+            zi += nih * (omega[((long)(t + tom) * 4 + 3) * N + j] / SQRT2);
           }
         }
         Dre[((long)b * NP + j) * TP + t] = dr;
@@ -400,6 +401,8 @@ struct ResArgs {
   long cr_bstride, fg_bstride, chisq_bstride;
   int N, M, T, NP, TP, npad, fg_shared, any_flags;
   int nbl, npart;                       // fused kernel: batch size, column groups per baseline
+  const uint8_t* flags_t;               // k_resid, per-time mode: [nbl][T][N] flags and inverse noise
+  const double* ninv_t;                 // variances (NULL: the time-independent ones above)
   int resid_to_g;                       // k_resid: write the residual d - model to G (dense noise: the
                                         // quadratic form r^H Ninv r is taken afterwards; needs !any_flags)
 };
@@ -459,8 +462,9 @@ __global__ __launch_bounds__(256) void k_resid(const ResArgs A) {
       mi += gr * fi + gi * fr;
     }
     const double rr = dre[o] - mr, ri = dim_[o] - mi;
-    const double w = fl[x] ? 1.0 : 0.0;
-    const double c2 = (rr * rr + ri * ri) * ninv[x];
+    const long ot = ((long)b * T + t) * N + x;
+    const double w = (A.flags_t ? A.flags_t[ot] : fl[x]) ? 1.0 : 0.0;
+    const double c2 = (rr * rr + ri * ri) * (A.ninv_t ? A.ninv_t[ot] : ninv[x]);
     acc += w * c2;
     if (A.any_flags) {
       A.Gre[(long)b * A.NP * TP + o] = w * sr;
@@ -1099,9 +1103,13 @@ int dev_alloc(hpx_plan* p, Tp** ptr, size_t count) {
 }  // namespace
 
 // ---------------------------------------------------------------------------
+static int plan_create_impl(hpx_plan** out, int nbl, int T, int N, int M);
 extern "C" int hpx_plan_create(hpx_plan** out, int nbl, int T, int N, int M) {
   HPX_REQUIRE(out, "hpx_plan_create: null out");
   HPX_REQUIRE(nbl > 0 && T > 1 && N > 0 && M >= 0, "hpx_plan_create: need nbl>0, T>1, N>0, M>=0");
+  return plan_create_impl(out, nbl, T, N, M);
+}
+static int plan_create_impl(hpx_plan** out, int nbl, int T, int N, int M) {
   hpx_plan* p = new hpx_plan();
   p->nbl = nbl; p->T = T; p->N = N; p->M = M;
   p->n = N + M;
@@ -1155,13 +1163,16 @@ extern "C" int hpx_plan_create(hpx_plan** out, int nbl, int T, int N, int M) {
 
 extern "C" int hpx_plan_destroy(hpx_plan* p) {
   if (!p) return HPX_OK;
+  if (p->child) { hpx_plan_destroy(p->child); p->child = nullptr; }
   for (auto& q : p->allocs) (void)hipFree(q.first);
   for (hipEvent_t ev : p->events) (void)hipEventDestroy(ev);
   delete p;
   return HPX_OK;
 }
 
-extern "C" int64_t hpx_plan_bytes(const hpx_plan* p) { return p ? p->bytes : 0; }
+extern "C" int64_t hpx_plan_bytes(const hpx_plan* p) {
+  return p ? p->bytes + (p->child ? p->child->bytes : 0) : 0;
+}
 
 extern "C" int hpx_plan_dims(const hpx_plan* p, int* npad, int* tpad, int* ld) {
   HPX_REQUIRE(p, "hpx_plan_dims: null plan");
@@ -1226,7 +1237,7 @@ static int set_static_impl(hpx_plan* p, const double* vis, const uint8_t* flags,
   const double isn = 1.0 / sqrt((double)N);
   if (!ninv_dense) {
     hipLaunchKernelGGL(k_prep, dim3(128, nbl), dim3(256), 0, st, vis, flags, ninv, fgp, p->fg_shared,
-                       omega, p->Zre, p->Zim, p->Dre, p->Dim, p->ni, T, N, M, NP, TP, MP, p->ncolR);
+                       omega, p->Zre, p->Zim, p->Dre, p->Dim, p->ni, T, N, M, NP, TP, MP, p->ncolR, p->omega_mod);
     HPX_HIP(hipGetLastError());
   } else {
     // Z = Ninv [d | F | .] + Ninv^1/2 [omega_b | 0]: the operand block with unit weights (into R as
@@ -1234,7 +1245,7 @@ static int set_static_impl(hpx_plan* p, const double* vis, const uint8_t* flags,
     // buffer[k][x] = conj(W[x][k]), hence conjW = 1)
     const long mstr = (long)NP * NP, zstr = (long)NP * p->ncolR;
     hipLaunchKernelGGL(k_prep, dim3(128, nbl), dim3(256), 0, st, vis, flags, ones.p, fgp, p->fg_shared,
-                       (const double*)nullptr, p->Rre, p->Rim, p->Dre, p->Dim, p->ni, T, N, M, NP, TP, MP, p->ncolR);
+                       (const double*)nullptr, p->Rre, p->Rim, p->Dre, p->Dim, p->ni, T, N, M, NP, TP, MP, p->ncolR, 0);
     HPX_HIP(hipGetLastError());
     HPX_TRY(hpx_launch_dft(nbl, NP, p->ncolR, p->NIre, p->NIim, 1, p->Rre, p->Rim, zstr, p->ncolR, nullptr, 0,
                            p->Zre, p->Zim, zstr, p->ncolR, 1.0, st, 0, mstr));
@@ -1334,6 +1345,138 @@ extern "C" int hpx_plan_set_rng(hpx_plan* p, const double* uniforms, const doubl
   return HPX_OK;
 }
 
+// ---- time-dependent flags / noise (reference docstrings pspec.py:337-340, :398-401,
+// FIXMEs :361, :450-451; run-hydra-pspec.py:524-541 reduces them to an any-time mask instead) -------
+namespace {
+// flags_any[b][x] = AND_t flags_t[b][t][x];  ninv_any[b][x] = ninv_t[b][0][x]
+__global__ void k_pt_reduce(const uint8_t* __restrict__ ft, const double* __restrict__ nt,
+                            uint8_t* __restrict__ fany, double* __restrict__ nany, const int T, const int N) {
+  const int b = blockIdx.y;
+  for (int x = blockIdx.x * blockDim.x + threadIdx.x; x < N; x += gridDim.x * blockDim.x) {
+    uint8_t a = 1;
+    for (int t = 0; t < T; ++t) a &= (ft[((long)b * T + t) * N + x] ? 1 : 0);
+    fany[(long)b * N + x] = a;
+    nany[(long)b * N + x] = nt[(long)b * T * N + x];
+  }
+}
+// D[b][x][t] = w_bt[x] vis[b][t][x]  (the masked data of pspec.py:613, per time)
+__global__ void k_pt_data(const double* __restrict__ vis, const uint8_t* __restrict__ ft,
+                          double* __restrict__ Dre, double* __restrict__ Dim, const int T, const int N,
+                          const int NP, const int TP) {
+  const int b = blockIdx.y;
+  const long tot = (long)N * T;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < tot; e += (long)gridDim.x * blockDim.x) {
+    const int t = (int)(e / N), x = (int)(e % N);
+    const long o = ((long)b * T + t) * N + x;
+    const double w = ft[o] ? 1.0 : 0.0;
+    Dre[((long)b * NP + x) * TP + t] = w * vis[2 * o];
+    Dim[((long)b * NP + x) * TP + t] = w * vis[2 * o + 1];
+  }
+}
+// child's omega_a block: PT[t][x][0] = P2[x][t], other columns zero
+__global__ void k_pt_p2(const double* __restrict__ p2re, const double* __restrict__ p2im,
+                        double* __restrict__ ptre, double* __restrict__ ptim, const int T, const int NP,
+                        const int TP, const int TPc) {
+  const long tot = (long)T * NP * TPc;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < tot; e += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(e % TPc), x = (int)((e / TPc) % NP), t = (int)(e / ((long)TPc * NP));
+    ptre[e] = (c == 0) ? p2re[(long)x * TP + t] : 0.0;
+    ptim[e] = (c == 0) ? p2im[(long)x * TP + t] : 0.0;
+  }
+}
+// fg[u] = fg[u / T]  ((nbl,N,M) c128 -> (nbl*T,N,M))
+__global__ void k_pt_expand_fg(const double* __restrict__ src, double* __restrict__ dst, const int T, const long per) {
+  const int u = blockIdx.y;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < per; e += (long)gridDim.x * blockDim.x)
+    dst[(long)u * per + e] = src[(long)(u / T) * per + e];
+}
+// parent X[b][row][t] = child X[b*T + t][row][0]
+__global__ void k_pt_gather(const double* __restrict__ cre, const double* __restrict__ cim,
+                            double* __restrict__ xre, double* __restrict__ xim, const int T, const int npad,
+                            const int TP, const int TPc) {
+  const int b = blockIdx.y;
+  const long tot = (long)npad * T;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < tot; e += (long)gridDim.x * blockDim.x) {
+    const int row = (int)(e / T), t = (int)(e % T);
+    const long oc = ((long)(b * T + t) * npad + row) * TPc;
+    xre[((long)b * npad + row) * TP + t] = cre[oc];
+    xim[((long)b * npad + row) * TP + t] = cim[oc];
+  }
+}
+}  // namespace
+
+static int set_static_impl(hpx_plan* p, const double* vis, const uint8_t* flags,
+                           const double* ninv, const double* ninv_dense, const double* nih_dense,
+                           int noise_shared, const double* fgmodes, int fg_shared,
+                           const int32_t* prior_map, const double* xgrid, int nxrows,
+                           int prior_shared, int ngrid, const double* omega,
+                           const double* fop, int any_flags, void* stream);
+
+extern "C" int hpx_plan_set_static_pertime(hpx_plan* p, const double* vis, const uint8_t* flags_t,
+                                           const double* ninv_t, const double* fgmodes, int fg_shared,
+                                           const int32_t* prior_map, const double* xgrid, int nxrows,
+                                           int prior_shared, int ngrid, const double* omega,
+                                           const double* fop, int any_flags, void* stream) {
+  HPX_REQUIRE(p && vis && flags_t && ninv_t && fop && prior_map, "hpx_plan_set_static_pertime: null argument");
+  hipStream_t st = (hipStream_t)stream;
+  const int nbl = p->nbl, T = p->T, N = p->N, M = p->M, NP = p->NP, TP = p->TP;
+  // 1. the parent's time-independent parts (foreground planes, operator, prior tables, omega_a block)
+  //    with the any-time mask -- its own solve operators are never used in this mode
+  hpx_devbuf tmp;
+  HPX_TRY(tmp.alloc((size_t)nbl * N + ((size_t)nbl * N + 7) / 8 + 8));
+  double* nany = tmp.p;
+  uint8_t* fany = (uint8_t*)(tmp.p + (size_t)nbl * N);
+  hipLaunchKernelGGL(k_pt_reduce, dim3(4, nbl), dim3(256), 0, st, flags_t, ninv_t, fany, nany, T, N);
+  HPX_HIP(hipGetLastError());
+  HPX_TRY(set_static_impl(p, vis, fany, nany, nullptr, nullptr, 0, fgmodes, fg_shared, prior_map, xgrid, nxrows,
+                          prior_shared, ngrid, omega, fop, any_flags, stream));
+  // 2. per-time data, flags, noise
+  HPX_TRY(dev_alloc(p, &p->flags_t, (size_t)nbl * T * N));
+  HPX_TRY(dev_alloc(p, &p->ninv_t, (size_t)nbl * T * N));
+  HPX_HIP(hipMemcpyAsync(p->flags_t, flags_t, (size_t)nbl * T * N, hipMemcpyDeviceToDevice, st));
+  HPX_HIP(hipMemcpyAsync(p->ninv_t, ninv_t, (size_t)nbl * T * N * sizeof(double), hipMemcpyDeviceToDevice, st));
+  hipLaunchKernelGGL(k_pt_data, dim3(64, nbl), dim3(256), 0, st, vis, flags_t, p->Dre, p->Dim, T, N, NP, TP);
+  HPX_HIP(hipGetLastError());
+  // 3. the child: nbl*T units of one time sample each
+  if (p->child) { hpx_plan_destroy(p->child); p->child = nullptr; }
+  HPX_TRY(plan_create_impl(&p->child, nbl * T, 1, N, M));
+  hpx_plan* c = p->child;
+  c->omega_mod = T;
+  hpx_devbuf fgx;
+  const double* fgc = fgmodes;
+  if (M > 0 && !fg_shared) {
+    const long per = (long)N * M * 2;
+    HPX_TRY(fgx.alloc((size_t)nbl * T * per));
+    hipLaunchKernelGGL(k_pt_expand_fg, dim3(16, nbl * T), dim3(256), 0, st, fgmodes, fgx.p, T, per);
+    HPX_HIP(hipGetLastError());
+    fgc = fgx.p;
+  }
+  // (vis (nbl,T,N) is (nbl*T,1,N); flags_t / ninv_t (nbl,T,N) are (nbl*T,N); the child never draws: no priors)
+  HPX_TRY(set_static_impl(c, vis, flags_t, ninv_t, nullptr, nullptr, 0, fgc, fg_shared, p->pmap, nullptr, 0, 1,
+                          ngrid, omega, fop, any_flags, stream));
+  HPX_TRY(dev_alloc(p, &p->PTre, (size_t)T * NP * c->TP));
+  HPX_TRY(dev_alloc(p, &p->PTim, (size_t)T * NP * c->TP));
+  hipLaunchKernelGGL(k_pt_p2, dim3(64), dim3(256), 0, st, p->P2re, p->P2im, p->PTre, p->PTim, T, NP, TP, c->TP);
+  HPX_HIP(hipGetLastError());
+  HPX_HIP(hipStreamSynchronize(st));
+  p->per_time = 1;
+  p->solver = HPX_SOLVER_DENSE;
+  return HPX_OK;
+}
+
+// the child's generator: 1/a of the unit's baseline, omega_a of the unit's time
+static hpx_gen_batch gen_of(const hpx_plan* p);
+static hpx_gen_batch gen_of_child(const hpx_plan* p) {
+  hpx_gen_batch B = gen_of(p->child);
+  B.ia = p->ia;
+  B.ia_div = p->T;
+  B.p2re = p->PTre;
+  B.p2im = p->PTim;
+  B.p2_mod = p->T;
+  B.p2_stride = (long)p->NP * p->child->TP;
+  return B;
+}
+
 static hpx_gen_batch gen_of(const hpx_plan* p) {
   hpx_gen_batch B;
   B.ia = p->ia; B.cre = p->Cre; B.cim = p->Cim; B.rre = p->Rre; B.rim = p->Rim;
@@ -1341,6 +1484,7 @@ static hpx_gen_batch gen_of(const hpx_plan* p) {
   B.p4re = p->P4re; B.p4im = p->P4im;
   B.cdre = p->dense_noise ? p->CDre : nullptr;
   B.cdim = p->dense_noise ? p->CDim : nullptr;
+  B.ia_div = 1; B.p2_mod = 1; B.p2_stride = 0;
   B.N = p->N; B.M = p->M; B.NP = p->NP; B.TP = p->TP; B.ncol = p->ncolR;
   B.has_omega = p->has_omega;
   B.rmin = 32 * (p->N / 32);
@@ -1362,6 +1506,7 @@ static int launch_assemble(hpx_plan* p, hipStream_t st, int rlo) {
 
 extern "C" int hpx_assemble_K(hpx_plan* p, const double* ps, double* k_out, void* stream) {
   HPX_REQUIRE(p && p->have_static && ps, "hpx_assemble_K: plan not initialised or null ps");
+  HPX_REQUIRE(!p->per_time, "hpx_assemble_K: not available with time-dependent flags / noise");
   hipStream_t st = (hipStream_t)stream;
   const long tot = (long)p->nbl * p->N;
   hipLaunchKernelGGL(k_set_a, dim3(256), dim3(256), 0, st, ps, p->ia, p->ps_cur, tot, (double)p->N);
@@ -1381,6 +1526,8 @@ extern "C" int hpx_plan_set_solver(hpx_plan* p, int mode) {
               mode == HPX_SOLVER_LOWRANK_DIRECT, "hpx_plan_set_solver: unknown mode");
   HPX_REQUIRE(mode == HPX_SOLVER_DENSE || !p->dense_noise,
               "hpx_plan_set_solver: a dense inverse noise covariance needs the dense solver");
+  HPX_REQUIRE(mode == HPX_SOLVER_DENSE || !p->per_time,
+              "hpx_plan_set_solver: time-dependent flags / noise need the dense solver");
   if (mode == HPX_SOLVER_FLAT) {
     HPX_REQUIRE(!p->any_flags, "hpx_plan_set_solver: the flat-noise solver needs unflagged data");
     HPX_REQUIRE(p->M <= 16 && p->TP <= 256, "hpx_plan_set_solver: the flat-noise solver needs M <= 16, T <= 256");
@@ -1549,11 +1696,14 @@ static int post_solve(hpx_plan* p, int it_abs, const IterOut& O, hipStream_t st)
   R.fg_shared = p->fg_shared; R.any_flags = p->any_flags;
   R.twre = p->Fopre; R.twim = p->Fopim; R.isn = isn; R.logN = 0; R.tcs = 0; R.nbl = nbl; R.npart = 1;
   R.resid_to_g = p->dense_noise;
+  R.flags_t = p->per_time ? p->flags_t : nullptr;
+  R.ninv_t = p->per_time ? p->ninv_t : nullptr;
   // time columns per block of the fused kernel: 64 KiB of LDS for the signal, as k_fft
   int npart = 1, TC = 4096 / NP;
   if (TC > 16) TC = 16;
   const bool pow2 = N == NP && (N & (N - 1)) == 0 && N >= 32 && N <= 4096;
-  if (pow2 && hpx_dft_use_fft && TC >= HPX_FUSE_TC && TP / TC <= HPX_NPART && !p->dense_noise) {   // fewer columns per block: two kernels win
+  const bool generic_post = p->dense_noise || p->per_time;      // modes only the two-kernel form implements
+  if (pow2 && hpx_dft_use_fft && TC >= HPX_FUSE_TC && TP / TC <= HPX_NPART && !generic_post) {   // fewer columns per block: two kernels win
     while ((1 << R.logN) < N) ++R.logN;
     while ((1 << R.tcs) < TC) ++R.tcs;
     npart = TP / TC;
@@ -1566,7 +1716,7 @@ static int post_solve(hpx_plan* p, int it_abs, const IterOut& O, hipStream_t st)
     hipLaunchKernelGGL(k_fft_resid, dim3(((nbl + 7) / 8) * 8 * npart), dim3(256), lds, st, R);
     HPX_HIP(hipGetLastError());
     HPX_TRY(mark(p, st));
-  } else if (HPX_DFT_RESID && NP <= 256 && M <= 16 && hpx_dft_use_fft && !p->dense_noise) {
+  } else if (HPX_DFT_RESID && NP <= 256 && M <= 16 && hpx_dft_use_fft && !generic_post) {
     // small N without an in-LDS FFT: dense transform fused with the residual (k_dft_resid), booked
     // under "transform"
     npart = (NP / 16 + 3) / 4;
@@ -1643,6 +1793,16 @@ static int finish_run(hpx_plan* p, int niter, double* ps_last, hipStream_t st) {
       hpx_set_error("non-positive pivot: baseline %d, iteration %d", b, info[b] - 1);
       return HPX_ENOTPD;
     }
+  if (p->child) {
+    std::vector<int32_t> ci(p->child->nbl);
+    HPX_HIP(hipMemcpy(ci.data(), p->child->info, ci.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+    for (size_t u = 0; u < ci.size(); ++u)
+      if (ci[u] != 0) {
+        hpx_set_error("non-positive pivot: baseline %d, time %d, iteration %d", (int)(u / p->T), (int)(u % p->T),
+                      ci[u] - 1);
+        return HPX_ENOTPD;
+      }
+  }
   return HPX_OK;
 }
 
@@ -1664,6 +1824,7 @@ extern "C" int hpx_gibbs_run(hpx_plan* p, const double* ps0, int iter0, int nite
     HPX_HIP(hipGetLastError());
   }
   HPX_HIP(hipMemsetAsync(p->info, 0, (size_t)nbl * sizeof(int32_t), st));
+  if (p->child) HPX_HIP(hipMemsetAsync(p->child->info, 0, (size_t)p->child->nbl * sizeof(int32_t), st));
   p->ev_used = 0;
   for (int it = 0; it < niter; ++it) {
     HPX_TRY(mark(p, st));
@@ -1679,7 +1840,22 @@ extern "C" int hpx_gibbs_run(hpx_plan* p, const double* ps0, int iter0, int nite
       HPX_TRY(mark(p, st));
     } else {
       const hpx_gen_batch gen = gen_of(p);
-      if (p->dense_noise) {
+      if (p->per_time) {
+        // one system per (baseline, time): assemble / factor / solve over the child's nbl*T units,
+        // then the solutions go to their time column of this plan's X
+        hpx_plan* c = p->child;
+        const hpx_gen_batch gc = gen_of_child(p);
+        hipLaunchKernelGGL(k_assemble_edge, dim3(c->nbl, 1), dim3(256), 0, st, gc, c->L, c->npad, c->ld);
+        HPX_HIP(hipGetLastError());
+        HPX_TRY(mark(p, st));
+        HPX_TRY(hpx_launch_factor(c->nbl, c->npad, c->ld, c->L, c->Wre, c->Wim, c->info, iter0 + it + 1, &gc, st));
+        HPX_TRY(mark(p, st));
+        HPX_TRY(hpx_launch_backsolve(c->nbl, c->npad, c->TP, c->ld, c->L, c->Wre, c->Wim, c->Xre, c->Xim, st));
+        hipLaunchKernelGGL(k_pt_gather, dim3(32, nbl), dim3(256), 0, st, c->Xre, c->Xim, p->Xre, p->Xim, T, p->npad,
+                           TP, c->TP);
+        HPX_HIP(hipGetLastError());
+        HPX_TRY(mark(p, st));
+      } else if (p->dense_noise) {
         // general Hermitian C: the whole augmented matrix is laid out, then factored in place
         HPX_TRY(launch_assemble(p, st, 0));
         HPX_TRY(mark(p, st));
@@ -1691,9 +1867,11 @@ extern "C" int hpx_gibbs_run(hpx_plan* p, const double* ps0, int iter0, int nite
         HPX_TRY(hpx_launch_factor(nbl, p->npad, p->ld, p->L, p->Wre, p->Wim, p->info, iter0 + it + 1,
                                   &gen, st));
       }
-      HPX_TRY(mark(p, st));
-      HPX_TRY(hpx_launch_backsolve(nbl, p->npad, TP, p->ld, p->L, p->Wre, p->Wim, p->Xre, p->Xim, st));
-      HPX_TRY(mark(p, st));
+      if (!p->per_time) {
+        HPX_TRY(mark(p, st));
+        HPX_TRY(hpx_launch_backsolve(nbl, p->npad, TP, p->ld, p->L, p->Wre, p->Wim, p->Xre, p->Xim, st));
+        HPX_TRY(mark(p, st));
+      }
     }
     const bool keep = (it % thin) == 0;
     const long slot = it / thin;
@@ -1809,6 +1987,7 @@ extern "C" int hpx_gibbs_step_general(hpx_plan* p, const double* shp, int iter0,
                                       double* lnpost_out, double* cr_out, double* fg_out,
                                       double* chisq_out, double* ps_last, void* stream) {
   HPX_REQUIRE(p && p->have_static && shp && ps_out && lnpost_out, "hpx_gibbs_step_general: bad argument");
+  HPX_REQUIRE(!p->per_time, "hpx_gibbs_step_general: not available with time-dependent flags / noise");
   HPX_REQUIRE(p->uni && iter0 >= 0 && iter0 < p->niter_tab, "hpx_gibbs_step_general: random tables too short");
   hipStream_t st = (hipStream_t)stream;
   const int nbl = p->nbl, N = p->N, M = p->M, T = p->T, NP = p->NP, TP = p->TP;

@@ -61,6 +61,15 @@ struct hpx_plan {
   int dense_noise;
   double *NIre, *NIim;     // [nbl][NP][NP] Ninv, planar row-major (zero padded)
   double *CDre, *CDim;     // [nbl][NP][NP] C = U^H Ninv U
+  // time-dependent flags / noise (hpx_plan_set_static_pertime): every time sample has its own system.
+  // `child` is a plan over the nbl*T units (one right-hand side each) that holds the per-unit
+  // operators and factors; this (parent) plan keeps the chain state and everything after the solve.
+  int per_time;
+  int omega_mod;           // > 0 (child plans): unit u takes the noise draws of time u % omega_mod
+  hpx_plan* child;
+  uint8_t* flags_t;        // [nbl][T][N]
+  double* ninv_t;          // [nbl][T][N]
+  double *PTre, *PTim;     // [T][NP][16]: column 0 = U^H omega_a of time t (the child's P2, per unit u % T)
   int solver;   // HPX_SOLVER_DENSE / HPX_SOLVER_FLAT / HPX_SOLVER_LOWRANK (hpx_plan_set_solver)
   // HPX_SOLVER_LOWRANK: flagged channels per baseline, the small Schur system and its solution
   int lr_fmax, lr_npad;
@@ -186,16 +195,19 @@ struct hpx_gen_batch {
   const double *ia, *cre, *cim, *rre, *rim, *p2re, *p2im, *hre, *him, *p4re, *p4im;
   const double *cdre, *cdim;   // dense C, [nbl][NP][NP], or NULL
   int N, M, NP, TP, ncol, has_omega, rmin;
+  int ia_div;                  // baseline b reads 1/a of chain b / ia_div (per-time units share their baseline's)
+  int p2_mod;                  // ... and the omega_a block (b % p2_mod) * p2_stride (0 / 1: one shared block)
+  long p2_stride;
 };
 __device__ __forceinline__ hpx_gen hpx_gen_for(const hpx_gen_batch& B, const int b) {
   hpx_gen G;
-  G.ia = B.ia + (long)b * B.N;
+  G.ia = B.ia + (long)(B.ia_div > 1 ? b / B.ia_div : b) * B.N;
   G.cre = B.cre + (long)b * B.N;
   G.cim = B.cim + (long)b * B.N;
   G.rre = B.rre + (long)b * B.NP * B.ncol;
   G.rim = B.rim + (long)b * B.NP * B.ncol;
-  G.p2re = B.p2re;
-  G.p2im = B.p2im;
+  G.p2re = B.p2re + (B.p2_mod > 1 ? (long)(b % B.p2_mod) * B.p2_stride : 0);
+  G.p2im = B.p2im + (B.p2_mod > 1 ? (long)(b % B.p2_mod) * B.p2_stride : 0);
   G.hre = B.hre + (long)b * B.M * B.M;
   G.him = B.him + (long)b * B.M * B.M;
   G.p4re = B.p4re + (long)b * B.M * B.TP;

@@ -32,6 +32,7 @@ SIGNATURES = {
     "hpx_plan_bytes": (_i64, [_vp]),
     "hpx_plan_set_static": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _i, _vp]),
     "hpx_plan_set_static_dense": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _i, _vp]),
+    "hpx_plan_set_static_pertime": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _i, _vp]),
     "hpx_plan_set_rng": (_i, [_vp, _vp, _vp, _i, _vp]),
     "hpx_gibbs_run": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
     "hpx_gibbs_step_general": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

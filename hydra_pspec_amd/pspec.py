@@ -122,9 +122,14 @@ def _ninv_diag(Ninv, nbl, T, N):
             return Ninv
         Ninv = Ninv.detach().cpu().numpy()
     Ninv = np.asarray(Ninv)
-    if Ninv.ndim == 3 and Ninv.shape[0] == T and Ninv.shape[0] != nbl:
-        raise NotImplementedError("time-dependent Ninv (Ntimes,Nfreqs,Nfreqs) is not supported "
-                                  "(the reference documents but does not implement it either)")
+    if Ninv.shape in ((T, N, N), (nbl, T, N, N)) and (Ninv.ndim == 4 or T != nbl):
+        # time-dependent Ninv (pspec.py:337-340): one diagonal matrix per time -> (nbl, T, N)
+        d = np.diagonal(Ninv, axis1=-2, axis2=-1)
+        if np.any(Ninv - d[..., None] * np.eye(N) != 0):
+            raise NotImplementedError("time-dependent inverse noise covariances must be diagonal")
+        return np.ascontiguousarray(np.broadcast_to(d.real, (nbl, T, N)), dtype=float)
+    if Ninv.shape == (nbl, T, N) and not (T == N and Ninv.ndim == 3 and nbl == T):
+        return np.ascontiguousarray(Ninv.real, dtype=float)
     if Ninv.shape in ((N,), (nbl, N)):
         return np.ascontiguousarray(np.broadcast_to(Ninv.real, (nbl, N)), dtype=float)
     if Ninv.shape in ((N, N), (nbl, N, N)):
@@ -187,7 +192,9 @@ class GibbsBatch:
         fg_shape = tuple(fgmodes.shape)
         assert fg_shape[-2] == N, "fgmodes must have shape (Nfreqs, Nmodes)"
         M = fg_shape[-1]
-        assert tuple(flags.shape) == (nbl, N), "`flags` array must have shape (Nbl, Nfreqs)"
+        self.per_time = len(tuple(flags.shape)) == 3
+        assert tuple(flags.shape) in ((nbl, N), (nbl, T, N)), \
+            "`flags` array must have shape (Nbl, Nfreqs) or, time dependent, (Nbl, Ntimes, Nfreqs)"
         self.nbl, self.T, self.N, self.M = nbl, T, N, M
         self.map_estimate = bool(map_estimate)
         self.Niter = 1 if map_estimate else int(Niter)
@@ -198,6 +205,8 @@ class GibbsBatch:
             d_flags = hpx.to_dev(torch, np.ascontiguousarray(fl_np).astype(np.uint8), torch.uint8,
                                  self.device)
             self.dense_noise = ninv_dense is not None
+            if self.per_time and self.dense_noise:
+                raise NotImplementedError("time-dependent flags with a non-diagonal inverse noise covariance")
             if self.dense_noise:
                 nd = np.asarray(ninv_dense, dtype=complex)
                 assert nd.shape in ((N, N), (nbl, N, N)), "Ninv shape must be (Nfreqs, Nfreqs) or (Nbl, Nfreqs, Nfreqs)"
@@ -206,7 +215,9 @@ class GibbsBatch:
                 d_ninv = None
             else:
                 d_ninv = hpx.to_dev(torch, ninv_diag, f64, self.device)
-                assert tuple(d_ninv.shape) == (nbl, N)
+                if self.per_time and tuple(d_ninv.shape) == (nbl, N):
+                    d_ninv = d_ninv[:, None, :].expand(nbl, T, N).contiguous()
+                assert tuple(d_ninv.shape) == ((nbl, T, N) if self.per_time else (nbl, N))
             fg_shared = len(fg_shape) == 2
             d_fg = hpx.to_dev(torch, fgmodes, c128, self.device)
             pmap, xgrid = _prior_tables(ps_prior if isinstance(ps_prior, np.ndarray)
@@ -226,7 +237,16 @@ class GibbsBatch:
             self.any_flags = bool((~fl_np.astype(bool)).any())
             self.plan = hpx.Plan(nbl, T, N, M)
             L = hpx.lib()
-            if self.dense_noise:
+            if self.per_time:
+                # every time sample has its own flags / noise, hence its own system: Nbl x Ntimes
+                # factorisations per iteration (the mode the reference documents but does not
+                # implement: pspec.py:337-340, :398-401, FIXMEs :361, :450-451)
+                hpx.check(L.hpx_plan_set_static_pertime(
+                    self.plan.handle, hpx.ptr(d_vis), hpx.ptr(d_flags), hpx.ptr(d_ninv),
+                    hpx.ptr(d_fg) if M > 0 else None, int(fg_shared), hpx.ptr(d_pmap), hpx.ptr(d_xgrid),
+                    int(len(xgrid)), int(prior_shared), NGRID, hpx.ptr(d_omega), hpx.ptr(d_fop),
+                    int(self.any_flags), hpx.stream_ptr(torch)), "hpx_plan_set_static_pertime")
+            elif self.dense_noise:
                 if self.any_flags:
                     raise NotImplementedError(
                         "a non-diagonal inverse noise covariance together with flagged channels is not "
@@ -256,9 +276,10 @@ class GibbsBatch:
             if direct:
                 solver = "lowrank"
             self.solver = "dense"
-            if self.dense_noise:
+            if self.dense_noise or self.per_time:
                 if solver not in ("auto", "dense"):
-                    raise ValueError("a non-diagonal inverse noise covariance needs solver='dense' (or 'auto')")
+                    raise ValueError("a non-diagonal inverse noise covariance / time-dependent flags need "
+                                     "solver='dense' (or 'auto')")
                 solver = "dense"
             if solver != "dense":
                 use = d_flags.bool()
@@ -352,6 +373,8 @@ class GibbsBatch:
         torch = self.torch
         nbl, T, N, M = self.nbl, self.T, self.N, self.M
         assert self.iter_done == 0, "a general starting covariance only makes sense for iteration 0"
+        if self.per_time:
+            raise NotImplementedError("time-dependent flags need an initial covariance of the form F^H diag(ps) F")
         with torch.cuda.device(self.device):
             f64, c128, dev = torch.float64, torch.complex128, self.device
             d_shp = hpx.to_dev(torch, shp0, c128, dev)
@@ -397,9 +420,12 @@ def make_batch(vis, flags, fgmodes, Ninv, ps_prior, Niter, seed=None, map_estima
     diagonals ``(Nfreqs,)`` / ``(Nbl,Nfreqs)`` or matrices ``(Nfreqs,Nfreqs)`` / ``(Nbl,Nfreqs,Nfreqs)``
     (reference run-hydra-pspec.py:427-438 passes ``inv(noise_cov)``)."""
     nbl, T, N = tuple(vis.shape)
-    # (a 2-D (Nbl, Nfreqs) array is a stack of diagonals unless Nbl == Nfreqs, where the matrix reading wins
-    # as in the reference, which only knows (Nfreqs, Nfreqs))
-    nd = _ninv_dense(Ninv, nbl, N) if len(np.shape(Ninv)) >= 2 else None
+    # (a 2-D (Nbl, Nfreqs) array with Nbl > 1 is a stack of diagonals, also when Nbl == Nfreqs; a matrix shared
+    # by Nbl == Nfreqs baselines has to be given as (Nbl, Nfreqs, Nfreqs))
+    per_time_ninv = np.shape(Ninv) in ((T, N, N), (nbl, T, N, N), (nbl, T, N)) and (len(np.shape(Ninv)) == 4 or T != nbl
+                                                                                    or np.shape(Ninv) == (nbl, T, N))
+    diag_stack = tuple(np.shape(Ninv)) == (nbl, N) and nbl > 1
+    nd = _ninv_dense(Ninv, nbl, N) if len(np.shape(Ninv)) >= 2 and not per_time_ninv and not diag_stack else None
     if nd is not None:
         return GibbsBatch(vis, flags, fgmodes, None, ps_prior, Niter, seed=seed, map_estimate=map_estimate,
                           device=device, solver=solver, ninv_dense=nd, tables=tables)
@@ -764,7 +790,8 @@ def gibbs_sample_with_fg(vis, flags, S_initial, fgmodes, Ninv, ps_prior, Niter=1
         write_Niter = 1
     Ntimes, Nfreqs = vis.shape
     Nmodes = fgmodes.shape[1]
-    assert flags.shape == (Nfreqs,), "`flags` array must have shape (Nfreqs,)"
+    assert flags.shape in ((Nfreqs,), (Ntimes, Nfreqs)), \
+        "`flags` array must have shape (Nfreqs,) or, time dependent (extension), (Ntimes, Nfreqs)"
     assert fgmodes.shape[0] == Nfreqs, "fgmodes must have shape (Nfreqs, Nmodes)"
     if len(np.shape(Ninv)) == 3:
         assert np.shape(Ninv)[0] == Ntimes, \
@@ -818,7 +845,7 @@ def gibbs_sample_with_fg(vis, flags, S_initial, fgmodes, Ninv, ps_prior, Niter=1
             if verbose:
                 dt = (time.perf_counter() - t0) / n
                 for i in range(done - n, done):
-                    cm = chisq[i][:, flags].mean()
+                    cm = chisq[i][:, flags].mean() if flags.ndim == 1 else chisq[i][flags].mean()
                     print(f"{i + 1:<9d}{dt:<12.3g}{cm:<9.3f}{ln_post[i]:<12.1f}")
             if out_dir is not None and done % write_Niter == 0:
                 # periodic checkpoint: everything so far; cov-eor.npy gets rows [:done] of

@@ -94,6 +94,21 @@ int hpx_plan_set_static_dense(hpx_plan* p, const double* vis, const uint8_t* fla
                               const double* xgrid, int nxrows, int prior_shared, int ngrid,
                               const double* omega, const double* fop, int any_flags, void* stream);
 
+/* Time-dependent flags and noise: flags_t (nbl,T,N) u8 and ninv_t (nbl,T,N) f64 (diagonal inverse
+ * noise variances per time sample).  The mode the reference documents but does not implement
+ * (docstrings pspec.py:337-340, :398-401; FIXMEs :361, :450-451; its driver reduces per-time flags to
+ * an any-time mask instead, run-hydra-pspec.py:524-541): every time sample then has its own noise
+ * matrix Ni_t = diag(ninv_t w_t), hence its own system -- nbl*T factorisations per iteration, the
+ * "(baseline x time, Nfreq, Nfreq)" batch.  Per time: data w_t d_t, chi^2 with ninv_t, the
+ * ln-posterior's noise term over the channels unflagged at t and its signal term through the
+ * flags_t x flags_t sub-block of inv(S).  With flags_t[b][t] = flags[b] and ninv_t[b][t] = ninv[b] for
+ * every t the chains are those of hpx_plan_set_static.  Dense solver only. */
+int hpx_plan_set_static_pertime(hpx_plan* p, const double* vis, const uint8_t* flags_t,
+                                const double* ninv_t, const double* fgmodes, int fg_shared,
+                                const int32_t* prior_map, const double* xgrid, int nxrows,
+                                int prior_shared, int ngrid, const double* omega,
+                                const double* fop, int any_flags, void* stream);
+
 /* Random tables of the bandpower draw (pspec.py:113-125): one uniform per
  * channel per iteration from the chain's global stream.
  *   uniforms (niter,N) f64   U

@@ -225,3 +225,62 @@ def gibbs_sample_with_fg(vis, flags, S_initial, fgmodes, Ninv, ps_prior, Niter=1
                                f0=None, nproc=nproc, map_estimate=map_estimate,
                                verbose=False, solver=solver)
     return signal_cr, signal_S, signal_ps, fg_amps, chisq, ln_post, 0.0
+
+
+# ---- time-dependent flags / noise ------------------------------------------------------
+# The reference documents this mode (Ninv of shape (Ntimes, Nfreqs, Nfreqs): pspec.py:337-340, :398-401)
+# but does not implement it (FIXMEs :361, :450-451); its driver reduces per-time flags to an any-time
+# mask (run-hydra-pspec.py:524-541).  What follows is the reference's own per-time solve
+# (gcr_fgmodes_1d, :151-235) given, for time t, the operators build_matrices (:325-374) makes from
+# flags_t[t] and Ninv_t[t] -- the natural completion of the FIXMEs -- with chi^2 and the two
+# ln-posterior terms (:452, :472-485) taken per time with that time's flags and noise.  With
+# flags_t[t] = flags and Ninv_t[t] = Ninv for every t it is gibbs_step_fgmodes above, operation for
+# operation (tests/test_oracle_golden.py pins that against the reference's golden steps).
+def gibbs_step_fgmodes_pertime(vis, flags_t, signal_S, fgmodes, Ninv_t, ps_prior=None, map_estimate=False,
+                               solver="direct"):
+    """``vis`` (T,N) already multiplied by flags_t; ``flags_t`` (T,N) bool; ``Ninv_t`` (T,N) diagonals."""
+    T, nfreq = vis.shape
+    nmodes = fgmodes.shape[1]
+    assert flags_t.shape == (T, nfreq) and Ninv_t.shape == (T, nfreq)
+    fop = fourier_operator(nfreq)
+    keep = np.random.get_state()
+    rows = []
+    try:
+        for t in range(T):
+            mats = build_matrices(nfreq + nmodes, flags_t[t], signal_S, np.diag(Ninv_t[t]).astype(complex), fgmodes)
+            x, _, _ = gcr_fgmodes_1d(t, vis[t], flags_t[t], mats, fgmodes, map_estimate=map_estimate, solver=solver)
+            rows.append(x)
+    finally:
+        np.random.set_state(keep)
+    cr = np.array(rows).reshape((T, -1))
+    signal_cr = cr[:, :-nmodes]
+    fg_amps = cr[:, -nmodes:]
+    model = signal_cr + fg_amps @ fgmodes.T
+    chisq = np.abs(vis - model) ** 2 * Ninv_t
+    ps_sample = sample_S(s=signal_cr, prior=ps_prior)
+    S_sample = covariance_from_pspec(ps_sample / nfreq ** 2, fop)
+    Sinv = np.linalg.inv(S_sample)
+    ln_post = 0.0
+    for t in range(T):
+        f = flags_t[t]
+        r = (vis[t] - model[t])[f]
+        sf = signal_cr[t][f]
+        ln_post += (-(r.conj() @ (Ninv_t[t][f] * r)) - (sf.conj() @ Sinv[f][:, f] @ sf)).real
+    return signal_cr, S_sample, ps_sample, fg_amps, chisq, ln_post
+
+
+def gibbs_sample_with_fg_pertime(vis, flags_t, S_initial, fgmodes, Ninv_t, ps_prior, Niter=100, seed=None,
+                                 solver="direct"):
+    np.random.seed(seed)
+    T, N = vis.shape
+    M = fgmodes.shape[1]
+    signal_cr = np.zeros((Niter, T, N), dtype=complex)
+    signal_ps = np.zeros((Niter, N))
+    fg_amps = np.zeros((Niter, T, M), dtype=complex)
+    chisq = np.zeros((Niter, T, N))
+    ln_post = np.zeros(Niter)
+    signal_S = S_initial.copy()
+    for i in range(Niter):
+        signal_cr[i], signal_S, signal_ps[i], fg_amps[i], chisq[i], ln_post[i] = \
+            gibbs_step_fgmodes_pertime(vis * flags_t, flags_t, signal_S, fgmodes, Ninv_t, ps_prior, solver=solver)
+    return signal_cr, signal_S, signal_ps, fg_amps, chisq, ln_post, 0.0

@@ -141,3 +141,19 @@ def test_statistical_recovery_flagged_lowrank():
     _, dense = _run(16, 256, frac=0.15, niter=20, solver="dense")
     live = dense["signal_ps"] > 1e-9 * np.median(dense["signal_ps"])
     assert np.max(np.abs(out["signal_ps"][:, :20][live] / dense["signal_ps"][live] - 1)) < 1e-6
+
+
+@pytest.mark.parametrize("N,frac,solver", [(512, 0.0, "dense"), (1024, 0.15, "auto")])
+def test_full_batch_at_the_baseline_configs(N, frac, solver):
+    """The BASELINE.json batches at FULL size (C3: 1024 x (32, 512, 12) on the dense path; C5: 1024 x
+    (32, 1024, 12) with 15 % flags through solver="auto"), 2 iterations: baseline k alone gives bit for
+    bit the chain it gives inside the batch, for the first, a middle and the last baseline; every sample
+    is finite and no factorisation reports a non-positive pivot."""
+    nbl = 1024
+    d, big = _run(nbl, N, frac=frac, niter=2, solver=solver)
+    assert big["signal_ps"].shape == (nbl, 2, N)
+    assert np.isfinite(big["signal_ps"]).all() and (big["signal_ps"] > 0).all() and np.isfinite(big["ln_post"]).all()
+    for k in (0, 511, 1023):
+        _, one = _run(1, N, frac=frac, niter=2, k0=k, solver=solver)
+        assert np.array_equal(one["signal_ps"][0], big["signal_ps"][k]), k
+        assert np.array_equal(one["ln_post"][0], big["ln_post"][k]), k

@@ -1,0 +1,76 @@
+"""Time-dependent flags / per-time inverse noise variances: every
+time sample has its own system, Nbl x Ntimes factorisations per iteration.  The oracle is the exact-solve
+per-time restatement (oracle.pspec_ref.gibbs_step_fgmodes_pertime), pinned on the CPU to the reference's
+golden steps where the two overlap (tests/test_oracle_golden.py)."""
+import numpy as np
+import pytest
+
+from conftest import relerr
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-6
+
+
+def _pertime_inputs(nbl, T, N, M, seed=0, frac_common=0.1, frac_time=0.08):
+    from hydra_pspec_amd import synthetic
+    d = synthetic.make_baselines(N, T, M, k0=40, nbl=nbl, flag_frac=frac_common, dense=True)
+    rng = np.random.default_rng(seed)
+    flt = np.broadcast_to(d["flags"][:, None, :], (nbl, T, N)).copy()
+    flt &= rng.uniform(size=(nbl, T, N)) > frac_time            # RFI-like flags that change with time
+    nt = d["ninv_diag"][:, None, :] * rng.uniform(0.6, 1.4, size=(nbl, T, 1))    # noise level drifts with time
+    return d, flt, np.ascontiguousarray(np.broadcast_to(nt, (nbl, T, N)))
+
+
+def test_identical_per_time_inputs_reproduce_the_standard_chain():
+    """flags_t[t] = flags, ninv_t[t] = ninv for every t: the per-time mode (Nbl*T systems) gives the chain
+    of the time-independent mode (one system per baseline, T right-hand sides)."""
+    from hydra_pspec_amd import pspec, synthetic
+    nbl, T, N, M = 3, 8, 64, 6
+    d = synthetic.make_baselines(N, T, M, k0=7, nbl=nbl, flag_frac=0.12, dense=False)
+    std = pspec.gibbs_sample_with_fg_batched(d["vis"], d["flags"], d["fgmodes"], d["ninv_diag"], d["ps_prior"],
+                                             ps_initial=d["ps0"], Niter=5, seed=3, solver="dense",
+                                             keep=("signal_cr", "fg_amps", "chisq"))
+    flt = np.broadcast_to(d["flags"][:, None, :], (nbl, T, N)).copy()
+    nt = np.broadcast_to(d["ninv_diag"][:, None, :], (nbl, T, N)).copy()
+    pt = pspec.gibbs_sample_with_fg_batched(d["vis"], flt, d["fgmodes"], nt, d["ps_prior"], ps_initial=d["ps0"],
+                                            Niter=5, seed=3, keep=("signal_cr", "fg_amps", "chisq"))
+    assert np.max(np.abs(pt["signal_ps"] / std["signal_ps"] - 1)) < 1e-10
+    assert relerr(pt["signal_cr"], std["signal_cr"]) < 1e-10 and relerr(pt["fg_amps"], std["fg_amps"]) < 1e-10
+    assert relerr(pt["chisq"], std["chisq"]) < 1e-8 and np.allclose(pt["ln_post"], std["ln_post"], rtol=1e-10)
+
+
+def test_pertime_chain_vs_oracle():
+    """(Nbl, T, N, M) = (4, 16, 64, 6) with flags and noise levels that change from time to time, against
+    the per-time exact-solve oracle: P(k), signal realisations, foreground amplitudes, chi^2, ln-posterior."""
+    from hydra_pspec_amd import pspec
+    from oracle import pspec_ref
+    nbl, T, N, M, niter = 4, 16, 64, 6, 4
+    d, flt, nt = _pertime_inputs(nbl, T, N, M)
+    nt_used = flt.sum(axis=1)
+    assert ((nt_used > 0) & (nt_used < T)).any()                              # genuinely time dependent
+    out = pspec.gibbs_sample_with_fg_batched(d["vis"], flt, d["fgmodes"], nt, d["ps_prior"], ps_initial=d["ps0"],
+                                             Niter=niter, seed=9, keep=("signal_cr", "fg_amps", "chisq"))
+    for b in range(nbl):
+        ref = pspec_ref.gibbs_sample_with_fg_pertime(d["vis"][b], flt[b], d["S_initial"], d["fgmodes"], nt[b],
+                                                     d["ps_prior"], Niter=niter, seed=9)
+        assert np.max(np.abs(out["signal_ps"][b] / ref[2] - 1)) < RTOL, b
+        assert relerr(out["signal_cr"][b], ref[0]) < RTOL and relerr(out["fg_amps"][b], ref[3]) < RTOL
+        assert relerr(out["chisq"][b], ref[4]) < 1e-6 and np.allclose(out["ln_post"][b], ref[5], rtol=1e-7)
+
+
+def test_pertime_through_the_reference_call_surface():
+    """gibbs_sample_with_fg with flags (Ntimes, Nfreqs) and Ninv (Ntimes, Nfreqs, Nfreqs) -- the shapes the
+    reference's docstrings promise (pspec.py:337-340, :398-401)."""
+    from hydra_pspec_amd import pspec
+    from oracle import pspec_ref
+    d, flt, nt = _pertime_inputs(1, 8, 32, 4, seed=2)
+    Ninv_t = np.stack([np.diag(nt[0, t]) for t in range(8)])
+    res = pspec.gibbs_sample_with_fg(d["vis"][0], flt[0], d["S_initial"], d["fgmodes"], Ninv_t, d["ps_prior"],
+                                     Niter=3, seed=5, verbose=False)
+    ref = pspec_ref.gibbs_sample_with_fg_pertime(d["vis"][0], flt[0], d["S_initial"], d["fgmodes"], nt[0],
+                                                 d["ps_prior"], Niter=3, seed=5)
+    assert np.max(np.abs(res[2] / ref[2] - 1)) < RTOL and relerr(res[0], ref[0]) < RTOL
+    assert res[4].shape == (3, 8, 32)
+    with pytest.raises(ValueError):
+        pspec.gibbs_sample_with_fg_batched(d["vis"], flt, d["fgmodes"], nt, d["ps_prior"], ps_initial=d["ps0"],
+                                           Niter=2, seed=1, solver="flat")

@@ -121,8 +121,12 @@ def test_ninv_diag_validation():
     assert pspec._ninv_diag(np.arange(6.0), 2, 4, 6).shape == (2, 6)
     with pytest.raises(NotImplementedError):
         pspec._ninv_diag(np.eye(6) + 0.1, 1, 4, 6)
+    # time-dependent Ninv (Ntimes,Nfreqs,Nfreqs): diagonal matrices per time -> (Nbl, Ntimes, Nfreqs)
+    nt = np.stack([np.eye(6) * (t + 1.0) for t in range(4)])
+    dt = pspec._ninv_diag(nt, 1, 4, 6)
+    assert dt.shape == (1, 4, 6) and (dt[0, 2] == 3.0).all()
     with pytest.raises(NotImplementedError):
-        pspec._ninv_diag(np.zeros((4, 6, 6)), 1, 4, 6)
+        pspec._ninv_diag(nt + 0.1, 1, 4, 6)
 
 
 def test_synthetic_recipe_statistics():

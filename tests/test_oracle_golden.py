@@ -225,3 +225,23 @@ def test_dense_noise_covariance_step_and_chain():
     r = R.gibbs_sample_with_fg(g["in_vis"], g["in_flags"], g["in_S"], g["in_fgmodes"], g["in_Ninv"], g["in_prior"],
                                Niter=6, seed=77)
     assert np.max(np.abs(r[2] / g["chain_ps"] - 1)) < 1e-6
+
+
+@pytest.mark.parametrize("name", ["a", "b", "f"])
+def test_pertime_oracle_reduces_to_the_reference(name):
+    """oracle.gibbs_step_fgmodes_pertime with the SAME flags and noise at every time is the reference's
+    step (golden steps.npz): this is what pins the per-time restatement."""
+    g = dict(np.load(GOLDEN / "steps.npz"))
+    vis, fl, S, F, Ninv, prior = (g[f"{name}_in_{k}"] for k in ("vis", "flags", "S", "fgmodes", "Ninv", "prior"))
+    T, N = vis.shape
+    flt = np.broadcast_to(fl, (T, N)).copy()
+    nt = np.broadcast_to(np.diag(Ninv).real, (T, N)).copy()
+    np.random.seed(4242)
+    a = R.gibbs_step_fgmodes(vis * fl, fl, S, F, Ninv, prior, solver="direct")
+    np.random.seed(4242)
+    b = R.gibbs_step_fgmodes_pertime(vis * flt, flt, S, F, nt, prior, solver="direct")
+    assert np.array_equal(a[2], b[2]) and np.array_equal(a[0], b[0]) and np.array_equal(a[3], b[3])
+    assert np.allclose(a[4], b[4], rtol=1e-14) and b[5] == pytest.approx(a[5], rel=1e-12)
+    np.random.seed(4242)
+    c = R.gibbs_step_fgmodes_pertime(vis * flt, flt, S, F, nt, prior, solver="cg")
+    assert np.max(np.abs(c[2] / g[f"{name}_ps"] - 1)) < 1e-7        # and, with the reference's CG, the golden itself
