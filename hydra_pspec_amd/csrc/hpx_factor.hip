@@ -181,7 +181,13 @@ __device__ HPX_INL void offdiag_group(double* __restrict__ Lre, double* __restri
   // whole number of chunk pairs; operands of the next chunk are fetched into the other
   // register buffer while the current one feeds the MFMAs (explicit double buffering:
   // hipcc does not software-pipeline across loop iterations).
-  constexpr int KC = (RT >= 3) ? 1 : 2;     // k-steps per chunk
+#ifndef HPX_KC3
+#define HPX_KC3 1
+#endif
+#ifndef HPX_KC2
+#define HPX_KC2 2
+#endif
+  constexpr int KC = (RT >= 3) ? HPX_KC3 : HPX_KC2;     // k-steps per chunk (c0 / 4 is a multiple of 8: KC | 4)
   const int nch = (c0 >> 2) / KC;
   const double* pre = Lre + (long)g * 32;      // column k = 4 ks + g of every panel
   const double* pim = Lim + (long)g * 32;
@@ -333,6 +339,160 @@ __device__ HPX_INL void offdiag_group(double* __restrict__ Lre, double* __restri
   HPX_TICK(6);
 }
 
+// ---- tile groups with the panel operand shared through LDS (HPX_PANEL_LDS) -------------------
+// k_factor is bound by what a CU can pull through its memory path (a workgroup alone on a CU
+// factors a baseline in 1.3 ms, two share the CU's bandwidth and take 2.3 ms for two; 8 waves on one
+// baseline are no faster than 4: round-2 measurements), and a third of that
+// traffic is the 32 x c0 panel operand, which every wave fetches again for each of its tile groups
+// (L2 hit rate 0.24).  Here the four waves of the workgroup take their groups in rounds, sweep the
+// k range together in chunks of 16 columns, and the panel chunk (2 tiles x 16 columns = 8 KB) is
+// brought in ONCE per workgroup by LDS-DMA (global_load_lds, two 1 KB pieces per wave, no VGPRs),
+// double buffered, one s_barrier per chunk.  The row-tile operand still goes global -> registers,
+// one k-step ahead.  Odd columns are stored [im | re] so that the two lane halves of a ds_read_b64
+// hit disjoint banks.
+#if HPX_3M && HPX_PANEL_LDS
+static __device__ __forceinline__ void hpx_glds16(const double* src, double* dst) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                   (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+}
+template <int RT, bool GEN>
+__device__ HPX_INL void offdiag_group_lds(double* __restrict__ Lre, double* __restrict__ Lim,
+                                          double* __restrict__ pbuf, const int npad, const int c0,
+                                          const int r0, const int rstride, const double* Wre,
+                                          const double* Wim, const int wave, const int lane,
+                                          const hpx_gen& G, long long* st_) {
+  constexpr int CT = 2, RTA = (RT > 0) ? RT : 1;
+  const int li = lane & 15, g = lane >> 4;
+  HPX_T0();
+  d4 a1[RTA][CT], a2[RTA][CT], a3[RTA][CT];
+  const int nchunk = c0 >> 4;                   // 16 columns = 4 k-steps per chunk (c0 % 32 == 0: even)
+  const long kstep = 128, ptile = (long)npad * 32;
+  // LDS-DMA source of this lane inside a 1 KB piece (4 columns x [re16 | im16]); odd columns swapped
+  const int cl = lane >> 4, jj = lane & 15;
+  const int src_lane = cl * 32 + 2 * ((jj + 8 * (cl & 1)) & 15);
+  const int rd_re = g * 32 + li + 16 * (g & 1), rd_im = g * 32 + li + 16 * (1 - (g & 1));
+  // this wave's two pieces of a chunk: piece p = 2 wave + i -> tile p >> 2, k-step p & 3
+  const int p0 = 2 * wave, p1 = 2 * wave + 1;
+  const double* dsrc0 = Lre + (long)((c0 >> 4) + (p0 >> 2)) * ptile + (long)(p0 & 3) * kstep + src_lane;
+  const double* dsrc1 = Lre + (long)((c0 >> 4) + (p1 >> 2)) * ptile + (long)(p1 & 3) * kstep + src_lane;
+#define HPX_PL_DMA(ch_)                                                             \
+  {                                                                                 \
+    double* bb_ = pbuf + ((ch_) & 1) * 1024;                                        \
+    hpx_glds16(dsrc0 + (long)(ch_) * 4 * kstep, bb_ + p0 * 128);                    \
+    hpx_glds16(dsrc1 + (long)(ch_) * 4 * kstep, bb_ + p1 * 128);                    \
+  }
+  const double* pre = Lre + (long)g * 32;
+  const double* pim = Lim + (long)g * 32;
+  const long boff = (long)(r0 >> 4) * ptile + li, bstr = (long)(rstride >> 4) * ptile;
+  double b0r[RTA], b0i[RTA], b1r[RTA], b1i[RTA];
+#define HPX_PL_LOADB(br_, bi_, ks_)                                                 \
+  _Pragma("unroll") for (int t = 0; t < RT; ++t) {                                  \
+    br_[t] = HPX_LD(pre, (long)(ks_) * kstep + boff + t * bstr);                    \
+    bi_[t] = HPX_LD(pim, (long)(ks_) * kstep + boff + t * bstr);                    \
+  }
+#define HPX_PL_MMA(br_, bi_, buf_, s_)                                              \
+  {                                                                                 \
+    double bd_[RTA];                                                                \
+    _Pragma("unroll") for (int t = 0; t < RT; ++t) bd_[t] = br_[t] - bi_[t];        \
+    _Pragma("unroll") for (int ci = 0; ci < CT; ++ci) {                             \
+      const double pr_ = (buf_)[(4 * ci + (s_)) * 128 + rd_re];                     \
+      const double pi_ = (buf_)[(4 * ci + (s_)) * 128 + rd_im];                     \
+      const double npr = -pr_, npi = -pi_, psm = pr_ + pi_;                         \
+      _Pragma("unroll") for (int t = 0; t < RT; ++t) {                              \
+        a1[t][ci] = mfma64(npr, br_[t], a1[t][ci]);                                 \
+        a2[t][ci] = mfma64(npi, bi_[t], a2[t][ci]);                                 \
+        a3[t][ci] = mfma64(psm, bd_[t], a3[t][ci]);                                 \
+      }                                                                             \
+    }                                                                               \
+  }
+  if (nchunk > 0) {
+    HPX_PL_DMA(0)
+    // (the counted vmcnt waits below rely on the issue order: DMA pieces first, operand loads after)
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    HPX_PL_LOADB(b0r, b0i, 0)
+  }
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int t = 0; t < RT; ++t)
+#pragma unroll
+    for (int ci = 0; ci < CT; ++ci) {
+      if (GEN && r0 + t * rstride < G.rmin) {
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          double vr, vi;
+          hpx_gen_signal(G, r0 + t * rstride + li, c0 + 16 * ci + HPX_ACC_ROW(g, v), vr, vi);
+          a1[t][ci][v] = 0.5 * vr;
+          a2[t][ci][v] = 0.5 * vr;
+          a3[t][ci][v] = vi;
+        }
+      } else {
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          const long off = HPX_LIDX(r0 + t * rstride + li, c0 + 16 * ci + HPX_ACC_ROW(g, v), npad);
+          const double vr = Lre[off];
+          a1[t][ci][v] = 0.5 * vr;
+          a2[t][ci][v] = 0.5 * vr;
+          a3[t][ci][v] = Lim[off];
+        }
+      }
+    }
+  HPX_TICK(4);
+  const int nks = c0 >> 2;
+  for (int ch = 0; ch < nchunk; ++ch) {
+    // this wave's pieces of chunk `ch` have landed: everything older than the one row-tile
+    // operand set still in flight (2 RT loads) is complete; then all waves' pieces have
+    if (RT == 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else if (RT == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if (RT == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (ch + 1 < nchunk) HPX_PL_DMA(ch + 1)        // into the buffer every wave has finished reading
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    if (RT > 0) {
+      const lds_f64* B = (const lds_f64*)(pbuf + (ch & 1) * 1024);
+      const int ks = ch << 2;
+      HPX_PL_LOADB(b1r, b1i, ks + 1)
+      __builtin_amdgcn_sched_barrier(0);
+      HPX_PL_MMA(b0r, b0i, B, 0)
+      __builtin_amdgcn_sched_barrier(0);
+      HPX_PL_LOADB(b0r, b0i, ks + 2)
+      __builtin_amdgcn_sched_barrier(0);
+      HPX_PL_MMA(b1r, b1i, B, 1)
+      __builtin_amdgcn_sched_barrier(0);
+      HPX_PL_LOADB(b1r, b1i, ks + 3)
+      __builtin_amdgcn_sched_barrier(0);
+      HPX_PL_MMA(b0r, b0i, B, 2)
+      __builtin_amdgcn_sched_barrier(0);
+      HPX_PL_LOADB(b0r, b0i, min(ks + 4, nks - 1))          // branch-free tail: harmless re-read
+      __builtin_amdgcn_sched_barrier(0);
+      HPX_PL_MMA(b1r, b1i, B, 3)
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+#undef HPX_PL_DMA
+#undef HPX_PL_LOADB
+#undef HPX_PL_MMA
+  HPX_TICK(5);
+  if (RT > 0) trsm_store_3m<CT, RTA>(a1, a2, a3, Lre, Lim, npad, c0, r0, rstride, Wre, Wim, lane);
+  HPX_TICK(6);
+}
+
+// number of groups the 3 / 2+2 / 1 rule cuts `cnt` tiles into
+__device__ __forceinline__ int hpx_group_count(int cnt) {
+  int n = 0;
+  while (cnt > 0) {
+    if (cnt >= 3 && cnt != 4) cnt -= 3;
+    else if (cnt >= 2) cnt -= 2;
+    else cnt -= 1;
+    ++n;
+  }
+  return n;
+}
+#endif
+
 // Measured round 2 (C3, 1024 baselines; tools/build_variant.sh + tools/stamps.py): fusing the next
 // diagonal block's update into the pass cuts k_factor's FETCH_SIZE by 12 % and the separate partial
 // phase from 8.9 % to 1.8 % of a wave's cycles, but the closing barrier and the per-group fixed costs
@@ -343,6 +503,14 @@ __device__ HPX_INL void offdiag_group(double* __restrict__ Lre, double* __restri
 #endif
 #ifndef HPX_BALANCED
 #define HPX_BALANCED 0
+#endif
+// HPX_PANEL_LDS (round 2, measured, off): tile groups taken in rounds with the panel operand brought in
+// once per workgroup by LDS-DMA (offdiag_group_lds).  Parity-green, FETCH_SIZE down, but the lock-step
+// (one s_barrier per 16 columns, counted vmcnt waits that also drain the previous group's stores) costs
+// more than the traffic it saves: 5.31 ms against 4.58 at C3, 1.84 against 1.34 ms for a workgroup alone
+// on its CU.
+#ifndef HPX_PANEL_LDS
+#define HPX_PANEL_LDS 0
 #endif
 #if HPX_3M && HPX_FUSE_DIAG
 // The two row tiles directly below block column (c0, 32 wide) -- rows c1 = c0 + 32 .. c1 + 31, i.e.
@@ -599,12 +767,15 @@ __device__ HPX_OUTLINE void diag_partial_next(const glb_f64* __restrict__ Lre,
 // (one 16 x 16 tile per wave), then D = Ljj Ljj^H and Ljj^-1 by the fused in-LDS elimination.
 // On return (after the trailing barrier) Yre/Yim hold W = conj(Ljj^-1); Ljj and Ljj^-1 are
 // in global memory.
+// The block may have more than 256 threads (8-wave workgroups): only the first 256 hold entries of
+// the 16 x 16 elimination, the others just keep the barriers.
 template <bool GEN, bool GLDS>
 __device__ HPX_OUTLINE bool diag_panel(glb_f64* __restrict__ Lre, glb_f64* __restrict__ Lim,
                                            glb_f64* __restrict__ Wgre, glb_f64* __restrict__ Wgim,
                                            lds_FactorShared* __restrict__ shp,
                                            const int npad, const int c0, const int wj,
                                            const int tid, const gen_signal<GLDS> G, long long* st_) {
+  const bool act = tid < 256;
   lds_FactorShared& sh = *shp;
   lds_f64* const Yre = sh.Yre;
   lds_f64* const Yim = sh.Yim;
@@ -636,7 +807,7 @@ __device__ HPX_OUTLINE bool diag_panel(glb_f64* __restrict__ Lre, glb_f64* __res
   // workgroup's 64-cycle MFMAs on the shared DP pipe: let them go first
   __builtin_amdgcn_s_setprio(HPX_PRIO);
 #endif
-  for (int e = tid; e < 32 * 32; e += 256) {     // identity for the running inverse
+  for (int e = tid; act && e < 32 * 32; e += 256) {     // identity for the running inverse
     const int i = e >> 5, q = e & 31;
     Yre[i * WLD + q] = (i == q) ? 1.0 : 0.0;
     Yim[i * WLD + q] = 0.0;
@@ -735,16 +906,21 @@ __device__ HPX_OUTLINE bool diag_panel(glb_f64* __restrict__ Lre, glb_f64* __res
       // streaming MFMAs leaves only scraps of (tools/elim_step_probe.hip).  Retired entries
       // never change, so one copy of the matrices is enough (a wave that runs ahead rewrites
       // what the others still read with the same values).
-      const bool dia = (q == ib), low = (q < ib);
-      double dr = sh.Dre[(o + ib) * WLD + o + q], di = sh.Dim[(o + ib) * WLD + o + q];
-      if (!low) Dm[ib * 17 + q] = (cplx){0.0, 0.0};      // diagonal and above stay zero in LDS
+      const bool dia = act && (q == ib), low = act && (q < ib);
+      double dr = 0.0, di = 0.0;
+      if (act) {
+        dr = sh.Dre[(o + ib) * WLD + o + q];
+        di = sh.Dim[(o + ib) * WLD + o + q];
+        if (!low) Dm[ib * 17 + q] = (cplx){0.0, 0.0};      // diagonal and above stay zero in LDS
+      }
       double yr = (ib == q) ? 1.0 : 0.0, yi = 0.0;
       const int nsteps = (HPX_DIAG & 4) ? 0 : 16;
 #pragma unroll
       for (int k = 0; k < nsteps; ++k) {
         if (dia) dg[ib] = dr; else if (low) Dm[ib * 17 + q] = (cplx){dr, di};
-        Ym[ib * 17 + q] = (cplx){yr, yi};
+        if (act) Ym[ib * 17 + q] = (cplx){yr, yi};
         __syncthreads();
+        if (!act) continue;
         const double dkk = dg[k];
         const cplx c = Dm[ib * 17 + k], cq = Dm[q * 17 + k], sy = Ym[k * 17 + q];
         // v_rcp_f64 (24 bits) + one Newton step (2e-15) instead of the IEEE division sequence
@@ -763,7 +939,7 @@ __device__ HPX_OUTLINE bool diag_panel(glb_f64* __restrict__ Lre, glb_f64* __res
       if (nsteps == 0 && dia) dg[ib] = dr;
       __syncthreads();
       // scaling: L block to global, W = conj(L^-1) block to LDS (Y), L^-1 block to the side buffer
-      {
+      if (act) {
         double wr = 0.0, wi = 0.0;
         if (q <= ib) {
           const double pq = dg[q], pib = dg[ib];
@@ -841,13 +1017,13 @@ __device__ HPX_OUTLINE bool diag_panel(glb_f64* __restrict__ Lre, glb_f64* __res
 // GLDS: the per-baseline vectors the closed-form entries are made of (1/a, circ: 3 N doubles)
 // are staged in LDS behind FactorShared.  From global memory every tile group's initialisation
 // waits for loads that miss L1 and L2 (the factor streams through both), ~1e4 cycles a group.
-template <bool GEN, bool GLDS>
-__global__ __launch_bounds__(256, HPX_WGS) void k_factor(double* __restrict__ L_all,
+template <bool GEN, bool GLDS, int NW>
+__global__ __launch_bounds__(NW * 64, (NW == 4) ? HPX_WGS : 2) void k_factor(double* __restrict__ L_all,
                                                    double* __restrict__ Wre_all,
                                                    double* __restrict__ Wim_all,
                                                    int32_t* __restrict__ info, const int npad,
                                                    const int ld, const int iter_tag,
-                                                   const hpx_gen_batch GB) {
+                                                   const hpx_gen_batch GB, const int pb_off) {
   extern __shared__ double lds_raw[];
   FactorShared& sh = *reinterpret_cast<FactorShared*>(lds_raw);
   const int b = blockIdx.x;
@@ -857,7 +1033,7 @@ __global__ __launch_bounds__(256, HPX_WGS) void k_factor(double* __restrict__ L_
   // which wave takes the first tile below the diagonal block (the one that ends up with the
   // extra tile) rotates with the block column, two steps apart for the two workgroups that
   // share a CU's SIMDs (dispatch puts blocks b and b + 256 on the same CU)
-  const int rot0 = 2 * ((b >> 8) & 1);
+  const int rot0 = (NW == 4) ? 2 * ((b >> 8) & 1) : 0;
   double* Lre = L_all + (long)b * npad * ld * 2;
   double* Lim = Lre + 16;
   const int nblk = (npad + HPX_NB - 1) / HPX_NB;
@@ -868,12 +1044,16 @@ __global__ __launch_bounds__(256, HPX_WGS) void k_factor(double* __restrict__ L_
   long long st_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   typedef typename gen_ptr<GLDS>::type gsrc;
   gen_signal<GLDS> GS = {nullptr, nullptr, nullptr, 0};
+  // panel chunks of the LDS-shared tile groups: 2 buffers x 8 KB behind FactorShared and the staged vectors
+  double* pbuf = nullptr;
+  if (pb_off > 0) pbuf = lds_raw + pb_off;
+  (void)pbuf;
   if (GEN) {
     if (GLDS) {
       double* ga = lds_raw + sizeof(FactorShared) / sizeof(double);
       double* gcr = ga + G.N;
       double* gci = gcr + G.N;
-      for (int i = tid; i < G.N; i += 256) {
+      for (int i = tid; i < G.N; i += NW * 64) {
         ga[i] = G.ia[i];
         gcr[i] = G.cre[i];
         gci[i] = G.cim[i];
@@ -895,12 +1075,12 @@ __global__ __launch_bounds__(256, HPX_WGS) void k_factor(double* __restrict__ L_
                                  (glb_f64*)(Wgim + jb * 1024), (lds_FactorShared*)&sh, npad, c0, wj, tid,
                                  GS, st_);
     // tiles below the diagonal block (incl. the right-hand-side rows)
-    const int pos = (wave + rot0 + jb * HPX_ROT) & 3;
+    const int pos = (wave + rot0 + jb * HPX_ROT) & (NW - 1);
     int rt = ((c0 + wj) >> 4) + pos;
     if (wj == 32) {
       const int c1 = c0 + 32;
 #if HPX_3M && HPX_FUSE_DIAG
-      const bool fuse = c0 > 0 && npad - c1 >= 32;
+      const bool fuse = NW == 4 && c0 > 0 && npad - c1 >= 32;
 #else
       const bool fuse = false;
 #endif
@@ -952,24 +1132,50 @@ __global__ __launch_bounds__(256, HPX_WGS) void k_factor(double* __restrict__ L_
         rt = base + 9 + pos;
 #endif
       }
-      // this wave's (remaining) tiles rt + 4 i in groups of 3 (2 + 2 rather than 3 + 1: a single-tile
+      // this wave's (remaining) tiles rt + NW i in groups of 3 (2 + 2 rather than 3 + 1: a single-tile
       // pass costs nearly as much as a three-tile one, its k-loop is bound by load latency)
-      int cnt = (nrt - rt + 3) >> 2;
+      int cnt = (nrt - rt + NW - 1) / NW;
+      if (nrt <= rt) cnt = 0;
+#if HPX_3M && HPX_PANEL_LDS
+      if (NW == 4 && pbuf && c0 > 0) {
+        // rounds: every wave takes one group (or none) per round and all sweep the k range together,
+        // the panel operand coming through LDS once per workgroup (offdiag_group_lds)
+        const int first = (c0 + wj) >> 4;
+        const int nrounds = hpx_group_count((nrt - first + NW - 1) / NW);      // position 0 has the most tiles
+        for (int rd = 0; rd < nrounds; ++rd) {
+          if (cnt >= 3 && cnt != 4) {
+            offdiag_group_lds<3, GEN>(Lre, Lim, pbuf, npad, c0, rt << 4, 16 * NW, sh.Yre, sh.Yim, wave, lane, G, st_);
+            rt += 3 * NW;
+            cnt -= 3;
+          } else if (cnt >= 2) {
+            offdiag_group_lds<2, GEN>(Lre, Lim, pbuf, npad, c0, rt << 4, 16 * NW, sh.Yre, sh.Yim, wave, lane, G, st_);
+            rt += 2 * NW;
+            cnt -= 2;
+          } else if (cnt == 1) {
+            offdiag_group_lds<1, GEN>(Lre, Lim, pbuf, npad, c0, rt << 4, 16 * NW, sh.Yre, sh.Yim, wave, lane, G, st_);
+            rt += NW;
+            cnt -= 1;
+          } else {
+            offdiag_group_lds<0, GEN>(Lre, Lim, pbuf, npad, c0, 0, 16 * NW, sh.Yre, sh.Yim, wave, lane, G, st_);
+          }
+        }
+      }
+#endif
       while (cnt > 0) {
 #if HPX_RT3
         if (cnt >= 3 && cnt != 4) {
-          offdiag_group<2, 3, GEN>(Lre, Lim, npad, c0, rt << 4, 64, sh.Yre, sh.Yim, lane, G, st_);
-          rt += 12;
+          offdiag_group<2, 3, GEN>(Lre, Lim, npad, c0, rt << 4, 16 * NW, sh.Yre, sh.Yim, lane, G, st_);
+          rt += 3 * NW;
           cnt -= 3;
         } else
 #endif
         if (cnt >= 2) {
-          offdiag_group<2, 2, GEN>(Lre, Lim, npad, c0, rt << 4, 64, sh.Yre, sh.Yim, lane, G, st_);
-          rt += 8;
+          offdiag_group<2, 2, GEN>(Lre, Lim, npad, c0, rt << 4, 16 * NW, sh.Yre, sh.Yim, lane, G, st_);
+          rt += 2 * NW;
           cnt -= 2;
         } else {
-          offdiag_group<2, 1, GEN>(Lre, Lim, npad, c0, rt << 4, 64, sh.Yre, sh.Yim, lane, G, st_);
-          rt += 4;
+          offdiag_group<2, 1, GEN>(Lre, Lim, npad, c0, rt << 4, 16 * NW, sh.Yre, sh.Yim, lane, G, st_);
+          rt += NW;
           cnt -= 1;
         }
       }
@@ -977,7 +1183,7 @@ __global__ __launch_bounds__(256, HPX_WGS) void k_factor(double* __restrict__ L_
       // early part of the next diagonal block (columns < c0) where the fused group did not form it:
       // its tiles go to the waves that got the fewest off-diagonal tiles in this pass
       if (!fuse && c0 > 0 && c1 < npad) {
-        const int t = 3 - pos;
+        const int t = NW - 1 - pos;
         if (t < ((npad - c1 >= 32) ? 3 : 1)) {
           HPX_T0();
           diag_partial_next((const glb_f64*)Lre, (const glb_f64*)Lim, (lds_FactorShared*)&sh, npad, c1, c0,
@@ -986,7 +1192,7 @@ __global__ __launch_bounds__(256, HPX_WGS) void k_factor(double* __restrict__ L_
         }
       }
     } else {
-      for (; rt < nrt; rt += 4) offdiag_narrow<GEN>(Lre, Lim, npad, c0, rt << 4, sh.Yre, sh.Yim, lane, G, st_);
+      for (; rt < nrt; rt += NW) offdiag_narrow<GEN>(Lre, Lim, npad, c0, rt << 4, sh.Yre, sh.Yim, lane, G, st_);
     }
 #if HPX_STAMP
     { HPX_T0(); __syncthreads(); HPX_TICK(7); }
@@ -996,7 +1202,7 @@ __global__ __launch_bounds__(256, HPX_WGS) void k_factor(double* __restrict__ L_
     c0 += wj;
   }
 #if HPX_STAMP
-  if (lane == 0 && b < 2048)
+  if (lane == 0 && b < 2048 && wave < 4)
     for (int i = 0; i < 8; ++i) g_stamps[(b * 4 + wave) * 8 + i] = st_[i];
 #endif
   (void)st_;
@@ -1442,13 +1648,34 @@ __global__ void k_unpack_x(const double* __restrict__ Xre, const double* __restr
 
 }  // namespace
 
+// Waves per workgroup: 4 (two workgroups per CU) or 8 (one per CU, the baseline's tile passes spread over
+// twice the waves; HPX_FACTOR_WAVES in the environment, read once -- see DESIGN.md section 6 for the
+// measurements behind the default).
+static int factor_waves() {
+  static const int nw = (getenv("HPX_FACTOR_WAVES") && atoi(getenv("HPX_FACTOR_WAVES")) == 8) ? 8 : 4;
+  return nw;
+}
 template <bool GEN, bool GLDS>
 static int launch_factor_t(int nbl, size_t lds, int npad, int ld, double* L, double* Wre, double* Wim,
                            int32_t* info, int iter_tag, const hpx_gen_batch& gen, hipStream_t st) {
-  static hpx_lds_limit limit;      // per instantiation
-  HPX_TRY(limit.ensure(reinterpret_cast<const void*>(&k_factor<GEN, GLDS>), lds));
-  hipLaunchKernelGGL((k_factor<GEN, GLDS>), dim3(nbl), dim3(256), lds, st, L, Wre, Wim, info, npad, ld,
-                     iter_tag, gen);
+  static hpx_lds_limit limit4, limit8;      // per instantiation
+  if (factor_waves() == 8) {
+    HPX_TRY(limit8.ensure(reinterpret_cast<const void*>(&k_factor<GEN, GLDS, 8>), lds));
+    hipLaunchKernelGGL((k_factor<GEN, GLDS, 8>), dim3(nbl), dim3(512), lds, st, L, Wre, Wim, info, npad, ld,
+                       iter_tag, gen, 0);
+  } else {
+    // panel buffers (2 x 8 KB) behind what is there, while two workgroups still fit a CU
+    static const int panel_lds = (HPX_3M && HPX_PANEL_LDS && !(getenv("HPX_PANEL_LDS") && atoi(getenv("HPX_PANEL_LDS")) == 0)) ? 1 : 0;
+    int pb_off = 0;
+    const size_t lds_al = (lds + 15) & ~(size_t)15;
+    if (panel_lds && lds_al + 2 * 8192 <= (size_t)80 * 1024) {
+      pb_off = (int)(lds_al / sizeof(double));
+      lds = lds_al + 2 * 8192;
+    }
+    HPX_TRY(limit4.ensure(reinterpret_cast<const void*>(&k_factor<GEN, GLDS, 4>), lds));
+    hipLaunchKernelGGL((k_factor<GEN, GLDS, 4>), dim3(nbl), dim3(256), lds, st, L, Wre, Wim, info, npad, ld,
+                       iter_tag, gen, pb_off);
+  }
   HPX_HIP(hipGetLastError());
   return HPX_OK;
 }

@@ -69,6 +69,10 @@ def build_parser():
     p.add_argument("--resume", action="store_true",
                    help="continue chains from the checkpoints in the output tree (written every --write_Niter "
                         "iterations); the earlier run's args.json must name the same inputs and seed")
+    p.add_argument("--per_time_flags", action="store_true",
+                   help="keep the flags time dependent: every time sample is solved with its own noise matrix "
+                        "(Nbl x Ntimes factorisations per iteration) instead of masking a channel at all times "
+                        "as soon as one sample is flagged, which is what the reference driver does (:524-541)")
     p.add_argument("--outputs", type=str, default="all",
                    help="'all' (the six reference files) or 'ps' (dps-eor.npy and ln-post.npy only)")
     return p
@@ -174,6 +178,7 @@ def main(argv=None):
     ninv_dense = None        # (nbl,N,N) once any baseline has a non-diagonal inverse noise covariance
     fg = None
     flags_any = np.empty((nbl, N), bool)
+    flags_pt = np.empty((nbl, T, N), bool) if args.per_time_flags else None
     for b, ap in enumerate(antpairs):
         bl = f"{ap[0]}-{ap[1]}"
         if args.flags:
@@ -182,6 +187,8 @@ def main(argv=None):
         else:
             fl = flags_td[b]
         flags_any[b] = any_time_unflagged(~fl)
+        if flags_pt is not None:
+            flags_pt[b] = ~fl
         if args.noise:
             noise = load_aux(args.noise, args.noise_file, bl)
             if args.nsamples:
@@ -302,8 +309,8 @@ def main(argv=None):
         hist = {k: [] for k in names}
 
     Ninv_arg = ninv if ninv_dense is None else ninv_dense
-    gb = pspec.make_batch(vis, flags_any, fg, Ninv_arg, ps_prior, Niter, seed=args.seed,
-                          map_estimate=args.map_estimate)
+    gb = pspec.make_batch(vis, flags_any if flags_pt is None else flags_pt, fg, Ninv_arg, ps_prior, Niter,
+                          seed=args.seed, map_estimate=args.map_estimate)
     fop = utils.fourier_operator(N)
     write_times, ant_strs = [0.0] * nbl, [f"{ap[0]}_{ap[1]}" for ap in antpairs]
 

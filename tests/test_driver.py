@@ -212,3 +212,31 @@ def test_driver_correlated_noise_cov(golden, tmp_path):
     assert rc == 0
     ps = np.load(tmp_path / "res" / "0-1" / "dps-eor.npy")
     assert np.max(np.abs(ps / g["chain_ps"] - 1)) < 1e-6
+
+
+@pytest.mark.gpu
+def test_driver_per_time_flags(tmp_path):
+    """--per_time_flags keeps (Nbl, Ntimes, Nfreqs) flags from the input cube time dependent
+    instead of the reference driver's any-time reduction (run-hydra-pspec.py:524-541)."""
+    from hydra_pspec_amd import pspec, synthetic
+    drv = _driver()
+    nbl, T, N, M = 2, 8, 32, 4
+    d = synthetic.make_baselines(N, T, M, k0=3, nbl=nbl, dense=False)
+    rng = np.random.default_rng(4)
+    flagged = rng.uniform(size=(nbl, T, N)) < 0.1                        # True = flagged sample, as in UVH5
+    fg = np.broadcast_to(d["fgmodes"], (nbl, N, M)).copy()
+    for b in range(nbl):
+        (tmp_path / "fg" / f"0-{b + 1}").mkdir(parents=True)
+        np.save(tmp_path / "fg" / f"0-{b + 1}" / "fgmodes.npy", fg[b])
+    np.savez(tmp_path / "vis.npz", vis=d["vis"], flags=flagged, antpairs=np.array([[0, 1], [0, 2]]))
+    common = ["--file_paths", str(tmp_path / "vis.npz"), "--fgmodes", str(tmp_path / "fg"), "--Nfgmodes", str(M),
+              "--seed", "5", "--Niter", "3", "--out_dir", str(tmp_path), "--outputs", "ps"]
+    assert drv.main(common + ["--dirname", "pt", "--per_time_flags"]) == 0
+    assert drv.main(common + ["--dirname", "any"]) == 0
+    ninv = np.full((nbl, N), 1.0 / 100.0)
+    want = pspec.gibbs_sample_with_fg_batched(d["vis"], ~flagged, fg, ninv, np.zeros((2, N)),
+                                              ps_initial=np.full((nbl, N), float(N)), Niter=3, seed=5)
+    for b in range(nbl):
+        got = np.load(tmp_path / "pt" / f"0-{b + 1}" / "dps-eor.npy")
+        assert np.array_equal(got, want["signal_ps"][b])
+        assert not np.array_equal(got, np.load(tmp_path / "any" / f"0-{b + 1}" / "dps-eor.npy"))

@@ -13,6 +13,9 @@
 #include <math.h>
 #include <vector>
 #include <complex>
+#ifndef PROBE_3M
+#define PROBE_3M 1
+#endif
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) double lds_f64;
@@ -48,6 +51,9 @@ __device__ __forceinline__ void tile_pass(double* __restrict__ Lb, const double*
   const double* row0 = Lb + (long)rt0 * ptile + src_lane;
   const double* row1 = Lb + (long)(rt0 + (RT > 1 ? 1 : 0)) * ptile + src_lane;
   d4 ar[RT][4], ai[RT][4];
+#if PROBE_3M
+  d4 a3[RT][4];       // three-product form: ar = Kre/2 - S1, ai = Kre/2 - S2, a3 = Kim + S3 during the k-loop
+#endif
 #pragma unroll
   for (int t = 0; t < RT; ++t)
 #pragma unroll
@@ -55,8 +61,14 @@ __device__ __forceinline__ void tile_pass(double* __restrict__ Lb, const double*
 #pragma unroll
       for (int v = 0; v < 4; ++v) {
         const long off = LIDX((rt0 + t) * 16 + li, c0 + 16 * ci + ACC_ROW(g, v), npad);
+#if PROBE_3M
+        ar[t][ci][v] = 0.5 * Lb[off];
+        ai[t][ci][v] = ar[t][ci][v];
+        a3[t][ci][v] = Lb[off + 16];
+#else
         ar[t][ci][v] = Lb[off];
         ai[t][ci][v] = Lb[off + 16];
+#endif
       }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   const int nch = c0 / KC;
@@ -96,21 +108,45 @@ __device__ __forceinline__ void tile_pass(double* __restrict__ Lb, const double*
           br[t] = B[(4 + 2 * wave + t) * TILE_CH + s * 128 + rd_re];
           bm[t] = B[(4 + 2 * wave + t) * TILE_CH + s * 128 + rd_im];
         }
+#if PROBE_3M
+        double bd[RT];
+#pragma unroll
+        for (int t = 0; t < RT; ++t) bd[t] = br[t] - bm[t];
+#endif
 #pragma unroll
         for (int ci = 0; ci < 4; ++ci) {
           const double npr = -pr[ci], npi = -pi[ci];
+#if PROBE_3M
+          const double psm = pr[ci] + pi[ci];
+#endif
 #pragma unroll
           for (int t = 0; t < RT; ++t) {
+#if PROBE_3M
+            ar[t][ci] = mfma64(npr, br[t], ar[t][ci]);
+            ai[t][ci] = mfma64(npi, bm[t], ai[t][ci]);
+            a3[t][ci] = mfma64(psm, bd[t], a3[t][ci]);
+#else
             ar[t][ci] = mfma64(npr, br[t], ar[t][ci]);
             ar[t][ci] = mfma64(npi, bm[t], ar[t][ci]);
             ai[t][ci] = mfma64(npr, bm[t], ai[t][ci]);
             ai[t][ci] = mfma64(pi[ci], br[t], ai[t][ci]);
+#endif
           }
         }
       }
       bi = (bi + 1 == NBUF) ? 0 : bi + 1;
     }
   }
+#if PROBE_3M
+#pragma unroll
+  for (int t = 0; t < RT; ++t)
+#pragma unroll
+    for (int ci = 0; ci < 4; ++ci) {
+      const d4 re_ = ar[t][ci] + ai[t][ci], im_ = ar[t][ci] - ai[t][ci] + a3[t][ci];
+      ar[t][ci] = re_;
+      ai[t][ci] = im_;
+    }
+#endif
   // ---- block operands: W fragments (24 KB) and the two L10 tiles (16 KB) over the staging buffers
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
