@@ -1534,13 +1534,18 @@ extern "C" int hpx_plan_set_solver(hpx_plan* p, int mode) {
     HPX_REQUIRE(hpx_flat_lds_bytes(p) <= 160 * 1024, "hpx_plan_set_solver: too many channels for the flat-noise solver");
     std::vector<double> ni((size_t)p->nbl * p->N);
     HPX_HIP(hipMemcpy(ni.data(), p->ni, ni.size() * sizeof(double), hipMemcpyDeviceToHost));
-    for (int b = 0; b < p->nbl; ++b)
+    for (int b = 0; b < p->nbl; ++b) {
+      if (!(ni[(size_t)b * p->N] > 0.0)) {
+        hpx_set_error("hpx_plan_set_solver: inverse noise variance of baseline %d is not positive", b);
+        return HPX_EINVAL;
+      }
       for (int k = 1; k < p->N; ++k)
         if (ni[(size_t)b * p->N + k] != ni[(size_t)b * p->N]) {
           hpx_set_error("hpx_plan_set_solver: inverse noise variance of baseline %d is not flat (channel %d)",
                         b, k);
           return HPX_EINVAL;
         }
+    }
   }
   if (mode == HPX_SOLVER_LOWRANK || mode == HPX_SOLVER_LOWRANK_DIRECT) {
     HPX_REQUIRE(p->TP <= 256, "hpx_plan_set_solver: the low-rank solver needs T <= 256");

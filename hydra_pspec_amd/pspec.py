@@ -282,28 +282,26 @@ class GibbsBatch:
                                      "solver='dense' (or 'auto')")
                 solver = "dense"
             if solver != "dense":
-                use = d_flags.bool()
-                ref = torch.where(use, d_ninv, torch.nan).nan_to_num(nan=-1.0).max(dim=1, keepdim=True).values
-                flat_unflagged = bool((torch.where(use, d_ninv, ref) == ref).all().item()) and bool((ref > 0).all().item())
-                nflag = int((~use).sum(dim=1).max().item())
-                if flat_unflagged and T <= 256:
-                    if not self.any_flags and M <= 16 and N <= 4096:
-                        self.solver = "flat"
-                    elif self.any_flags and M + nflag <= 240:
-                        self.solver = "lowrank"
-                if solver in ("flat", "lowrank") and self.solver != solver:
+                # The library decides whether a structured solver applies (one inverse noise variance
+                # over the unflagged channels of every baseline, size limits: hpx_plan_set_solver
+                # inspects the plan's own copies once); "auto" falls back to the dense factorisation,
+                # an explicit request that does not apply is an error.
+                cand = "lowrank" if self.any_flags else "flat"
+                want = cand if solver == "auto" else solver
+                mode = hpx.SOLVER_FLAT if want == "flat" else \
+                    (hpx.SOLVER_LOWRANK_DIRECT if direct else hpx.SOLVER_LOWRANK)
+                size_ok = T <= 256 and (M <= 16 and N <= 4096 if want == "flat" else True)
+                rc = L.hpx_plan_set_solver(self.plan.handle, mode) if (want == cand and size_ok) else hpx.HPX_EINVAL
+                if rc == hpx.HPX_OK:
+                    self.solver = want
+                elif rc == hpx.HPX_EINVAL and solver == "auto":
+                    self.solver = "dense"
+                elif rc == hpx.HPX_EINVAL:
                     raise ValueError(f"solver={solver!r} does not apply: it needs one inverse noise variance over the "
                                      "unflagged channels of every baseline, Ntimes <= 256 and "
                                      + ("no flags, Nmodes <= 16" if solver == "flat"
-                                        else "flags with Nmodes + max flagged channels <= 240"))
-            if self.solver != "dense":
-                mode = hpx.SOLVER_FLAT if self.solver == "flat" else \
-                    (hpx.SOLVER_LOWRANK_DIRECT if direct else hpx.SOLVER_LOWRANK)
-                rc = L.hpx_plan_set_solver(self.plan.handle, mode)
-                if rc == hpx.HPX_EINVAL and solver == "auto":
-                    # the C side has the last word on what a structured solver can hold (LDS of the
-                    # border form, transform sizes): "auto" then stays on the dense factorisation
-                    self.solver = "dense"
+                                        else "flags with Nmodes + max flagged channels <= 240")
+                                     + (f" ({hpx.last_error()})" if want == cand and size_ok else ""))
                 else:
                     hpx.check(rc, "hpx_plan_set_solver")
         self.iter_done = 0

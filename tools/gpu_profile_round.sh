@@ -1,39 +1,51 @@
 #!/bin/bash
 # Produce the round's measurement artefacts on the GPU box (copied to profiles/ afterwards):
-#   bench lines for C3 (with CPU baseline), C5, C2; rocprofv3 kernel stats of the C3 bench;
-#   PMC passes (FETCH_SIZE, WRITE_SIZE, MFMA busy) of the C3 bench, one counter set per pass.
-# usage: tools/gpu_profile_round.sh <tag>      e.g. r01
-TAG=${1:-r01}
+#   bench lines for C3 (with CPU baseline), C5, C2, N4, dpss, oqe and a 2-rank rehearsal; rocprofv3 kernel
+#   stats of the C3 / C5-auto / dpss / oqe benches; PMC passes (FETCH_SIZE, WRITE_SIZE, MFMA busy, L2 hits)
+#   of the C3 bench, one counter set per pass; the FETCH_SIZE calibration probe.
+# usage: tools/gpu_profile_round.sh <tag>      e.g. r02
+TAG=${1:-r02}
 export TMPDIR=/tmp
 R=$PWD; O=$R/gpurun_out/prof; mkdir -p $O
-timeout -k 10 400 python3 bench.py > $O/bench_c3.log 2>&1 || { tail -5 $O/bench_c3.log; exit 1; }
-grep -o '{"metric.*' $O/bench_c3.log > $O/${TAG}_bench_c3.json; echo "C3 done"
-timeout -k 10 300 python3 bench.py --steps 5 --warmup 1 --config C5 --no-cpu-baseline > $O/bench_c5.log 2>&1 && grep -o '{"metric.*' $O/bench_c5.log > $O/${TAG}_bench_c5.json; echo "C5 done"
-timeout -k 10 300 python3 bench.py --steps 20 --warmup 2 --config C2 --no-cpu-baseline > $O/bench_c2.log 2>&1 && grep -o '{"metric.*' $O/bench_c2.log > $O/${TAG}_bench_c2.json; echo "C2 done"
-cd /tmp
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python3 $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline > $O/kt.log 2>&1
-cd $R
-cp $(ls $O/kt/*/*kernel_stats.csv | head -1) $O/${TAG}_kernel_stats_c3.csv 2>/dev/null; echo "kernel stats done"
-# the structured (flagged, flat-noise) path at C5: per-kernel times of solver=auto
-cd /tmp
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt5 -- python3 $R/bench.py --config C5 --solver auto --steps 10 --warmup 2 --no-cpu-baseline > $O/kt5.log 2>&1
-cd $R
-cp $(ls $O/kt5/*/*kernel_stats.csv | head -1) $O/${TAG}_kernel_stats_c5_auto.csv 2>/dev/null
-grep -o '{"metric.*' $O/kt5.log > $O/${TAG}_bench_c5_auto_under_rocprof.json; echo "C5 auto kernel stats done"
+line() { grep -o '{"metric.*' $1 > $2; }
+timeout -k 10 500 python3 bench.py > $O/bench_c3.log 2>&1 || { tail -5 $O/bench_c3.log; exit 1; }
+line $O/bench_c3.log $O/${TAG}_bench_c3.json; echo "C3 done"
+timeout -k 10 300 python3 bench.py --steps 5 --warmup 1 --config C5 --no-cpu-baseline > $O/bench_c5.log 2>&1 && line $O/bench_c5.log $O/${TAG}_bench_c5.json; echo "C5 done"
+timeout -k 10 300 python3 bench.py --steps 20 --warmup 2 --config C2 --no-cpu-baseline > $O/bench_c2.log 2>&1 && line $O/bench_c2.log $O/${TAG}_bench_c2.json; echo "C2 done"
+timeout -k 10 300 python3 bench.py --steps 10 --warmup 2 --config N4 --no-cpu-baseline > $O/bench_n4.log 2>&1 && line $O/bench_n4.log $O/${TAG}_bench_n4.json; echo "N4 done"
+timeout -k 10 300 python3 bench.py --config dpss --steps 20 --warmup 2 > $O/bench_dpss.log 2>&1 && line $O/bench_dpss.log $O/${TAG}_bench_dpss.json; echo "dpss done"
+timeout -k 10 300 python3 bench.py --config oqe --steps 5 --warmup 1 > $O/bench_oqe.log 2>&1 && line $O/bench_oqe.log $O/${TAG}_bench_oqe.json; echo "oqe done"
+HPX_BENCH_DEVICE=0 HPX_BENCH_BACKEND=gloo timeout -k 10 400 python3 bench.py --gpus 2 --steps 10 --warmup 2 --no-cpu-baseline > $O/bench_2rank.log 2>&1 && line $O/bench_2rank.log $O/${TAG}_bench_2ranks_one_gpu.json; echo "2-rank rehearsal done"
+kt() {   # kernel-trace stats: kt <name> <bench args...>
+  local name=$1; shift
+  cd /tmp
+  timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_$name -- python3 $R/bench.py "$@" > $O/kt_$name.log 2>&1
+  cd $R
+  cp $(ls $O/kt_$name/*/*kernel_stats.csv | head -1) $O/${TAG}_kernel_stats_$name.csv 2>/dev/null
+  grep -o '{"metric.*' $O/kt_$name.log > $O/${TAG}_bench_${name}_under_rocprof.json
+  echo "kernel stats $name done"
+}
+kt c3 --steps 10 --warmup 2 --no-cpu-baseline
+kt c5_auto --config C5 --solver auto --steps 10 --warmup 2 --no-cpu-baseline
+kt dpss --config dpss --steps 10 --warmup 2
+kt oqe --config oqe --steps 3 --warmup 1
 i=0
-for set in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
+for set in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" "TCC_HIT_sum TCC_MISS_sum"; do
   i=$((i+1))
   cd /tmp
   timeout -k 10 300 rocprofv3 --pmc $set --output-format csv -d $O/pmc$i -- python3 $R/bench.py --steps 2 --warmup 0 --no-cpu-baseline > $O/pmc$i.log 2>&1
   cd $R
   echo "pmc pass $i done"
 done
+cd /tmp
+timeout -k 10 200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/calib -- $R/tools/fetch_calib_probe > $O/calib.log 2>&1; echo "calib rc=$?"
+cd $R
 python3 - "$TAG" <<'PY'
 import csv, collections, glob, json, sys
 tag = sys.argv[1]
 O = "gpurun_out/prof"
 lines = ["rocprofv3 --pmc <set> --output-format csv -- python3 bench.py --steps 2 --warmup 0 --no-cpu-baseline   (C3: 1024 baselines x (32,512,12)); separate passes per counter set.",
-         "Per-dispatch averages.  FETCH_SIZE / WRITE_SIZE in KB.  gfx950 correction (MI355X_MICROARCH.md, HBM): FETCH_SIZE counts TCC_EA0_RDREQ x 64 B while requests are 128 B wide -> double it.", ""]
+         "Per-dispatch averages.  FETCH_SIZE / WRITE_SIZE in KB.  gfx950: FETCH_SIZE reads 1/2 of the bytes fetched -- calibrated for k_factor's own load shape (8 B/lane, 4 x 128-B segments) by tools/fetch_calib.hip, see the calibration lines at the end.", ""]
 tot = {}
 for i, f in enumerate(sorted(glob.glob(O + "/pmc*/*/*counter_collection.csv")), 1):
     acc = collections.defaultdict(lambda: collections.defaultdict(list)); dur = collections.defaultdict(list)
@@ -44,26 +56,41 @@ for i, f in enumerate(sorted(glob.glob(O + "/pmc*/*/*counter_collection.csv")), 
     for k in sorted(acc):
         cs = {c: sum(v) / len(v) for c, v in acc[k].items()}
         n = len(next(iter(acc[k].values())))
-        lines.append("pass%d %-24s n=%2d dur_ms=%7.3f %s" % (i, k, n, sum(dur[k]) / len(dur[k]) / 1e6,
+        lines.append("pass%d %-34s n=%2d dur_ms=%7.3f %s" % (i, k[:34], n, sum(dur[k]) / len(dur[k]) / 1e6,
                                                            " ".join("%s=%.4g" % kv for kv in cs.items())))
-        tot.setdefault(k, {}).update(cs)
+        tot.setdefault(k.split("<")[0], {}).update(cs)
+lines += ["", "FETCH_SIZE calibration (tools/fetch_calib.hip: 1 GiB = 1048576 KB streamed once per shape):"]
+for f in glob.glob(O + "/calib/*/*counter_collection.csv"):
+    acc = collections.defaultdict(list)
+    for r in csv.DictReader(open(f)):
+        acc[r["Kernel_Name"].split("(")[0]].append(float(r["Counter_Value"]))
+    for k, v in acc.items():
+        if k.startswith("k_shape"):
+            lines.append("  %-22s FETCH_SIZE_KB %s -> bytes / (FETCH_SIZE*1024) = %.3f" % (k, ["%.0f" % x for x in v], 1048576.0 / (sum(v) / len(v))))
+for l in open(O + "/calib.log"):
+    if l.startswith("rep 1"):
+        lines.append("  " + l.rstrip())
 open(O + "/%s_pmc_c3.txt" % tag, "w").write("\n".join(lines) + "\n")
-kf = [k for k in tot if k.startswith("k_factor")]
-if kf and "FETCH_SIZE" in tot[kf[0]] and "WRITE_SIZE" in tot[kf[0]]:
-    t = tot[kf[0]]
-    json.dump({"C3": {"k_factor": {"fetch_kb": t["FETCH_SIZE"], "write_kb": t["WRITE_SIZE"],
-                                   "bytes_per_launch": (2 * t["FETCH_SIZE"] + t["WRITE_SIZE"]) * 1024,
-                                   "baselines": 1024, "source": "profiles/%s_pmc_c3.txt" % tag,
-                                   "mfma_busy": t.get("SQ_VALU_MFMA_BUSY_CYCLES"), "sq_busy": t.get("SQ_BUSY_CYCLES"),
-                                   "gui_active": t.get("GRBM_GUI_ACTIVE")}}},
-              open(O + "/pmc_traffic.json", "w"), indent=1)
-print("\n".join(l for l in lines if "k_factor" in l or "k_backsolve" in l))
+out = {}
+for kname in ("k_factor", "k_backsolve"):
+    if kname in tot and "FETCH_SIZE" in tot[kname] and "WRITE_SIZE" in tot[kname]:
+        t = tot[kname]
+        out[kname] = {"fetch_kb": t["FETCH_SIZE"], "write_kb": t["WRITE_SIZE"],
+                      "bytes_per_launch": (2 * t["FETCH_SIZE"] + t["WRITE_SIZE"]) * 1024, "baselines": 1024,
+                      "source": "profiles/%s_pmc_c3.txt" % tag,
+                      "fetch_size_factor": 2.0, "fetch_size_factor_source": "tools/fetch_calib.hip on this kernel's load shape (ratio 2.000)",
+                      "mfma_busy": t.get("SQ_VALU_MFMA_BUSY_CYCLES"), "sq_busy": t.get("SQ_BUSY_CYCLES"),
+                      "gui_active": t.get("GRBM_GUI_ACTIVE"), "l2_hit": t.get("TCC_HIT_sum"), "l2_miss": t.get("TCC_MISS_sum")}
+if out:
+    json.dump({"C3": out}, open(O + "/pmc_traffic.json", "w"), indent=1)
+print("\n".join(l for l in lines if "k_factor" in l or "k_backsolve" in l or "k_shape" in l))
 PY
-head -8 $O/${TAG}_kernel_stats_c3.csv | cut -c1-150
+head -12 $O/${TAG}_kernel_stats_c3.csv | cut -c1-160
 python3 -c "
 import json
-for c in ('c3','c5','c2'):
+for c in ('c3','c5','c2','n4','dpss','oqe','2ranks_one_gpu'):
     try:
-        d=json.load(open('$O/${TAG}_bench_%s.json'%c)); print(c, 'value %.4g ms/step %.3f factor TF %.1f frac %.3f'%(d['value'], d['ms_per_step'], d['roofline']['achieved'], d['roofline']['frac']), {k: round(v,3) for k,v in d['stage_ms_per_step'].items()}, 'cpu', d.get('cpu_baseline',{}).get('value'), 'dev', d.get('pk_max_rel_dev_vs_cpu'))
+        d=json.load(open('$O/${TAG}_bench_%s.json'%c)); r=d['roofline']
+        print(c, 'value %.4g %s ms/step %.3f roofline %s %.4g frac %.3f n_gpus %d' % (d['value'], d['unit'], d['ms_per_step'], r['unit'], r['achieved'], r['frac'], d['n_gpus']), {k: round(v,3) for k,v in d.get('stage_ms_per_step',{}).items()}, 'cpu', d.get('cpu_baseline',{}).get('value'), 'dev', d.get('pk_max_rel_dev_vs_cpu', d.get('max_rel_dev_vs_cpu')))
     except Exception as e: print(c, 'missing', e)
 "
