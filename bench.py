@@ -378,8 +378,9 @@ def bench_aux(args):
 
     # ---- oqe
     nb, s = args.nbl or 64, 512
-    a = (torch.randn((nb, s, s), dtype=torch.float64, device=dev) + 1j * torch.randn((nb, s, s), dtype=torch.float64, device=dev)) / s ** 0.5
-    R = (a @ a.conj().transpose(1, 2) + torch.eye(s, dtype=torch.complex128, device=dev)).contiguous()
+    # Hermitian, diagonally dominant weightings (input synthesis only: element-wise, no library GEMM anywhere)
+    a = (torch.randn((nb, s, s), dtype=torch.float64, device=dev) + 1j * torch.randn((nb, s, s), dtype=torch.float64, device=dev)) / s
+    R = (0.5 * (a + a.conj().transpose(1, 2)) + 2.0 * torch.eye(s, dtype=torch.complex128, device=dev)).contiguous()
     Fo = torch.empty_like(R)
     L = hpx.lib()
     nbytes = int(L.hpx_oqe_workspace_bytes(nb, s, 0))
