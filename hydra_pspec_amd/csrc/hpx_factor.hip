@@ -53,13 +53,27 @@
 #else
 #define HPX_OUTLINE __noinline__
 #endif
+// Cache policy of the factor's streams (k_factor sits on the CUs' memory path).
+// HPX_NT bit 0 (default): the row-tile (B) operand loads of the k-loops are non-temporal -- each tile is
+// streamed once per block column by one wave, and the hint keeps it from displacing the panel operand, which
+// every wave of the workgroup re-reads: 4.63 -> 4.30 ms at C3 (measured on one box, tools/gpu_variants.sh).
+// Measured and left off: bit 1 the panel (A) operand as well (5.06 ms), bit 2 the tile stores (4.51 alone,
+// 4.38 with bit 0), bit 3 the diagonal-update loads (4.77 with bit 0), bit 4 k_backsolve's L loads (0.867 vs
+// 0.840 ms).
+#ifndef HPX_NT
+#define HPX_NT 1
+#endif
 #if HPX_DIAG & 1
 #define HPX_LD(base, off) (1e-3 * (double)((off) & 7))
+#elif HPX_NT & 1
+#define HPX_LD(base, off) __builtin_nontemporal_load(&(base)[off])
 #else
 #define HPX_LD(base, off) (base)[off]
 #endif
 #if HPX_DIAG & 2
 #define HPX_LDA(base, off) (1e-3 * (double)((off) & 7))
+#elif HPX_NT & 2
+#define HPX_LDA(base, off) __builtin_nontemporal_load(&(base)[off])
 #else
 #define HPX_LDA(base, off) (base)[off]
 #endif
@@ -152,8 +166,13 @@ __device__ HPX_INL void trsm_store_3m(d4 (&a1)[RT][CT], d4 (&a2)[RT][CT], d4 (&a
 #pragma unroll
       for (int v = 0; v < 4; ++v) {
         const long off = HPX_LIDX(r0 + t * rstride + li, c0 + 16 * ci + HPX_ACC_ROW(g, v), npad);
+#if HPX_NT & 4
+        __builtin_nontemporal_store(x1[v] - x2[v], &Lre[off]);
+        __builtin_nontemporal_store(x3[v] - x1[v] - x2[v], &Lim[off]);
+#else
         Lre[off] = x1[v] - x2[v];
         Lim[off] = x3[v] - x1[v] - x2[v];
+#endif
       }
     }
   }
@@ -693,14 +712,19 @@ __device__ __forceinline__ void diag_tile(const glb_f64* __restrict__ Lre,
   const glb_f64* pBr = Lre + HPX_LIDX(c0 + 16 + li, k0 + g, npad);
   const glb_f64* pBi = Lim + HPX_LIDX(c0 + 16 + li, k0 + g, npad);
   double xr[2][4], xi[2][4], yr[2][4], yi[2][4];
+#if HPX_NT & 8
+#define HPX_DT_LD(p_, o_) __builtin_nontemporal_load(&(p_)[o_])
+#else
+#define HPX_DT_LD(p_, o_) (p_)[o_]
+#endif
 #define HPX_DT_LOAD(buf, ch)                                   \
   _Pragma("unroll") for (int u = 0; u < 4; ++u) {              \
     const int o_ = ((ch) * 16 + 4 * u) << 5;                   \
-    xr[buf][u] = pAr[o_];                                      \
-    xi[buf][u] = pAi[o_];                                      \
+    xr[buf][u] = HPX_DT_LD(pAr, o_);                           \
+    xi[buf][u] = HPX_DT_LD(pAi, o_);                           \
     if (TILE == 1) {                                           \
-      yr[buf][u] = pBr[o_];                                    \
-      yi[buf][u] = pBi[o_];                                    \
+      yr[buf][u] = HPX_DT_LD(pBr, o_);                         \
+      yi[buf][u] = HPX_DT_LD(pBi, o_);                         \
     }                                                          \
   }
 #if HPX_3M
@@ -1405,6 +1429,18 @@ __global__ __launch_bounds__(256, 3) void k_backsolve_v1(const double* __restric
 // different waves) this reads X n/128 instead of n/32 times and never streams a tile of L through
 // two waves.  Complex products are three real MFMAs each (HPX_3M, see the top of this file):
 // A1 = Zr/2 - S1, A2 = Zr/2 - S2, A3 = Zi + S3 with S1 = lr xr, S2 = lm xi, S3 = (lr + lm)(xr - xi).
+// the factor is streamed exactly once by the back substitution: non-temporal loads (HPX_NT bit 4) keep it
+// from displacing X, which is re-read
+typedef double hpx_v2d __attribute__((ext_vector_type(2)));
+#if HPX_NT & 16
+__device__ __forceinline__ double2 hpx_ld2_nt(const double* p) {
+  const hpx_v2d v = __builtin_nontemporal_load(reinterpret_cast<const hpx_v2d*>(p));
+  return make_double2(v.x, v.y);
+}
+#define HPX_BS_LD2(p_) hpx_ld2_nt(p_)
+#else
+#define HPX_BS_LD2(p_) (*reinterpret_cast<const double2*>(p_))
+#endif
 template <int CT, int NT>
 __device__ __forceinline__ void bs_accumulate(d4 (&a1)[2][2], d4 (&a2)[2][2], d4 (&a3)[2][2],
                                               const double* __restrict__ Lre, const double* __restrict__ Lim,
@@ -1420,10 +1456,10 @@ __device__ __forceinline__ void bs_accumulate(d4 (&a1)[2][2], d4 (&a2)[2][2], d4
     const int rb_ = rbeg + ((ch_) << 4);                                                 \
     _Pragma("unroll") for (int ci = 0; ci < CT; ++ci) {                                  \
       const long off = HPX_LIDX(rb_ + 4 * g, c0 + 16 * ci + li, npad);                   \
-      const double2 q0 = *reinterpret_cast<const double2*>(Lre + off);                   \
-      const double2 q1 = *reinterpret_cast<const double2*>(Lre + off + 2);               \
-      const double2 q2 = *reinterpret_cast<const double2*>(Lim + off);                   \
-      const double2 q3 = *reinterpret_cast<const double2*>(Lim + off + 2);               \
+      const double2 q0 = HPX_BS_LD2(Lre + off);                                          \
+      const double2 q1 = HPX_BS_LD2(Lre + off + 2);                                      \
+      const double2 q2 = HPX_BS_LD2(Lim + off);                                          \
+      const double2 q3 = HPX_BS_LD2(Lim + off + 2);                                      \
       lr[ci][0] = q0.x; lr[ci][1] = q0.y; lr[ci][2] = q1.x; lr[ci][3] = q1.y;            \
       lm[ci][0] = q2.x; lm[ci][1] = q2.y; lm[ci][2] = q3.x; lm[ci][3] = q3.y;            \
     }                                                                                    \
