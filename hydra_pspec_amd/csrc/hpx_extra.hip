@@ -151,6 +151,21 @@ __global__ __launch_bounds__(256) void k_dpss_group(const double* __restrict__ t
   if (tid == 0 && info) info[gI] = bad;
 }
 
+// the visibility cube is read exactly once: non-temporal loads keep it from displacing the projector,
+// which every wave of the group re-reads (HPX_DPSS_NT=0: plain loads, for A/B)
+#ifndef HPX_DPSS_NT
+#define HPX_DPSS_NT 1
+#endif
+typedef double hpx_v2d_ __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ double2 hpx_ld2_stream(const double* p) {
+#if HPX_DPSS_NT
+  const hpx_v2d_ v = __builtin_nontemporal_load(reinterpret_cast<const hpx_v2d_*>(p));
+  return make_double2(v.x, v.y);
+#else
+  return *reinterpret_cast<const double2*>(p);
+#endif
+}
+
 // Tall-skinny projection + nm x nm solve for 16 spectra per wave (4 waves per workgroup):
 //   rhs[k][b] = sum_j PT[j][k] d_b[j]   (A operand = projector, unit stride along k; B operand = the
 //   spectra, fetched as 16 spectra x 16 channels tiles with 256-byte rows and turned through a
@@ -189,7 +204,7 @@ __global__ __launch_bounds__(256) void k_dpss_apply(const double* __restrict__ d
   _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                       \
     const int row_ = g + 4 * i, j_ = ((ch_) << 4) + li;                                 \
     const int bb_ = min(b0 + row_, per - 1);                                            \
-    dst[i] = (j_ < N) ? *reinterpret_cast<const double2*>(dg + ((long)bb_ * N + j_) * 2) \
+    dst[i] = (j_ < N) ? hpx_ld2_stream(dg + ((long)bb_ * N + j_) * 2)                    \
                       : make_double2(0.0, 0.0);                                         \
   }
   HPX_DP_FETCH(cur, 0)

@@ -499,6 +499,7 @@ __device__ HPX_INL void offdiag_group_lds(double* __restrict__ Lre, double* __re
   HPX_TICK(6);
 }
 
+#endif
 // number of groups the 3 / 2+2 / 1 rule cuts `cnt` tiles into
 __device__ __forceinline__ int hpx_group_count(int cnt) {
   int n = 0;
@@ -510,7 +511,6 @@ __device__ __forceinline__ int hpx_group_count(int cnt) {
   }
   return n;
 }
-#endif
 
 // Measured round 2 (C3, 1024 baselines; tools/build_variant.sh + tools/stamps.py): fusing the next
 // diagonal block's update into the pass cuts k_factor's FETCH_SIZE by 12 % and the separate partial
@@ -530,6 +530,9 @@ __device__ __forceinline__ int hpx_group_count(int cnt) {
 // on its CU.
 #ifndef HPX_PANEL_LDS
 #define HPX_PANEL_LDS 0
+#endif
+#ifndef HPX_ROUND_SYNC
+#define HPX_ROUND_SYNC 0
 #endif
 #if HPX_3M && HPX_FUSE_DIAG
 // The two row tiles directly below block column (c0, 32 wide) -- rows c1 = c0 + 32 .. c1 + 31, i.e.
@@ -1182,6 +1185,27 @@ __global__ __launch_bounds__(NW * 64, (NW == 4) ? HPX_WGS : 2) void k_factor(dou
           } else {
             offdiag_group_lds<0, GEN>(Lre, Lim, pbuf, npad, c0, 0, 16 * NW, sh.Yre, sh.Yim, wave, lane, G, st_);
           }
+        }
+      }
+#endif
+#if HPX_ROUND_SYNC
+      // experiment: the waves of the workgroup start their g-th groups together (they then sweep the
+      // same k range at about the same time and share the panel operand's cache lines)
+      const int nrounds_ = hpx_group_count((nrt - ((c0 + wj) >> 4) + NW - 1) / NW);
+      for (int rd_ = 0; rd_ < nrounds_; ++rd_) {
+        if (rd_ > 0) __syncthreads();
+        if (cnt >= 3 && cnt != 4) {
+          offdiag_group<2, 3, GEN>(Lre, Lim, npad, c0, rt << 4, 16 * NW, sh.Yre, sh.Yim, lane, G, st_);
+          rt += 3 * NW;
+          cnt -= 3;
+        } else if (cnt >= 2) {
+          offdiag_group<2, 2, GEN>(Lre, Lim, npad, c0, rt << 4, 16 * NW, sh.Yre, sh.Yim, lane, G, st_);
+          rt += 2 * NW;
+          cnt -= 2;
+        } else if (cnt == 1) {
+          offdiag_group<2, 1, GEN>(Lre, Lim, npad, c0, rt << 4, 16 * NW, sh.Yre, sh.Yim, lane, G, st_);
+          rt += NW;
+          cnt -= 1;
         }
       }
 #endif
