@@ -440,8 +440,14 @@ def gibbs_sample_with_fg_batched(vis, flags, fgmodes, Ninv, ps_prior, S_initial=
     Parameters mirror the reference (pspec.py:493-571) with a leading baseline
     axis: ``vis`` (Nbl,Ntimes,Nfreqs) complex, ``flags`` (Nbl,Nfreqs) bool
     (True = use), ``fgmodes`` (Nfreqs,Nmodes) or (Nbl,Nfreqs,Nmodes), ``Ninv``
-    diagonal (Nbl,Nfreqs)/(Nfreqs,) or dense-but-diagonal matrices, ``ps_prior``
-    (2,Nfreqs) or (Nbl,2,Nfreqs) with rows [hi, lo].  The initial covariance is
+    diagonal (Nbl,Nfreqs)/(Nfreqs,) or matrices (Nfreqs,Nfreqs)/(Nbl,Nfreqs,Nfreqs) --
+    diagonal ones, or Hermitian with off-diagonal terms (a correlated noise covariance;
+    unflagged data only, dense solver) --, ``ps_prior`` (2,Nfreqs) or (Nbl,2,Nfreqs) with
+    rows [hi, lo].  Time-dependent flags ``(Nbl,Ntimes,Nfreqs)``, optionally with per-time
+    inverse noise variances ``Ninv`` (Nbl,Ntimes,Nfreqs) or diagonal matrices
+    (Ntimes,Nfreqs,Nfreqs), select the mode in which every time sample is solved with its own
+    noise matrix (Nbl x Ntimes factorisations per iteration; memory: one factor buffer of
+    (Nfreqs+Nmodes)^2 x 16 bytes, ~ 5 MB at Nfreqs = 512, per baseline and time).  The initial covariance is
     given either as ``ps_initial`` (Nbl,Nfreqs)/(Nfreqs,) bandpowers
     (``S = F^H diag(ps/N^2) F``) or as ``S_initial`` matrices of that form.
     ``seed`` is shared by all baselines, as in the reference driver.
