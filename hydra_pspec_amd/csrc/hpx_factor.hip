@@ -790,6 +790,83 @@ __device__ HPX_OUTLINE void diag_partial_next(const glb_f64* __restrict__ Lre,
   }
 }
 
+// HPX_DIAG3 (round 2, measured, off): the three tiles of the next diagonal block's early update on one wave
+// (operands fetched once for all three) instead of one tile each on three waves: 4.42 vs 4.37 ms -- the wave
+// that takes them becomes the pass's critical path.
+#ifndef HPX_DIAG3
+#define HPX_DIAG3 0
+#endif
+#if HPX_3M
+// All three lower tiles of the diagonal block at c1 over the columns k < kend on ONE wave: the two
+// 16-row operands are fetched once per k-step for the nine MFMAs of the three tiles, instead of three
+// waves each running a single-tile loop of their own (which is bound by load latency and fetches
+// the same rows up to twice more).  Same sums as diag_partial_next(t = 0, 1, 2).
+__device__ HPX_OUTLINE void diag_partial_next3(const glb_f64* __restrict__ Lre,
+                                               const glb_f64* __restrict__ Lim,
+                                               lds_FactorShared* __restrict__ shp, const int npad,
+                                               const int c1, const int kend, const int lane) {
+  const int li = lane & 15, g = lane >> 4;
+  d4 q1[3], q2[3], q3[3];
+#pragma unroll
+  for (int t = 0; t < 3; ++t) {
+    q1[t] = (d4){0., 0., 0., 0.};
+    q2[t] = (d4){0., 0., 0., 0.};
+    q3[t] = (d4){0., 0., 0., 0.};
+  }
+  const int nks = (HPX_DIAG & 8) ? 0 : (kend >> 2);          // k-steps (kend % 32 == 0: a multiple of 8)
+  const glb_f64* pAr = Lre + HPX_LIDX(c1 + li, g, npad);
+  const glb_f64* pAi = Lim + HPX_LIDX(c1 + li, g, npad);
+  const glb_f64* pBr = Lre + HPX_LIDX(c1 + 16 + li, g, npad);
+  const glb_f64* pBi = Lim + HPX_LIDX(c1 + 16 + li, g, npad);
+  double xr[2][2], xi[2][2], yr[2][2], yi[2][2];                // [set][k-step of the pair]
+#define HPX_D3_LOAD(S, ks_)                                      \
+  _Pragma("unroll") for (int u = 0; u < 2; ++u) {                \
+    const long o_ = (long)((ks_) + u) << 7;                      \
+    xr[S][u] = pAr[o_];                                          \
+    xi[S][u] = pAi[o_];                                          \
+    yr[S][u] = pBr[o_];                                          \
+    yi[S][u] = pBi[o_];                                          \
+  }
+#define HPX_D3_MMA(S)                                            \
+  _Pragma("unroll") for (int u = 0; u < 2; ++u) {                \
+    const double ar_ = xr[S][u], ai_ = xi[S][u], br_ = yr[S][u], bi_ = yi[S][u]; \
+    const double as_ = ar_ + ai_, ad_ = ar_ - ai_, bs_ = br_ + bi_, bd_ = br_ - bi_; \
+    q1[0] = mfma64(-ar_, ar_, q1[0]);                            \
+    q2[0] = mfma64(-ai_, ai_, q2[0]);                            \
+    q3[0] = mfma64(as_, ad_, q3[0]);                             \
+    q1[1] = mfma64(-ar_, br_, q1[1]);                            \
+    q2[1] = mfma64(-ai_, bi_, q2[1]);                            \
+    q3[1] = mfma64(as_, bd_, q3[1]);                             \
+    q1[2] = mfma64(-br_, br_, q1[2]);                            \
+    q2[2] = mfma64(-bi_, bi_, q2[2]);                            \
+    q3[2] = mfma64(bs_, bd_, q3[2]);                             \
+  }
+  if (nks > 0) {
+    HPX_D3_LOAD(0, 0)
+    for (int ks = 0; ks < nks; ks += 4) {
+      HPX_D3_LOAD(1, ks + 2)
+      __builtin_amdgcn_sched_barrier(0);
+      HPX_D3_MMA(0)
+      __builtin_amdgcn_sched_barrier(0);
+      const int nx = (ks + 4 < nks) ? ks + 4 : ks;             // branch-free tail: harmless re-read
+      HPX_D3_LOAD(0, nx)
+      __builtin_amdgcn_sched_barrier(0);
+      HPX_D3_MMA(1)
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+#undef HPX_D3_LOAD
+#undef HPX_D3_MMA
+#pragma unroll
+  for (int t = 0; t < 3; ++t)
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      shp->part[t][0][v][lane] = q1[t][v] + q2[t][v];
+      shp->part[t][1][v][lane] = q1[t][v] - q2[t][v] + q3[t][v];
+    }
+}
+#endif
+
 // Diagonal block at c0 (width wj = 16 or 32): D = K[j,j] - sum_{k<c0} L[j,k] L[j,k]^H
 // (one 16 x 16 tile per wave), then D = Ljj Ljj^H and Ljj^-1 by the fused in-LDS elimination.
 // On return (after the trailing barrier) Yre/Yim hold W = conj(Ljj^-1); Ljj and Ljj^-1 are
@@ -1230,6 +1307,15 @@ __global__ __launch_bounds__(NW * 64, (NW == 4) ? HPX_WGS : 2) void k_factor(dou
 #endif
       // early part of the next diagonal block (columns < c0) where the fused group did not form it:
       // its tiles go to the waves that got the fewest off-diagonal tiles in this pass
+#if HPX_3M && HPX_DIAG3
+      if (!fuse && c0 > 0 && npad - c1 >= 32) {
+        if (pos == NW - 1) {          // the wave with the fewest tiles of this pass takes all three
+          HPX_T0();
+          diag_partial_next3((const glb_f64*)Lre, (const glb_f64*)Lim, (lds_FactorShared*)&sh, npad, c1, c0, lane);
+          HPX_TICK(1);
+        }
+      } else
+#endif
       if (!fuse && c0 > 0 && c1 < npad) {
         const int t = NW - 1 - pos;
         if (t < ((npad - c1 >= 32) ? 3 : 1)) {
