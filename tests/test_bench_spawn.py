@@ -56,3 +56,20 @@ def test_launcher_never_touches_the_gpu_stack():
     assert "import torch" not in main[:spawn_at] and "hpx" not in main[:spawn_at]
     body = src[src.index("def spawn_ranks"):src.index("def init_ranks")]
     assert "import torch" not in body and "hydra_pspec_amd" not in body and "hpx." not in body
+
+
+def test_under_torch_distributed_run_the_ranks_are_used_as_given():
+    """The driver's launch line (`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`):
+    WORLD_SIZE is set, so bench.py does not spawn again and the ranks take the same blocks."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), str(REPO / "bench.py"),
+                        "--gpus", "2", "--steps", "3", "--warmup", "1", "--dry-run"],
+                       env=env, cwd=str(REPO), capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0, r.stderr[-2000:]
+    res = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert res["n_gpus"] == 2 and res["blocks"] == [[0, 1024], [1024, 2048]] and len(set(res["pids"])) == 2
