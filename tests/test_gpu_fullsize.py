@@ -157,3 +157,53 @@ def test_full_batch_at_the_baseline_configs(N, frac, solver):
         _, one = _run(1, N, frac=frac, niter=2, k0=k, solver=solver)
         assert np.array_equal(one["signal_ps"][0], big["signal_ps"][k]), k
         assert np.array_equal(one["ln_post"][0], big["ln_post"][k]), k
+
+
+def _banded_ninv(N, sig2, seed=0):
+    i = np.arange(N)
+    band = np.zeros((N, N), dtype=complex)
+    band[i, i] = 1.0 + 0.2 * np.cos(0.3 * i)
+    band[i[:-1], i[:-1] + 1] = 0.3 * np.exp(0.4j)
+    band[i[:-1] + 1, i[:-1]] = 0.3 * np.exp(-0.4j)
+    band[i[:-2], i[:-2] + 2] = 0.1
+    band[i[:-2] + 2, i[:-2]] = 0.1
+    return np.linalg.inv(sig2 * band)
+
+
+@pytest.mark.parametrize("N,T,M", [(30, 6, 5), (512, 32, 12)])
+def test_correlated_noise_vs_oracle_at_other_sizes(N, T, M):
+    """Hermitian non-diagonal inverse noise covariance at a non-power-of-two channel count (dense
+    transforms at set-up) and at the C3 shape (FFT path), against the exact-solve oracle."""
+    from hydra_pspec_amd import pspec, synthetic
+    from oracle import pspec_ref
+    d = synthetic.make_baselines(N, T, M, k0=5, nbl=1, dense=True)
+    Ninv = _banded_ninv(N, 1.0 / d["Ninv"][0, 0].real)
+    niter = 2 if N < 100 else 1          # (the CPU oracle takes ~20 s per iteration at N = 512)
+    res = pspec.gibbs_sample_with_fg(d["vis"][0], d["flags"][0], d["S_initial"], d["fgmodes"], Ninv, d["ps_prior"],
+                                     Niter=niter, seed=21, verbose=False)
+    ref = pspec_ref.gibbs_sample_with_fg(d["vis"][0], d["flags"][0], d["S_initial"], d["fgmodes"], Ninv, d["ps_prior"],
+                                         Niter=niter, seed=21, solver="direct")
+    assert np.max(np.abs(res[2] / ref[2] - 1)) < 1e-6
+    assert np.max(np.abs(res[0] - ref[0])) < 1e-6 * np.max(np.abs(ref[0]))
+    assert np.allclose(res[5], ref[5], rtol=1e-6)
+
+
+def test_time_dependent_flags_at_c3_shape():
+    """Per-time mode at (Ntimes, Nfreq, Nmodes) = (32, 512, 12), 2 baselines = 64 systems per iteration:
+    baseline 1 against the per-time exact-solve oracle."""
+    from hydra_pspec_amd import pspec, synthetic
+    from oracle import pspec_ref
+    nbl, T, N, M = 2, 32, 512, 12
+    d = synthetic.make_baselines(N, T, M, k0=8, nbl=nbl, flag_frac=0.1, dense=True)
+    rng = np.random.default_rng(1)
+    flt = np.broadcast_to(d["flags"][:, None, :], (nbl, T, N)).copy()
+    flt &= rng.uniform(size=(nbl, T, N)) > 0.05
+    nt = np.ascontiguousarray(np.broadcast_to(d["ninv_diag"][:, None, :] * rng.uniform(0.7, 1.3, size=(nbl, T, 1)),
+                                              (nbl, T, N)))
+    out = pspec.gibbs_sample_with_fg_batched(d["vis"], flt, d["fgmodes"], nt, d["ps_prior"], ps_initial=d["ps0"],
+                                             Niter=1, seed=4, keep=("signal_cr",))
+    ref = pspec_ref.gibbs_sample_with_fg_pertime(d["vis"][1], flt[1], d["S_initial"], d["fgmodes"], nt[1],
+                                                 d["ps_prior"], Niter=1, seed=4)     # (32 per-time operator builds)
+    assert np.max(np.abs(out["signal_ps"][1] / ref[2] - 1)) < 1e-6
+    assert np.max(np.abs(out["signal_cr"][1] - ref[0])) < 1e-6 * np.max(np.abs(ref[0]))
+    assert np.allclose(out["ln_post"][1], ref[5], rtol=1e-6)
