@@ -166,3 +166,22 @@ def test_reference_call_surface_is_importable():
                               "qhat", "q", "p", "Sig_QEN", "Sig_QESN", "matc", "getqs"])):
         for n in names:
             assert callable(getattr(mod, n)), (mod.__name__, n)
+
+
+def test_dense_noise_detection_rules():
+    """Which `Ninv` inputs select the dense-noise path (host logic only; no GPU touched)."""
+    from hydra_pspec_amd import pspec
+    N = 6
+    herm = np.eye(N, dtype=complex) * 2.0
+    herm[0, 1], herm[1, 0] = 0.3 + 0.1j, 0.3 - 0.1j
+    assert pspec._ninv_dense(np.eye(N) * 3.0, 1, N) is None                     # diagonal matrix: not dense
+    got = pspec._ninv_dense(herm, 1, N)
+    assert got is not None and got.dtype == complex and np.array_equal(got, herm)
+    assert pspec._ninv_dense(np.stack([herm, herm]), 2, N).shape == (2, N, N)
+    bad = herm.copy()
+    bad[0, 1] = 0.5                                                              # not Hermitian
+    with pytest.raises(NotImplementedError):
+        pspec._ninv_dense(bad, 1, N)
+    assert pspec._ninv_dense(np.ones((3, N)), 3, N) is None                      # a stack of diagonals
+    root = pspec.sqrtm_hermitian(herm)
+    assert np.allclose(root @ root, herm, atol=1e-14) and np.allclose(root, root.conj().T)
