@@ -498,6 +498,9 @@ __global__ __launch_bounds__(256) void k_resid(const ResArgs A) {
   }
 }
 
+#ifndef HPX_FR_NT
+#define HPX_FR_NT 0          // bit 0: solution (z) loads non-temporal, bit 1: data loads
+#endif
 // Back transform s = U z and everything k_resid does, in one kernel (N a power of two): the
 // block that holds TC time columns of the signal in LDS after the FFT goes straight on to the
 // model, residual, chi^2 and the optional sample write-back for those columns, so s never goes
@@ -540,8 +543,13 @@ __global__ __launch_bounds__(256) void k_fft_resid(const ResArgs A) {
 #pragma unroll
       for (int u = 0; u < UB; ++u) {
         const int e = min(e0 + 256 * u, total - 1), k = e >> tcs, tc = e & (TC - 1);
+#if HPX_FR_NT & 1
+        zr[u] = __builtin_nontemporal_load(&xre[(long)k * TP + c0 + tc]);
+        zi[u] = __builtin_nontemporal_load(&xim[(long)k * TP + c0 + tc]);
+#else
         zr[u] = xre[(long)k * TP + c0 + tc];
         zi[u] = xim[(long)k * TP + c0 + tc];
+#endif
       }
 #pragma unroll
       for (int u = 0; u < UB; ++u) {
@@ -601,6 +609,11 @@ __global__ __launch_bounds__(256) void k_fft_resid(const ResArgs A) {
     const int tlast = wave + 4 * ((ntile - 1 - wave) >> 2);       // this wave's last tile
     const bool tvalid = (li < TC) && (t < T);
     double nfr[4], nfi[4], ndr[4], ndi[4], nnv[4], nw[4];
+#if HPX_FR_NT & 2
+#define HPX_FR_LDD(p_, o_) __builtin_nontemporal_load(&(p_)[o_])
+#else
+#define HPX_FR_LDD(p_, o_) (p_)[o_]
+#endif
 #define HPX_FR_LOAD(xt_)                                                              \
   {                                                                                   \
     const int x0_ = (xt_) << 4;                                                       \
@@ -614,8 +627,8 @@ __global__ __launch_bounds__(256) void k_fft_resid(const ResArgs A) {
     _Pragma("unroll") for (int v = 0; v < 4; ++v) {                                   \
       const int x_ = x0_ + HPX_ACC_ROW(g, v);                                         \
       const long o_ = (long)x_ * TP + (tvalid ? t : 0);                               \
-      ndr[v] = dre[o_];                                                               \
-      ndi[v] = dim_[o_];                                                              \
+      ndr[v] = HPX_FR_LDD(dre, o_);                                                   \
+      ndi[v] = HPX_FR_LDD(dim_, o_);                                                  \
       nnv[v] = ninv[x_];                                                              \
       nw[v] = fl8[x_] ? 1.0 : 0.0;                                                    \
     }                                                                                 \

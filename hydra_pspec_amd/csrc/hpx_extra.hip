@@ -719,6 +719,26 @@ extern "C" int hpx_oqe_mopt(int nb, int s, const double* F, double* M_out, void*
   return HPX_OK;
 }
 
+// beta_k = sum_t |sk[t][k]|^2  (sample_S, pspec.py:96-100), (nb, T, N) c128 -> (nb, N) f64
+__global__ void k_power_sum(const double* __restrict__ sk, double* __restrict__ out, const int T, const int N) {
+  const int b = blockIdx.y;
+  for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < N; k += gridDim.x * blockDim.x) {
+    double acc = 0.0;
+    for (int t = 0; t < T; ++t) {                       // threads along k: unit-stride reads, fixed order
+      const long o = (((long)b * T + t) * N + k) * 2;
+      acc += sk[o] * sk[o] + sk[o + 1] * sk[o + 1];
+    }
+    out[(long)b * N + k] = acc;
+  }
+}
+
+extern "C" int hpx_power_sum(int nb, int T, int N, const double* sk, double* out, void* stream) {
+  HPX_REQUIRE(nb > 0 && T > 0 && N > 0 && sk && out, "hpx_power_sum: bad argument");
+  hipLaunchKernelGGL(k_power_sum, dim3((N + 255) / 256, nb), dim3(256), 0, (hipStream_t)stream, sk, out, T, N);
+  HPX_HIP(hipGetLastError());
+  return HPX_OK;
+}
+
 extern "C" int hpx_lincomb(int64_t n, double a, const double* x, double b, const double* y, double* out,
                            void* stream) {
   HPX_REQUIRE(n > 0 && x && y && out, "hpx_lincomb: bad argument");

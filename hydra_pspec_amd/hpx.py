@@ -54,6 +54,7 @@ SIGNATURES = {
     "hpx_oqe_qh": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _i64, _vp]),
     "hpx_oqe_sandwich_diag": (_i, [_i, _i, _vp, _vp, _i, _vp, _vp, _i64, _vp]),
     "hpx_oqe_mopt": (_i, [_i, _i, _vp, _vp, _vp]),
+    "hpx_power_sum": (_i, [_i, _i, _i, _vp, _vp, _vp]),
     "hpx_lincomb": (_i, [_i64, C.c_double, _vp, C.c_double, _vp, _vp, _vp]),
     "hpx_fgmodes_eig": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "hpx_oqe_qauto": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _i64, _vp]),

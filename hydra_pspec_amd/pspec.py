@@ -701,7 +701,10 @@ def sample_S(s=None, sk=None, prior=None):
         sk = np.asarray(sk, dtype=complex)
         nobs, nfreq = sk.shape
         sk_t = hpx.to_dev(torch, sk, c128, dev)
-    beta = (sk_t.real ** 2 + sk_t.imag ** 2).sum(dim=0).cpu().numpy()
+    d_beta = torch.empty(nfreq, dtype=f64, device=dev)
+    hpx.check(hpx.lib().hpx_power_sum(1, nobs, nfreq, hpx.ptr(sk_t.contiguous()), hpx.ptr(d_beta),
+                                      hpx.stream_ptr(torch)), "hpx_power_sum")
+    beta = d_beta.cpu().numpy()
     if prior is None:
         prior = np.zeros((2, nfreq))
     pmap, xgrid = _prior_tables(prior, nfreq)
@@ -733,7 +736,10 @@ def sprior(signals, bins, factor):
     d_fop = hpx.to_dev(torch, utils.fourier_operator(nfreq), c128, dev)
     hpx.check(hpx.lib().hpx_dft_batched(1, nobs, nfreq, hpx.ptr(d_fop), hpx.ptr(d_s), hpx.ptr(d_sk), 0,
                                         hpx.stream_ptr(torch)), "hpx_dft_batched")
-    ds = np.fft.ifftshift((d_sk[0].real ** 2 + d_sk[0].imag ** 2).sum(dim=0).cpu().numpy())
+    d_ds = torch.empty(nfreq, dtype=torch.float64, device=dev)
+    hpx.check(hpx.lib().hpx_power_sum(1, nobs, nfreq, hpx.ptr(d_sk), hpx.ptr(d_ds), hpx.stream_ptr(torch)),
+              "hpx_power_sum")
+    ds = np.fft.ifftshift(d_ds.cpu().numpy())
     prior = np.zeros((2, nfreq))
     prior[0] = ds * factor
     prior[1] = ds / factor

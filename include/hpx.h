@@ -264,6 +264,9 @@ int hpx_oqe_sandwich_diag(int nb, int s, const double* R, const double* C, int c
                           double* out, void* work, int64_t work_bytes, void* stream);
 /* M_opt (oqe.py:77-84): diag(1/F_aa) with row a divided by sum_b (M F)_ab; (nb,s,s) c128 -> same. */
 int hpx_oqe_mopt(int nb, int s, const double* F, double* M_out, void* stream);
+/* beta[b][k] = sum_t |sk[b][t][k]|^2: the statistic of the bandpower draw (sample_S, pspec.py:96-100);
+ * sk (nb,T,N) c128 -> out (nb,N) f64. */
+int hpx_power_sum(int nb, int T, int N, const double* sk, double* out, void* stream);
 /* out = a x + b y over n doubles (the averaging step of the inverse-square-root iteration behind
  * oqe.M_Fhalf, whose inverses run on hpx_zpotrs_batched). */
 int hpx_lincomb(int64_t n, double a, const double* x, double b, const double* y, double* out,
