@@ -5,6 +5,7 @@
 #include <stdarg.h>
 #include <string.h>
 #include "hpx_internal.h"
+#include <stdlib.h>
 #include "hpx_fft.h"
 
 // ---------------------------------------------------------------------------
@@ -364,6 +365,59 @@ __global__ __launch_bounds__(256) void k_assemble_edge(const hpx_gen_batch B, do
   const int ncl = npad - N, nrl = ld - N;
   for (int e = tid; e < ncl * nrl; e += 256) {
     const int c = N + e / nrl, r = N + e % nrl;
+    if (r < c) continue;
+    double vr, vi;
+    hpx_gen_entry(G, r, c, npad, vr, vi);
+    const long o = HPX_LIDX(r, c, npad);
+    L[o] = vr;
+    L[o + 16] = vi;
+  }
+}
+
+// Edge tiles (hpx_internal.h: E): the iteration-invariant part of rows >= rmin for the columns c < rmin,
+// in the factor's tile layout.  Right-hand-side rows hold Q un-conjugated (hpx_edge_init adds P2 / a and
+// conjugates, as hpx_gen_entry does); everything else is the entry itself.
+__global__ __launch_bounds__(256) void k_build_edge(const hpx_gen_batch B, double* __restrict__ E_all,
+                                                    const int npad, const int ld) {
+  const int b = blockIdx.y;
+  hpx_gen_batch B0 = B;
+  B0.has_omega = 0;                                   // the invariant part only
+  const hpx_gen G = hpx_gen_for(B0, b);
+  const int rmin = B.rmin, nrow = ld - rmin;
+  double* E = E_all + (long)b * B.e_bstride;
+  const long tot = (long)nrow * rmin;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < tot; e += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(e / nrow), r = rmin + (int)(e % nrow);
+    double vr, vi;
+    hpx_gen_entry(G, r, c, npad, vr, vi);
+    if (r >= npad) vi = -vi;                          // Q itself: the conjugation happens at the use
+    const long o = HPX_EIDX(r, c, rmin);
+    E[o] = vr;
+    E[o + 16] = vi;
+  }
+}
+// P2T[(t >> 4)][c][t & 15] = P2[c][t]
+__global__ void k_p2_tiles(const double* __restrict__ p2re, const double* __restrict__ p2im,
+                           double* __restrict__ tre, double* __restrict__ tim, const int NP, const int TP) {
+  const long tot = (long)NP * TP;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < tot; e += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(e / TP), t = (int)(e % TP);
+    const long q = (((long)(t >> 4) * NP + c) << 4) + (t & 15);
+    tre[q] = p2re[e];
+    tim[q] = p2im[e];
+  }
+}
+// What is left to lay out per iteration once the factor reads the edge tiles itself: the columns
+// c >= rmin (foreground x foreground block, identity padding, their right-hand sides; signal columns
+// rmin..N-1 when N % 32 != 0), rows r >= c.
+__global__ __launch_bounds__(256) void k_assemble_tail(const hpx_gen_batch B, double* __restrict__ L_all,
+                                                       const int npad, const int ld) {
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const hpx_gen G = hpx_gen_for(B, b);
+  double* L = L_all + (long)b * npad * ld * 2;
+  const int rmin = B.rmin, ncl = npad - rmin, nrl = ld - rmin;
+  for (int e = tid; e < ncl * nrl; e += 256) {
+    const int c = rmin + e / nrl, r = rmin + e % nrl;
     if (r < c) continue;
     double vr, vi;
     hpx_gen_entry(G, r, c, npad, vr, vi);
@@ -1148,6 +1202,11 @@ static int plan_create_impl(hpx_plan** out, int nbl, int T, int N, int M) {
   A_(Rre, nb * rsz); A_(Rim, nb * rsz); A_(Zre, nb * rsz); A_(Zim, nb * rsz);
   A_(Cre, nb * N); A_(Cim, nb * N);
   A_(P2re, ssz); A_(P2im, ssz);
+  {
+    const size_t rmin = 32 * (size_t)(N / 32);
+    A_(E, nb * ((size_t)(p->ld - rmin) / 16) * rmin * 32 + 8);
+    A_(P2Tre, (size_t)(p->TP / 16) * p->NP * 16); A_(P2Tim, (size_t)(p->TP / 16) * p->NP * 16);
+  }
   A_(Hre, nb * M * M); A_(Him, nb * M * M);
   A_(P4re, nb * M * p->TP); A_(P4im, nb * M * p->TP);
   A_(Fopre, (size_t)p->NP * p->NP); A_(Fopim, (size_t)p->NP * p->NP);
@@ -1195,6 +1254,7 @@ extern "C" int hpx_plan_dims(const hpx_plan* p, int* npad, int* tpad, int* ld) {
   return HPX_OK;
 }
 
+static hpx_gen_batch gen_of(const hpx_plan* p);
 static int set_static_impl(hpx_plan* p, const double* vis, const uint8_t* flags,
                            const double* ninv, const double* ninv_dense, const double* nih_dense,
                            int noise_shared, const double* fgmodes, int fg_shared,
@@ -1315,6 +1375,22 @@ static int set_static_impl(hpx_plan* p, const double* vis, const uint8_t* flags,
     HPX_HIP(hipMemsetAsync(p->P2re, 0, (size_t)NP * TP * sizeof(double), st));
     HPX_HIP(hipMemsetAsync(p->P2im, 0, (size_t)NP * TP * sizeof(double), st));
   }
+  // edge tiles for the factor (circulant mode): invariant rows >= rmin of the columns < rmin, P2 by row tile
+  p->have_edge = 0;
+  {
+    static const int edge_on = !(getenv("HPX_EDGE_TILES") && atoi(getenv("HPX_EDGE_TILES")) == 0);
+    const int rmin = 32 * (N / 32);
+    if (edge_on && !p->dense_noise && rmin > 0) {
+      p->have_static = 1;                  // (gen_of reads the plan as it stands)
+      hpx_gen_batch B = gen_of(p);
+      B.rmin = rmin;
+      B.e_bstride = (long)((p->ld - rmin) / 16) * rmin * 32;
+      hipLaunchKernelGGL(k_build_edge, dim3(32, nbl), dim3(256), 0, st, B, p->E, p->npad, p->ld);
+      hipLaunchKernelGGL(k_p2_tiles, dim3(64), dim3(256), 0, st, p->P2re, p->P2im, p->P2Tre, p->P2Tim, NP, TP);
+      HPX_HIP(hipGetLastError());
+      p->have_edge = 1;
+    }
+  }
   HPX_HIP(hipStreamSynchronize(st));
   p->have_static = 1;
   if (p->dense_noise) p->solver = HPX_SOLVER_DENSE;
@@ -1397,6 +1473,17 @@ __global__ void k_pt_p2(const double* __restrict__ p2re, const double* __restric
     ptim[e] = (c == 0) ? p2im[(long)x * TP + t] : 0.0;
   }
 }
+// child's P2 by row tile: PTT[t][c][0] = P2[c][t]  (rows 1..15 of the unit's only RHS tile stay zero)
+__global__ void k_pt_p2t(const double* __restrict__ p2re, const double* __restrict__ p2im,
+                         double* __restrict__ tre, double* __restrict__ tim, const int T, const int NP,
+                         const int TP) {
+  const long tot = (long)T * NP;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < tot; e += (long)gridDim.x * blockDim.x) {
+    const int t = (int)(e / NP), c = (int)(e % NP);
+    tre[e << 4] = p2re[(long)c * TP + t];
+    tim[e << 4] = p2im[(long)c * TP + t];
+  }
+}
 // fg[u] = fg[u / T]  ((nbl,N,M) c128 -> (nbl*T,N,M))
 __global__ void k_pt_expand_fg(const double* __restrict__ src, double* __restrict__ dst, const int T, const long per) {
   const int u = blockIdx.y;
@@ -1471,6 +1558,13 @@ extern "C" int hpx_plan_set_static_pertime(hpx_plan* p, const double* vis, const
   HPX_TRY(dev_alloc(p, &p->PTim, (size_t)T * NP * c->TP));
   hipLaunchKernelGGL(k_pt_p2, dim3(64), dim3(256), 0, st, p->P2re, p->P2im, p->PTre, p->PTim, T, NP, TP, c->TP);
   HPX_HIP(hipGetLastError());
+  // ... and by row tile for the factor's edge tiles: unit u = (b, t) has one right-hand-side row, time t
+  HPX_TRY(dev_alloc(p, &p->PTTre, (size_t)T * NP * 16));
+  HPX_TRY(dev_alloc(p, &p->PTTim, (size_t)T * NP * 16));
+  HPX_HIP(hipMemsetAsync(p->PTTre, 0, (size_t)T * NP * 16 * sizeof(double), st));
+  HPX_HIP(hipMemsetAsync(p->PTTim, 0, (size_t)T * NP * 16 * sizeof(double), st));
+  hipLaunchKernelGGL(k_pt_p2t, dim3(64), dim3(256), 0, st, p->P2re, p->P2im, p->PTTre, p->PTTim, T, NP, TP);
+  HPX_HIP(hipGetLastError());
   HPX_HIP(hipStreamSynchronize(st));
   p->per_time = 1;
   p->solver = HPX_SOLVER_DENSE;
@@ -1487,6 +1581,9 @@ static hpx_gen_batch gen_of_child(const hpx_plan* p) {
   B.p2im = p->PTim;
   B.p2_mod = p->T;
   B.p2_stride = (long)p->NP * p->child->TP;
+  B.p2tre = p->PTTre;
+  B.p2tim = p->PTTim;
+  B.p2t_stride = (long)p->NP * 16;
   return B;
 }
 
@@ -1498,6 +1595,12 @@ static hpx_gen_batch gen_of(const hpx_plan* p) {
   B.cdre = p->dense_noise ? p->CDre : nullptr;
   B.cdim = p->dense_noise ? p->CDim : nullptr;
   B.ia_div = 1; B.p2_mod = 1; B.p2_stride = 0;
+  {
+    const long rmin = 32 * (long)(p->N / 32);
+    B.ere = (p->have_edge && rmin > 0) ? p->E : nullptr;
+    B.e_bstride = (long)((p->ld - rmin) / 16) * rmin * 32;
+    B.p2tre = p->P2Tre; B.p2tim = p->P2Tim; B.p2t_stride = 0;
+  }
   B.N = p->N; B.M = p->M; B.NP = p->NP; B.TP = p->TP; B.ncol = p->ncolR;
   B.has_omega = p->has_omega;
   B.rmin = 32 * (p->N / 32);
@@ -1505,7 +1608,11 @@ static hpx_gen_batch gen_of(const hpx_plan* p) {
 }
 
 static int launch_assemble_edge(hpx_plan* p, hipStream_t st) {
-  hipLaunchKernelGGL(k_assemble_edge, dim3(p->nbl, 1), dim3(256), 0, st, gen_of(p), p->L, p->npad, p->ld);
+  const hpx_gen_batch B = gen_of(p);
+  if (B.ere)      // the factor reads the edge tiles itself: only the last columns are laid out
+    hipLaunchKernelGGL(k_assemble_tail, dim3(p->nbl), dim3(256), 0, st, B, p->L, p->npad, p->ld);
+  else
+    hipLaunchKernelGGL(k_assemble_edge, dim3(p->nbl, 1), dim3(256), 0, st, B, p->L, p->npad, p->ld);
   HPX_HIP(hipGetLastError());
   return HPX_OK;
 }
@@ -1863,7 +1970,8 @@ extern "C" int hpx_gibbs_run(hpx_plan* p, const double* ps0, int iter0, int nite
         // then the solutions go to their time column of this plan's X
         hpx_plan* c = p->child;
         const hpx_gen_batch gc = gen_of_child(p);
-        hipLaunchKernelGGL(k_assemble_edge, dim3(c->nbl, 1), dim3(256), 0, st, gc, c->L, c->npad, c->ld);
+        if (gc.ere) hipLaunchKernelGGL(k_assemble_tail, dim3(c->nbl), dim3(256), 0, st, gc, c->L, c->npad, c->ld);
+        else hipLaunchKernelGGL(k_assemble_edge, dim3(c->nbl, 1), dim3(256), 0, st, gc, c->L, c->npad, c->ld);
         HPX_HIP(hipGetLastError());
         HPX_TRY(mark(p, st));
         HPX_TRY(hpx_launch_factor(c->nbl, c->npad, c->ld, c->L, c->Wre, c->Wim, c->info, iter0 + it + 1, &gc, st));

@@ -190,6 +190,8 @@ __device__ HPX_INL void offdiag_group(double* __restrict__ Lre, double* __restri
                                               const double* Wim, const int lane,
                                               const hpx_gen& G, long long* st_) {
   const int li = lane & 15, g = lane >> 4;
+  // rows >= rmin of a block column below rmin: straight from the plan's edge tiles when it has them
+  const bool use_e = GEN && G.ere != nullptr && c0 + 16 * CT <= G.rmin;
   HPX_T0();
 #if HPX_3M
   d4 a1[RT][CT], a2[RT][CT], a3[RT][CT];
@@ -282,15 +284,16 @@ __device__ HPX_INL void offdiag_group(double* __restrict__ Lre, double* __restri
       } else {
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
-          const long off = HPX_LIDX(r0 + t * rstride + li, c0 + 16 * ci + HPX_ACC_ROW(g, v), npad);
+          double vr, vi;
+          hpx_edge_init<GEN>(G, Lre, Lim, r0 + t * rstride + li, c0 + 16 * ci + HPX_ACC_ROW(g, v), npad, use_e,
+                             vr, vi);
 #if HPX_3M
-          const double vr = Lre[off];
           a1[t][ci][v] = 0.5 * vr;
           a2[t][ci][v] = 0.5 * vr;
-          a3[t][ci][v] = Lim[off];
+          a3[t][ci][v] = vi;
 #else
-          ar[t][ci][v] = Lre[off];
-          ai[t][ci][v] = Lim[off];
+          ar[t][ci][v] = vr;
+          ai[t][ci][v] = vi;
 #endif
         }
       }
@@ -448,11 +451,12 @@ __device__ HPX_INL void offdiag_group_lds(double* __restrict__ Lre, double* __re
       } else {
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
-          const long off = HPX_LIDX(r0 + t * rstride + li, c0 + 16 * ci + HPX_ACC_ROW(g, v), npad);
-          const double vr = Lre[off];
+          double vr, vi;
+          hpx_edge_init<GEN>(G, Lre, Lim, r0 + t * rstride + li, c0 + 16 * ci + HPX_ACC_ROW(g, v), npad,
+                             GEN && G.ere != nullptr && c0 + 32 <= G.rmin, vr, vi);
           a1[t][ci][v] = 0.5 * vr;
           a2[t][ci][v] = 0.5 * vr;
-          a3[t][ci][v] = Lim[off];
+          a3[t][ci][v] = vi;
         }
       }
     }
@@ -624,11 +628,12 @@ __device__ HPX_INL void offdiag_diag_group(double* __restrict__ Lre, double* __r
       } else {
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
-          const long off = HPX_LIDX(r0 + 16 * t + li, c0 + 16 * ci + HPX_ACC_ROW(g, v), npad);
-          const double vr = Lre[off];
+          double vr, vi;
+          hpx_edge_init<GEN>(G, Lre, Lim, r0 + 16 * t + li, c0 + 16 * ci + HPX_ACC_ROW(g, v), npad,
+                             GEN && G.ere != nullptr && c0 + 32 <= G.rmin, vr, vi);
           a1[t][ci][v] = 0.5 * vr;
           a2[t][ci][v] = 0.5 * vr;
-          a3[t][ci][v] = Lim[off];
+          a3[t][ci][v] = vi;
         }
       }
     }

@@ -55,6 +55,7 @@ struct hpx_plan {
   int nblk;     // number of block columns
   int ngrid, nxrows, niter_tab;
   int fg_shared, prior_shared, has_omega, any_flags, have_static, profiling;
+  int have_edge; // E / P2T hold the edge tiles of the current static inputs (the factor reads them directly)
   int have_ps;  // the chain state (ps_cur, ia) holds bandpowers: a run may continue without ps0
   // dense (non-diagonal, Hermitian) inverse noise covariance (hpx_plan_set_static_dense): C = U^H Ni U
   // is a general Hermitian matrix instead of a circulant
@@ -70,6 +71,12 @@ struct hpx_plan {
   uint8_t* flags_t;        // [nbl][T][N]
   double* ninv_t;          // [nbl][T][N]
   double *PTre, *PTim;     // [T][NP][16]: column 0 = U^H omega_a of time t (the child's P2, per unit u % T)
+  double *PTTre, *PTTim;   // the same by row tile, [T][NP][16] with row 0 = that time (the child's P2T)
+  // iteration-invariant part of the augmented matrix's rows >= rmin (foreground rows, padding, right-hand
+  // sides; signal rows rmin..N-1 when N % 32 != 0) for the columns c < rmin, in the factor's tile layout:
+  // the factor reads them directly (hpx_edge_init) instead of a per-iteration copy into its buffer
+  double *E;               // [nbl][(ld - rmin)/16 tiles][rmin columns][re16|im16]; RHS rows hold Q (not conjugated)
+  double *P2Tre, *P2Tim;   // [TP/16 tiles][NP columns][16 rows]: P2 by row tile (shared by the baselines)
   int solver;   // HPX_SOLVER_DENSE / HPX_SOLVER_FLAT / HPX_SOLVER_LOWRANK (hpx_plan_set_solver)
   // HPX_SOLVER_LOWRANK: flagged channels per baseline, the small Schur system and its solution
   int lr_fmax, lr_npad;
@@ -133,8 +140,39 @@ struct hpx_plan {
 struct hpx_gen {
   const double *ia, *cre, *cim, *rre, *rim, *p2re, *p2im, *hre, *him, *p4re, *p4im;
   const double *cdre, *cdim;   // dense C[r][c] (leading dimension NP) or NULL: circulant circ[r-c]
+  const double *ere, *eim;     // edge tiles (rows >= rmin, columns < rmin) or NULL; p2t: P2 in tile layout
+  const double *p2tre, *p2tim;
   int N, M, NP, TP, ncol, has_omega, rmin;
 };
+// offset of (r, c), r >= rmin, c < rmin in the edge tiles (imaginary part 16 doubles further)
+#define HPX_EIDX(r, c, rmin) ((((long)(((r) - (rmin)) >> 4) * (rmin) + (c)) << 5) + ((r) & 15))
+// Entry (r, c) of a row tile r >= rmin in a block column c < rmin: from the edge tiles when the plan has
+// them (GEN), adding the bandpower-dependent P2 / a term to the right-hand-side rows -- the arithmetic
+// of hpx_gen_entry, operation for operation -- otherwise from the factor buffer (assembled by the caller).
+template <bool GEN>
+__device__ __forceinline__ void hpx_edge_init(const hpx_gen& G, const double* __restrict__ Lre,
+                                              const double* __restrict__ Lim, const int r, const int c,
+                                              const int npad, const bool use_e, double& vr, double& vi) {
+  if (GEN && use_e) {
+    const long o = HPX_EIDX(r, c, G.rmin);
+    vr = G.ere[o];
+    vi = G.eim[o];
+    if (r >= npad) {
+      if (G.has_omega) {
+        const int t = r - npad;
+        const long q = (((long)(t >> 4) * G.NP + c) << 4) + (t & 15);
+        const double ic = G.ia[c];
+        vr = fma(ic, G.p2tre[q], vr);
+        vi = fma(ic, G.p2tim[q], vi);
+      }
+      vi = -vi;
+    }
+  } else {
+    const long off = HPX_LIDX(r, c, npad);
+    vr = Lre[off];
+    vi = Lim[off];
+  }
+}
 __device__ __forceinline__ void hpx_gen_entry(const hpx_gen& G, const int r, const int c,
                                               const int npad, double& vr, double& vi) {
   vr = 0.0;
@@ -194,6 +232,9 @@ __device__ __forceinline__ void hpx_gen_signal(const hpx_gen& G, const int r, co
 struct hpx_gen_batch {
   const double *ia, *cre, *cim, *rre, *rim, *p2re, *p2im, *hre, *him, *p4re, *p4im;
   const double *cdre, *cdim;   // dense C, [nbl][NP][NP], or NULL
+  const double *ere;           // edge tiles [nbl][e_bstride] or NULL
+  const double *p2tre, *p2tim; // P2 in tile layout; per-time units: block (b % p2_mod) * p2t_stride
+  long e_bstride, p2t_stride;
   int N, M, NP, TP, ncol, has_omega, rmin;
   int ia_div;                  // baseline b reads 1/a of chain b / ia_div (per-time units share their baseline's)
   int p2_mod;                  // ... and the omega_a block (b % p2_mod) * p2_stride (0 / 1: one shared block)
@@ -212,6 +253,10 @@ __device__ __forceinline__ hpx_gen hpx_gen_for(const hpx_gen_batch& B, const int
   G.him = B.him + (long)b * B.M * B.M;
   G.p4re = B.p4re + (long)b * B.M * B.TP;
   G.p4im = B.p4im + (long)b * B.M * B.TP;
+  G.ere = B.ere ? B.ere + (long)b * B.e_bstride : nullptr;
+  G.eim = B.ere ? G.ere + 16 : nullptr;
+  G.p2tre = B.p2tre ? B.p2tre + (B.p2_mod > 1 ? (long)(b % B.p2_mod) * B.p2t_stride : 0) : nullptr;
+  G.p2tim = B.p2tim ? B.p2tim + (B.p2_mod > 1 ? (long)(b % B.p2_mod) * B.p2t_stride : 0) : nullptr;
   G.cdre = B.cdre ? B.cdre + (long)b * B.NP * B.NP : nullptr;
   G.cdim = B.cdim ? B.cdim + (long)b * B.NP * B.NP : nullptr;
   G.N = B.N; G.M = B.M; G.NP = B.NP; G.TP = B.TP; G.ncol = B.ncol; G.has_omega = B.has_omega;
