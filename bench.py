@@ -554,11 +554,14 @@ def main():
     if rank == 0:
         total_units = sum(counts) * K
         value = total_units / dt
-        traffic = None
+        traffic, step_traffic = None, None
         if gb.solver == "dense":
             try:   # HBM bytes per k_factor launch from the committed PMC passes (profiles/), same workload
-                pm = json.load(open(REPO / "profiles" / "pmc_traffic.json"))[args.config]["k_factor"]
+                pmj = json.load(open(REPO / "profiles" / "pmc_traffic.json"))[args.config]
+                pm = pmj["k_factor"]
                 traffic = pm["bytes_per_launch"] * nbl / pm["baselines"]
+                if "step" in pmj:
+                    step_traffic = pmj["step"]["bytes_per_step"] * nbl / pmj["step"]["baselines"]
             except Exception:
                 pass
         peak_meas = np.zeros(1)
@@ -572,6 +575,11 @@ def main():
         else:
             roof = roofline_for(gb.solver, stage, nbl, N, M, T, fmax, K, traffic, float(peak_meas[0]))
             roof["whole_step"] = whole_step_for(gb.solver, value / world, N, M, T, fmax)
+            if step_traffic:     # measured HBM-side bytes of one whole iteration (PMC passes) against this run's step time
+                gbs = step_traffic / (dt / K) / 1e9
+                roof["whole_step"].update(traffic_measured=step_traffic, hbm_gbs_measured=gbs,
+                                          frac_hbm_measured=gbs / HBM_PEAK_GBS,
+                                          frac_hbm_achievable=gbs / 6300.0)
         res = {
             "metric": "baseline x Gibbs-iter/sec at Nfreq=512; P(k) rtol vs CPU ref",
             "value": value, "unit": "baseline*iter/s", "n_gpus": world, "steps": K, "warmup": W,

@@ -81,6 +81,18 @@ for kname in ("k_factor", "k_backsolve"):
                       "fetch_size_factor": 2.0, "fetch_size_factor_source": "tools/fetch_calib.hip on this kernel's load shape (ratio 2.000)",
                       "mfma_busy": t.get("SQ_VALU_MFMA_BUSY_CYCLES"), "sq_busy": t.get("SQ_BUSY_CYCLES"),
                       "gui_active": t.get("GRBM_GUI_ACTIVE"), "l2_hit": t.get("TCC_HIT_sum"), "l2_miss": t.get("TCC_MISS_sum")}
+# the whole dense iteration: every kernel hpx_gibbs_run launches per step (names as in the trace)
+step_kernels = ("k_assemble_tail", "k_assemble_edge", "k_factor", "k_backsolve", "k_fft_resid", "k_draw")
+sb = 0.0
+parts = {}
+for kname in step_kernels:
+    t = tot.get(kname)
+    if t and "FETCH_SIZE" in t and "WRITE_SIZE" in t:
+        parts[kname] = (2 * t["FETCH_SIZE"] + t["WRITE_SIZE"]) * 1024
+        sb += parts[kname]
+if sb > 0:
+    out["step"] = {"bytes_per_step": sb, "baselines": 1024, "by_kernel": parts,
+                   "note": "sum of (2 FETCH_SIZE + WRITE_SIZE) x 1024 over the kernels of one dense Gibbs iteration"}
 if out:
     json.dump({"C3": out}, open(O + "/pmc_traffic.json", "w"), indent=1)
 print("\n".join(l for l in lines if "k_factor" in l or "k_backsolve" in l or "k_shape" in l))
