@@ -1378,9 +1378,8 @@ static int set_static_impl(hpx_plan* p, const double* vis, const uint8_t* flags,
   // edge tiles for the factor (circulant mode): invariant rows >= rmin of the columns < rmin, P2 by row tile
   p->have_edge = 0;
   {
-    static const int edge_on = !(getenv("HPX_EDGE_TILES") && atoi(getenv("HPX_EDGE_TILES")) == 0);
     const int rmin = 32 * (N / 32);
-    if (edge_on && !p->dense_noise && rmin > 0) {
+    if (!p->dense_noise && rmin > 0) {
       p->have_static = 1;                  // (gen_of reads the plan as it stands)
       hpx_gen_batch B = gen_of(p);
       B.rmin = rmin;
