@@ -42,6 +42,9 @@ CONFIGS = {
     # factorisations of the C3 order per iteration
     "N4": (32, 32, 512, 12, 0.10),
 }
+# iterations BASELINE.json names per config (C5: "iteration count as C3", cut to 500 on the dense path to bound
+# the run time -- SURVEY 8d allows it when stated); the `full_length` leg runs them in one call
+FULL_ITERS = {"C2": 1000, "C3": 2000, "C5": 500}
 FP64_MFMA_PEAK_TFLOPS = 78.6   # AMD spec (32 FLOP/clk/SIMD x 1024 SIMDs x 2.4 GHz); the local
 #                                microarch guide has no f64 row -- the measured issue peak is
 #                                reported next to it as roofline.peak_measured.
@@ -89,16 +92,32 @@ def cpu_baseline(N, T, M, flag_frac, nbl=2, niter=3):
                        f"one process, default BLAS threads, {dt:.1f} s"), np.array(chains), d
 
 
-def cpu_baseline_multiproc(N, T, M, flag_frac, niter=8, max_procs=16):
-    """SURVEY 8(d)(ii): P independent single-BLAS-thread processes, one baseline stream each (the
-    reference's MPI deployment model), aggregate rate.  Child processes are plain `python -m
-    oracle.cpu_worker` runs: they never touch the GPU."""
-    import subprocess
+def host_cores():
+    """Cores this process may use: the affinity mask, cut to the cgroup CPU quota where one is set."""
     try:
         avail = len(os.sched_getaffinity(0))
     except AttributeError:
         avail = os.cpu_count() or 1
-    P = max(1, min(avail, max_procs))
+    quota = None
+    try:       # cgroup v2: "<quota> <period>" or "max <period>"
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            quota = max(1, int(np.ceil(int(q) / int(per))))
+    except Exception:
+        pass
+    return (min(avail, quota) if quota else avail), avail, quota
+
+
+def cpu_baseline_multiproc(N, T, M, flag_frac, niter=8, max_procs=None):
+    """SURVEY 8(d)(ii): P independent single-BLAS-thread processes, one baseline stream each (the
+    reference's MPI deployment model), aggregate rate, on every core this process is allowed to use
+    (affinity mask and cgroup quota; `max_procs` / HPX_BENCH_CPU_PROCS caps it).  Child processes are plain
+    `python -m oracle.cpu_worker` runs: they never touch the GPU."""
+    import subprocess
+    usable, avail, quota = host_cores()
+    if max_procs is None and os.environ.get("HPX_BENCH_CPU_PROCS"):
+        max_procs = int(os.environ["HPX_BENCH_CPU_PROCS"])
+    P = max(1, min(usable, max_procs) if max_procs else usable)
     env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1",
                HIP_VISIBLE_DEVICES="", ROCR_VISIBLE_DEVICES="")
     t0 = time.perf_counter()
@@ -119,9 +138,23 @@ def cpu_baseline_multiproc(N, T, M, flag_frac, niter=8, max_procs=16):
     if not secs:
         return None
     return dict(value=len(secs) * niter / max(secs), unit="baseline*iter/s", processes=len(secs), blas_threads=1,
-                sample=f"{len(secs)} of {os.cpu_count()} cores: {len(secs)} processes x 1 baseline x {niter} iterations, "
-                       f"slowest {max(secs):.1f} s, wall incl. start-up {wall:.1f} s (capped at {max_procs} processes "
-                       "to bound memory and the run time of the default bench)")
+                host_cores=os.cpu_count(), affinity_cores=avail, cgroup_quota_cores=quota,
+                sample=f"{len(secs)} single-thread processes (of {os.cpu_count()} host cores; affinity mask {avail}, "
+                       f"cgroup quota {quota if quota else 'none'}"
+                       f"{', capped at ' + str(max_procs) if max_procs else ''}) x 1 baseline x {niter} iterations, "
+                       f"slowest {max(secs):.1f} s, wall incl. start-up {wall:.1f} s")
+
+
+def kernel_source_hash():
+    """Hash of the sources libhpx.so is built from: profiles/pmc_traffic.json carries the hash it was measured
+    on, and a different library gets no `roofline.traffic` from it."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted((REPO / "hydra_pspec_amd" / "csrc").glob("*")):
+        if f.suffix in (".hip", ".h") or f.name == "Makefile":
+            h.update(f.name.encode())
+            h.update(f.read_bytes())
+    return h.hexdigest()[:16]
 
 
 def flops_flat(N, M, T):
@@ -424,6 +457,8 @@ def main():
     ap.add_argument("--config", default="C3", choices=sorted(CONFIGS) + ["dpss", "oqe"])
     ap.add_argument("--nbl", type=int, default=None, help="baselines per GPU (default: config)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-full-length", action="store_true",
+                    help="skip the full-length leg (the config's 1000 / 2000 iterations, ~10 s at C3)")
     ap.add_argument("--solver", default="dense", choices=["dense", "auto"],
                     help="dense (default): the general batched-Cholesky path the metric is about; auto: let "
                          "unflagged flat-noise batches take the structured solve (reported separately anyway)")
@@ -523,6 +558,31 @@ def main():
         dt_incl = float(tt.item())
     del o2
 
+    # the config as BASELINE.json states it: the same batch for the config's full iteration count (its own
+    # plan and tables; bracketed like the timed region, max over ranks)
+    full_len = None
+    n_full = FULL_ITERS.get(args.config)
+    if n_full and not args.no_full_length:
+        gfull = pspec.GibbsBatch(d["vis"], flags_in, d["fgmodes"], ninv_in, d["ps_prior"], n_full, seed=d["seed"],
+                                 solver=args.solver)
+        barrier()
+        t1 = time.perf_counter()
+        ofull = gfull.run(n_full, ps0=ps0)
+        torch.cuda.synchronize()
+        dt_full = time.perf_counter() - t1
+        finite = bool(torch.isfinite(ofull["signal_ps"]).all()) and bool(torch.isfinite(ofull["ln_post"]).all())
+        prefix_same = bool(torch.equal(ofull["signal_ps"][:, W:W + K], out["signal_ps"])) if W + K <= n_full else None
+        if dist is not None:
+            tt = torch.tensor([dt_full], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt_full = float(tt.item())
+        full_len = {"iters": n_full, "seconds": dt_full, "value": sum(counts) * n_full / dt_full,
+                    "unit": "baseline*iter/s", "all_finite": finite, "timed_steps_are_its_iterations": prefix_same,
+                    "note": "the same batch for the iteration count BASELINE.json names for this config, one "
+                            "hpx_gibbs_run call, no profiling events; inputs resident, P(k) history kept on the device"}
+        del ofull
+        gfull.close()
+
     # the same batch through solver="auto" (outside the timed region): unflagged flat-noise inputs
     # such as C3's then take the O(N M (M+T)) structured solve instead of the dense factorisation
     flat_extra = None
@@ -551,17 +611,27 @@ def main():
                                   "on the general dense path"}
         gf.close()
 
+    # which physical device every rank ran on (a rehearsal pins all ranks to one: HPX_BENCH_DEVICE)
+    devices = [dev_index]
+    if dist is not None:
+        devices = [None] * world
+        dist.all_gather_object(devices, dev_index)
     if rank == 0:
         total_units = sum(counts) * K
         value = total_units / dt
-        traffic, step_traffic = None, None
+        traffic, step_traffic, traffic_stale = None, None, False
         if gb.solver == "dense":
-            try:   # HBM bytes per k_factor launch from the committed PMC passes (profiles/), same workload
-                pmj = json.load(open(REPO / "profiles" / "pmc_traffic.json"))[args.config]
-                pm = pmj["k_factor"]
-                traffic = pm["bytes_per_launch"] * nbl / pm["baselines"]
-                if "step" in pmj:
-                    step_traffic = pmj["step"]["bytes_per_step"] * nbl / pmj["step"]["baselines"]
+            try:   # HBM bytes per k_factor launch from the committed PMC passes (profiles/), same workload --
+                # only when they were measured on THIS library's sources
+                pmall = json.load(open(REPO / "profiles" / "pmc_traffic.json"))
+                pmj = pmall[args.config]
+                if pmall.get("source_hash") == kernel_source_hash():
+                    pm = pmj["k_factor"]
+                    traffic = pm["bytes_per_launch"] * nbl / pm["baselines"]
+                    if "step" in pmj:
+                        step_traffic = pmj["step"]["bytes_per_step"] * nbl / pmj["step"]["baselines"]
+                else:
+                    traffic_stale = True
             except Exception:
                 pass
         peak_meas = np.zeros(1)
@@ -582,7 +652,7 @@ def main():
                                           frac_hbm_achievable=gbs / 6300.0)
         res = {
             "metric": "baseline x Gibbs-iter/sec at Nfreq=512; P(k) rtol vs CPU ref",
-            "value": value, "unit": "baseline*iter/s", "n_gpus": world, "steps": K, "warmup": W,
+            "value": value, "unit": "baseline*iter/s", "n_gpus": len(set(devices)), "steps": K, "warmup": W,
             "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{args.config}: {nbl_gpu} synthetic baselines per GPU x "
@@ -599,6 +669,15 @@ def main():
             "stage_ms_per_step": {k: v / K for k, v in stage.items()},
         }
         res["config"]["solver"] = gb.solver
+        if len(set(devices)) != world or "HPX_BENCH_BACKEND" in os.environ:
+            res["rehearsal"] = {"ranks": world, "ranks_per_device": world // len(set(devices)), "backend": backend,
+                                "note": "launcher rehearsal: several ranks share one physical GPU -- NOT a multi-GPU result"}
+            res["scaling"] = "rehearsal"
+        if traffic_stale:
+            roof["traffic_note"] = ("profiles/pmc_traffic.json was measured on other kernel sources (source_hash "
+                                    "differs): no traffic figure for this build")
+        if full_len:
+            res["full_length"] = full_len
         if flat_extra:
             res["flat_noise_structured_solve"] = flat_extra     # (key kept from the unflagged case)
         if args.config == "N4":

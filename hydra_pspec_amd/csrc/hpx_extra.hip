@@ -144,7 +144,7 @@ __global__ __launch_bounds__(256) void k_dpss_group(const double* __restrict__ t
   for (int e = tid; e < ncol * ncol; e += 256) {  // AiT[k][k'] = Ainv[k'][k]
     const int k = e / ncol, k2 = e % ncol;
     double vr = 0.0, vi = 0.0;
-    if (k < nm && k2 < nm) { vr = Are[k2][nm + k]; vi = Aim[k2][nm + k]; }
+    if (k < nm && k2 < nm && !bad) { vr = Are[k2][nm + k]; vi = Aim[k2][nm + k]; }   // singular group: zero amplitudes
     aitre[(long)gI * ncol * ncol + e] = vr;
     aitim[(long)gI * ncol * ncol + e] = vi;
   }
@@ -539,6 +539,19 @@ extern "C" int64_t hpx_dpss_workspace_bytes(int ngroups, int per, int N, int nm)
   // icov planar (2 NP^2) + per group: in, out, projector (3 x 2 NP ncol) + inverse (2 ncol^2) + info
   return (int64_t)((2 * NP * NP + (size_t)ngroups * (6 * NP * ncol + 2 * ncol * ncol)) * sizeof(double) +
                    (size_t)ngroups * sizeof(int32_t) + 256);
+}
+
+extern "C" int hpx_dpss_group_info(const void* work, int64_t work_bytes, int ngroups, int per, int N, int nm,
+                                   int32_t* info_host, void* stream) {
+  HPX_REQUIRE(work && info_host && ngroups > 0 && per > 0 && N > 0 && nm > 0, "hpx_dpss_group_info: bad argument");
+  HPX_REQUIRE(work_bytes >= hpx_dpss_workspace_bytes(ngroups, per, N, nm), "hpx_dpss_group_info: workspace too small");
+  const size_t NP = ceil16(N), ncol = ceil16(nm);
+  const double* base = (const double*)work;      // (layout of hpx_dpss_project_grouped)
+  const int32_t* info = (const int32_t*)(base + 2 * NP * NP + (size_t)ngroups * (6 * NP * ncol + 2 * ncol * ncol));
+  hipStream_t st = (hipStream_t)stream;
+  HPX_HIP(hipMemcpyAsync(info_host, info, (size_t)ngroups * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+  HPX_HIP(hipStreamSynchronize(st));
+  return HPX_OK;
 }
 
 extern "C" int hpx_dpss_project_grouped(int ngroups, int per, int N, int nm, const double* d,

@@ -84,6 +84,16 @@ class DpssProjector:
         self._have_projector = True
         return out
 
+    def singular_groups(self):
+        """Indices of the groups whose weighted normal matrix was not positive definite in the last fit with
+        weights (fully flagged, or fewer unflagged channels than modes): their amplitudes are zero.
+        Synchronises the stream."""
+        info = np.zeros(self.ng, dtype=np.int32)
+        hpx.check(hpx.lib().hpx_dpss_group_info(hpx.ptr(self.work), self.work_bytes, self.ng, self.per, self.N,
+                                                self.nm, info.ctypes.data, hpx.stream_ptr(self.torch)),
+                  "hpx_dpss_group_info")
+        return np.flatnonzero(info)
+
 
 def dpss_fit_modes_batched(d, w, freqs, cov, nmodes=10, alpha=1., taper=None):
     """Many spectra that share ``cov``.  ``d`` (nb,N) complex with ``w`` (nb,N) (every spectrum its own
@@ -106,7 +116,12 @@ def dpss_fit_modes_batched(d, w, freqs, cov, nmodes=10, alpha=1., taper=None):
         ng, per, shape = d.shape[0], 1, (d.shape[0],)
     pr = DpssProjector(ng, per, freqs, cov, nmodes=nmodes, alpha=alpha, taper=taper)
     out = pr.fit(np.ascontiguousarray(d).reshape(ng, per, N), np.broadcast_to(w, (ng, N)))
-    pr.torch.cuda.synchronize()
+    bad = pr.singular_groups()
+    if bad.size:
+        import warnings
+        warnings.warn(f"dpss fit: the weighted normal matrix of {bad.size} group(s) (first: {int(bad[0])}) is not "
+                      "positive definite (fully flagged, or fewer unflagged channels than modes); their amplitudes "
+                      "are zero", RuntimeWarning, stacklevel=2)
     return pr.modes, out.cpu().numpy().reshape(shape + (2 * nmodes,))
 
 

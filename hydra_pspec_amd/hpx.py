@@ -48,6 +48,7 @@ SIGNATURES = {
     "hpx_invgamma_inversion": (_i, [_i, _i, _vp, _vp, _vp, _i, _vp, _vp]),
     "hpx_dpss_project": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "hpx_dpss_workspace_bytes": (_i64, [_i, _i, _i, _i]),
+    "hpx_dpss_group_info": (_i, [_vp, _i64, _i, _i, _i, _i, _vp, _vp]),
     "hpx_dpss_project_grouped": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _vp]),
     "hpx_oqe_workspace_bytes": (_i64, [_i, _i, _i]),
     "hpx_oqe_fisher": (_i, [_i, _i, _vp, _vp, _i, _vp, _i64, _vp]),

@@ -156,8 +156,20 @@ def bias_all(s, R, C_noise_total):
     return 0.5 * _sandwich_diag(R, C_noise_total, True)
 
 
+_bias_cache = {"key": None, "val": None}
+
+
 def bias(tau, s, R, C_noise_total):  # oqe.py:23-24
-    return bias_all(s, R, C_noise_total)[tau]
+    """One delay of :func:`bias_all`.  The reference is called once per delay (oqe.py:88-101 loops over tau):
+    the O(s^3) sandwich of the last (R, C) pair is kept, keyed by the arrays' contents, so that such a loop
+    costs one device pass instead of s."""
+    import hashlib
+    key = (s, hashlib.sha1(np.ascontiguousarray(R).tobytes()).digest(),
+           hashlib.sha1(np.ascontiguousarray(C_noise_total).tobytes()).digest())
+    if _bias_cache["key"] != key:
+        _bias_cache["val"] = bias_all(s, R, C_noise_total)
+        _bias_cache["key"] = key
+    return _bias_cache["val"][tau]
 
 
 def _q_auto(V, s, R):
@@ -228,11 +240,13 @@ def getqs(Vis, R):                  # oqe.py:130-144
 def Sig_QEN(R, C_noise, norm):      # oqe.py:161-173
     """``E_i = norm R Q_i R`` is rank one (``u_i v_i^T``), so ``1/2 tr(E C E C) = 1/2 norm^2 n_i^2`` with
     ``n = diag(M (R C R) M^H)`` (device)."""
+    assert np.ndim(norm) == 0, "Sig_QEN: `norm` must be a scalar (the rank-one identity does not hold for an array)"
     n = _sandwich_diag(R, C_noise, False)
     return 0.5 * norm ** 2 * n * n
 
 
 def Sig_QESN(R, C_noise, C_S, norm):  # oqe.py:177-186
+    assert np.ndim(norm) == 0, "Sig_QESN: `norm` must be a scalar (the rank-one identity does not hold for an array)"
     n = _sandwich_diag(R, C_noise, False)
     sg = _sandwich_diag(R, C_S, False)
     return 0.5 * norm ** 2 * (n * n + 2.0 * sg * n)

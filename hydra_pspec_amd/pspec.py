@@ -106,9 +106,11 @@ def _ninv_dense(Ninv, nbl, N):
     if not np.any(Ninv - d[..., None] * np.eye(N) != 0):
         return None
     herm = np.conj(np.swapaxes(Ninv, -1, -2))
-    if not np.allclose(Ninv, herm, rtol=1e-12, atol=1e-14 * np.abs(Ninv).max()):
+    # inv(noise_cov) of an ill-conditioned covariance is Hermitian only to eps * cond (the reference driver passes
+    # it unsymmetrised, run-hydra-pspec.py:436): accept that round-off and work with the Hermitian part
+    if not np.allclose(Ninv, herm, rtol=0.0, atol=1e-8 * np.abs(Ninv).max()):
         raise NotImplementedError("a non-Hermitian inverse noise covariance is not supported")
-    return np.ascontiguousarray(Ninv, dtype=complex)
+    return np.ascontiguousarray(0.5 * (Ninv + herm), dtype=complex)
 
 
 def _ninv_diag(Ninv, nbl, T, N):
@@ -192,9 +194,14 @@ class GibbsBatch:
         fg_shape = tuple(fgmodes.shape)
         assert fg_shape[-2] == N, "fgmodes must have shape (Nfreqs, Nmodes)"
         M = fg_shape[-1]
-        self.per_time = len(tuple(flags.shape)) == 3
         assert tuple(flags.shape) in ((nbl, N), (nbl, T, N)), \
             "`flags` array must have shape (Nbl, Nfreqs) or, time dependent, (Nbl, Ntimes, Nfreqs)"
+        if ninv_dense is None and tuple(np.shape(ninv_diag)) == (nbl, T, N) and len(tuple(flags.shape)) == 2 \
+                and not (T == N and nbl == T):
+            # time-dependent noise with time-independent flags: the same flags at every time
+            fl2 = flags if isinstance(flags, np.ndarray) else flags.detach().cpu().numpy()
+            flags = np.ascontiguousarray(np.broadcast_to(np.asarray(fl2)[:, None, :], (nbl, T, N)))
+        self.per_time = len(tuple(flags.shape)) == 3
         self.nbl, self.T, self.N, self.M = nbl, T, N, M
         self.map_estimate = bool(map_estimate)
         self.Niter = 1 if map_estimate else int(Niter)
@@ -217,7 +224,9 @@ class GibbsBatch:
                 d_ninv = hpx.to_dev(torch, ninv_diag, f64, self.device)
                 if self.per_time and tuple(d_ninv.shape) == (nbl, N):
                     d_ninv = d_ninv[:, None, :].expand(nbl, T, N).contiguous()
-                assert tuple(d_ninv.shape) == ((nbl, T, N) if self.per_time else (nbl, N))
+                if tuple(d_ninv.shape) != ((nbl, T, N) if self.per_time else (nbl, N)):
+                    raise ValueError(f"inverse noise variances of shape {tuple(d_ninv.shape)} do not match flags of shape "
+                                     f"{tuple(flags.shape)}: expected (Nbl, Nfreqs) or, time dependent, (Nbl, Ntimes, Nfreqs)")
             fg_shared = len(fg_shape) == 2
             d_fg = hpx.to_dev(torch, fgmodes, c128, self.device)
             pmap, xgrid = _prior_tables(ps_prior if isinstance(ps_prior, np.ndarray)

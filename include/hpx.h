@@ -238,8 +238,15 @@ int hpx_dpss_project(int nb, int N, int nm, const double* d, const double* tw,
  * allocates nothing; NULL: allocated and released inside the call (which then synchronises and
  * reports a non-positive-definite normal matrix as HPX_ENOTPD).  reuse_projector != 0: the per-group
  * stage is skipped and the projector the previous call left in the SAME caller workspace is used
- * (new data, unchanged weights: tw / modes / icov may then be NULL). */
+ * (new data, unchanged weights: tw / modes / icov may then be NULL).
+ * A group whose weighted normal matrix is not positive definite (a fully flagged baseline, fewer
+ * unflagged channels than modes) gets ZERO amplitudes (what the reference's L-BFGS fit from a zero start
+ * returns for a fully flagged spectrum, dpss.py:81-92) and is marked in the workspace;
+ * hpx_dpss_group_info copies the marks of the last per-group stage to the host (info_host (ngroups,) i32,
+ * 1 = singular; synchronises `stream`) -- the way to learn of it with a caller workspace. */
 int64_t hpx_dpss_workspace_bytes(int ngroups, int per, int N, int nm);
+int hpx_dpss_group_info(const void* work, int64_t work_bytes, int ngroups, int per, int N, int nm,
+                        int32_t* info_host, void* stream);
 int hpx_dpss_project_grouped(int ngroups, int per, int N, int nm, const double* d,
                              const double* tw, const double* modes, const double* icov,
                              double* amps, void* work, int64_t work_bytes, int reuse_projector,

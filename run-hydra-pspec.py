@@ -75,6 +75,9 @@ def build_parser():
                         "as soon as one sample is flagged, which is what the reference driver does (:524-541)")
     p.add_argument("--outputs", type=str, default="all",
                    help="'all' (the six reference files) or 'ps' (dps-eor.npy and ln-post.npy only)")
+    p.add_argument("--dry_run", action="store_true",
+                   help="everything but the sampling (no GPU touched): inputs, rank blocks, output tree, "
+                        "checkpoint files (zeros) and timings -- exercises the multi-rank plumbing")
     return p
 
 
@@ -109,6 +112,38 @@ def any_time_unflagged(w):
     return np.all(w, axis=0)
 
 
+def launch_token():
+    """What the ranks of ONE launch have in common (and an earlier launch does not): names the files they
+    meet through.  torchrun exports TORCHELASTIC_RUN_ID / MASTER_PORT; plain `RANK=.. WORLD_SIZE=..` launches of
+    one parent share its pid."""
+    for k in ("HYDRA_PSPEC_RUN_ID", "TORCHELASTIC_RUN_ID", "MASTER_PORT"):
+        if os.environ.get(k):
+            return f"{k.lower()}-{os.environ[k]}"
+    return f"ppid-{os.getppid()}"
+
+
+def write_json_atomic(path, obj):
+    tmp = Path(str(path) + f".tmp{os.getpid()}")
+    with open(tmp, "w") as f:
+        json.dump(obj, f, indent=2)
+    os.replace(tmp, path)
+
+
+def wait_for_file(path, newer_than, timeout=900.0, what=""):
+    """Poll for a JSON file written (atomically) after `newer_than` by another rank of this launch."""
+    t_end = time.time() + timeout
+    while time.time() < t_end:
+        try:
+            with open(path) as f:
+                obj = json.load(f)
+            if obj.get("created", 0.0) >= newer_than:
+                return obj
+        except (FileNotFoundError, json.JSONDecodeError):
+            pass
+        time.sleep(0.05)
+    raise SystemExit(f"rank synchronisation timed out waiting for {what or path}")
+
+
 def load_aux(path, file_name, bl_str):
     """'file or directory' convention of the reference (:248-266): a directory means
     ``<dir>/<ant1>-<ant2>/<file_name>``."""
@@ -124,6 +159,7 @@ def main(argv=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     t_start = time.perf_counter()
+    t_launch = time.time()
 
     from hydra_pspec_amd import pspec, synthetic, utils
     from hydra_pspec_amd.sharding import block_range
@@ -245,24 +281,33 @@ def main(argv=None):
     else:
         dirname = f"results-seed-{args.seed}-Niter-{args.Niter}"
     results = out_dir / dirname
-    # --resume needs the earlier run's arguments before this run overwrites args.json
+    # Rank 0 alone prepares the tree (moves an earlier one aside, creates the directory) and reads the earlier
+    # run's args.json for --resume; the other ranks wait for its marker file before they touch the tree and take
+    # the earlier arguments from it (no rank reads args.json while rank 0 rewrites it).  The reference does this
+    # with MPI barriers / bcast (run-hydra-pspec.py:343-366); here the ranks of a launch meet through files.
+    marker = out_dir / f".{dirname}.{launch_token()}.ranks.json"
     old_args = None
-    if args.resume and (results / "args.json").exists():
-        with open(results / "args.json") as f:
-            old_args = json.load(f)
     if rank == 0:
-        if results.exists() and not args.clobber and not args.resume and world == 1:
+        if args.resume and (results / "args.json").exists():
+            with open(results / "args.json") as f:
+                old_args = json.load(f)
+        if results.exists() and not args.clobber and not args.resume:
             # keep earlier results: move them aside under their modification time (reference :343-345,
-            # utils.add_mtime_to_filepath); single-process runs only -- ranks do not synchronise here
+            # utils.add_mtime_to_filepath)
             from datetime import datetime
             import shutil
             mtime = datetime.fromtimestamp(os.path.getmtime(results)).isoformat()
             shutil.move(str(results), str(results.with_name(f"{results.name}-{mtime}")))
         results.mkdir(parents=True, exist_ok=True)
+        if world > 1:
+            write_json_atomic(marker, {"created": time.time(), "old_args": old_args})
+    else:
+        old_args = wait_for_file(marker, t_launch - 300.0, what="rank 0 to prepare the output tree")["old_args"]
 
     # ---- sampling -----------------------------------------------------------------------
     import torch
-    torch.cuda.set_device(local_rank)
+    if not args.dry_run:
+        torch.cuda.set_device(local_rank)
     all_out = args.outputs == "all"
     keep = ("signal_cr", "fg_amps", "chisq") if all_out else ()
     t0 = time.perf_counter()
@@ -278,10 +323,13 @@ def main(argv=None):
     # inputs and seed (args.json); baselines caught mid-write at different iterations are rolled
     # back to the earliest one (the chain is deterministic, nothing is lost but time).
     iter0, hist = 0, None
-    if args.resume and not args.map_estimate and S_general is None:
+    if args.resume and (args.map_estimate or S_general is not None):
+        raise SystemExit("--resume is not available with --map_estimate or a sigcov0 that is not of the form "
+                         "Fop^H diag(p) Fop: such a run cannot be continued from its bandpowers")
+    if args.resume:
         if old_args is None:
             raise SystemExit(f"--resume: no args.json of an earlier run in {results}")
-        run_only = {"Niter", "resume", "clobber", "verbose", "write_Niter", "Nproc", "config", "outputs"}
+        run_only = {"Niter", "resume", "clobber", "verbose", "write_Niter", "Nproc", "config", "outputs", "dry_run"}
         diff = sorted(k for k in vars(args) if k not in run_only and old_args.get(k) != getattr(args, k))
         if diff:
             raise SystemExit("--resume: the earlier run in " + str(results) + " used different "
@@ -290,27 +338,31 @@ def main(argv=None):
         previous = []
         for ap in antpairs:
             bdir = results / f"{ap[0]}-{ap[1]}"
-            if not all((bdir / n).exists() for n in names.values()):
-                previous = None
-                break
+            missing = [n for n in names.values() if not (bdir / n).exists()]
+            if missing:
+                raise SystemExit(f"--resume: {bdir} has no {', '.join(missing)} (an earlier run with --outputs ps "
+                                 "cannot be continued with --outputs all)")
             previous.append({k: np.load(bdir / n) for k, n in names.items()})
-        if previous:
-            k_done = min(len(pv["signal_ps"]) for pv in previous)
-            if any(len(pv[k]) < k_done for pv in previous for k in names):
-                k_done = min(len(pv[k]) for pv in previous for k in names)
-            if 0 < k_done < Niter:
-                iter0 = k_done
-                hist = {k: [np.stack([pv[k][:k_done] for pv in previous])] for k in names}
-                ps0 = hist["signal_ps"][0][:, -1].copy()
+        k_done = min(len(pv[k]) for pv in previous for k in names) if previous else 0
+        if k_done >= Niter:
+            raise SystemExit(f"--resume: the chains in {results} already hold {k_done} iterations (--Niter {Niter}): "
+                             "nothing to do")
+        if k_done > 0:
+            iter0 = k_done
+            hist = {k: [np.stack([pv[k][:k_done] for pv in previous])] for k in names}
+            ps0 = hist["signal_ps"][0][:, -1].copy()
+        elif rank == 0:
+            print("--resume: the checkpoints hold no iteration yet; starting at 0", flush=True)
     if rank == 0:
-        with open(results / "args.json", "w") as f:
-            json.dump(vars(args), f, indent=2)
+        write_json_atomic(results / "args.json", vars(args))
     if hist is None:
         hist = {k: [] for k in names}
 
     Ninv_arg = ninv if ninv_dense is None else ninv_dense
-    gb = pspec.make_batch(vis, flags_any if flags_pt is None else flags_pt, fg, Ninv_arg, ps_prior, Niter,
-                          seed=args.seed, map_estimate=args.map_estimate)
+    gb = None
+    if not args.dry_run:
+        gb = pspec.make_batch(vis, flags_any if flags_pt is None else flags_pt, fg, Ninv_arg, ps_prior, Niter,
+                              seed=args.seed, map_estimate=args.map_estimate)
     fop = utils.fourier_operator(N)
     write_times, ant_strs = [0.0] * nbl, [f"{ap[0]}_{ap[1]}" for ap in antpairs]
 
@@ -337,13 +389,19 @@ def main(argv=None):
                 os.replace(tmp, bdir / fn)
             write_times[b] += time.perf_counter() - tw
 
-    done = gb.iter_done = iter0
+    done = iter0
+    if gb is not None:
+        gb.iter_done = iter0
     t_process = 0.0
+    shapes = {"signal_ps": (N,), "ln_post": (), "signal_cr": (T, N), "fg_amps": (T, args.Nfgmodes), "chisq": (T, N)}
     try:
         while done < Niter:
             n = min(chunk - done % chunk, Niter - done)
             tp = time.perf_counter()
-            if done == 0 and S_general is not None:
+            if gb is None:            # --dry_run: files of the right shapes, no sampling
+                out = {k: torch.zeros((nbl, n) + shapes[k], dtype=torch.complex128 if k in ("signal_cr", "fg_amps")
+                                      else torch.float64) for k in names}
+            elif done == 0 and S_general is not None:
                 shp0 = np.stack([pspec.sqrt_cov_delay_basis(S_general[b]) for b in range(nbl)])
                 out = gb.run(n, shp0=shp0, keep=keep)
             else:
@@ -357,17 +415,34 @@ def main(argv=None):
             if args.verbose and rank == 0:
                 print(f"iteration {done}/{Niter}: {nbl * n / (time.perf_counter() - tp):.1f} baseline*iter/s", flush=True)
     finally:
-        gb.close()
+        if gb is not None:
+            gb.close()
     _ = t0
 
+    # every rank's write times reach rank 0 (the reference gathers them, run-hydra-pspec.py:557, and writes
+    # one timings.json, :570-581): per-rank files, merged and removed by rank 0
+    mine = {"created": time.time(), "rank": rank, "ant_pairs": ant_strs, "write_times": write_times}
+    if rank > 0:
+        write_json_atomic(results / f".timings-{rank}.json", mine)
     if rank == 0:
+        t_bar = time.perf_counter()
+        write_data = [{k: mine[k] for k in ("rank", "ant_pairs", "write_times")}]
+        for r in range(1, world):
+            other = wait_for_file(results / f".timings-{r}.json", t_launch - 300.0, what=f"rank {r} to finish")
+            write_data.append({k: other[k] for k in ("rank", "ant_pairs", "write_times")})
+            os.remove(results / f".timings-{r}.json")
+        if world > 1:
+            try:
+                os.remove(marker)
+            except FileNotFoundError:
+                pass
+        t_bar = time.perf_counter() - t_bar
         total = time.perf_counter() - t_start
         timings = {"num_ranks": world, "num_baselines": int(nbl_all),
                    "rank_0_timers": {"load_data": t_load, "scatter": 0.0, "process": t_process,
-                                     "barrier": 0.0, "total": total},
-                   "write_data": [{"rank": rank, "ant_pairs": ant_strs, "write_times": write_times}]}
-        with open(results / "timings.json", "w") as f:
-            json.dump(timings, f, indent=2)
+                                     "barrier": t_bar, "total": total},
+                   "write_data": write_data}
+        write_json_atomic(results / "timings.json", timings)
         ru = getrusage(RUSAGE_SELF)
         with open(results / "resources.json", "w") as f:
             json.dump({"ru_maxrss": ru.ru_maxrss, "ru_utime": ru.ru_utime, "ru_stime": ru.ru_stime}, f, indent=2)

@@ -240,3 +240,58 @@ def test_driver_per_time_flags(tmp_path):
         got = np.load(tmp_path / "pt" / f"0-{b + 1}" / "dps-eor.npy")
         assert np.array_equal(got, want["signal_ps"][b])
         assert not np.array_equal(got, np.load(tmp_path / "any" / f"0-{b + 1}" / "dps-eor.npy"))
+
+
+def _spawn_ranks(world, argv, env_extra=None, cwd=None):
+    """Launch the driver as `world` plain processes (RANK / WORLD_SIZE / LOCAL_RANK, one shared run id), the
+    way a launcher without MPI would; returns their exit codes and outputs."""
+    import os, subprocess, sys, uuid
+    root = Path(__file__).resolve().parent.parent
+    run_id = uuid.uuid4().hex
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r), HYDRA_PSPEC_RUN_ID=run_id,
+                   **(env_extra or {}))
+        procs.append(subprocess.Popen([sys.executable, str(root / "run-hydra-pspec.py")] + argv, env=env, cwd=cwd or root,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=240)[0] for p in procs]
+    return [p.returncode for p in procs], outs
+
+
+def test_driver_two_ranks_dry_run(tmp_path):
+    """The driver's multi-rank plumbing without a GPU (--dry_run): rank 0 prepares the output tree before the
+    other rank touches it, every rank writes the directories of ITS block of baselines (the reference's quot/rem
+    split, run-hydra-pspec.py:268-287), the ranks' write times are merged into one timings.json as the reference's
+    gather does (:557, :570-581), --resume takes the earlier arguments from rank 0 (no rank reads args.json while
+    it is rewritten) and an earlier tree is moved aside once."""
+    import json
+    common = ["--synthetic", "5,4,32", "--Nfgmodes", "3", "--seed", "4", "--out_dir", str(tmp_path), "--dry_run",
+              "--outputs", "ps", "--write_Niter", "2"]
+    rcs, outs = _spawn_ranks(2, common + ["--Niter", "4", "--dirname", "run"])
+    assert rcs == [0, 0], outs
+    res = tmp_path / "run"
+    for k in range(1, 6):                                            # 5 baselines: rank 0 owns 3, rank 1 owns 2
+        assert np.load(res / f"0-{k}" / "dps-eor.npy").shape == (4, 32)
+    tm = json.load(open(res / "timings.json"))
+    assert tm["num_ranks"] == 2 and tm["num_baselines"] == 5
+    assert sorted(w["rank"] for w in tm["write_data"]) == [0, 1]
+    assert sorted(len(w["ant_pairs"]) for w in tm["write_data"]) == [2, 3]
+    assert json.load(open(res / "args.json"))["Niter"] == 4
+    assert not [p for p in res.iterdir() if p.name.startswith(".timings-")]
+    assert not [p for p in tmp_path.iterdir() if p.name.endswith(".ranks.json")]
+    # resume on both ranks: 4 -> 6 iterations, the earlier arguments come through rank 0
+    rcs, outs = _spawn_ranks(2, common + ["--Niter", "6", "--dirname", "run", "--resume"])
+    assert rcs == [0, 0], outs
+    for k in range(1, 6):
+        assert np.load(res / f"0-{k}" / "dps-eor.npy").shape == (6, 32)
+    # a resume that cannot be honoured says so instead of restarting at 0
+    rcs, outs = _spawn_ranks(1, common + ["--Niter", "6", "--dirname", "run", "--resume"])
+    assert rcs[0] != 0 and "nothing to do" in outs[0]
+    rcs, outs = _spawn_ranks(1, common + ["--Niter", "8", "--dirname", "run", "--resume", "--seed", "9"])
+    assert rcs[0] != 0 and "different" in outs[0]
+    # a second plain run moves the first tree aside (rank 0, before rank 1 proceeds) and writes a fresh one
+    rcs, outs = _spawn_ranks(2, common + ["--Niter", "2", "--dirname", "run"])
+    assert rcs == [0, 0], outs
+    moved = [p for p in tmp_path.iterdir() if p.name.startswith("run-")]
+    assert len(moved) == 1 and np.load(moved[0] / "0-5" / "dps-eor.npy").shape == (6, 32)
+    assert np.load(res / "0-5" / "dps-eor.npy").shape == (2, 32) and np.load(res / "0-1" / "dps-eor.npy").shape == (2, 32)

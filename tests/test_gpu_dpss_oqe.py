@@ -25,7 +25,7 @@ def test_dpss_fit_modes_vs_reference(golden):
         assert np.array_equal(modes, g[f"F10_{i}_modes"])
         scale = np.max(np.abs(g[f"F10_{i}_amps"]))
         # reference = L-BFGS-B stop point: within its slack, and never a better cost than ours
-        assert np.max(np.abs(amps - g[f"F10_{i}_amps"])) < 1e-3 * scale
+        assert np.max(np.abs(amps - g[f"F10_{i}_amps"])) < 1e-4 * scale       # (measured 1.4e-6 .. 1.9e-5)
         assert _cost(amps, modes, d, w, cov, taper) <= _cost(g[f"F10_{i}_amps"], modes, d, w, cov, taper) * (1 + 1e-12)
         _, cf = dpss_ref.dpss_fit_closed_form(d, w, fr, cov, nmodes=int(nm), alpha=al, taper=taper)
         assert np.max(np.abs(amps - cf)) < 1e-9 * scale       # same minimiser as the CPU closed form
@@ -162,3 +162,27 @@ def test_dpss_grouped_at_bench_size_vs_closed_form():
     for t in (0, 4):
         _, cf = dpss_ref.dpss_fit_closed_form(d[1, t], w[1], freqs, cov, nmodes=20, alpha=11.0)
         assert np.max(np.abs(a20[t] - cf)) < 1e-8 * np.max(np.abs(cf))
+
+
+def test_dpss_singular_group_gives_zero_amplitudes_and_a_warning():
+    """A fully flagged spectrum (all-zero weights) has a singular weighted normal matrix: the reference's
+    L-BFGS fit from a zero start returns zeros (dpss.py:81-92); here the group is marked, its amplitudes are
+    zero (not NaN) and the batched entry warns.  The other groups are unaffected."""
+    from hydra_pspec_amd import dpss
+    from oracle import dpss_ref
+    rng = np.random.default_rng(5)
+    N, nm, nb = 64, 6, 4
+    freqs = np.linspace(100., 110., N)
+    cov = np.eye(N) * 2.0
+    d = rng.standard_normal((nb, N)) + 1j * rng.standard_normal((nb, N))
+    w = np.ones((nb, N))
+    w[2] = 0.0
+    with pytest.warns(RuntimeWarning, match="not positive definite"):
+        modes, amps = dpss.dpss_fit_modes_batched(d, w, freqs, cov, nmodes=nm, alpha=3.0)
+    assert np.isfinite(amps).all() and not amps[2].any()
+    for b in (0, 1, 3):
+        _, cf = dpss_ref.dpss_fit_closed_form(d[b], w[b], freqs, cov, nmodes=nm, alpha=3.0)
+        assert np.max(np.abs(amps[b] - cf)) < 1e-9 * np.max(np.abs(cf))
+    pr = dpss.DpssProjector(nb, 1, freqs, cov, nmodes=nm, alpha=3.0)
+    pr.fit(d[:, None, :], w)
+    assert list(pr.singular_groups()) == [2]

@@ -74,3 +74,18 @@ def test_pertime_through_the_reference_call_surface():
     with pytest.raises(ValueError):
         pspec.gibbs_sample_with_fg_batched(d["vis"], flt, d["fgmodes"], nt, d["ps_prior"], ps_initial=d["ps0"],
                                            Niter=2, seed=1, solver="flat")
+
+
+def test_pertime_noise_with_time_independent_flags():
+    """Per-time inverse noise variances (Nbl, Ntimes, Nfreqs) together with time-INDEPENDENT flags (Nbl, Nfreqs):
+    the flags are used at every time (same chain as the explicitly broadcast flags); a shape that matches neither
+    form is a ValueError, not a bare assert."""
+    from hydra_pspec_amd import pspec
+    nbl, T, N, M = 2, 8, 64, 6
+    d, flt, nt = _pertime_inputs(nbl, T, N, M, seed=3, frac_time=0.0)
+    kw = dict(ps_initial=d["ps0"], Niter=3, seed=2)
+    a = pspec.gibbs_sample_with_fg_batched(d["vis"], d["flags"], d["fgmodes"], nt, d["ps_prior"], **kw)
+    b = pspec.gibbs_sample_with_fg_batched(d["vis"], flt, d["fgmodes"], nt, d["ps_prior"], **kw)
+    assert np.array_equal(a["signal_ps"], b["signal_ps"]) and np.array_equal(a["ln_post"], b["ln_post"])
+    with pytest.raises(ValueError):
+        pspec.GibbsBatch(d["vis"], d["flags"], d["fgmodes"], nt[:, :4], d["ps_prior"], 2, seed=1)

@@ -185,3 +185,14 @@ def test_dense_noise_detection_rules():
     assert pspec._ninv_dense(np.ones((3, N)), 3, N) is None                      # a stack of diagonals
     root = pspec.sqrtm_hermitian(herm)
     assert np.allclose(root @ root, herm, atol=1e-14) and np.allclose(root, root.conj().T)
+    # inv() of an ill-conditioned covariance (cond ~ 1e4) is Hermitian only to eps * cond -- what the reference
+    # driver passes on unsymmetrised (run-hydra-pspec.py:436): accepted, and the Hermitian part is used
+    x = np.arange(64.0)
+    cov = np.exp(-0.5 * ((x[:, None] - x[None, :]) / 4.0) ** 2) * (1 + 0j) + 1e-4 * np.eye(64)
+    cov[0, 1] += 0.01j
+    cov[1, 0] -= 0.01j
+    ni = np.linalg.inv(cov)
+    asym = np.abs(ni - ni.conj().T).max() / np.abs(ni).max()
+    assert 0 < asym < 1e-8
+    got = pspec._ninv_dense(ni, 1, 64)
+    assert got is not None and np.array_equal(got, got.conj().T) and np.allclose(got, ni, rtol=0, atol=1e-8 * np.abs(ni).max())

@@ -156,7 +156,7 @@ def test_dpss_fit(golden):
         # The reference stops where L-BFGS-B (finite-difference gradients, default
         # tolerances) stops; the closed form is the true minimiser of the same
         # quadratic: it must not be worse, and it sits within the optimiser's slack.
-        assert np.max(np.abs(amps_cf - g[f"F10_{i}_amps"])) < 1e-3 * scale
+        assert np.max(np.abs(amps_cf - g[f"F10_{i}_amps"])) < 1e-4 * scale      # the optimiser's slack: measured 1.4e-6 .. 1.9e-5
         assert _dpss_cost(amps_cf, modes, *args[:2], args[3], taper) <= \
             _dpss_cost(g[f"F10_{i}_amps"], modes, *args[:2], args[3], taper) * (1 + 1e-12)
 

@@ -4,7 +4,7 @@
 #   stats of the C3 / C5-auto / dpss / oqe benches; PMC passes (FETCH_SIZE, WRITE_SIZE, MFMA busy, L2 hits)
 #   of the C3 bench, one counter set per pass; the FETCH_SIZE calibration probe.
 # usage: tools/gpu_profile_round.sh <tag>      e.g. r02
-TAG=${1:-r02}
+TAG=${1:-r03}
 export TMPDIR=/tmp
 R=$PWD; O=$R/gpurun_out/prof; mkdir -p $O
 line() { grep -o '{"metric.*' $1 > $2; }
@@ -94,7 +94,9 @@ if sb > 0:
     out["step"] = {"bytes_per_step": sb, "baselines": 1024, "by_kernel": parts,
                    "note": "sum of (2 FETCH_SIZE + WRITE_SIZE) x 1024 over the kernels of one dense Gibbs iteration"}
 if out:
-    json.dump({"C3": out}, open(O + "/pmc_traffic.json", "w"), indent=1)
+    sys.path.insert(0, ".")
+    import bench           # (the hash of the kernel sources these counters were measured on: bench.py drops the
+    json.dump({"source_hash": bench.kernel_source_hash(), "C3": out}, open(O + "/pmc_traffic.json", "w"), indent=1)   # traffic figure for any other build)
 print("\n".join(l for l in lines if "k_factor" in l or "k_backsolve" in l or "k_shape" in l))
 PY
 head -12 $O/${TAG}_kernel_stats_c3.csv | cut -c1-160
