@@ -409,6 +409,52 @@ def bench_aux(args):
         print(json.dumps(res))
         return
 
+    if args.config == "fgmodes":
+        # leading eigenvectors of np.cov(bl_data.T) per baseline (scripts/calc-vis-cov-matrices.py:235-249)
+        from hydra_pspec_amd import fgmodes
+        nb, T, N, nm = args.nbl or 1024, 32, 512, 12
+        rng = np.random.default_rng(2)
+        nu = np.linspace(-1, 1, N)
+        basis = np.stack([np.cos(np.pi * k * nu / 2 + 0.3 * k) * np.exp(0.2j * k * nu) for k in range(16)], axis=1)
+        amps = (rng.standard_normal((nb, T, 16)) + 1j * rng.standard_normal((nb, T, 16))) * (2.0 ** -np.arange(16))
+        vis = amps @ basis.T + 0.01 * (rng.standard_normal((nb, T, N)) + 1j * rng.standard_normal((nb, T, N)))
+        d_vis = hpx.to_dev(torch, vis, torch.complex128, dev)
+        out = {}
+
+        def run():
+            out["m"], out["e"] = fgmodes.cov_eig_modes(d_vis, nm, return_evals=True, as_numpy=False)
+        for _ in range(max(W, 1)):
+            run()
+        wall, ms = timed(run, K)
+        t0 = time.perf_counter()
+        worst = 0.0
+        hm, he = out["m"][:4].cpu().numpy(), out["e"][:4].cpu().numpy()
+        for b in range(4):
+            lam, U = np.linalg.eigh(np.cov(vis[b].T))
+            lam, U = lam[::-1][:nm], U[:, ::-1][:, :nm]
+            worst = max(worst, float(np.max(np.abs(he[b] / lam - 1))),
+                        float(np.max(1 - np.abs(np.sum(U.conj() * hm[b], axis=0)))))
+        cpu_s = (time.perf_counter() - t0) / 4
+        by = nb * (16.0 * T * N + 16.0 * N * nm + 8.0 * nm)
+        res = {"metric": "foreground-mode sets (baselines) per second: leading eigenvectors of np.cov(vis.T), "
+                         "Ntimes 32, Nfreq 512, 12 modes", "value": nb / wall, "unit": "baselines/s", "n_gpus": 1,
+               "steps": K, "warmup": W, "ms_per_step": wall * 1e3, "higher_is_better": True, "scaling": "weak",
+               "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+               "config": {"workload": f"fgmodes: {nb} baselines x (Ntimes {T}, Nfreq {N}), {nm} modes through the "
+                                      "Ntimes x Ntimes Gram matrix (hpx_fgmodes_eig: centring, Gram matrix, cyclic "
+                                      "Jacobi, mode reconstruction); includes the allocation of its workspace"},
+               "roofline": {"kernel": "hpx_fgmodes_eig (k_center + k_gram + k_jacobi + k_modes_out)", "bound": "hbm",
+                            "achieved": by / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                            "frac": by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": ms,
+                            "bytes_per_unit": by / nb, "units_per_launch": nb,
+                            "note": "algorithmic bytes = the visibility cube in, the modes and eigenvalues out"},
+               "cpu_baseline": {"value": 1.0 / cpu_s, "unit": "baselines/s", "cores": os.cpu_count(), "kind": "port",
+                                "sample": "np.cov + np.linalg.eigh (the reference script's own calls, default BLAS "
+                                          "threads) on 4 baselines, incl. the comparison"},
+               "max_rel_dev_vs_cpu": worst}
+        print(json.dumps(res))
+        return
+
     # ---- oqe
     nb, s = args.nbl or 64, 512
     # Hermitian, diagonally dominant weightings (input synthesis only: element-wise, no library GEMM anywhere)
@@ -454,7 +500,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--config", default="C3", choices=sorted(CONFIGS) + ["dpss", "oqe"])
+    ap.add_argument("--config", default="C3", choices=sorted(CONFIGS) + ["dpss", "oqe", "fgmodes"])
     ap.add_argument("--nbl", type=int, default=None, help="baselines per GPU (default: config)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-full-length", action="store_true",
@@ -471,7 +517,7 @@ def main():
         sys.exit(spawn_ranks(args, sys.argv[1:]))
     if args.dry_run:
         return dry_run(args)
-    if args.config in ("dpss", "oqe"):
+    if args.config in ("dpss", "oqe", "fgmodes"):
         return bench_aux(args)
 
     rank, world, local_rank = init_ranks(args)

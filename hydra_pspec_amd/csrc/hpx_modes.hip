@@ -5,10 +5,12 @@
 // The covariance C = A A^H, A = Xc^T / sqrt(T-1) (Xc = data minus its time mean), has rank at
 // most T-1, so for T <= N its eigenvectors come from the T x T Gram matrix A^H A:
 // (lambda, v) -> u = A v / sqrt(lambda).  Either way a Hermitian n x n problem with
-// n = min(T, N) <= 256 is diagonalised per baseline by a cyclic two-sided Jacobi method with the
+// n = min(T, N) <= 1024 is diagonalised per baseline by a cyclic two-sided Jacobi method with the
 // round-robin parallel ordering: n/2 disjoint rotations per step, applied as a column phase and
 // a row phase by the whole workgroup.  One workgroup per baseline; the matrices live in global
-// memory (L2-resident, <= 1 MB per baseline).
+// memory (L2-resident up to n ~ 256, 1 MB per baseline; beyond that a step streams 32 n^2 bytes
+// through the cache hierarchy and a baseline takes O(n^3) rotations on one CU -- seconds at n = 1024,
+// measured in DESIGN.md; the usual case is the Gram path with n = Ntimes).
 #include "hpx_internal.h"
 
 namespace {
@@ -34,33 +36,59 @@ __global__ void k_center(const double* __restrict__ vis, double* __restrict__ xr
 
 // gram != 0:  G[t][t'] = sum_k conj(xc_t(k)) xc_t'(k) / (T-1)      (n = T)
 // gram == 0:  G[i][j]  = sum_t xc_t(i) conj(xc_t(j)) / (T-1)       (n = N, the covariance itself)
-__global__ void k_gram(const double* __restrict__ xr, const double* __restrict__ xi,
-                       double* __restrict__ gr, double* __restrict__ gi, const int T, const int N,
-                       const int n, const int pitch, const int gram) {
-  const int b = blockIdx.y;
+// One workgroup per 32 x 32 tile of G: the two 32-row operand tiles go through LDS in chunks of 32
+// along the reduction index (coalesced along the contiguous index of the cube either way), every
+// thread accumulates four entries.
+__global__ __launch_bounds__(256) void k_gram(const double* __restrict__ xr, const double* __restrict__ xi,
+                                              double* __restrict__ gr, double* __restrict__ gi, const int T,
+                                              const int N, const int n, const int pitch, const int gram) {
+  __shared__ double Ar[32][33], Ai[32][33], Br[32][33], Bi[32][33];     // [row of G][reduction index]
+  const int b = blockIdx.z, i0 = blockIdx.y * 32, j0 = blockIdx.x * 32, tid = threadIdx.x;
   const double* ar = xr + (long)b * T * N;
   const double* ai = xi + (long)b * T * N;
-  const double sc = 1.0 / (double)(T - 1);
-  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < n * n; e += gridDim.x * blockDim.x) {
-    const int i = e / n, j = e % n;
-    double sr = 0.0, si = 0.0;
-    if (gram) {
-      for (int k = 0; k < N; ++k) {
-        const double pr = ar[(long)i * N + k], pi = ai[(long)i * N + k];
-        const double qr = ar[(long)j * N + k], qi = ai[(long)j * N + k];
-        sr += pr * qr + pi * qi;        // conj(p) q
-        si += pr * qi - pi * qr;
-      }
-    } else {
-      for (int t = 0; t < T; ++t) {
-        const double pr = ar[(long)t * N + i], pi = ai[(long)t * N + i];
-        const double qr = ar[(long)t * N + j], qi = ai[(long)t * N + j];
-        sr += pr * qr + pi * qi;        // p conj(q)
-        si += pi * qr - pr * qi;
+  const int nred = gram ? N : T;
+  const int tj = tid & 31, ti = tid >> 5;            // entries (i0 + ti + 8 m, j0 + tj), m = 0..3
+  double sr[4] = {0., 0., 0., 0.}, si[4] = {0., 0., 0., 0.};
+  for (int k0 = 0; k0 < nred; k0 += 32) {
+    // gram: element (row r, reduction k) is X[r][k] (contiguous in k); otherwise X[k][r] (contiguous in r)
+    for (int e = tid; e < 32 * 32; e += 256) {
+      const int fast = e & 31, slow = e >> 5;
+      const int r = gram ? slow : fast, k = gram ? fast : slow;
+      const bool okk = k0 + k < nred;
+      const long oa = gram ? (long)(i0 + r) * N + k0 + k : (long)(k0 + k) * N + i0 + r;
+      const long ob = gram ? (long)(j0 + r) * N + k0 + k : (long)(k0 + k) * N + j0 + r;
+      const bool oka = okk && i0 + r < n, okb = okk && j0 + r < n;
+      Ar[r][k] = oka ? ar[oa] : 0.0;
+      Ai[r][k] = oka ? ai[oa] : 0.0;
+      Br[r][k] = okb ? ar[ob] : 0.0;
+      Bi[r][k] = okb ? ai[ob] : 0.0;
+    }
+    __syncthreads();
+#pragma unroll 8
+    for (int k = 0; k < 32; ++k) {
+      const double qr = Br[tj][k], qi = Bi[tj][k];
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        const double pr = Ar[ti + 8 * m][k], pi = Ai[ti + 8 * m][k];
+        if (gram) {                                   // conj(p) q
+          sr[m] += pr * qr + pi * qi;
+          si[m] += pr * qi - pi * qr;
+        } else {                                      // p conj(q)
+          sr[m] += pr * qr + pi * qi;
+          si[m] += pi * qr - pr * qi;
+        }
       }
     }
-    gr[(long)b * pitch * pitch + (long)i * pitch + j] = sr * sc;      // order n inside a pitch x pitch slot
-    gi[(long)b * pitch * pitch + (long)i * pitch + j] = si * sc;
+    __syncthreads();
+  }
+  const double sc = 1.0 / (double)(T - 1);
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+    const int i = i0 + ti + 8 * m, j = j0 + tj;
+    if (i < n && j < n) {                             // order n inside a pitch x pitch slot
+      gr[(long)b * pitch * pitch + (long)i * pitch + j] = sr[m] * sc;
+      gi[(long)b * pitch * pitch + (long)i * pitch + j] = si[m] * sc;
+    }
   }
 }
 
@@ -187,7 +215,7 @@ __global__ __launch_bounds__(256) void k_modes_out(const double* __restrict__ gr
                                                    const int n, const int nreal, const int nm,
                                                    const int gram) {
   extern __shared__ double sh[];               // lam[n], then u_re[N], u_im[N]
-  __shared__ int order[256];
+  __shared__ int order[256];                   // (nm <= 256)
   __shared__ double red[4];
   __shared__ int redi[4];
   const int b = blockIdx.x, tid = threadIdx.x;
@@ -196,7 +224,7 @@ __global__ __launch_bounds__(256) void k_modes_out(const double* __restrict__ gr
   double* ui = ur + N;
   for (int i = tid; i < n; i += 256) lam[i] = (i < nreal) ? gr[(long)b * n * n + (long)i * n + i] : -INFINITY;
   __syncthreads();
-  if (tid == 0) {                              // selection of the nm largest (n <= 256: trivial)
+  if (tid == 0) {                              // selection of the nm largest (nm n compares: trivial)
     for (int m = 0; m < nm; ++m) {
       int best = 0;
       for (int i = 1; i < n; ++i)
@@ -274,7 +302,7 @@ extern "C" int hpx_fgmodes_eig(int nb, int T, int N, int nmodes, const double* v
   HPX_REQUIRE(nb > 0 && T > 1 && N > 0 && vis && modes && evals, "hpx_fgmodes_eig: bad argument");
   const int gram = (T <= N) ? 1 : 0;
   const int nreal = gram ? T : N;
-  HPX_REQUIRE(nreal <= 256, "hpx_fgmodes_eig: min(Ntimes, Nfreqs) must be <= 256");
+  HPX_REQUIRE(nreal <= 1024, "hpx_fgmodes_eig: min(Ntimes, Nfreqs) must be <= 1024");
   HPX_REQUIRE(nmodes > 0 && nmodes <= nreal && nmodes <= 256, "hpx_fgmodes_eig: bad number of modes");
   const int n = nreal + (nreal & 1);           // even order for the round-robin pairing
   hipStream_t st = (hipStream_t)stream;
@@ -286,8 +314,8 @@ extern "C" int hpx_fgmodes_eig(int nb, int T, int N, int nmodes, const double* v
   HPX_HIP(hipMemsetAsync(gbuf.p, 0, (size_t)4 * nb * n * n * sizeof(double), st));
   hipLaunchKernelGGL(k_center, dim3((N + 255) / 256, nb), dim3(256), 0, st, vis, xr, xi, T, N);
   // an odd order is padded with an isolated zero row / column (never rotated, never selected)
-  hipLaunchKernelGGL(k_gram, dim3((nreal * nreal + 255) / 256, nb), dim3(256), 0, st, xr, xi, gr, gi, T, N, nreal, n,
-                     gram);
+  hipLaunchKernelGGL(k_gram, dim3((nreal + 31) / 32, (nreal + 31) / 32, nb), dim3(256), 0, st, xr, xi, gr, gi, T, N,
+                     nreal, n, gram);
   HPX_HIP(hipGetLastError());
   hipLaunchKernelGGL(k_jacobi, dim3(nb), dim3(256), (size_t)(n / 2) * 4 * sizeof(double), st, gr, gi, vr, vi, n, 30);
   hipLaunchKernelGGL(k_modes_out, dim3(nb), dim3(256), (size_t)(n + 2 * N) * sizeof(double), st, gr, vr, vi, xr, xi,

@@ -22,8 +22,8 @@ def cov_eig_modes(vis, nmodes, return_evals=False, as_numpy=True):
     if single:
         vis = vis[None]
     nbl, T, N = tuple(vis.shape)
-    if min(T, N) > 256:
-        raise NotImplementedError("cov_eig_modes needs min(Ntimes, Nfreqs) <= 256")
+    if min(T, N) > 1024:
+        raise NotImplementedError("cov_eig_modes needs min(Ntimes, Nfreqs) <= 1024")
     if not 0 < nmodes <= min(T - 1, N):
         raise ValueError("nmodes must be between 1 and min(Ntimes - 1, Nfreqs) (the rank of the covariance)")
     dev = torch.device("cuda", torch.cuda.current_device())

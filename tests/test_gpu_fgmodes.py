@@ -7,22 +7,22 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-def _fg_like(rng, nbl, T, N, nstrong=5):
+def _fg_like(rng, nbl, T, N, nstrong=5, base=10.0):
     """Smooth-spectrum 'foregrounds' with a steep eigenvalue spectrum plus a little noise."""
     nu = np.linspace(-1, 1, N)
     basis = np.stack([np.cos(np.pi * k * nu / 2 + 0.3 * k) * np.exp(0.2j * k * nu) for k in range(nstrong)], axis=1)
     amps = (rng.standard_normal((nbl, T, nstrong)) + 1j * rng.standard_normal((nbl, T, nstrong))) \
-        * (10.0 ** -np.arange(nstrong))[None, None, :] * 100
+        * (base ** -np.arange(nstrong))[None, None, :] * 100
     noise = 1e-6 * (rng.standard_normal((nbl, T, N)) + 1j * rng.standard_normal((nbl, T, N)))
     return amps @ basis.T + 3.0 + noise                 # + a constant that np.cov removes
 
 
 @pytest.mark.parametrize("nbl,T,N,nm", [(3, 32, 96, 4), (2, 40, 24, 4), (2, 31, 64, 3), (1, 60, 25, 5),
-                                        (2, 203, 120, 4)])
+                                        (2, 203, 120, 4), (2, 32, 512, 12), (1, 300, 320, 4), (1, 330, 300, 3)])
 def test_cov_eig_modes_vs_numpy(nbl, T, N, nm):
     from hydra_pspec_amd import fgmodes
     rng = np.random.default_rng(100 * T + N)
-    vis = _fg_like(rng, nbl, T, N)
+    vis = _fg_like(rng, nbl, T, N) if nm <= 5 else _fg_like(rng, nbl, T, N, nstrong=nm + 2, base=2.0)
     modes, evals = fgmodes.cov_eig_modes(vis, nm, return_evals=True)
     assert modes.shape == (nbl, N, nm) and evals.shape == (nbl, nm)
     for b in range(nbl):
@@ -51,7 +51,7 @@ def test_cov_eig_modes_single_baseline_and_errors():
     with pytest.raises(ValueError):
         fgmodes.cov_eig_modes(vis, 16)                   # rank of the covariance is Ntimes - 1
     with pytest.raises(NotImplementedError):
-        fgmodes.cov_eig_modes(np.zeros((1, 300, 400), complex), 2)
+        fgmodes.cov_eig_modes(np.zeros((1, 1030, 1040), complex), 2)
 
 
 def test_modes_drive_the_sampler():
