@@ -75,7 +75,10 @@ __global__ void k_prep(const double* __restrict__ vis, const uint8_t* __restrict
                        double* __restrict__ Zre, double* __restrict__ Zim,
                        double* __restrict__ Dre, double* __restrict__ Dim,
                        double* __restrict__ ni_out, const int T, const int N, const int M,
-                       const int NP, const int TP, const int MP, const int ncol, const int omega_mod) {
+                       const int NP, const int TP, const int MP, const int ncol, const int omega_mod,
+                       const int mask_data_only) {
+  // mask_data_only: the flags mask the data columns only (dense noise with flags: the matrix blocks are
+  // those of the unflagged noise, the mask comes in through the Woodbury correction)
   const int b = blockIdx.y;
   const int tom = omega_mod > 0 ? b % omega_mod : 0;      // per-time units: the draws of "their" time
   const long tot = (long)NP * ncol;
@@ -86,7 +89,7 @@ __global__ void k_prep(const double* __restrict__ vis, const uint8_t* __restrict
     double zr = 0.0, zi = 0.0;
     if (j < N) {
       const double w = flags[(long)b * N + j] ? 1.0 : 0.0;
-      const double ni = ninv[(long)b * N + j] * w;
+      const double ni = ninv[(long)b * N + j] * ((mask_data_only && col >= TP) ? 1.0 : w);
       if (col < TP) {
         const int t = col;
         double dr = 0.0, di = 0.0;
@@ -94,8 +97,8 @@ __global__ void k_prep(const double* __restrict__ vis, const uint8_t* __restrict
           const long o = (((long)b * T + t) * N + j) * 2;
           dr = vis[o] * w;
           di = vis[o + 1] * w;
-          zr = ni * dr;
-          zi = ni * di;
+          zr = ninv[(long)b * N + j] * dr;
+          zi = ninv[(long)b * N + j] * di;
           if (omega) {
             const double nih = sqrt(ni);
             zr += nih * (omega[((long)(t + tom) * 4 + 2) * N + j] / SQRT2);
@@ -457,8 +460,9 @@ struct ResArgs {
   int nbl, npart;                       // fused kernel: batch size, column groups per baseline
   const uint8_t* flags_t;               // k_resid, per-time mode: [nbl][T][N] flags and inverse noise
   const double* ninv_t;                 // variances (NULL: the time-independent ones above)
-  int resid_to_g;                       // k_resid: write the residual d - model to G (dense noise: the
-                                        // quadratic form r^H Ninv r is taken afterwards; needs !any_flags)
+  double *Rdre, *Rdim;                  // k_resid: where the masked residual w (d - model) goes, or NULL (dense
+                                        // noise: the quadratic form r^H Ninv r over the unflagged channels is
+                                        // taken afterwards).  May be G itself when there are no flags.
 };
 
 __global__ __launch_bounds__(256) void k_resid(const ResArgs A) {
@@ -493,7 +497,7 @@ __global__ __launch_bounds__(256) void k_resid(const ResArgs A) {
     const long o = (long)x * TP + t;
     // beta partial: |z_xt|^2 summed over 16 consecutive times
     double v = 0.0;
-    if (in) {
+    if (in && t < T) {          // (columns >= T are padding, or the Woodbury columns of the dense-noise-with-flags mode)
       const double yr = xre[o], yi = xim[o];
       v = yr * yr + yi * yi;
     }
@@ -504,7 +508,8 @@ __global__ __launch_bounds__(256) void k_resid(const ResArgs A) {
     if (in && (t & 15) == 0) part[x * TG + (t >> 4)] = v;
     if (!in) continue;
     if (t >= T) {
-      if (A.any_flags || A.resid_to_g) { A.Gre[(long)b * A.NP * TP + o] = 0.0; A.Gim[(long)b * A.NP * TP + o] = 0.0; }
+      if (A.any_flags) { A.Gre[(long)b * A.NP * TP + o] = 0.0; A.Gim[(long)b * A.NP * TP + o] = 0.0; }
+      if (A.Rdre) { A.Rdre[(long)b * A.NP * TP + o] = 0.0; A.Rdim[(long)b * A.NP * TP + o] = 0.0; }
       continue;
     }
     const double sr = sre[o], si = sim[o];
@@ -523,9 +528,10 @@ __global__ __launch_bounds__(256) void k_resid(const ResArgs A) {
     if (A.any_flags) {
       A.Gre[(long)b * A.NP * TP + o] = w * sr;
       A.Gim[(long)b * A.NP * TP + o] = w * si;
-    } else if (A.resid_to_g) {
-      A.Gre[(long)b * A.NP * TP + o] = rr;
-      A.Gim[(long)b * A.NP * TP + o] = ri;
+    }
+    if (A.Rdre) {
+      A.Rdre[(long)b * A.NP * TP + o] = w * rr;
+      A.Rdim[(long)b * A.NP * TP + o] = w * ri;
     }
     if (A.cr_out) {
       double* q = A.cr_out + (long)b * A.cr_bstride + ((long)t * N + x) * 2;
@@ -1170,18 +1176,24 @@ int dev_alloc(hpx_plan* p, Tp** ptr, size_t count) {
 }  // namespace
 
 // ---------------------------------------------------------------------------
-static int plan_create_impl(hpx_plan** out, int nbl, int T, int N, int M);
+static int plan_create_impl(hpx_plan** out, int nbl, int T, int N, int M, int extra_rhs);
 extern "C" int hpx_plan_create(hpx_plan** out, int nbl, int T, int N, int M) {
   HPX_REQUIRE(out, "hpx_plan_create: null out");
   HPX_REQUIRE(nbl > 0 && T > 1 && N > 0 && M >= 0, "hpx_plan_create: need nbl>0, T>1, N>0, M>=0");
-  return plan_create_impl(out, nbl, T, N, M);
+  return plan_create_impl(out, nbl, T, N, M, 0);
 }
-static int plan_create_impl(hpx_plan** out, int nbl, int T, int N, int M) {
+extern "C" int hpx_plan_create_ex(hpx_plan** out, int nbl, int T, int N, int M, int extra_rhs) {
+  HPX_REQUIRE(out, "hpx_plan_create_ex: null out");
+  HPX_REQUIRE(nbl > 0 && T > 1 && N > 0 && M >= 0 && extra_rhs >= 0 && extra_rhs <= N,
+              "hpx_plan_create_ex: need nbl>0, T>1, N>0, M>=0, 0 <= extra_rhs <= N");
+  return plan_create_impl(out, nbl, T, N, M, extra_rhs);
+}
+static int plan_create_impl(hpx_plan** out, int nbl, int T, int N, int M, int extra_rhs) {
   hpx_plan* p = new hpx_plan();
   p->nbl = nbl; p->T = T; p->N = N; p->M = M;
   p->n = N + M;
   p->npad = ceil16(p->n);
-  p->TP = ceil16(T);
+  p->TP = ceil16(T + extra_rhs);      // right-hand-side columns: the times (+ one per flagged channel, dense noise)
   p->ld = p->npad + p->TP;
   p->NP = ceil16(N);
   p->MP = ceil16(M > 0 ? M : 1);
@@ -1255,12 +1267,23 @@ extern "C" int hpx_plan_dims(const hpx_plan* p, int* npad, int* tpad, int* ld) {
 }
 
 static hpx_gen_batch gen_of(const hpx_plan* p);
+// dense noise with flags (hpx_plan_set_static_dense_flagged): unit vectors of the flagged channels into the
+// padded time columns T .. T+f-1 of the operand block, so that Z = Ninv [d | e_j ..] carries the Woodbury
+// vectors P = B^H Ninv E through the same transforms as the data (their omega / P2 parts stay zero)
+__global__ void k_wb_inject(double* __restrict__ Rre, const int32_t* __restrict__ flist,
+                            const int32_t* __restrict__ fcount, const int fmax, const int T, const int NP,
+                            const int ncol) {
+  const int b = blockIdx.x;
+  for (int kf = threadIdx.x; kf < fcount[b]; kf += blockDim.x)
+    Rre[((long)b * NP + flist[(long)b * fmax + kf]) * ncol + T + kf] = 1.0;
+}
+
 static int set_static_impl(hpx_plan* p, const double* vis, const uint8_t* flags,
                            const double* ninv, const double* ninv_dense, const double* nih_dense,
                            int noise_shared, const double* fgmodes, int fg_shared,
                            const int32_t* prior_map, const double* xgrid, int nxrows,
                            int prior_shared, int ngrid, const double* omega,
-                           const double* fop, int any_flags, void* stream) {
+                           const double* fop, int any_flags, void* stream, int wb = 0) {
   HPX_REQUIRE(p && vis && flags && (ninv || ninv_dense) && fop && prior_map, "hpx_plan_set_static: null argument");
   HPX_REQUIRE(p->M == 0 || fgmodes, "hpx_plan_set_static: fgmodes required when M > 0");
   HPX_REQUIRE(nxrows == 0 || (xgrid && ngrid >= 2 && ngrid <= 8192),
@@ -1274,12 +1297,40 @@ static int set_static_impl(hpx_plan* p, const double* vis, const uint8_t* flags,
   p->ngrid = ngrid;
   p->nxrows = nxrows;
   HPX_HIP(hipMemcpyAsync(p->flags, flags, (size_t)nbl * N, hipMemcpyDeviceToDevice, st));
-  p->dense_noise = ninv_dense ? 1 : 0;
+  p->dense_noise = ninv_dense ? (wb ? 2 : 1) : 0;
   hpx_devbuf ones, tmp;                    // dense noise only
   if (ninv_dense) {
-    HPX_REQUIRE(nih_dense && !any_flags,
+    HPX_REQUIRE(nih_dense && (!any_flags || wb),
                 "hpx_plan_set_static_dense: needs sqrtm(Ninv) and unflagged data (the reference's column-masked "
-                "Ni = Ninv diag(w) is not Hermitian, pspec.py:361)");
+                "Ni = Ninv diag(w) is not Hermitian, pspec.py:361: hpx_plan_set_static_dense_flagged)");
+    if (wb) {      // flagged channels per baseline (host lists), correction systems, masked residual
+      std::vector<uint8_t> hf((size_t)nbl * N);
+      HPX_HIP(hipMemcpyAsync(hf.data(), flags, hf.size(), hipMemcpyDeviceToHost, st));
+      HPX_HIP(hipStreamSynchronize(st));
+      std::vector<int32_t> cnt(nbl, 0);
+      int fmax = 0;
+      for (int b = 0; b < nbl; ++b) {
+        for (int j = 0; j < N; ++j) cnt[b] += hf[(size_t)b * N + j] ? 0 : 1;
+        fmax = std::max(fmax, cnt[b]);
+      }
+      HPX_REQUIRE(T + fmax <= TP, "hpx_plan_set_static_dense_flagged: the plan has too few right-hand-side columns "
+                                  "(hpx_plan_create_ex with extra_rhs >= the largest number of flagged channels)");
+      HPX_REQUIRE(fmax <= 512, "hpx_plan_set_static_dense_flagged: at most 512 flagged channels per baseline");
+      p->wb_fmax = fmax > 0 ? fmax : 1;
+      std::vector<int32_t> list((size_t)nbl * p->wb_fmax, 0);
+      for (int b = 0; b < nbl; ++b) {
+        int k = 0;
+        for (int j = 0; j < N; ++j)
+          if (!hf[(size_t)b * N + j]) list[(size_t)b * p->wb_fmax + k++] = j;
+      }
+      HPX_TRY(dev_alloc(p, &p->wb_flist, list.size()));
+      HPX_TRY(dev_alloc(p, &p->wb_fcount, (size_t)nbl));
+      HPX_TRY(dev_alloc(p, &p->wb_W, (size_t)nbl * p->wb_fmax * (p->wb_fmax + T) * 2));
+      HPX_TRY(dev_alloc(p, &p->RDre, (size_t)nbl * NP * TP));
+      HPX_TRY(dev_alloc(p, &p->RDim, (size_t)nbl * NP * TP));
+      HPX_HIP(hipMemcpy(p->wb_flist, list.data(), list.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+      HPX_HIP(hipMemcpy(p->wb_fcount, cnt.data(), cnt.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    }
     const size_t msz = (size_t)nbl * NP * NP;
     HPX_TRY(dev_alloc(p, &p->NIre, msz)); HPX_TRY(dev_alloc(p, &p->NIim, msz));
     HPX_TRY(dev_alloc(p, &p->CDre, msz)); HPX_TRY(dev_alloc(p, &p->CDim, msz));
@@ -1310,7 +1361,7 @@ static int set_static_impl(hpx_plan* p, const double* vis, const uint8_t* flags,
   const double isn = 1.0 / sqrt((double)N);
   if (!ninv_dense) {
     hipLaunchKernelGGL(k_prep, dim3(128, nbl), dim3(256), 0, st, vis, flags, ninv, fgp, p->fg_shared,
-                       omega, p->Zre, p->Zim, p->Dre, p->Dim, p->ni, T, N, M, NP, TP, MP, p->ncolR, p->omega_mod);
+                       omega, p->Zre, p->Zim, p->Dre, p->Dim, p->ni, T, N, M, NP, TP, MP, p->ncolR, p->omega_mod, 0);
     HPX_HIP(hipGetLastError());
   } else {
     // Z = Ninv [d | F | .] + Ninv^1/2 [omega_b | 0]: the operand block with unit weights (into R as
@@ -1318,15 +1369,24 @@ static int set_static_impl(hpx_plan* p, const double* vis, const uint8_t* flags,
     // buffer[k][x] = conj(W[x][k]), hence conjW = 1)
     const long mstr = (long)NP * NP, zstr = (long)NP * p->ncolR;
     hipLaunchKernelGGL(k_prep, dim3(128, nbl), dim3(256), 0, st, vis, flags, ones.p, fgp, p->fg_shared,
-                       (const double*)nullptr, p->Rre, p->Rim, p->Dre, p->Dim, p->ni, T, N, M, NP, TP, MP, p->ncolR, 0);
+                       (const double*)nullptr, p->Rre, p->Rim, p->Dre, p->Dim, p->ni, T, N, M, NP, TP, MP, p->ncolR, 0,
+                       wb);
+    if (wb) hipLaunchKernelGGL(k_wb_inject, dim3(nbl), dim3(256), 0, st, p->Rre, p->wb_flist, p->wb_fcount,
+                               p->wb_fmax, T, NP, p->ncolR);
     HPX_HIP(hipGetLastError());
     HPX_TRY(hpx_launch_dft(nbl, NP, p->ncolR, p->NIre, p->NIim, 1, p->Rre, p->Rim, zstr, p->ncolR, nullptr, 0,
                            p->Zre, p->Zim, zstr, p->ncolR, 1.0, st, 0, mstr));
     hipLaunchKernelGGL(k_take_diag, dim3(4, nbl), dim3(256), 0, st, p->NIre, p->ni, N, NP);
     if (omega) {
       const size_t msz = (size_t)nbl * NP * NP, osz = (size_t)nbl * NP * TP;
-      HPX_TRY(tmp.alloc(2 * msz + 4 * osz));
+      HPX_TRY(tmp.alloc((wb ? 4 : 2) * msz + 4 * osz));
       double *hre = tmp.p, *him = hre + msz, *ore = him + msz, *oim = ore + osz, *ure = oim + osz, *uim = ure + osz;
+      if (wb) {     // sqrtm of the column-masked Ni is a general matrix: the product below (conjW = 1) wants its
+                    // conjugate transpose stored; one matrix per baseline
+        double *gre = uim + osz, *gim = gre + msz;
+        hipLaunchKernelGGL(k_dense_planar, dim3(64, nbl), dim3(256), 0, st, nih_dense, 0, gre, gim, N, NP);
+        hipLaunchKernelGGL(k_conj_transpose, dim3(64, nbl), dim3(256), 0, st, gre, gim, hre, him, NP);
+      } else
       hipLaunchKernelGGL(k_dense_planar, dim3(64, nbl), dim3(256), 0, st, nih_dense, noise_shared, hre, him, N, NP);
       hipLaunchKernelGGL(k_prep_omega_b, dim3(32, nbl), dim3(256), 0, st, omega, ore, oim, T, N, NP, TP);
       HPX_HIP(hipGetLastError());
@@ -1414,6 +1474,17 @@ extern "C" int hpx_plan_set_static_dense(hpx_plan* p, const double* vis, const u
   HPX_REQUIRE(ninv_dense && nih_dense, "hpx_plan_set_static_dense: null noise matrices");
   return set_static_impl(p, vis, flags, nullptr, ninv_dense, nih_dense, noise_shared, fgmodes, fg_shared, prior_map,
                          xgrid, nxrows, prior_shared, ngrid, omega, fop, any_flags, stream);
+}
+
+extern "C" int hpx_plan_set_static_dense_flagged(hpx_plan* p, const double* vis, const uint8_t* flags,
+                                                 const double* ninv_dense, int noise_shared,
+                                                 const double* nih_masked, const double* fgmodes, int fg_shared,
+                                                 const int32_t* prior_map, const double* xgrid, int nxrows,
+                                                 int prior_shared, int ngrid, const double* omega, const double* fop,
+                                                 void* stream) {
+  HPX_REQUIRE(ninv_dense && nih_masked, "hpx_plan_set_static_dense_flagged: null noise matrices");
+  return set_static_impl(p, vis, flags, nullptr, ninv_dense, nih_masked, noise_shared, fgmodes, fg_shared, prior_map,
+                         xgrid, nxrows, prior_shared, ngrid, omega, fop, 1, stream, 1);
 }
 
 extern "C" int hpx_plan_set_rng(hpx_plan* p, const double* uniforms, const double* igy, int niter,
@@ -1509,7 +1580,7 @@ static int set_static_impl(hpx_plan* p, const double* vis, const uint8_t* flags,
                            int noise_shared, const double* fgmodes, int fg_shared,
                            const int32_t* prior_map, const double* xgrid, int nxrows,
                            int prior_shared, int ngrid, const double* omega,
-                           const double* fop, int any_flags, void* stream);
+                           const double* fop, int any_flags, void* stream, int wb);
 
 extern "C" int hpx_plan_set_static_pertime(hpx_plan* p, const double* vis, const uint8_t* flags_t,
                                            const double* ninv_t, const double* fgmodes, int fg_shared,
@@ -1538,7 +1609,7 @@ extern "C" int hpx_plan_set_static_pertime(hpx_plan* p, const double* vis, const
   HPX_HIP(hipGetLastError());
   // 3. the child: nbl*T units of one time sample each
   if (p->child) { hpx_plan_destroy(p->child); p->child = nullptr; }
-  HPX_TRY(plan_create_impl(&p->child, nbl * T, 1, N, M));
+  HPX_TRY(plan_create_impl(&p->child, nbl * T, 1, N, M, 0));
   hpx_plan* c = p->child;
   c->omega_mod = T;
   hpx_devbuf fgx;
@@ -1792,6 +1863,155 @@ static int mark(hpx_plan* p, hipStream_t st) {
 }
 
 // Everything after the solve of one iteration: back transform, residual / chi^2 / first
+// ---- dense noise with flags: Woodbury correction of the unflagged-noise solution -----------------
+// (hpx.h, hpx_plan_set_static_dense_flagged).  W[b] is the f x (f + T) system [I - Q^H Y_P | Q^H Y_r],
+// row-major interleaved complex with leading dimension fmax + T, where (Q^H Y)[jf][col] is the model
+// (U y + F f)[channel flist[jf]] of solution column col; Y_P are the columns T .. T+f-1 of X.
+__global__ __launch_bounds__(256) void k_wb_system(const double* __restrict__ Sre, const double* __restrict__ Sim,
+                                                   const double* __restrict__ Xre, const double* __restrict__ Xim,
+                                                   const double* __restrict__ Fre, const double* __restrict__ Fim,
+                                                   const int fg_shared, const int32_t* __restrict__ flist,
+                                                   const int32_t* __restrict__ fcount, double* __restrict__ W_all,
+                                                   const int fmax, const int N, const int M, const int T,
+                                                   const int NP, const int TP, const int npad) {
+  const int b = blockIdx.x, f = fcount[b], ldw = fmax + T;
+  double* W = W_all + (long)b * fmax * ldw * 2;
+  const double* sre = Sre + (long)b * NP * TP;
+  const double* sim = Sim + (long)b * NP * TP;
+  const double* xre = Xre + (long)b * npad * TP;
+  const double* xim = Xim + (long)b * npad * TP;
+  const double* fre = Fre + (fg_shared ? 0 : (long)b * N * M);
+  const double* fim = Fim + (fg_shared ? 0 : (long)b * N * M);
+  for (int e = threadIdx.x; e < f * (f + T); e += 256) {
+    const int jf = e / (f + T), c = e % (f + T);
+    const int col = (c < f) ? T + c : c - f;            // solution column: Y_P first, then Y_r
+    const int j = flist[(long)b * fmax + jf];
+    double mr = sre[(long)j * TP + col], mi = sim[(long)j * TP + col];
+    for (int m = 0; m < M; ++m) {
+      const double fr = fre[(long)j * M + m], fi = fim[(long)j * M + m];
+      const double gr = xre[(long)(N + m) * TP + col], gi = xim[(long)(N + m) * TP + col];
+      mr += gr * fr - gi * fi;
+      mi += gr * fi + gi * fr;
+    }
+    double* w = W + ((long)jf * ldw + (c < f ? c : fmax + (c - f))) * 2;
+    if (c < f) {
+      w[0] = (jf == c ? 1.0 : 0.0) - mr;
+      w[1] = -mi;
+    } else {
+      w[0] = mr;
+      w[1] = mi;
+    }
+  }
+}
+// Gaussian elimination with partial pivoting on the f x (f + T) system of one baseline (global memory,
+// one workgroup), then the back substitution: the coefficients c[kf][t] end up in the right-hand-side
+// columns fmax .. fmax+T-1.  A zero pivot marks the baseline in info.
+__global__ __launch_bounds__(256) void k_wb_solve(double* __restrict__ W_all, const int32_t* __restrict__ fcount,
+                                                  const int fmax, const int T, int32_t* __restrict__ info,
+                                                  const int iter_tag) {
+  __shared__ double redv[4];
+  __shared__ int redi[4], piv_s;
+  __shared__ double lre[512], lim[512];
+  const int b = blockIdx.x, f = fcount[b], ldw = fmax + T, tid = threadIdx.x;
+  if (f == 0) return;
+  double* W = W_all + (long)b * fmax * ldw * 2;
+  const int ncol = fmax + T;                               // columns f .. fmax-1 are unused (never touched)
+  for (int k = 0; k < f; ++k) {
+    double best = -1.0;
+    int at = k;
+    for (int r = k + tid; r < f; r += 256) {
+      const double a2 = W[((long)r * ldw + k) * 2] * W[((long)r * ldw + k) * 2] +
+                        W[((long)r * ldw + k) * 2 + 1] * W[((long)r * ldw + k) * 2 + 1];
+      if (a2 > best) { best = a2; at = r; }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+      const double ob = __shfl_xor(best, o, 64);
+      const int oa = __shfl_xor(at, o, 64);
+      if (ob > best || (ob == best && oa < at)) { best = ob; at = oa; }
+    }
+    if ((tid & 63) == 0) { redv[tid >> 6] = best; redi[tid >> 6] = at; }
+    __syncthreads();
+    if (tid == 0) {
+      int w = 0;
+      for (int q = 1; q < 4; ++q)
+        if (redv[q] > redv[w] || (redv[q] == redv[w] && redi[q] < redi[w])) w = q;
+      piv_s = redi[w];
+      if (!(redv[w] > 0.0)) atomicCAS(&info[b], 0, iter_tag);
+    }
+    __syncthreads();
+    const int pv = piv_s;
+    if (pv != k)
+      for (int c = k + tid; c < ncol; c += 256) {
+        if (c >= f && c < fmax) continue;
+        double* x = W + ((long)k * ldw + c) * 2;
+        double* y = W + ((long)pv * ldw + c) * 2;
+        const double t0 = x[0], t1 = x[1];
+        x[0] = y[0]; x[1] = y[1];
+        y[0] = t0; y[1] = t1;
+      }
+    __syncthreads();
+    const double pr = W[((long)k * ldw + k) * 2], pi = W[((long)k * ldw + k) * 2 + 1];
+    const double den = 1.0 / (pr * pr + pi * pi);
+    for (int r = k + 1 + tid; r < f; r += 256) {           // multipliers l_r = W[r][k] / W[k][k]
+      const double ar = W[((long)r * ldw + k) * 2], ai = W[((long)r * ldw + k) * 2 + 1];
+      lre[r] = (ar * pr + ai * pi) * den;
+      lim[r] = (ai * pr - ar * pi) * den;
+    }
+    __syncthreads();
+    const int nc = (f - k - 1) + T, nr = f - k - 1;
+    for (int e = tid; e < nr * nc; e += 256) {
+      const int r = k + 1 + e / nc, ci = e % nc;
+      const int c = (ci < f - k - 1) ? k + 1 + ci : fmax + (ci - (f - k - 1));
+      const double ur = W[((long)k * ldw + c) * 2], ui = W[((long)k * ldw + c) * 2 + 1];
+      double* x = W + ((long)r * ldw + c) * 2;
+      x[0] -= lre[r] * ur - lim[r] * ui;
+      x[1] -= lre[r] * ui + lim[r] * ur;
+    }
+    __syncthreads();
+  }
+  // back substitution, one thread per right-hand side
+  for (int t = tid; t < T; t += 256) {
+    for (int k = f - 1; k >= 0; --k) {
+      double sr = W[((long)k * ldw + fmax + t) * 2], si = W[((long)k * ldw + fmax + t) * 2 + 1];
+      for (int q = k + 1; q < f; ++q) {
+        const double ur = W[((long)k * ldw + q) * 2], ui = W[((long)k * ldw + q) * 2 + 1];
+        const double cr = W[((long)q * ldw + fmax + t) * 2], ci = W[((long)q * ldw + fmax + t) * 2 + 1];
+        sr -= ur * cr - ui * ci;
+        si -= ur * ci + ui * cr;
+      }
+      const double pr = W[((long)k * ldw + k) * 2], pi = W[((long)k * ldw + k) * 2 + 1];
+      const double den = 1.0 / (pr * pr + pi * pi);
+      W[((long)k * ldw + fmax + t) * 2] = (sr * pr + si * pi) * den;
+      W[((long)k * ldw + fmax + t) * 2 + 1] = (si * pr - sr * pi) * den;
+    }
+  }
+}
+// X[:, t] += sum_kf X[:, T + kf] c[kf][t]  for the solution rows (npad) and the signal realisation S (N rows)
+__global__ __launch_bounds__(256) void k_wb_correct(double* __restrict__ Sre, double* __restrict__ Sim,
+                                                    double* __restrict__ Xre, double* __restrict__ Xim,
+                                                    const double* __restrict__ W_all,
+                                                    const int32_t* __restrict__ fcount, const int fmax, const int T,
+                                                    const int NP, const int TP, const int npad) {
+  const int b = blockIdx.y, f = fcount[b], ldw = fmax + T;
+  if (f == 0) return;
+  const double* W = W_all + (long)b * fmax * ldw * 2;
+  const int nrow = npad + NP;                              // rows of X, then rows of S
+  for (int e = blockIdx.x * 256 + threadIdx.x; e < nrow * T; e += gridDim.x * 256) {
+    const int r = e / T, t = e % T;
+    double* pr = (r < npad) ? Xre + ((long)b * npad + r) * TP : Sre + ((long)b * NP + (r - npad)) * TP;
+    double* pi = (r < npad) ? Xim + ((long)b * npad + r) * TP : Sim + ((long)b * NP + (r - npad)) * TP;
+    double ar = pr[t], ai = pi[t];
+    for (int kf = 0; kf < f; ++kf) {
+      const double cr = W[((long)kf * ldw + fmax + t) * 2], ci = W[((long)kf * ldw + fmax + t) * 2 + 1];
+      const double yr = pr[T + kf], yi = pi[T + kf];
+      ar += yr * cr - yi * ci;
+      ai += yr * ci + yi * cr;
+    }
+    pr[t] = ar;
+    pi[t] = ai;
+  }
+}
+
 // ln-posterior term / beta, masked transform (flags), bandpower draw.  `rs` = row scaling of
 // y' in the back transform (a = sqrt(ps/N), or NULL when X already holds s' = Sh' y').
 struct IterOut {
@@ -1819,7 +2039,9 @@ static int post_solve(hpx_plan* p, int it_abs, const IterOut& O, hipStream_t st)
   R.N = N; R.M = M; R.T = T; R.NP = NP; R.TP = TP; R.npad = p->npad;
   R.fg_shared = p->fg_shared; R.any_flags = p->any_flags;
   R.twre = p->Fopre; R.twim = p->Fopim; R.isn = isn; R.logN = 0; R.tcs = 0; R.nbl = nbl; R.npart = 1;
-  R.resid_to_g = p->dense_noise;
+  // dense noise: the masked residual for the quadratic form; it can share G unless G holds w s (flags)
+  R.Rdre = p->dense_noise ? (p->dense_noise == 2 ? p->RDre : p->Gre) : nullptr;
+  R.Rdim = p->dense_noise ? (p->dense_noise == 2 ? p->RDim : p->Gim) : nullptr;
   R.flags_t = p->per_time ? p->flags_t : nullptr;
   R.ninv_t = p->per_time ? p->ninv_t : nullptr;
   // time columns per block of the fused kernel: 64 KiB of LDS for the signal, as k_fft
@@ -1852,16 +2074,31 @@ static int post_solve(hpx_plan* p, int it_abs, const IterOut& O, hipStream_t st)
     // s = U z = conj(F) X / sqrt(N)   (rows >= N of X meet the zero padding of the operator)
     HPX_TRY(hpx_launch_dft(nbl, NP, TP, p->Fopre, p->Fopim, 1, p->Xre, p->Xim, (long)p->npad * TP,
                            TP, nullptr, 0, p->Sre, p->Sim, (long)NP * TP, TP, isn, st, N == NP));
+    if (p->dense_noise == 2) {
+      // dense noise with flags: X = [Y_r | Y_P] so far (unflagged-noise system); the Woodbury correction
+      // x = Y_r + Y_P (I - Q^H Y_P)^-1 Q^H Y_r, where Q^H Y is the model U y + F f at the flagged channels
+      const int fm = p->wb_fmax;
+      hipLaunchKernelGGL(k_wb_system, dim3(nbl), dim3(256), 0, st, p->Sre, p->Sim, p->Xre, p->Xim, p->Fre, p->Fim,
+                         p->fg_shared, p->wb_flist, p->wb_fcount, p->wb_W, fm, N, M, T, NP, TP, p->npad);
+      hipLaunchKernelGGL(k_wb_solve, dim3(nbl), dim3(256), 0, st, p->wb_W, p->wb_fcount, fm, T, p->info, it_abs + 1);
+      hipLaunchKernelGGL(k_wb_correct, dim3(8, nbl), dim3(256), 0, st, p->Sre, p->Sim, p->Xre, p->Xim, p->wb_W,
+                         p->wb_fcount, fm, T, NP, TP, p->npad);
+      HPX_HIP(hipGetLastError());
+    }
     HPX_TRY(mark(p, st));
-    hipLaunchKernelGGL(k_resid, dim3(nbl), dim3(256),
-                       (size_t)(2 * M * TP + N * (TP / 16)) * sizeof(double), st, R);
+    {
+      const size_t lds = (size_t)(2 * M * TP + N * (TP / 16)) * sizeof(double);
+      static hpx_lds_limit limit;
+      if (lds > 48 * 1024) HPX_TRY(limit.ensure(reinterpret_cast<const void*>(&k_resid), lds));
+      hipLaunchKernelGGL(k_resid, dim3(nbl), dim3(256), lds, st, R);
+    }
     HPX_HIP(hipGetLastError());
     if (p->dense_noise) {
-      // first ln-posterior term with the full matrix: sum_t r_t^H Ninv r_t  (pspec.py:472-477);
-      // k_resid left the residual in G, v = Ninv r goes to the Z scratch
-      HPX_TRY(hpx_launch_dft(nbl, NP, TP, p->NIre, p->NIim, 1, p->Gre, p->Gim, (long)NP * TP, TP, nullptr, 0,
+      // first ln-posterior term with the full matrix over the unflagged channels: sum_t (w r_t)^H Ninv (w r_t)
+      // (pspec.py:472-477); k_resid left the masked residual behind, v = Ninv (w r) goes to the Z scratch
+      HPX_TRY(hpx_launch_dft(nbl, NP, TP, p->NIre, p->NIim, 1, R.Rdre, R.Rdim, (long)NP * TP, TP, nullptr, 0,
                              p->Zre, p->Zim, (long)NP * p->ncolR, p->ncolR, 1.0, st, 0, (long)NP * NP));
-      hipLaunchKernelGGL(k_quadform, dim3(nbl), dim3(256), 0, st, p->Gre, p->Gim, (long)NP * TP, TP, p->Zre, p->Zim,
+      hipLaunchKernelGGL(k_quadform, dim3(nbl), dim3(256), 0, st, R.Rdre, R.Rdim, (long)NP * TP, TP, p->Zre, p->Zim,
                          (long)NP * p->ncolR, p->ncolR, p->lnpart, N, T);
       HPX_HIP(hipGetLastError());
     }

@@ -59,7 +59,12 @@ struct hpx_plan {
   int have_ps;  // the chain state (ps_cur, ia) holds bandpowers: a run may continue without ps0
   // dense (non-diagonal, Hermitian) inverse noise covariance (hpx_plan_set_static_dense): C = U^H Ni U
   // is a general Hermitian matrix instead of a circulant
-  int dense_noise;
+  int dense_noise;         // 1: unflagged; 2: with flags (Woodbury correction of the unflagged-noise system)
+  // dense noise with flags: flagged channels per baseline, the f x (f + T) correction systems, the masked residual
+  int wb_fmax;
+  int32_t *wb_flist, *wb_fcount;     // [nbl][wb_fmax], [nbl]
+  double *wb_W;                      // [nbl][wb_fmax][wb_fmax + T] interleaved complex
+  double *RDre, *RDim;               // [nbl][NP][TP] residual w (d - model)
   double *NIre, *NIim;     // [nbl][NP][NP] Ninv, planar row-major (zero padded)
   double *CDre, *CDim;     // [nbl][NP][NP] C = U^H Ninv U
   // time-dependent flags / noise (hpx_plan_set_static_pertime): every time sample has its own system.

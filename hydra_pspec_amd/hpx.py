@@ -28,10 +28,12 @@ SIGNATURES = {
     "hpx_device_count": (_i, []),
     "hpx_set_device": (_i, [_i]),
     "hpx_plan_create": (_i, [C.POINTER(_vp), _i, _i, _i, _i]),
+    "hpx_plan_create_ex": (_i, [C.POINTER(_vp), _i, _i, _i, _i, _i]),
     "hpx_plan_destroy": (_i, [_vp]),
     "hpx_plan_bytes": (_i64, [_vp]),
     "hpx_plan_set_static": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _i, _vp]),
     "hpx_plan_set_static_dense": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _i, _vp]),
+    "hpx_plan_set_static_dense_flagged": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
     "hpx_plan_set_static_pertime": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _i, _vp]),
     "hpx_plan_set_rng": (_i, [_vp, _vp, _vp, _i, _vp]),
     "hpx_gibbs_run": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
@@ -135,9 +137,12 @@ def to_dev(torch, x, dtype, device):
 class Plan:
     """RAII wrapper of hpx_plan (one batch of baselines on one GPU)."""
 
-    def __init__(self, nbl, T, N, M):
+    def __init__(self, nbl, T, N, M, extra_rhs=0):
         self._h = C.c_void_p()
-        check(lib().hpx_plan_create(C.byref(self._h), nbl, T, N, M), "hpx_plan_create")
+        if extra_rhs:
+            check(lib().hpx_plan_create_ex(C.byref(self._h), nbl, T, N, M, int(extra_rhs)), "hpx_plan_create_ex")
+        else:
+            check(lib().hpx_plan_create(C.byref(self._h), nbl, T, N, M), "hpx_plan_create")
         self.nbl, self.T, self.N, self.M = nbl, T, N, M
         self._keep = []
 

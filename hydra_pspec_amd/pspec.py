@@ -183,7 +183,9 @@ class GibbsBatch:
     def __init__(self, vis, flags, fgmodes, ninv_diag, ps_prior, Niter, seed=None,
                  map_estimate=False, device=None, tables=None, omega=None, solver="auto", ninv_dense=None):
         """``ninv_dense``: Hermitian non-diagonal inverse noise covariance(s) (N,N) or (Nbl,N,N) instead of
-        ``ninv_diag`` (:func:`make_batch` routes them here): dense solver only, unflagged data only."""
+        ``ninv_diag`` (:func:`make_batch` routes them here): dense solver only.  With flagged channels the
+        reference's column-masked ``Ni`` is not Hermitian (pspec.py:361): the solution then comes from the
+        unflagged-noise factorisation through a rank-f Woodbury correction (``hpx_plan_set_static_dense_flagged``)."""
         torch = hpx.require_gpu()
         self.torch = torch
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None \
@@ -214,11 +216,23 @@ class GibbsBatch:
             self.dense_noise = ninv_dense is not None
             if self.per_time and self.dense_noise:
                 raise NotImplementedError("time-dependent flags with a non-diagonal inverse noise covariance")
+            self.any_flags = bool((~fl_np.astype(bool)).any())
+            extra_rhs = 0
             if self.dense_noise:
                 nd = np.asarray(ninv_dense, dtype=complex)
                 assert nd.shape in ((N, N), (nbl, N, N)), "Ninv shape must be (Nfreqs, Nfreqs) or (Nbl, Nfreqs, Nfreqs)"
                 d_nd = hpx.to_dev(torch, nd, c128, self.device)
-                d_nh = hpx.to_dev(torch, sqrtm_hermitian(nd), c128, self.device)
+                if self.any_flags:
+                    # the reference masks the COLUMNS of Ninv (Ni = flags.T * Ninv * flags, pspec.py:361) and takes
+                    # scipy's sqrtm of that general matrix (:362): the same call, per baseline, on the host
+                    import scipy.linalg
+                    w = fl_np.astype(bool)
+                    nih = np.stack([scipy.linalg.sqrtm((nd if nd.ndim == 2 else nd[b]) * w[b][None, :])
+                                    for b in range(nbl)]).astype(complex)
+                    d_nh = hpx.to_dev(torch, nih, c128, self.device)
+                    extra_rhs = int((~w).sum(axis=1).max())        # one more right-hand side per flagged channel
+                else:
+                    d_nh = hpx.to_dev(torch, sqrtm_hermitian(nd), c128, self.device)
                 d_ninv = None
             else:
                 d_ninv = hpx.to_dev(torch, ninv_diag, f64, self.device)
@@ -243,8 +257,7 @@ class GibbsBatch:
             assert tuple(omega.shape) == (T, 4, N)
             d_omega = None if map_estimate else hpx.to_dev(torch, omega, f64, self.device)
             d_fop = hpx.to_dev(torch, utils.fourier_operator(N), c128, self.device)
-            self.any_flags = bool((~fl_np.astype(bool)).any())
-            self.plan = hpx.Plan(nbl, T, N, M)
+            self.plan = hpx.Plan(nbl, T, N, M, extra_rhs=extra_rhs)
             L = hpx.lib()
             if self.per_time:
                 # every time sample has its own flags / noise, hence its own system: Nbl x Ntimes
@@ -255,12 +268,15 @@ class GibbsBatch:
                     hpx.ptr(d_fg) if M > 0 else None, int(fg_shared), hpx.ptr(d_pmap), hpx.ptr(d_xgrid),
                     int(len(xgrid)), int(prior_shared), NGRID, hpx.ptr(d_omega), hpx.ptr(d_fop),
                     int(self.any_flags), hpx.stream_ptr(torch)), "hpx_plan_set_static_pertime")
+            elif self.dense_noise and self.any_flags:
+                # non-Hermitian in the reference (pspec.py:361 FIXME): a rank-f update of the unflagged-noise
+                # system, solved through the Woodbury identity (hpx.h)
+                hpx.check(L.hpx_plan_set_static_dense_flagged(
+                    self.plan.handle, hpx.ptr(d_vis), hpx.ptr(d_flags), hpx.ptr(d_nd), int(nd.ndim == 2),
+                    hpx.ptr(d_nh), hpx.ptr(d_fg) if M > 0 else None, int(fg_shared), hpx.ptr(d_pmap),
+                    hpx.ptr(d_xgrid), int(len(xgrid)), int(prior_shared), NGRID, hpx.ptr(d_omega), hpx.ptr(d_fop),
+                    hpx.stream_ptr(torch)), "hpx_plan_set_static_dense_flagged")
             elif self.dense_noise:
-                if self.any_flags:
-                    raise NotImplementedError(
-                        "a non-diagonal inverse noise covariance together with flagged channels is not "
-                        "supported: the reference's column-masked Ni = Ninv * flags is not Hermitian there "
-                        "(pspec.py:361 FIXME)")
                 hpx.check(L.hpx_plan_set_static_dense(
                     self.plan.handle, hpx.ptr(d_vis), hpx.ptr(d_flags), hpx.ptr(d_nd), hpx.ptr(d_nh),
                     int(nd.ndim == 2), hpx.ptr(d_fg) if M > 0 else None, int(fg_shared), hpx.ptr(d_pmap),
@@ -451,7 +467,7 @@ def gibbs_sample_with_fg_batched(vis, flags, fgmodes, Ninv, ps_prior, S_initial=
     (True = use), ``fgmodes`` (Nfreqs,Nmodes) or (Nbl,Nfreqs,Nmodes), ``Ninv``
     diagonal (Nbl,Nfreqs)/(Nfreqs,) or matrices (Nfreqs,Nfreqs)/(Nbl,Nfreqs,Nfreqs) --
     diagonal ones, or Hermitian with off-diagonal terms (a correlated noise covariance;
-    unflagged data only, dense solver) --, ``ps_prior`` (2,Nfreqs) or (Nbl,2,Nfreqs) with
+    dense solver; with flags through a Woodbury correction) --, ``ps_prior`` (2,Nfreqs) or (Nbl,2,Nfreqs) with
     rows [hi, lo].  Time-dependent flags ``(Nbl,Ntimes,Nfreqs)``, optionally with per-time
     inverse noise variances ``Ninv`` (Nbl,Ntimes,Nfreqs) or diagonal matrices
     (Ntimes,Nfreqs,Nfreqs), select the mode in which every time sample is solved with its own

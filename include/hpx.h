@@ -46,6 +46,9 @@ int hpx_set_device(int dev);
  * hydra_pspec/pspec.py:493-507 (gibbs_sample_with_fg).  Allocates every
  * workspace up front; hpx_gibbs_run allocates nothing. */
 int hpx_plan_create(hpx_plan** out, int nbl, int T, int N, int M);
+/* The same with room for `extra_rhs` more right-hand-side columns per system besides the Ntimes
+ * data columns (hpx_plan_set_static_dense_flagged carries one per flagged channel). */
+int hpx_plan_create_ex(hpx_plan** out, int nbl, int T, int N, int M, int extra_rhs);
 int hpx_plan_destroy(hpx_plan* p);
 /* bytes of device memory held by the plan */
 int64_t hpx_plan_bytes(const hpx_plan* p);
@@ -86,13 +89,32 @@ int hpx_plan_set_static(hpx_plan* p, const double* vis, const uint8_t* flags,
  * C = U^H Ninv U is then a general Hermitian matrix (not a circulant): every iteration lays the
  * whole augmented system out and factors it in place; the first ln-posterior term is the full
  * quadratic form r^H Ninv r (pspec.py:472-477), chi^2 uses Ninv.diagonal() (pspec.py:452).
- * Needs unflagged data (any_flags == 0): the reference's column-masked Ni = Ninv diag(w) is not
+ * Needs unflagged data (any_flags == 0; with flags: hpx_plan_set_static_dense_flagged below): the reference's column-masked Ni = Ninv diag(w) is not
  * Hermitian (pspec.py:361 FIXME) and is refused with HPX_EINVAL. */
 int hpx_plan_set_static_dense(hpx_plan* p, const double* vis, const uint8_t* flags,
                               const double* ninv_dense, const double* nih_dense, int noise_shared,
                               const double* fgmodes, int fg_shared, const int32_t* prior_map,
                               const double* xgrid, int nxrows, int prior_shared, int ngrid,
                               const double* omega, const double* fop, int any_flags, void* stream);
+
+/* A dense Hermitian inverse noise covariance TOGETHER WITH flagged channels.  The reference masks the
+ * COLUMNS of Ninv, Ni = flags.T * Ninv * flags = Ninv diag(w) (pspec.py:361), so its system
+ * A = [[1 + S Ni, S Ni F], [F^H Ni, F^H Ni F]] (pspec.py:365-369) is not Hermitian; it is, however, a rank-f
+ * update of the Hermitian one (f = number of flagged channels): with B = [U F], E the unit vectors of the
+ * flagged channels,  B^H Ni B = B^H Ninv B - (B^H Ninv E)(E^T B), both factors iteration-invariant.  The
+ * unflagged-noise system is factored as in hpx_plan_set_static_dense with f more right-hand sides (one
+ * per flagged channel; the plan must come from hpx_plan_create_ex(.., extra_rhs >= the largest flag count))
+ * and the solution follows from the Woodbury identity: an f x f system solved with partial pivoting.
+ *   ninv_dense (nbl|1,N,N) c128   Ninv = inv(noise_cov), Hermitian, NOT masked
+ *   nih_masked (nbl,N,N)   c128   sqrtm(Ni) of the column-masked Ni, as the reference takes it
+ *                                 (pspec.py:362; a general matrix: scipy.linalg.sqrtm on the host)
+ * The first ln-posterior term is the quadratic form over the unflagged channels with
+ * Ninv[flags][:, flags] (pspec.py:472-477), chi^2 uses the unmasked Ninv.diagonal() (pspec.py:452). */
+int hpx_plan_set_static_dense_flagged(hpx_plan* p, const double* vis, const uint8_t* flags,
+                                      const double* ninv_dense, int noise_shared, const double* nih_masked,
+                                      const double* fgmodes, int fg_shared, const int32_t* prior_map,
+                                      const double* xgrid, int nxrows, int prior_shared, int ngrid,
+                                      const double* omega, const double* fop, void* stream);
 
 /* Time-dependent flags and noise: flags_t (nbl,T,N) u8 and ninv_t (nbl,T,N) f64 (diagonal inverse
  * noise variances per time sample).  The mode the reference documents but does not implement

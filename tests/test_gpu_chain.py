@@ -537,11 +537,42 @@ def test_dense_noise_covariance_vs_reference(golden):
     out = pspec.gibbs_sample_with_fg_batched(np.stack([vis, vis[::-1]]), np.stack([fl, fl]), F, Ninv, prior,
                                              S_initial=S, Niter=3, seed=77)
     assert np.array_equal(out["signal_ps"][0], res[2][:3])
-    # flags together with a non-diagonal matrix: refused (the reference's masked Ni is not Hermitian there)
-    fl2 = fl.copy()
-    fl2[3] = False
-    with pytest.raises(NotImplementedError):
-        pspec.gibbs_sample_with_fg(vis, fl2, S, F, Ninv, prior, Niter=2, seed=1, verbose=False)
     with pytest.raises(NotImplementedError):
         pspec.gibbs_sample_with_fg(vis, fl, S, F, Ninv + 0.1j * np.triu(np.ones_like(Ninv), 1), prior, Niter=2,
                                    seed=1, verbose=False)
+
+
+def test_dense_noise_covariance_with_flags_vs_reference(golden):
+    """Hermitian non-diagonal inverse noise covariance TOGETHER WITH flagged channels: the
+    reference's column-masked Ni = flags.T * Ninv * flags makes its system non-Hermitian (pspec.py:361-369, CG at
+    :228); here it is a rank-f Woodbury update of the unflagged-noise Cholesky solve.  Single step and a
+    free-running chain against the reference's own output (golden steps_dense.npz, fl_*), the exact-solve
+    control, and the batched entry with baselines that have different numbers of flags."""
+    from hydra_pspec_amd import pspec
+    g = golden("steps_dense")
+    vis, S, F, Ninv, prior = (g[f"in_{k}"] for k in ("vis", "S", "fgmodes", "Ninv", "prior"))
+    fl = g["fl_flags"]
+    assert (~fl).sum() == 5
+    np.random.seed(4242)
+    cr, S_s, ps, fg, chi, lp = pspec.gibbs_step_fgmodes(vis * fl, fl, S, F, Ninv, prior)
+    assert np.max(np.abs(ps / g["fl_step_ps"] - 1)) < RTOL
+    assert relerr(cr, g["fl_step_cr"]) < RTOL and relerr(fg, g["fl_step_fg"]) < RTOL
+    assert relerr(chi, g["fl_step_chisq"].real) < 2e-3          # (residual-based: the reference's CG noise)
+    assert lp == pytest.approx(float(g["fl_step_lnpost"]), rel=2e-5)
+    res = pspec.gibbs_sample_with_fg(vis, fl, S, F, Ninv, prior, Niter=6, seed=77, verbose=False)
+    assert np.max(np.abs(res[2] / g["fl_chain_ps"] - 1)) < RTOL
+    assert np.max(np.abs(res[2] / g["fl_chain_exact_ps"] - 1)) < 1e-7
+    assert np.allclose(res[5], g["fl_chain_exact_lnpost"], rtol=1e-8)
+    sel = g["fl_chain_sel"]
+    assert relerr(res[0][sel], g["fl_chain_cr_sel"]) < RTOL and relerr(res[3][sel], g["fl_chain_fg_sel"]) < RTOL
+    # a batch whose baselines have 5, 0 and 2 flagged channels: each equals its single-baseline chain
+    fl0 = np.ones_like(fl)
+    fl2 = fl0.copy()
+    fl2[[4, 20]] = False
+    out = pspec.gibbs_sample_with_fg_batched(np.stack([vis, vis[::-1], vis]), np.stack([fl, fl0, fl2]), F, Ninv,
+                                             prior, S_initial=S, Niter=3, seed=77)
+    assert np.max(np.abs(out["signal_ps"][0] / res[2][:3] - 1)) < 1e-10
+    for b, (v, f) in enumerate([(vis, fl), (vis[::-1], fl0), (vis, fl2)]):
+        one = pspec.gibbs_sample_with_fg(v, f, S, F, Ninv, prior, Niter=3, seed=77, verbose=False)
+        assert np.max(np.abs(out["signal_ps"][b] / one[2] - 1)) < 1e-9
+        assert np.allclose(out["ln_post"][b], one[5], rtol=1e-9)

@@ -188,6 +188,26 @@ def test_correlated_noise_vs_oracle_at_other_sizes(N, T, M):
     assert np.allclose(res[5], ref[5], rtol=1e-6)
 
 
+def test_correlated_noise_with_flags_at_c3_shape():
+    """Dense Ninv together with 15 % flagged channels at (Ntimes, Nfreq, Nmodes) = (32, 512, 12): 77 Woodbury
+    columns next to the 32 data columns (TP = 112), against the exact-solve oracle (which solves the reference's
+    non-Hermitian system directly)."""
+    from hydra_pspec_amd import pspec, synthetic
+    from oracle import pspec_ref
+    N, T, M = 512, 32, 12
+    d = synthetic.make_baselines(N, T, M, k0=6, nbl=1, flag_frac=0.15, dense=True)
+    assert (~d["flags"][0]).sum() == 77
+    Ninv = _banded_ninv(N, 1.0 / d["Ninv"][0, 0].real)
+    res = pspec.gibbs_sample_with_fg(d["vis"][0], d["flags"][0], d["S_initial"], d["fgmodes"], Ninv, d["ps_prior"],
+                                     Niter=1, seed=21, verbose=False)
+    ref = pspec_ref.gibbs_sample_with_fg(d["vis"][0], d["flags"][0], d["S_initial"], d["fgmodes"], Ninv, d["ps_prior"],
+                                         Niter=1, seed=21, solver="direct")
+    assert np.max(np.abs(res[2] / ref[2] - 1)) < 1e-6
+    assert np.max(np.abs(res[0] - ref[0])) < 1e-6 * np.max(np.abs(ref[0]))
+    assert np.max(np.abs(res[3] - ref[3])) < 1e-6 * np.max(np.abs(ref[3]))
+    assert np.allclose(res[5], ref[5], rtol=1e-6)
+
+
 def test_time_dependent_flags_at_c3_shape():
     """Per-time mode at (Ntimes, Nfreq, Nmodes) = (32, 512, 12), 2 baselines = 64 systems per iteration:
     baseline 1 against the per-time exact-solve oracle."""

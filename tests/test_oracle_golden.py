@@ -225,6 +225,15 @@ def test_dense_noise_covariance_step_and_chain():
     r = R.gibbs_sample_with_fg(g["in_vis"], g["in_flags"], g["in_S"], g["in_fgmodes"], g["in_Ninv"], g["in_prior"],
                                Niter=6, seed=77)
     assert np.max(np.abs(r[2] / g["chain_ps"] - 1)) < 1e-6
+    # ... and with flagged channels on top (column-masked, non-Hermitian Ni: pspec.py:361)
+    fl = g["fl_flags"]
+    np.random.seed(4242)
+    o = R.gibbs_step_fgmodes(g["in_vis"] * fl, fl, g["in_S"], g["in_fgmodes"], g["in_Ninv"], g["in_prior"])
+    assert np.max(np.abs(o[2] / g["fl_step_ps"] - 1)) < 1e-7
+    assert relerr(o[0], g["fl_step_cr"]) < 1e-7 and relerr(o[3], g["fl_step_fg"]) < 1e-7
+    assert o[5] == pytest.approx(float(g["fl_step_lnpost"]), rel=1e-6)
+    r = R.gibbs_sample_with_fg(g["in_vis"], fl, g["in_S"], g["in_fgmodes"], g["in_Ninv"], g["in_prior"], Niter=6, seed=77)
+    assert np.max(np.abs(r[2] / g["fl_chain_ps"] - 1)) < 1e-6
 
 
 @pytest.mark.parametrize("name", ["a", "b", "f"])
