@@ -111,15 +111,28 @@ __device__ __forceinline__ void rr_pair(const int n, const int s, const int i, i
 // pads an odd order with an isolated zero row/column).
 __global__ __launch_bounds__(256) void k_jacobi(double* __restrict__ gr_all, double* __restrict__ gi_all,
                                                 double* __restrict__ vr_all, double* __restrict__ vi_all,
-                                                const int n, const int max_sweeps) {
-  extern __shared__ double rot[];             // [n/2][4]: cs, sn, cos(phi), sin(phi)
+                                                const int n, const int max_sweeps, const int in_lds) {
+  extern __shared__ double rot[];             // [n/2][4]: cs, sn, cos(phi), sin(phi); in_lds: + G and V (4 n^2)
   __shared__ double red[4];
   __shared__ int done;
   const int b = blockIdx.x, tid = threadIdx.x, half = n >> 1;
-  double* gr = gr_all + (long)b * n * n;
-  double* gi = gi_all + (long)b * n * n;
-  double* vr = vr_all + (long)b * n * n;
-  double* vi = vi_all + (long)b * n * n;
+  double* const ggr = gr_all + (long)b * n * n;
+  double* const ggi = gi_all + (long)b * n * n;
+  double* const gvr = vr_all + (long)b * n * n;
+  double* const gvi = vi_all + (long)b * n * n;
+  // small orders (the usual Gram path, n = Ntimes): the matrices live in LDS for the whole diagonalisation --
+  // every rotation step is three dependent read-modify-write passes over them, a cache round trip each otherwise
+  double *gr = ggr, *gi = ggi, *vr = gvr, *vi = gvi;
+  if (in_lds) {
+    gr = rot + 4 * half;
+    gi = gr + n * n;
+    vr = gi + n * n;
+    vi = vr + n * n;
+    for (int e = tid; e < n * n; e += 256) {
+      gr[e] = ggr[e];
+      gi[e] = ggi[e];
+    }
+  }
   for (int e = tid; e < n * n; e += 256) {
     vr[e] = (e / n == e % n) ? 1.0 : 0.0;
     vi[e] = 0.0;
@@ -199,6 +212,15 @@ __global__ __launch_bounds__(256) void k_jacobi(double* __restrict__ gr_all, dou
         gi[(long)q * n + k] = sn * epi + cs * qi;
       }
       __syncthreads();
+    }
+  }
+  if (in_lds) {
+    __syncthreads();
+    for (int e = tid; e < n * n; e += 256) {
+      ggr[e] = gr[e];
+      ggi[e] = gi[e];
+      gvr[e] = vr[e];
+      gvi[e] = vi[e];
     }
   }
 }
@@ -317,7 +339,13 @@ extern "C" int hpx_fgmodes_eig(int nb, int T, int N, int nmodes, const double* v
   hipLaunchKernelGGL(k_gram, dim3((nreal + 31) / 32, (nreal + 31) / 32, nb), dim3(256), 0, st, xr, xi, gr, gi, T, N,
                      nreal, n, gram);
   HPX_HIP(hipGetLastError());
-  hipLaunchKernelGGL(k_jacobi, dim3(nb), dim3(256), (size_t)(n / 2) * 4 * sizeof(double), st, gr, gi, vr, vi, n, 30);
+  {
+    const int in_lds = n <= 64;             // 4 n^2 doubles: 32 KB at n = 32, 128 KB at n = 64
+    const size_t lds = ((size_t)(n / 2) * 4 + (in_lds ? (size_t)4 * n * n : 0)) * sizeof(double);
+    static hpx_lds_limit limit;
+    if (lds > 48 * 1024) HPX_TRY(limit.ensure(reinterpret_cast<const void*>(&k_jacobi), lds));
+    hipLaunchKernelGGL(k_jacobi, dim3(nb), dim3(256), lds, st, gr, gi, vr, vi, n, 30, in_lds);
+  }
   hipLaunchKernelGGL(k_modes_out, dim3(nb), dim3(256), (size_t)(n + 2 * N) * sizeof(double), st, gr, vr, vi, xr, xi,
                      modes, evals, T, N, n, nreal, nmodes, gram);
   hipError_t e = hipGetLastError();

@@ -70,6 +70,77 @@ __device__ __forceinline__ void dft_tile(const double* __restrict__ Wre,
     }
 }
 
+// The same product for NB consecutive batch members that share ONE operator and have a single 16-column
+// tile each (the DPSS group stage: inv(cov) times every group's weighted modes): the wave keeps one
+// accumulator tile per member, so an operator fragment feeds 4 NB MFMAs instead of 4 -- with one member
+// per wave the kernel is bound by its loads (one operand load per MFMA pair), not by the matrix pipe.
+template <int NB>
+__global__ __launch_bounds__(256, 2) void k_dft_shared(const double* __restrict__ Wre, const double* __restrict__ Wim,
+                                                       const int conjW, const double* __restrict__ inre,
+                                                       const double* __restrict__ inim, const long in_bstride,
+                                                       const int in_ld, double* __restrict__ outre,
+                                                       double* __restrict__ outim, const long out_bstride,
+                                                       const int out_ld, const int NP, const double scale,
+                                                       const int nbl) {
+  const int b0 = blockIdx.y * NB;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int xt = blockIdx.x * 4 + wave;
+  if (xt * 16 >= NP) return;
+  const int li = lane & 15, g = lane >> 4, x0 = xt * 16;
+  const double wsign = conjW ? -1.0 : 1.0;
+  long boff[NB];
+#pragma unroll
+  for (int c = 0; c < NB; ++c) boff[c] = (long)min(b0 + c, nbl - 1) * in_bstride;     // (the tail repeats the last member)
+  d4 ar[NB], ai[NB];
+#pragma unroll
+  for (int c = 0; c < NB; ++c) {
+    ar[c] = (d4){0., 0., 0., 0.};
+    ai[c] = (d4){0., 0., 0., 0.};
+  }
+  const int nks = NP >> 2;
+  double w0r, w0i, w1r, w1i, b0r[NB], b0i[NB], b1r[NB], b1i[NB];
+#define HPX_DFS_LOAD(wr_, wi_, br_, bi_, ks_)                                       \
+  {                                                                                 \
+    const int k_ = 4 * (ks_) + g;                                                   \
+    wr_ = Wre[(long)k_ * NP + x0 + li];                                             \
+    wi_ = wsign * Wim[(long)k_ * NP + x0 + li];                                     \
+    _Pragma("unroll") for (int c = 0; c < NB; ++c) {                                \
+      const long o_ = boff[c] + (long)k_ * in_ld + li;                              \
+      br_[c] = inre[o_];                                                            \
+      bi_[c] = inim[o_];                                                            \
+    }                                                                               \
+  }
+#define HPX_DFS_MMA(wr_, wi_, br_, bi_)                                             \
+  _Pragma("unroll") for (int c = 0; c < NB; ++c) {                                  \
+    ar[c] = mfma64(wr_, br_[c], ar[c]);                                             \
+    ar[c] = mfma64(-wi_, bi_[c], ar[c]);                                            \
+    ai[c] = mfma64(wr_, bi_[c], ai[c]);                                             \
+    ai[c] = mfma64(wi_, br_[c], ai[c]);                                             \
+  }
+  HPX_DFS_LOAD(w0r, w0i, b0r, b0i, 0)
+  for (int ks = 0; ks < nks; ks += 2) {
+    HPX_DFS_LOAD(w1r, w1i, b1r, b1i, ks + 1)
+    __builtin_amdgcn_sched_barrier(0);
+    HPX_DFS_MMA(w0r, w0i, b0r, b0i)
+    __builtin_amdgcn_sched_barrier(0);
+    HPX_DFS_LOAD(w0r, w0i, b0r, b0i, min(ks + 2, nks - 1))
+    __builtin_amdgcn_sched_barrier(0);
+    HPX_DFS_MMA(w1r, w1i, b1r, b1i)
+    __builtin_amdgcn_sched_barrier(0);
+  }
+#undef HPX_DFS_LOAD
+#undef HPX_DFS_MMA
+#pragma unroll
+  for (int c = 0; c < NB; ++c)
+    if (b0 + c < nbl)
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const long o = (long)(b0 + c) * out_bstride + (long)(x0 + HPX_ACC_ROW(g, v)) * out_ld + li;
+        outre[o] = ar[c][v] * scale;
+        outim[o] = ai[c][v] * scale;
+      }
+}
+
 __global__ __launch_bounds__(256, 2) void k_dft(const double* Wre, const double* Wim,
                                                 const int conjW,
                                              const double* __restrict__ inre,
@@ -292,6 +363,13 @@ int hpx_launch_dft(int nbl, int NP, int ncol, const double* Wre, const double* W
     else
       hipLaunchKernelGGL(k_fft<-1>, grid, dim3(256), lds, st, Wre, Wim, inre, inim, in_bstride, in_ld,
                          rs, rs_n, outre, outim, out_bstride, out_ld, NP, logN, ncol, tcs, scale, nbl, ncg);
+    HPX_HIP(hipGetLastError());
+    return HPX_OK;
+  }
+  if (W_bstride == 0 && ncol == 16 && nbl >= 4 && !rs) {     // one operator, one column tile per member
+    dim3 grid4((NP / 16 + 3) / 4, (nbl + 3) / 4);
+    hipLaunchKernelGGL(k_dft_shared<4>, grid4, dim3(256), 0, st, Wre, Wim, conjW, inre, inim, in_bstride, in_ld,
+                       outre, outim, out_bstride, out_ld, NP, scale, nbl);
     HPX_HIP(hipGetLastError());
     return HPX_OK;
   }

@@ -108,7 +108,7 @@ def M_Fhalf(Fm, tol=1e-15, maxit=60):
         scale = float(np.trace(np.asarray(Fm)).real) / s          # F / scale has unit-order eigenvalues
         Y = (Y / scale).contiguous()
         Z = torch.eye(s, dtype=torch.complex128, device=dev)[None].contiguous()
-        ok = True
+        ok, converged, last = True, False, np.inf
         for _ in range(maxit):
             Yi, Zi = _device_inverse(torch, dev, Y), _device_inverse(torch, dev, Z)
             if Yi is None or Zi is None:
@@ -121,10 +121,19 @@ def M_Fhalf(Fm, tol=1e-15, maxit=60):
             delta = float((Zn - Z).abs().max() / Zn.abs().max())
             Y, Z = Yn, Zn
             if delta < tol:
+                converged = True
                 break
+            if not np.isfinite(delta) or (delta > 1e-3 and delta > 4.0 * last):
+                break                 # the iteration is not stable for very ill-conditioned F: it has started to diverge
+            last = delta
         if ok:
             out = (Z[0] / np.sqrt(scale)).cpu().numpy()
-            return out.real.copy() if np.isrealobj(Fm) else out
+            # accept only a solution: Z F Z = I to rounding x condition (one host product; the iteration's
+            # own stopping test cannot tell a stagnated run from a converged one)
+            Fh = np.asarray(Fm, dtype=complex)
+            resid = np.abs(out @ Fh @ out - np.eye(s)).max()
+            if (converged or resid < 1e-9) and np.isfinite(resid) and resid < 1e-6:
+                return out.real.copy() if np.isrealobj(Fm) else out
     return np.linalg.inv(scipy.linalg.sqrtm(Fm))
 
 

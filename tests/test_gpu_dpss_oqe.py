@@ -186,3 +186,22 @@ def test_dpss_singular_group_gives_zero_amplitudes_and_a_warning():
     pr = dpss.DpssProjector(nb, 1, freqs, cov, nmodes=nm, alpha=3.0)
     pr.fit(d[:, None, :], w)
     assert list(pr.singular_groups()) == [2]
+
+
+def test_m_fhalf_on_an_ill_conditioned_fisher_matrix():
+    """``M_Fhalf`` = inv(sqrtm(F)) through the Denman-Beavers iteration on the batched Cholesky solver: converges
+    for well-conditioned F, and for an ill-conditioned one (cond 1e10, where the iteration is not stable) the result
+    is still inv(sqrtm(F)) -- the convergence / residual guard falls back to scipy instead of returning a stagnated
+    iterate."""
+    from hydra_pspec_amd import oqe
+    rng = np.random.default_rng(12)
+    s = 48
+    q, _ = np.linalg.qr(rng.standard_normal((s, s)) + 1j * rng.standard_normal((s, s)))
+    for span in (2, 6, 10):
+        lam = np.logspace(0, -span, s)
+        F = (q * lam) @ q.conj().T
+        F = 0.5 * (F + F.conj().T)
+        want = (q / np.sqrt(lam)) @ q.conj().T
+        got = oqe.M_Fhalf(F)
+        assert np.abs(got - want).max() < 1e-6 * np.abs(want).max(), span
+        assert np.abs(got @ F @ got - np.eye(s)).max() < 1e-6
