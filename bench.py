@@ -145,15 +145,19 @@ def cpu_baseline_multiproc(N, T, M, flag_frac, niter=8, max_procs=None):
                        f"slowest {max(secs):.1f} s, wall incl. start-up {wall:.1f} s")
 
 
+DENSE_STEP_SOURCES = ("hpx_factor.hip", "hpx_chain.hip", "hpx_transform.hip", "hpx_internal.h", "hpx_fft.h", "Makefile")
+
+
 def kernel_source_hash():
-    """Hash of the sources libhpx.so is built from: profiles/pmc_traffic.json carries the hash it was measured
-    on, and a different library gets no `roofline.traffic` from it."""
+    """Hash of the sources the kernels of the dense Gibbs iteration are built from (k_assemble_tail, k_factor,
+    k_backsolve, k_fft_resid, k_draw): profiles/pmc_traffic.json carries the hash it was measured on, and a
+    library built from other sources gets no `roofline.traffic` from it."""
     import hashlib
     h = hashlib.sha256()
-    for f in sorted((REPO / "hydra_pspec_amd" / "csrc").glob("*")):
-        if f.suffix in (".hip", ".h") or f.name == "Makefile":
-            h.update(f.name.encode())
-            h.update(f.read_bytes())
+    for name in DENSE_STEP_SOURCES:
+        f = REPO / "hydra_pspec_amd" / "csrc" / name
+        h.update(name.encode())
+        h.update(f.read_bytes())
     return h.hexdigest()[:16]
 
 

@@ -15,7 +15,11 @@ timeout -k 10 300 python3 bench.py --steps 20 --warmup 2 --config C2 --no-cpu-ba
 timeout -k 10 300 python3 bench.py --steps 10 --warmup 2 --config N4 --no-cpu-baseline > $O/bench_n4.log 2>&1 && line $O/bench_n4.log $O/${TAG}_bench_n4.json; echo "N4 done"
 timeout -k 10 300 python3 bench.py --config dpss --steps 20 --warmup 2 > $O/bench_dpss.log 2>&1 && line $O/bench_dpss.log $O/${TAG}_bench_dpss.json; echo "dpss done"
 timeout -k 10 300 python3 bench.py --config oqe --steps 5 --warmup 1 > $O/bench_oqe.log 2>&1 && line $O/bench_oqe.log $O/${TAG}_bench_oqe.json; echo "oqe done"
-HPX_BENCH_DEVICE=0 HPX_BENCH_BACKEND=gloo timeout -k 10 400 python3 bench.py --gpus 2 --steps 10 --warmup 2 --no-cpu-baseline > $O/bench_2rank.log 2>&1 && line $O/bench_2rank.log $O/${TAG}_bench_2ranks_one_gpu.json; echo "2-rank rehearsal done"
+timeout -k 10 300 python3 bench.py --config fgmodes --steps 10 --warmup 2 > $O/bench_fgmodes.log 2>&1 && line $O/bench_fgmodes.log $O/${TAG}_bench_fgmodes.json; echo "fgmodes done"
+HPX_BENCH_DEVICE=0 HPX_BENCH_BACKEND=gloo timeout -k 10 400 python3 bench.py --gpus 2 --steps 10 --warmup 2 --no-cpu-baseline --no-full-length > $O/bench_2rank.log 2>&1 && line $O/bench_2rank.log $O/${TAG}_bench_2ranks_one_gpu.json; echo "2-rank rehearsal done"
+# the launcher with as many ranks as one box lets share its GPU (the pool's process guard allows six; the 8-rank
+# case is the driver's to run on a whole node): 6 ranks x 128 baselines
+HPX_BENCH_DEVICE=0 HPX_BENCH_BACKEND=gloo timeout -k 10 400 python3 bench.py --gpus 6 --nbl 128 --steps 10 --warmup 2 --no-cpu-baseline --no-full-length > $O/bench_6rank.log 2>&1 && line $O/bench_6rank.log $O/${TAG}_bench_6ranks_one_gpu.json; echo "6-rank rehearsal done"
 kt() {   # kernel-trace stats: kt <name> <bench args...>
   local name=$1; shift
   cd /tmp
@@ -25,15 +29,16 @@ kt() {   # kernel-trace stats: kt <name> <bench args...>
   grep -o '{"metric.*' $O/kt_$name.log > $O/${TAG}_bench_${name}_under_rocprof.json
   echo "kernel stats $name done"
 }
-kt c3 --steps 10 --warmup 2 --no-cpu-baseline
-kt c5_auto --config C5 --solver auto --steps 10 --warmup 2 --no-cpu-baseline
+kt c3 --steps 10 --warmup 2 --no-cpu-baseline --no-full-length
+kt c5_auto --config C5 --solver auto --steps 10 --warmup 2 --no-cpu-baseline --no-full-length
+kt fgmodes --config fgmodes --steps 5 --warmup 1
 kt dpss --config dpss --steps 10 --warmup 2
 kt oqe --config oqe --steps 3 --warmup 1
 i=0
 for set in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" "TCC_HIT_sum TCC_MISS_sum"; do
   i=$((i+1))
   cd /tmp
-  timeout -k 10 300 rocprofv3 --pmc $set --output-format csv -d $O/pmc$i -- python3 $R/bench.py --steps 2 --warmup 0 --no-cpu-baseline > $O/pmc$i.log 2>&1
+  timeout -k 10 300 rocprofv3 --pmc $set --output-format csv -d $O/pmc$i -- python3 $R/bench.py --steps 2 --warmup 0 --no-cpu-baseline --no-full-length > $O/pmc$i.log 2>&1
   cd $R
   echo "pmc pass $i done"
 done
@@ -102,7 +107,7 @@ PY
 head -12 $O/${TAG}_kernel_stats_c3.csv | cut -c1-160
 python3 -c "
 import json
-for c in ('c3','c5','c2','n4','dpss','oqe','2ranks_one_gpu'):
+for c in ('c3','c5','c2','n4','dpss','oqe','fgmodes','2ranks_one_gpu','6ranks_one_gpu'):
     try:
         d=json.load(open('$O/${TAG}_bench_%s.json'%c)); r=d['roofline']
         print(c, 'value %.4g %s ms/step %.3f roofline %s %.4g frac %.3f n_gpus %d' % (d['value'], d['unit'], d['ms_per_step'], r['unit'], r['achieved'], r['frac'], d['n_gpus']), {k: round(v,3) for k,v in d.get('stage_ms_per_step',{}).items()}, 'cpu', d.get('cpu_baseline',{}).get('value'), 'dev', d.get('pk_max_rel_dev_vs_cpu', d.get('max_rel_dev_vs_cpu')))
