@@ -113,7 +113,7 @@ __global__ __launch_bounds__(256) void k_jacobi(double* __restrict__ gr_all, dou
                                                 double* __restrict__ vr_all, double* __restrict__ vi_all,
                                                 const int n, const int max_sweeps, const int in_lds) {
   extern __shared__ double rot[];             // [n/2][4]: cs, sn, cos(phi), sin(phi); in_lds: + G and V (4 n^2)
-  __shared__ double red[4];
+  __shared__ double red[4], red2[4], floor_s;
   __shared__ int done;
   const int b = blockIdx.x, tid = threadIdx.x, half = n >> 1;
   double* const ggr = gr_all + (long)b * n * n;
@@ -122,50 +122,65 @@ __global__ __launch_bounds__(256) void k_jacobi(double* __restrict__ gr_all, dou
   double* const gvi = vi_all + (long)b * n * n;
   // small orders (the usual Gram path, n = Ntimes): the matrices live in LDS for the whole diagonalisation --
   // every rotation step is three dependent read-modify-write passes over them, a cache round trip each otherwise
+  // (leading dimension n + 1 there: the column phase walks a column with one thread per row, which at a
+  // power-of-two stride is a 32-way bank conflict)
   double *gr = ggr, *gi = ggi, *vr = gvr, *vi = gvi;
+  const int ld = in_lds ? n + 1 : n;
   if (in_lds) {
     gr = rot + 4 * half;
-    gi = gr + n * n;
-    vr = gi + n * n;
-    vi = vr + n * n;
+    gi = gr + n * ld;
+    vr = gi + n * ld;
+    vi = vr + n * ld;
     for (int e = tid; e < n * n; e += 256) {
-      gr[e] = ggr[e];
-      gi[e] = ggi[e];
+      gr[(e / n) * ld + e % n] = ggr[e];
+      gi[(e / n) * ld + e % n] = ggi[e];
     }
   }
   for (int e = tid; e < n * n; e += 256) {
-    vr[e] = (e / n == e % n) ? 1.0 : 0.0;
-    vi[e] = 0.0;
+    vr[(e / n) * ld + e % n] = (e / n == e % n) ? 1.0 : 0.0;
+    vi[(e / n) * ld + e % n] = 0.0;
   }
   __syncthreads();
   for (int sweep = 0; sweep < max_sweeps; ++sweep) {
-    // converged when every off-diagonal entry is negligible against its two diagonal entries
+    // converged when every off-diagonal entry is negligible against its two diagonal entries,
+    // |g_ij|^2 <= 1e-28 g_ii g_jj (eigenvalues exact to ~1e-14 relative, the level rounding allows), or against
+    // the matrix itself, |g_ij| <= 1e-16 max_k g_kk: a centred cube has an exact null vector (rank Ntimes - 1),
+    // whose diagonal entry is pure rounding -- the relative test alone is never met there and every run would
+    // take all max_sweeps
+    double gmax = 0.0;
+    for (int i = tid; i < n; i += 256) gmax = fmax(gmax, fabs(gr[(long)i * ld + i]));
+    for (int o = 32; o > 0; o >>= 1) gmax = fmax(gmax, __shfl_xor(gmax, o, 64));
+    if ((tid & 63) == 0) red2[tid >> 6] = gmax;
+    __syncthreads();
+    gmax = fmax(fmax(red2[0], red2[1]), fmax(red2[2], red2[3]));
+    const double floor2 = 1e-32 * gmax * gmax;
     double worst = 0.0;
     for (int e = tid; e < n * n; e += 256) {
       const int i = e / n, j = e % n;
       if (i >= j) continue;
-      const double off = gr[e] * gr[e] + gi[e] * gi[e];
-      const double dd = fabs(gr[(long)i * n + i] * gr[(long)j * n + j]);
-      if (off > 0.0) worst = fmax(worst, (dd > 0.0) ? off / dd : 1.0);
+      const double off = gr[i * ld + j] * gr[i * ld + j] + gi[i * ld + j] * gi[i * ld + j];
+      const double dd = fabs(gr[(long)i * ld + i] * gr[(long)j * ld + j]);
+      if (off > floor2) worst = fmax(worst, (dd > 0.0) ? off / dd : 1.0);
     }
     // block max through LDS
     for (int o = 32; o > 0; o >>= 1) worst = fmax(worst, __shfl_xor(worst, o, 64));
     if ((tid & 63) == 0) red[tid >> 6] = worst;
     __syncthreads();
-    // |g_ij|^2 <= 1e-28 g_ii g_jj: the eigenvalues are then exact to ~1e-14 relative, the level rounding allows
-    // (a tighter test is never met among nearly equal eigenvalues and costs every run all max_sweeps)
-    if (tid == 0) done = fmax(fmax(red[0], red[1]), fmax(red[2], red[3])) < 1e-28;
+    if (tid == 0) {
+      done = fmax(fmax(red[0], red[1]), fmax(red[2], red[3])) < 1e-28;
+      floor_s = floor2;
+    }
     __syncthreads();
     if (done) break;
     for (int s = 0; s < n - 1; ++s) {
       for (int i = tid; i < half; i += 256) {      // rotation parameters of the step's pairs
         int p, q;
         rr_pair(n, s, i, p, q);
-        const double a = gr[(long)p * n + p], bq = gr[(long)q * n + q];
-        const double cr = gr[(long)p * n + q], ci = gi[(long)p * n + q];
+        const double a = gr[(long)p * ld + p], bq = gr[(long)q * ld + q];
+        const double cr = gr[(long)p * ld + q], ci = gi[(long)p * ld + q];
         const double ac = sqrt(cr * cr + ci * ci);
         double cs = 1.0, sn = 0.0, cp = 1.0, sp = 0.0;
-        if (ac > 0.0 && ac * ac > 1e-34 * fabs(a * bq)) {
+        if (ac * ac > floor_s && ac * ac > 1e-34 * fabs(a * bq)) {
           const double tau = (bq - a) / (2.0 * ac);
           const double t = ((tau >= 0.0) ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
           cs = 1.0 / sqrt(1.0 + t * t);
@@ -186,15 +201,15 @@ __global__ __launch_bounds__(256) void k_jacobi(double* __restrict__ gr_all, dou
         for (int which = 0; which < 2; ++which) {
           double* mr = which ? vr : gr;
           double* mi = which ? vi : gi;
-          const double pr = mr[(long)k * n + p], pi = mi[(long)k * n + p];
-          const double qr = mr[(long)k * n + q], qi = mi[(long)k * n + q];
+          const double pr = mr[(long)k * ld + p], pi = mi[(long)k * ld + p];
+          const double qr = mr[(long)k * ld + q], qi = mi[(long)k * ld + q];
           // e^{-i phi} x_q = (cp - i sp)(qr + i qi);  e^{i phi} x_p = (cp + i sp)(pr + i pi)
           const double eqr = cp * qr + sp * qi, eqi = cp * qi - sp * qr;
           const double epr = cp * pr - sp * pi, epi = cp * pi + sp * pr;
-          mr[(long)k * n + p] = cs * pr - sn * eqr;
-          mi[(long)k * n + p] = cs * pi - sn * eqi;
-          mr[(long)k * n + q] = sn * epr + cs * qr;
-          mi[(long)k * n + q] = sn * epi + cs * qi;
+          mr[(long)k * ld + p] = cs * pr - sn * eqr;
+          mi[(long)k * ld + p] = cs * pi - sn * eqi;
+          mr[(long)k * ld + q] = sn * epr + cs * qr;
+          mi[(long)k * ld + q] = sn * epi + cs * qi;
         }
       }
       __syncthreads();
@@ -204,14 +219,14 @@ __global__ __launch_bounds__(256) void k_jacobi(double* __restrict__ gr_all, dou
         int p, q;
         rr_pair(n, s, i, p, q);
         const double cs = rot[4 * i], sn = rot[4 * i + 1], cp = rot[4 * i + 2], sp = rot[4 * i + 3];
-        const double pr = gr[(long)p * n + k], pi = gi[(long)p * n + k];
-        const double qr = gr[(long)q * n + k], qi = gi[(long)q * n + k];
+        const double pr = gr[(long)p * ld + k], pi = gi[(long)p * ld + k];
+        const double qr = gr[(long)q * ld + k], qi = gi[(long)q * ld + k];
         const double eqr = cp * qr - sp * qi, eqi = cp * qi + sp * qr;      // e^{i phi} y_q
         const double epr = cp * pr + sp * pi, epi = cp * pi - sp * pr;      // e^{-i phi} y_p
-        gr[(long)p * n + k] = cs * pr - sn * eqr;
-        gi[(long)p * n + k] = cs * pi - sn * eqi;
-        gr[(long)q * n + k] = sn * epr + cs * qr;
-        gi[(long)q * n + k] = sn * epi + cs * qi;
+        gr[(long)p * ld + k] = cs * pr - sn * eqr;
+        gi[(long)p * ld + k] = cs * pi - sn * eqi;
+        gr[(long)q * ld + k] = sn * epr + cs * qr;
+        gi[(long)q * ld + k] = sn * epi + cs * qi;
       }
       __syncthreads();
     }
@@ -219,10 +234,11 @@ __global__ __launch_bounds__(256) void k_jacobi(double* __restrict__ gr_all, dou
   if (in_lds) {
     __syncthreads();
     for (int e = tid; e < n * n; e += 256) {
-      ggr[e] = gr[e];
-      ggi[e] = gi[e];
-      gvr[e] = vr[e];
-      gvi[e] = vi[e];
+      const int o = (e / n) * ld + e % n;
+      ggr[e] = gr[o];
+      ggi[e] = gi[o];
+      gvr[e] = vr[o];
+      gvi[e] = vi[o];
     }
   }
 }
@@ -343,7 +359,7 @@ extern "C" int hpx_fgmodes_eig(int nb, int T, int N, int nmodes, const double* v
   HPX_HIP(hipGetLastError());
   {
     const int in_lds = n <= 64;             // 4 n^2 doubles: 32 KB at n = 32, 128 KB at n = 64
-    const size_t lds = ((size_t)(n / 2) * 4 + (in_lds ? (size_t)4 * n * n : 0)) * sizeof(double);
+    const size_t lds = ((size_t)(n / 2) * 4 + (in_lds ? (size_t)4 * n * (n + 1) : 0)) * sizeof(double);
     static hpx_lds_limit limit;
     if (lds > 48 * 1024) HPX_TRY(limit.ensure(reinterpret_cast<const void*>(&k_jacobi), lds));
     hipLaunchKernelGGL(k_jacobi, dim3(nb), dim3(256), lds, st, gr, gi, vr, vi, n, 30, in_lds);
