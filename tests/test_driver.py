@@ -212,6 +212,19 @@ def test_driver_correlated_noise_cov(golden, tmp_path):
     assert rc == 0
     ps = np.load(tmp_path / "res" / "0-1" / "dps-eor.npy")
     assert np.max(np.abs(ps / g["chain_ps"] - 1)) < 1e-6
+    # the same covariance with channels flagged in the input cube (all times, as the reference's any-time mask
+    # reduces them, run-hydra-pspec.py:531-535): the reference's column-masked, non-Hermitian system -- its own
+    # chain (golden fl_chain_ps) comes out of the driver
+    fl = g["fl_flags"]
+    flags_td = np.broadcast_to(~fl, g["in_vis"].shape)[None]                 # True = flagged sample
+    np.savez(tmp_path / "visf.npz", vis=g["in_vis"][None], antpairs=np.array([[0, 1]]), flags=flags_td)
+    rc = drv.main(["--file_paths", str(tmp_path / "visf.npz"), "--sigcov0", str(tmp_path / "aux"), "--sigcov0_file",
+                   "eor-cov.npy", "--fgmodes", str(tmp_path / "aux"), "--fgmodes_file", "fgmodes.npy", "--Nfgmodes", "4",
+                   "--noise_cov", str(tmp_path / "aux"), "--noise_cov_file", "noise-cov.npy", "--ps_prior_lo", "0.1",
+                   "--ps_prior_hi", "2", "--seed", "77", "--Niter", "6", "--out_dir", str(tmp_path), "--dirname", "resf"])
+    assert rc == 0
+    ps = np.load(tmp_path / "resf" / "0-1" / "dps-eor.npy")
+    assert np.max(np.abs(ps / g["fl_chain_ps"] - 1)) < 1e-6
 
 
 @pytest.mark.gpu

@@ -196,3 +196,16 @@ def test_dense_noise_detection_rules():
     assert 0 < asym < 1e-8
     got = pspec._ninv_dense(ni, 1, 64)
     assert got is not None and np.array_equal(got, got.conj().T) and np.allclose(got, ni, rtol=0, atol=1e-8 * np.abs(ni).max())
+
+
+def test_bench_traffic_guard_and_host_cores(tmp_path, monkeypatch):
+    """bench.py helpers (no GPU): the PMC traffic file is only trusted for the kernel sources it was measured on,
+    and the CPU baseline sizes itself to the cores the process is actually granted."""
+    import json
+    import bench
+    h = bench.kernel_source_hash()
+    assert len(h) == 16 and h == bench.kernel_source_hash()
+    committed = json.load(open(Path(bench.__file__).parent / "profiles" / "pmc_traffic.json"))
+    assert "source_hash" in committed and set(committed["source_hash_files"]) == set(bench.DENSE_STEP_SOURCES)
+    usable, avail, quota = bench.host_cores()
+    assert 1 <= usable <= avail and (quota is None or usable <= quota)
