@@ -663,9 +663,11 @@ def main():
 
     # which physical device every rank ran on (a rehearsal pins all ranks to one: HPX_BENCH_DEVICE)
     devices = [dev_index]
-    if dist is not None:
-        devices = [None] * world
-        dist.all_gather_object(devices, dev_index)
+    if dist is not None:      # one-hot over the device index, summed over the ranks (a plain all-reduce, as for the times)
+        onehot = torch.zeros(64, dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+        onehot[dev_index % 64] = 1.0
+        dist.all_reduce(onehot, op=dist.ReduceOp.SUM)
+        devices = [i for i in range(64) if float(onehot[i].item()) > 0]
     if rank == 0:
         total_units = sum(counts) * K
         value = total_units / dt
