@@ -576,3 +576,28 @@ def test_dense_noise_covariance_with_flags_vs_reference(golden):
         one = pspec.gibbs_sample_with_fg(v, f, S, F, Ninv, prior, Niter=3, seed=77, verbose=False)
         assert np.max(np.abs(out["signal_ps"][b] / one[2] - 1)) < 1e-9
         assert np.allclose(out["ln_post"][b], one[5], rtol=1e-9)
+
+
+def test_dense_noise_with_flags_general_S_and_map_estimate(golden):
+    """The dense-Ninv-with-flags path through the other two entry modes: an initial covariance that is NOT of the
+    form F^H diag F (first iteration through hpx_gibbs_step_general: the Woodbury columns ride along as
+    right-hand sides of the unscaled system) and map_estimate=True (no noise draws), against the exact-solve oracle."""
+    from hydra_pspec_amd import pspec
+    from oracle import pspec_ref
+    g = golden("steps_dense")
+    vis, S, F, Ninv, prior = (g[f"in_{k}"] for k in ("vis", "S", "fgmodes", "Ninv", "prior"))
+    fl = g["fl_flags"]
+    N = S.shape[0]
+    rng = np.random.default_rng(2)
+    a = rng.standard_normal((N, N)) + 1j * rng.standard_normal((N, N))
+    S2 = S + 0.05 * np.trace(S).real / N * (a @ a.conj().T) / N            # Hermitian positive definite, not Fourier-diagonal
+    res = pspec.gibbs_sample_with_fg(vis, fl, S2, F, Ninv, prior, Niter=3, seed=5, verbose=False)
+    ref = pspec_ref.gibbs_sample_with_fg(vis, fl, S2, F, Ninv, prior, Niter=3, seed=5, solver="direct")
+    assert np.max(np.abs(res[2] / ref[2] - 1)) < RTOL
+    assert relerr(res[0], ref[0]) < RTOL and relerr(res[3], ref[3]) < RTOL
+    assert np.allclose(res[5], ref[5], rtol=2e-5)
+    np.random.seed(3)
+    res = pspec.gibbs_sample_with_fg(vis, fl, S, F, Ninv, prior, Niter=5, seed=9, verbose=False, map_estimate=True)
+    np.random.seed(3)
+    ref = pspec_ref.gibbs_sample_with_fg(vis, fl, S, F, Ninv, prior, Niter=5, seed=9, solver="direct", map_estimate=True)
+    assert res[0].shape[0] == 1 and np.max(np.abs(res[2] / ref[2] - 1)) < RTOL and relerr(res[0], ref[0]) < RTOL
