@@ -248,15 +248,17 @@ __global__ void k_add_block(double* __restrict__ zre, double* __restrict__ zim, 
 }
 // omega_b block: O[j][t] = (omk + i oml)/sqrt2, replicated per baseline (the dense product is batched)
 __global__ void k_prep_omega_b(const double* __restrict__ omega, double* __restrict__ Ore,
-                               double* __restrict__ Oim, const int T, const int N, const int NP, const int TP) {
+                               double* __restrict__ Oim, const int T, const int N, const int NP, const int TP,
+                               const int omega_mod) {
   const int b = blockIdx.y;
+  const int tom = omega_mod > 0 ? b % omega_mod : 0;      // per-time units: the draws of "their" time
   const long tot = (long)NP * TP;
   for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < tot; e += (long)gridDim.x * blockDim.x) {
     const int j = (int)(e / TP), t = (int)(e % TP);
     double zr = 0.0, zi = 0.0;
     if (j < N && t < T) {
-      zr = omega[((long)t * 4 + 2) * N + j] / SQRT2;
-      zi = omega[((long)t * 4 + 3) * N + j] / SQRT2;
+      zr = omega[((long)(t + tom) * 4 + 2) * N + j] / SQRT2;
+      zi = omega[((long)(t + tom) * 4 + 3) * N + j] / SQRT2;
     }
     Ore[(long)b * tot + e] = zr;
     Oim[(long)b * tot + e] = zi;
@@ -1388,7 +1390,7 @@ static int set_static_impl(hpx_plan* p, const double* vis, const uint8_t* flags,
         hipLaunchKernelGGL(k_conj_transpose, dim3(64, nbl), dim3(256), 0, st, gre, gim, hre, him, NP);
       } else
       hipLaunchKernelGGL(k_dense_planar, dim3(64, nbl), dim3(256), 0, st, nih_dense, noise_shared, hre, him, N, NP);
-      hipLaunchKernelGGL(k_prep_omega_b, dim3(32, nbl), dim3(256), 0, st, omega, ore, oim, T, N, NP, TP);
+      hipLaunchKernelGGL(k_prep_omega_b, dim3(32, nbl), dim3(256), 0, st, omega, ore, oim, T, N, NP, TP, p->omega_mod);
       HPX_HIP(hipGetLastError());
       HPX_TRY(hpx_launch_dft(nbl, NP, TP, hre, him, 1, ore, oim, (long)NP * TP, TP, nullptr, 0, ure, uim,
                              (long)NP * TP, TP, 1.0, st, 0, mstr));
@@ -1507,6 +1509,38 @@ extern "C" int hpx_plan_set_rng(hpx_plan* p, const double* uniforms, const doubl
 // ---- time-dependent flags / noise (reference docstrings pspec.py:337-340, :398-401,
 // FIXMEs :361, :450-451; run-hydra-pspec.py:524-541 reduces them to an any-time mask instead) -------
 namespace {
+// diag of (nu, N, N) c128 matrices -> (nu, N) f64
+__global__ void k_pt_diag(const double* __restrict__ m, double* __restrict__ dg, const int N) {
+  const int u = blockIdx.y;
+  for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < N; k += gridDim.x * blockDim.x)
+    dg[(long)u * N + k] = m[(((long)u * N + k) * N + k) * 2];
+}
+// lnpart[b][0] = sum_t r_t^H Ninv_{b,t} r_t with the masked residual r [b][NP][TP] and the units' planar Ninv
+// [b*T + t][NP][NP] (Hermitian, row-major): one workgroup per baseline, times in order (deterministic)
+__global__ __launch_bounds__(256) void k_quadform_pt(const double* __restrict__ rre, const double* __restrict__ rim,
+                                                     const double* __restrict__ nre, const double* __restrict__ nim,
+                                                     double* __restrict__ lnpart, const int N, const int T,
+                                                     const int NP, const int TP) {
+  __shared__ double red[4];
+  const int b = blockIdx.x;
+  double acc = 0.0;
+  for (int t = 0; t < T; ++t) {
+    const double* mr = nre + ((long)b * T + t) * NP * NP;
+    const double* mi = nim + ((long)b * T + t) * NP * NP;
+    for (int x = threadIdx.x; x < N; x += 256) {
+      double vr = 0.0, vi = 0.0;                         // v = (Ninv r)[x]
+      for (int k = 0; k < N; ++k) {
+        const double ar = mr[(long)x * NP + k], ai = mi[(long)x * NP + k];
+        const double br = rre[((long)b * NP + k) * TP + t], bi = rim[((long)b * NP + k) * TP + t];
+        vr += ar * br - ai * bi;
+        vi += ar * bi + ai * br;
+      }
+      acc += rre[((long)b * NP + x) * TP + t] * vr + rim[((long)b * NP + x) * TP + t] * vi;
+    }
+  }
+  const double tot = block_sum(acc, red);
+  if (threadIdx.x == 0) lnpart[(long)b * HPX_NPART] = tot;
+}
 // flags_any[b][x] = AND_t flags_t[b][t][x];  ninv_any[b][x] = ninv_t[b][0][x]
 __global__ void k_pt_reduce(const uint8_t* __restrict__ ft, const double* __restrict__ nt,
                             uint8_t* __restrict__ fany, double* __restrict__ nany, const int T, const int N) {
@@ -1582,14 +1616,32 @@ static int set_static_impl(hpx_plan* p, const double* vis, const uint8_t* flags,
                            int prior_shared, int ngrid, const double* omega,
                            const double* fop, int any_flags, void* stream, int wb);
 
-extern "C" int hpx_plan_set_static_pertime(hpx_plan* p, const double* vis, const uint8_t* flags_t,
-                                           const double* ninv_t, const double* fgmodes, int fg_shared,
-                                           const int32_t* prior_map, const double* xgrid, int nxrows,
-                                           int prior_shared, int ngrid, const double* omega,
-                                           const double* fop, int any_flags, void* stream) {
-  HPX_REQUIRE(p && vis && flags_t && ninv_t && fop && prior_map, "hpx_plan_set_static_pertime: null argument");
+// `ninv_td` / `nih_td` non-NULL: full noise matrices per (baseline, time) -- the units of the child are then
+// dense-noise systems (with the Woodbury correction when a unit has flagged channels), and `ninv_t` is ignored
+// (the diagonals of ninv_td take its place for chi^2 and the parent's surrogate)
+static int pertime_impl(hpx_plan* p, const double* vis, const uint8_t* flags_t, const double* ninv_t,
+                        const double* ninv_td, const double* nih_td, const double* fgmodes, int fg_shared,
+                        const int32_t* prior_map, const double* xgrid, int nxrows, int prior_shared, int ngrid,
+                        const double* omega, const double* fop, int any_flags, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   const int nbl = p->nbl, T = p->T, N = p->N, M = p->M, NP = p->NP, TP = p->TP;
+  hpx_devbuf dgb;
+  int wb = 0, fmax = 0;
+  if (ninv_td) {
+    HPX_TRY(dgb.alloc((size_t)nbl * T * N));
+    hipLaunchKernelGGL(k_pt_diag, dim3(4, nbl * T), dim3(256), 0, st, ninv_td, dgb.p, N);
+    HPX_HIP(hipGetLastError());
+    ninv_t = dgb.p;
+    std::vector<uint8_t> hf((size_t)nbl * T * N);
+    HPX_HIP(hipMemcpyAsync(hf.data(), flags_t, hf.size(), hipMemcpyDeviceToHost, st));
+    HPX_HIP(hipStreamSynchronize(st));
+    for (size_t u = 0; u < (size_t)nbl * T; ++u) {
+      int f = 0;
+      for (int j = 0; j < N; ++j) f += hf[u * N + j] ? 0 : 1;
+      fmax = std::max(fmax, f);
+    }
+    wb = fmax > 0;
+  }
   // 1. the parent's time-independent parts (foreground planes, operator, prior tables, omega_a block)
   //    with the any-time mask -- its own solve operators are never used in this mode
   hpx_devbuf tmp;
@@ -1609,7 +1661,7 @@ extern "C" int hpx_plan_set_static_pertime(hpx_plan* p, const double* vis, const
   HPX_HIP(hipGetLastError());
   // 3. the child: nbl*T units of one time sample each
   if (p->child) { hpx_plan_destroy(p->child); p->child = nullptr; }
-  HPX_TRY(plan_create_impl(&p->child, nbl * T, 1, N, M, 0));
+  HPX_TRY(plan_create_impl(&p->child, nbl * T, 1, N, M, wb ? fmax : 0));
   hpx_plan* c = p->child;
   c->omega_mod = T;
   hpx_devbuf fgx;
@@ -1622,6 +1674,12 @@ extern "C" int hpx_plan_set_static_pertime(hpx_plan* p, const double* vis, const
     fgc = fgx.p;
   }
   // (vis (nbl,T,N) is (nbl*T,1,N); flags_t / ninv_t (nbl,T,N) are (nbl*T,N); the child never draws: no priors)
+  if (ninv_td) {
+    HPX_TRY(set_static_impl(c, vis, flags_t, nullptr, ninv_td, nih_td, 0, fgc, fg_shared, p->pmap, nullptr, 0, 1,
+                            ngrid, omega, fop, wb, stream, wb));
+    HPX_TRY(dev_alloc(p, &p->RDre, (size_t)nbl * NP * TP));     // masked residual for the quadratic form
+    HPX_TRY(dev_alloc(p, &p->RDim, (size_t)nbl * NP * TP));
+  } else
   HPX_TRY(set_static_impl(c, vis, flags_t, ninv_t, nullptr, nullptr, 0, fgc, fg_shared, p->pmap, nullptr, 0, 1,
                           ngrid, omega, fop, any_flags, stream));
   HPX_TRY(dev_alloc(p, &p->PTre, (size_t)T * NP * c->TP));
@@ -1636,9 +1694,31 @@ extern "C" int hpx_plan_set_static_pertime(hpx_plan* p, const double* vis, const
   hipLaunchKernelGGL(k_pt_p2t, dim3(64), dim3(256), 0, st, p->P2re, p->P2im, p->PTTre, p->PTTim, T, NP, TP);
   HPX_HIP(hipGetLastError());
   HPX_HIP(hipStreamSynchronize(st));
-  p->per_time = 1;
+  p->per_time = ninv_td ? 2 : 1;
   p->solver = HPX_SOLVER_DENSE;
   return HPX_OK;
+}
+
+extern "C" int hpx_plan_set_static_pertime(hpx_plan* p, const double* vis, const uint8_t* flags_t,
+                                           const double* ninv_t, const double* fgmodes, int fg_shared,
+                                           const int32_t* prior_map, const double* xgrid, int nxrows,
+                                           int prior_shared, int ngrid, const double* omega,
+                                           const double* fop, int any_flags, void* stream) {
+  HPX_REQUIRE(p && vis && flags_t && ninv_t && fop && prior_map, "hpx_plan_set_static_pertime: null argument");
+  return pertime_impl(p, vis, flags_t, ninv_t, nullptr, nullptr, fgmodes, fg_shared, prior_map, xgrid, nxrows,
+                      prior_shared, ngrid, omega, fop, any_flags, stream);
+}
+
+extern "C" int hpx_plan_set_static_pertime_dense(hpx_plan* p, const double* vis, const uint8_t* flags_t,
+                                                 const double* ninv_t_dense, const double* nih_t,
+                                                 const double* fgmodes, int fg_shared, const int32_t* prior_map,
+                                                 const double* xgrid, int nxrows, int prior_shared, int ngrid,
+                                                 const double* omega, const double* fop, int any_flags,
+                                                 void* stream) {
+  HPX_REQUIRE(p && vis && flags_t && ninv_t_dense && nih_t && fop && prior_map,
+              "hpx_plan_set_static_pertime_dense: null argument");
+  return pertime_impl(p, vis, flags_t, nullptr, ninv_t_dense, nih_t, fgmodes, fg_shared, prior_map, xgrid, nxrows,
+                      prior_shared, ngrid, omega, fop, any_flags, stream);
 }
 
 // the child's generator: 1/a of the unit's baseline, omega_a of the unit's time
@@ -2040,8 +2120,8 @@ static int post_solve(hpx_plan* p, int it_abs, const IterOut& O, hipStream_t st)
   R.fg_shared = p->fg_shared; R.any_flags = p->any_flags;
   R.twre = p->Fopre; R.twim = p->Fopim; R.isn = isn; R.logN = 0; R.tcs = 0; R.nbl = nbl; R.npart = 1;
   // dense noise: the masked residual for the quadratic form; it can share G unless G holds w s (flags)
-  R.Rdre = p->dense_noise ? (p->dense_noise == 2 ? p->RDre : p->Gre) : nullptr;
-  R.Rdim = p->dense_noise ? (p->dense_noise == 2 ? p->RDim : p->Gim) : nullptr;
+  R.Rdre = p->dense_noise ? (p->dense_noise == 2 ? p->RDre : p->Gre) : (p->per_time == 2 ? p->RDre : nullptr);
+  R.Rdim = p->dense_noise ? (p->dense_noise == 2 ? p->RDim : p->Gim) : (p->per_time == 2 ? p->RDim : nullptr);
   R.flags_t = p->per_time ? p->flags_t : nullptr;
   R.ninv_t = p->per_time ? p->ninv_t : nullptr;
   // time columns per block of the fused kernel: 64 KiB of LDS for the signal, as k_fft
@@ -2100,6 +2180,10 @@ static int post_solve(hpx_plan* p, int it_abs, const IterOut& O, hipStream_t st)
                              p->Zre, p->Zim, (long)NP * p->ncolR, p->ncolR, 1.0, st, 0, (long)NP * NP));
       hipLaunchKernelGGL(k_quadform, dim3(nbl), dim3(256), 0, st, R.Rdre, R.Rdim, (long)NP * TP, TP, p->Zre, p->Zim,
                          (long)NP * p->ncolR, p->ncolR, p->lnpart, N, T);
+      HPX_HIP(hipGetLastError());
+    } else if (p->per_time == 2) {      // ... with each time's own matrix (the child's units)
+      hipLaunchKernelGGL(k_quadform_pt, dim3(nbl), dim3(256), 0, st, R.Rdre, R.Rdim, p->child->NIre, p->child->NIim,
+                         p->lnpart, N, T, NP, TP);
       HPX_HIP(hipGetLastError());
     }
   }
@@ -2206,13 +2290,30 @@ extern "C" int hpx_gibbs_run(hpx_plan* p, const double* ps0, int iter0, int nite
         // then the solutions go to their time column of this plan's X
         hpx_plan* c = p->child;
         const hpx_gen_batch gc = gen_of_child(p);
-        if (gc.ere) hipLaunchKernelGGL(k_assemble_tail, dim3(c->nbl), dim3(256), 0, st, gc, c->L, c->npad, c->ld);
+        if (c->dense_noise)       // full noise matrix per unit: the whole matrix is laid out
+          hipLaunchKernelGGL(k_assemble, dim3(c->npad / 16, c->nbl), dim3(256), 0, st, gc, c->L, c->npad, c->ld, 0);
+        else if (gc.ere) hipLaunchKernelGGL(k_assemble_tail, dim3(c->nbl), dim3(256), 0, st, gc, c->L, c->npad, c->ld);
         else hipLaunchKernelGGL(k_assemble_edge, dim3(c->nbl, 1), dim3(256), 0, st, gc, c->L, c->npad, c->ld);
         HPX_HIP(hipGetLastError());
         HPX_TRY(mark(p, st));
-        HPX_TRY(hpx_launch_factor(c->nbl, c->npad, c->ld, c->L, c->Wre, c->Wim, c->info, iter0 + it + 1, &gc, st));
+        HPX_TRY(hpx_launch_factor(c->nbl, c->npad, c->ld, c->L, c->Wre, c->Wim, c->info, iter0 + it + 1,
+                                  c->dense_noise ? nullptr : &gc, st));
         HPX_TRY(mark(p, st));
         HPX_TRY(hpx_launch_backsolve(c->nbl, c->npad, c->TP, c->ld, c->L, c->Wre, c->Wim, c->Xre, c->Xim, st));
+        if (c->dense_noise == 2) {      // flagged units: the Woodbury correction per unit (as post_solve, T = 1)
+          HPX_TRY(hpx_launch_dft(c->nbl, c->NP, c->TP, c->Fopre, c->Fopim, 1, c->Xre, c->Xim, (long)c->npad * c->TP,
+                                 c->TP, nullptr, 0, c->Sre, c->Sim, (long)c->NP * c->TP, c->TP,
+                                 1.0 / sqrt((double)N), st, N == c->NP));
+          const int fm = c->wb_fmax;
+          hipLaunchKernelGGL(k_wb_system, dim3(c->nbl), dim3(256), 0, st, c->Sre, c->Sim, c->Xre, c->Xim, c->Fre,
+                             c->Fim, c->fg_shared, c->wb_flist, c->wb_fcount, c->wb_W, fm, N, M, 1, c->NP, c->TP,
+                             c->npad);
+          hipLaunchKernelGGL(k_wb_solve, dim3(c->nbl), dim3(256), 0, st, c->wb_W, c->wb_fcount, fm, 1, c->info,
+                             iter0 + it + 1);
+          hipLaunchKernelGGL(k_wb_correct, dim3(8, c->nbl), dim3(256), 0, st, c->Sre, c->Sim, c->Xre, c->Xim, c->wb_W,
+                             c->wb_fcount, fm, 1, c->NP, c->TP, c->npad);
+          HPX_HIP(hipGetLastError());
+        }
         hipLaunchKernelGGL(k_pt_gather, dim3(32, nbl), dim3(256), 0, st, c->Xre, c->Xim, p->Xre, p->Xim, T, p->npad,
                            TP, c->TP);
         HPX_HIP(hipGetLastError());

@@ -70,7 +70,7 @@ struct hpx_plan {
   // time-dependent flags / noise (hpx_plan_set_static_pertime): every time sample has its own system.
   // `child` is a plan over the nbl*T units (one right-hand side each) that holds the per-unit
   // operators and factors; this (parent) plan keeps the chain state and everything after the solve.
-  int per_time;
+  int per_time;            // 1: diagonal noise per time; 2: full noise matrix per time (dense-noise units)
   int omega_mod;           // > 0 (child plans): unit u takes the noise draws of time u % omega_mod
   hpx_plan* child;
   uint8_t* flags_t;        // [nbl][T][N]

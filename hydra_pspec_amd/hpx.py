@@ -35,6 +35,7 @@ SIGNATURES = {
     "hpx_plan_set_static_dense": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _i, _vp]),
     "hpx_plan_set_static_dense_flagged": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
     "hpx_plan_set_static_pertime": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _i, _vp]),
+    "hpx_plan_set_static_pertime_dense": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _i, _vp]),
     "hpx_plan_set_rng": (_i, [_vp, _vp, _vp, _i, _vp]),
     "hpx_gibbs_run": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
     "hpx_gibbs_step_general": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

@@ -113,6 +113,23 @@ def _ninv_dense(Ninv, nbl, N):
     return np.ascontiguousarray(0.5 * (Ninv + herm), dtype=complex)
 
 
+def _ninv_dense_pertime(Ninv, nbl, T, N):
+    """A time-dependent ``Ninv`` (Ntimes,N,N) / (Nbl,Ntimes,N,N) (pspec.py:337-340) with off-diagonal terms ->
+    (Nbl,Ntimes,N,N) Hermitian complex; None when every matrix is diagonal (the per-time diagonal mode)."""
+    if not isinstance(Ninv, np.ndarray) and hasattr(Ninv, "detach"):
+        Ninv = Ninv.detach().cpu().numpy()
+    Ninv = np.asarray(Ninv)
+    if not (Ninv.shape in ((T, N, N), (nbl, T, N, N)) and (Ninv.ndim == 4 or T != nbl)):
+        return None
+    d = np.diagonal(Ninv, axis1=-2, axis2=-1)
+    if not np.any(Ninv - d[..., None] * np.eye(N) != 0):
+        return None
+    herm = np.conj(np.swapaxes(Ninv, -1, -2))
+    if not np.allclose(Ninv, herm, rtol=0.0, atol=1e-8 * np.abs(Ninv).max()):
+        raise NotImplementedError("a non-Hermitian inverse noise covariance is not supported")
+    return np.ascontiguousarray(np.broadcast_to(0.5 * (Ninv + herm), (nbl, T, N, N)), dtype=complex)
+
+
 def _ninv_diag(Ninv, nbl, T, N):
     """Accept (N,), (nbl,N) diagonals or (N,N)/(nbl,N,N) dense matrices that are
     diagonal; return (nbl,N).  Dense non-diagonal inverse covariances make the
@@ -128,7 +145,8 @@ def _ninv_diag(Ninv, nbl, T, N):
         # time-dependent Ninv (pspec.py:337-340): one diagonal matrix per time -> (nbl, T, N)
         d = np.diagonal(Ninv, axis1=-2, axis2=-1)
         if np.any(Ninv - d[..., None] * np.eye(N) != 0):
-            raise NotImplementedError("time-dependent inverse noise covariances must be diagonal")
+            raise NotImplementedError("this entry point takes diagonal time-dependent inverse noise covariances only "
+                                      "(make_batch / gibbs_sample_with_fg[_batched] accept Hermitian matrices)")
         return np.ascontiguousarray(np.broadcast_to(d.real, (nbl, T, N)), dtype=float)
     if Ninv.shape == (nbl, T, N) and not (T == N and Ninv.ndim == 3 and nbl == T):
         return np.ascontiguousarray(Ninv.real, dtype=float)
@@ -182,7 +200,8 @@ class GibbsBatch:
 
     def __init__(self, vis, flags, fgmodes, ninv_diag, ps_prior, Niter, seed=None,
                  map_estimate=False, device=None, tables=None, omega=None, solver="auto", ninv_dense=None):
-        """``ninv_dense``: Hermitian non-diagonal inverse noise covariance(s) (N,N) or (Nbl,N,N) instead of
+        """``ninv_dense``: Hermitian non-diagonal inverse noise covariance(s) (N,N) or (Nbl,N,N) -- or, time
+        dependent, (Nbl,Ntimes,N,N) -- instead of
         ``ninv_diag`` (:func:`make_batch` routes them here): dense solver only.  With flagged channels the
         reference's column-masked ``Ni`` is not Hermitian (pspec.py:361): the solution then comes from the
         unflagged-noise factorisation through a rank-f Woodbury correction (``hpx_plan_set_static_dense_flagged``)."""
@@ -198,8 +217,9 @@ class GibbsBatch:
         M = fg_shape[-1]
         assert tuple(flags.shape) in ((nbl, N), (nbl, T, N)), \
             "`flags` array must have shape (Nbl, Nfreqs) or, time dependent, (Nbl, Ntimes, Nfreqs)"
-        if ninv_dense is None and tuple(np.shape(ninv_diag)) == (nbl, T, N) and len(tuple(flags.shape)) == 2 \
-                and not (T == N and nbl == T):
+        dense_t = ninv_dense is not None and np.ndim(ninv_dense) == 4
+        if (dense_t or (ninv_dense is None and tuple(np.shape(ninv_diag)) == (nbl, T, N)
+                        and not (T == N and nbl == T))) and len(tuple(flags.shape)) == 2:
             # time-dependent noise with time-independent flags: the same flags at every time
             fl2 = flags if isinstance(flags, np.ndarray) else flags.detach().cpu().numpy()
             flags = np.ascontiguousarray(np.broadcast_to(np.asarray(fl2)[:, None, :], (nbl, T, N)))
@@ -214,11 +234,27 @@ class GibbsBatch:
             d_flags = hpx.to_dev(torch, np.ascontiguousarray(fl_np).astype(np.uint8), torch.uint8,
                                  self.device)
             self.dense_noise = ninv_dense is not None
-            if self.per_time and self.dense_noise:
-                raise NotImplementedError("time-dependent flags with a non-diagonal inverse noise covariance")
             self.any_flags = bool((~fl_np.astype(bool)).any())
             extra_rhs = 0
-            if self.dense_noise:
+            if self.dense_noise and self.per_time:
+                # one full noise matrix per (baseline, time) (pspec.py:337-340): Ni = Ninv_t diag(w_t) and its
+                # scipy sqrtm per unit, as build_matrices would make them for that time (:361-362)
+                import scipy.linalg
+                nd = np.asarray(ninv_dense, dtype=complex)
+                if nd.ndim == 3:
+                    nd = np.broadcast_to(nd[:, None], (nbl, T, N, N))
+                assert nd.shape == (nbl, T, N, N), "time-dependent Ninv must have shape (Nbl, Ntimes, Nfreqs, Nfreqs)"
+                nd = np.ascontiguousarray(nd)
+                w = fl_np.astype(bool)
+                nih = np.empty((nbl, T, N, N), dtype=complex)
+                for b in range(nbl):
+                    for t in range(T):
+                        nih[b, t] = scipy.linalg.sqrtm(nd[b, t] * w[b, t][None, :]) if not w[b, t].all() \
+                            else sqrtm_hermitian(nd[b, t])
+                d_nd = hpx.to_dev(torch, nd, c128, self.device)
+                d_nh = hpx.to_dev(torch, nih, c128, self.device)
+                d_ninv = None
+            elif self.dense_noise:
                 nd = np.asarray(ninv_dense, dtype=complex)
                 assert nd.shape in ((N, N), (nbl, N, N)), "Ninv shape must be (Nfreqs, Nfreqs) or (Nbl, Nfreqs, Nfreqs)"
                 d_nd = hpx.to_dev(torch, nd, c128, self.device)
@@ -259,7 +295,13 @@ class GibbsBatch:
             d_fop = hpx.to_dev(torch, utils.fourier_operator(N), c128, self.device)
             self.plan = hpx.Plan(nbl, T, N, M, extra_rhs=extra_rhs)
             L = hpx.lib()
-            if self.per_time:
+            if self.per_time and self.dense_noise:
+                hpx.check(L.hpx_plan_set_static_pertime_dense(
+                    self.plan.handle, hpx.ptr(d_vis), hpx.ptr(d_flags), hpx.ptr(d_nd), hpx.ptr(d_nh),
+                    hpx.ptr(d_fg) if M > 0 else None, int(fg_shared), hpx.ptr(d_pmap), hpx.ptr(d_xgrid),
+                    int(len(xgrid)), int(prior_shared), NGRID, hpx.ptr(d_omega), hpx.ptr(d_fop),
+                    int(self.any_flags), hpx.stream_ptr(torch)), "hpx_plan_set_static_pertime_dense")
+            elif self.per_time:
                 # every time sample has its own flags / noise, hence its own system: Nbl x Ntimes
                 # factorisations per iteration (the mode the reference documents but does not
                 # implement: pspec.py:337-340, :398-401, FIXMEs :361, :450-451)
@@ -449,6 +491,12 @@ def make_batch(vis, flags, fgmodes, Ninv, ps_prior, Niter, seed=None, map_estima
                                                                                     or np.shape(Ninv) == (nbl, T, N))
     diag_stack = tuple(np.shape(Ninv)) == (nbl, N) and nbl > 1
     nd = _ninv_dense(Ninv, nbl, N) if len(np.shape(Ninv)) >= 2 and not per_time_ninv and not diag_stack else None
+    if nd is None and per_time_ninv and len(np.shape(Ninv)) >= 3:
+        nd = _ninv_dense_pertime(Ninv, nbl, T, N)        # None when the matrices are diagonal
+    if nd is not None and nd.ndim == 3 and len(tuple(flags.shape)) == 3:
+        nd = np.ascontiguousarray(np.broadcast_to(nd[:, None], (nbl, T, N, N)))    # time-dependent flags only
+    elif nd is not None and nd.ndim == 2 and len(tuple(flags.shape)) == 3:
+        nd = np.ascontiguousarray(np.broadcast_to(nd, (nbl, T, N, N)))
     if nd is not None:
         return GibbsBatch(vis, flags, fgmodes, None, ps_prior, Niter, seed=seed, map_estimate=map_estimate,
                           device=device, solver=solver, ninv_dense=nd, tables=tables)
@@ -469,8 +517,8 @@ def gibbs_sample_with_fg_batched(vis, flags, fgmodes, Ninv, ps_prior, S_initial=
     diagonal ones, or Hermitian with off-diagonal terms (a correlated noise covariance;
     dense solver; with flags through a Woodbury correction) --, ``ps_prior`` (2,Nfreqs) or (Nbl,2,Nfreqs) with
     rows [hi, lo].  Time-dependent flags ``(Nbl,Ntimes,Nfreqs)``, optionally with per-time
-    inverse noise variances ``Ninv`` (Nbl,Ntimes,Nfreqs) or diagonal matrices
-    (Ntimes,Nfreqs,Nfreqs), select the mode in which every time sample is solved with its own
+    inverse noise variances ``Ninv`` (Nbl,Ntimes,Nfreqs) or matrices (Ntimes,Nfreqs,Nfreqs) /
+    (Nbl,Ntimes,Nfreqs,Nfreqs) (diagonal, or Hermitian with off-diagonal terms), select the mode in which every time sample is solved with its own
     noise matrix (Nbl x Ntimes factorisations per iteration; memory: one factor buffer of
     (Nfreqs+Nmodes)^2 x 16 bytes, ~ 5 MB at Nfreqs = 512, per baseline and time).  The initial covariance is
     given either as ``ps_initial`` (Nbl,Nfreqs)/(Nfreqs,) bandpowers

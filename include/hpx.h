@@ -131,6 +131,22 @@ int hpx_plan_set_static_pertime(hpx_plan* p, const double* vis, const uint8_t* f
                                 int prior_shared, int ngrid, const double* omega,
                                 const double* fop, int any_flags, void* stream);
 
+/* The same with a full (non-diagonal) inverse noise covariance per time sample: the Ninv of shape
+ * (Ntimes, Nfreqs, Nfreqs) of the reference's docstrings (pspec.py:337-340, :398-401).  Every
+ * (baseline, time) unit is then a dense-noise system as in hpx_plan_set_static_dense; units with flagged
+ * channels take the Woodbury correction of hpx_plan_set_static_dense_flagged (one extra right-hand side
+ * per flagged channel of the unit, found here from flags_t).
+ *   ninv_t_dense (nbl,T,N,N) c128   Ninv_{b,t}, Hermitian, NOT masked
+ *   nih_t        (nbl,T,N,N) c128   sqrtm of the column-masked Ni_{b,t} = Ninv_{b,t} diag(w_{b,t}) (pspec.py:361-362)
+ * chi^2 uses Ninv_{b,t}.diagonal(), the first ln-posterior term is sum_t r_t^H Ninv_{b,t}[w_t][:, w_t] r_t.
+ * With ninv_t_dense[b][t] = Ninv[b] and flags_t[b][t] = flags[b] for every t the chains are those of
+ * hpx_plan_set_static_dense(_flagged).  Dense solver only. */
+int hpx_plan_set_static_pertime_dense(hpx_plan* p, const double* vis, const uint8_t* flags_t,
+                                      const double* ninv_t_dense, const double* nih_t, const double* fgmodes,
+                                      int fg_shared, const int32_t* prior_map, const double* xgrid, int nxrows,
+                                      int prior_shared, int ngrid, const double* omega, const double* fop,
+                                      int any_flags, void* stream);
+
 /* Random tables of the bandpower draw (pspec.py:113-125): one uniform per
  * channel per iteration from the chain's global stream.
  *   uniforms (niter,N) f64   U

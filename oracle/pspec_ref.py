@@ -238,16 +238,19 @@ def gibbs_sample_with_fg(vis, flags, S_initial, fgmodes, Ninv, ps_prior, Niter=1
 # operation (tests/test_oracle_golden.py pins that against the reference's golden steps).
 def gibbs_step_fgmodes_pertime(vis, flags_t, signal_S, fgmodes, Ninv_t, ps_prior=None, map_estimate=False,
                                solver="direct"):
-    """``vis`` (T,N) already multiplied by flags_t; ``flags_t`` (T,N) bool; ``Ninv_t`` (T,N) diagonals."""
+    """``vis`` (T,N) already multiplied by flags_t; ``flags_t`` (T,N) bool; ``Ninv_t`` (T,N) diagonals or
+    (T,N,N) matrices (the shape the reference's docstrings name, pspec.py:337-340)."""
     T, nfreq = vis.shape
     nmodes = fgmodes.shape[1]
-    assert flags_t.shape == (T, nfreq) and Ninv_t.shape == (T, nfreq)
+    assert flags_t.shape == (T, nfreq) and Ninv_t.shape in ((T, nfreq), (T, nfreq, nfreq))
+    full = Ninv_t.ndim == 3
     fop = fourier_operator(nfreq)
     keep = np.random.get_state()
     rows = []
     try:
         for t in range(T):
-            mats = build_matrices(nfreq + nmodes, flags_t[t], signal_S, np.diag(Ninv_t[t]).astype(complex), fgmodes)
+            mats = build_matrices(nfreq + nmodes, flags_t[t], signal_S,
+                                  Ninv_t[t] if full else np.diag(Ninv_t[t]).astype(complex), fgmodes)
             x, _, _ = gcr_fgmodes_1d(t, vis[t], flags_t[t], mats, fgmodes, map_estimate=map_estimate, solver=solver)
             rows.append(x)
     finally:
@@ -256,7 +259,7 @@ def gibbs_step_fgmodes_pertime(vis, flags_t, signal_S, fgmodes, Ninv_t, ps_prior
     signal_cr = cr[:, :-nmodes]
     fg_amps = cr[:, -nmodes:]
     model = signal_cr + fg_amps @ fgmodes.T
-    chisq = np.abs(vis - model) ** 2 * Ninv_t
+    chisq = np.abs(vis - model) ** 2 * (np.diagonal(Ninv_t, axis1=1, axis2=2).real if full else Ninv_t)   # :452
     ps_sample = sample_S(s=signal_cr, prior=ps_prior)
     S_sample = covariance_from_pspec(ps_sample / nfreq ** 2, fop)
     Sinv = np.linalg.inv(S_sample)
@@ -265,7 +268,8 @@ def gibbs_step_fgmodes_pertime(vis, flags_t, signal_S, fgmodes, Ninv_t, ps_prior
         f = flags_t[t]
         r = (vis[t] - model[t])[f]
         sf = signal_cr[t][f]
-        ln_post += (-(r.conj() @ (Ninv_t[t][f] * r)) - (sf.conj() @ Sinv[f][:, f] @ sf)).real
+        nr = Ninv_t[t][f][:, f] @ r if full else Ninv_t[t][f] * r                       # :472-477 per time
+        ln_post += (-(r.conj() @ nr) - (sf.conj() @ Sinv[f][:, f] @ sf)).real
     return signal_cr, S_sample, ps_sample, fg_amps, chisq, ln_post
 
 

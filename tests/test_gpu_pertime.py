@@ -89,3 +89,64 @@ def test_pertime_noise_with_time_independent_flags():
     assert np.array_equal(a["signal_ps"], b["signal_ps"]) and np.array_equal(a["ln_post"], b["ln_post"])
     with pytest.raises(ValueError):
         pspec.GibbsBatch(d["vis"], d["flags"], d["fgmodes"], nt[:, :4], d["ps_prior"], 2, seed=1)
+
+
+def _banded_ninv(N, sig2, phase=0.4):
+    i = np.arange(N)
+    band = np.zeros((N, N), dtype=complex)
+    band[i, i] = 1.0 + 0.2 * np.cos(0.3 * i)
+    band[i[:-1], i[:-1] + 1] = 0.3 * np.exp(1j * phase)
+    band[i[:-1] + 1, i[:-1]] = 0.3 * np.exp(-1j * phase)
+    band[i[:-2], i[:-2] + 2] = 0.1
+    band[i[:-2] + 2, i[:-2]] = 0.1
+    return np.linalg.inv(sig2 * band)
+
+
+@pytest.mark.parametrize("flag_frac", [0.0, 0.1])
+def test_identical_full_noise_matrices_per_time_reproduce_the_dense_chain(flag_frac):
+    """Ninv of shape (Ntimes, Nfreqs, Nfreqs) with off-diagonal terms (pspec.py:337-340), the same matrix at every
+    time: the per-time dense mode (Nbl*T dense-noise systems, Woodbury-corrected where flagged) gives the chain of
+    the time-independent dense mode."""
+    from hydra_pspec_amd import pspec, synthetic
+    nbl, T, N, M = 2, 6, 48, 5
+    d = synthetic.make_baselines(N, T, M, k0=11, nbl=nbl, flag_frac=flag_frac, dense=True)
+    Ninv = _banded_ninv(N, 1.0 / d["Ninv"][0, 0].real)
+    kw = dict(ps_initial=d["ps0"], Niter=4, seed=3, keep=("signal_cr", "fg_amps", "chisq"))
+    std = pspec.gibbs_sample_with_fg_batched(d["vis"], d["flags"], d["fgmodes"], Ninv, d["ps_prior"], **kw)
+    Ninv_t = np.broadcast_to(Ninv, (T, N, N)).copy()
+    pt = pspec.gibbs_sample_with_fg_batched(d["vis"], d["flags"], d["fgmodes"], Ninv_t, d["ps_prior"], **kw)
+    assert np.max(np.abs(pt["signal_ps"] / std["signal_ps"] - 1)) < 1e-9
+    assert relerr(pt["signal_cr"], std["signal_cr"]) < 1e-9 and relerr(pt["fg_amps"], std["fg_amps"]) < 1e-9
+    assert relerr(pt["chisq"], std["chisq"]) < 1e-7 and np.allclose(pt["ln_post"], std["ln_post"], rtol=1e-9)
+
+
+def test_full_noise_matrices_per_time_vs_oracle():
+    """Correlated noise whose level AND correlation change with time, together with time-dependent flags, against
+    the per-time exact-solve oracle (build_matrices / gcr_fgmodes_1d per time with that time's Ninv and flags)."""
+    from hydra_pspec_amd import pspec
+    from oracle import pspec_ref
+    nbl, T, N, M, niter = 2, 8, 32, 4, 3
+    d, flt, _ = _pertime_inputs(nbl, T, N, M, seed=5)
+    rng = np.random.default_rng(12)
+    sig2 = 1.0 / d["Ninv"][0, 0].real
+    Ninv_t = np.stack([[_banded_ninv(N, sig2 * rng.uniform(0.6, 1.4), phase=rng.uniform(-1, 1)) for _ in range(T)]
+                       for _ in range(nbl)])
+    assert (~flt).any()
+    out = pspec.gibbs_sample_with_fg_batched(d["vis"], flt, d["fgmodes"], Ninv_t, d["ps_prior"], ps_initial=d["ps0"],
+                                             Niter=niter, seed=9, keep=("signal_cr", "fg_amps", "chisq"))
+    for b in range(nbl):
+        ref = pspec_ref.gibbs_sample_with_fg_pertime(d["vis"][b], flt[b], d["S_initial"], d["fgmodes"], Ninv_t[b],
+                                                     d["ps_prior"], Niter=niter, seed=9)
+        assert np.max(np.abs(out["signal_ps"][b] / ref[2] - 1)) < RTOL, b
+        assert relerr(out["signal_cr"][b], ref[0]) < RTOL and relerr(out["fg_amps"][b], ref[3]) < RTOL
+        assert relerr(out["chisq"][b], ref[4]) < 1e-6 and np.allclose(out["ln_post"][b], ref[5], rtol=1e-7)
+    # the reference's call surface: flags (Ntimes, Nfreqs), Ninv (Ntimes, Nfreqs, Nfreqs)
+    res = pspec.gibbs_sample_with_fg(d["vis"][1], flt[1], d["S_initial"], d["fgmodes"], Ninv_t[1], d["ps_prior"],
+                                     Niter=niter, seed=9, verbose=False)
+    assert np.max(np.abs(res[2] / out["signal_ps"][1] - 1)) < 1e-8        # (ps0 recovered from S_initial there)
+    # one (N, N) matrix with time-dependent flags: the same matrix at every time
+    one = pspec.gibbs_sample_with_fg_batched(d["vis"], flt, d["fgmodes"], Ninv_t[0, 0], d["ps_prior"],
+                                             ps_initial=d["ps0"], Niter=2, seed=9)
+    same = pspec.gibbs_sample_with_fg_batched(d["vis"], flt, d["fgmodes"], np.broadcast_to(Ninv_t[0, 0], (T, N, N)),
+                                              d["ps_prior"], ps_initial=d["ps0"], Niter=2, seed=9)
+    assert np.array_equal(one["signal_ps"], same["signal_ps"])

@@ -254,3 +254,26 @@ def test_pertime_oracle_reduces_to_the_reference(name):
     np.random.seed(4242)
     c = R.gibbs_step_fgmodes_pertime(vis * flt, flt, S, F, nt, prior, solver="cg")
     assert np.max(np.abs(c[2] / g[f"{name}_ps"] - 1)) < 1e-7        # and, with the reference's CG, the golden itself
+
+
+@pytest.mark.parametrize("flagged", [False, True])
+def test_pertime_oracle_with_full_matrices_reduces_to_the_reference(flagged):
+    """The (Ntimes, Nfreqs, Nfreqs) form of the per-time oracle with the SAME correlated Ninv (and flags) at every
+    time is the reference's dense-noise step: pinned to the golden steps_dense.npz, which the reference itself
+    produced (without flags: step_*; with 5 flagged channels: fl_step_*)."""
+    g = dict(np.load(GOLDEN / "steps_dense.npz"))
+    vis, S, F, Ninv, prior = (g[f"in_{k}"] for k in ("vis", "S", "fgmodes", "Ninv", "prior"))
+    T, N = vis.shape
+    fl = g["fl_flags"] if flagged else np.ones(N, dtype=bool)
+    flt = np.broadcast_to(fl, (T, N)).copy()
+    Ninv_t = np.broadcast_to(Ninv, (T, N, N)).copy()
+    np.random.seed(4242)
+    a = R.gibbs_step_fgmodes(vis * fl, fl, S, F, Ninv, prior, solver="direct")
+    np.random.seed(4242)
+    b = R.gibbs_step_fgmodes_pertime(vis * flt, flt, S, F, Ninv_t, prior, solver="direct")
+    assert np.array_equal(a[2], b[2]) and np.array_equal(a[0], b[0]) and np.array_equal(a[3], b[3])
+    assert np.allclose(a[4], b[4], rtol=1e-14) and b[5] == pytest.approx(a[5], rel=1e-12)
+    np.random.seed(4242)
+    c = R.gibbs_step_fgmodes_pertime(vis * flt, flt, S, F, Ninv_t, prior, solver="cg")
+    key = "fl_step_ps" if flagged else "step_ps"
+    assert np.max(np.abs(c[2] / g[key] - 1)) < 1e-6
