@@ -2251,27 +2251,47 @@ static int finish_run(hpx_plan* p, int niter, double* ps_last, hipStream_t st) {
   return HPX_OK;
 }
 
-extern "C" int hpx_gibbs_run(hpx_plan* p, const double* ps0, int iter0, int niter,
-                             const double* ps_forced, double* ps_out, double* lnpost_out,
-                             double* cr_out, double* fg_out, double* chisq_out, int thin,
-                             double* ps_last, void* stream) {
-  HPX_REQUIRE(p && p->have_static, "hpx_gibbs_run: plan has no static inputs");
-  HPX_REQUIRE(ps_out && lnpost_out && niter > 0 && iter0 >= 0, "hpx_gibbs_run: bad argument");
-  HPX_REQUIRE(p->uni && iter0 + niter <= p->niter_tab, "hpx_gibbs_run: random tables too short");
-  HPX_REQUIRE(ps0 || p->have_ps, "hpx_gibbs_run: no starting bandpowers (ps0 is NULL on a plan that has not run yet)");
-  if (thin < 1) thin = 1;
-  hipStream_t st = (hipStream_t)stream;
-  const int nbl = p->nbl, N = p->N, M = p->M, T = p->T, TP = p->TP;
-  const int nkeep = (niter + thin - 1) / thin;
-  if (ps0) {
-    hipLaunchKernelGGL(k_set_a, dim3(256), dim3(256), 0, st, ps0, p->ia, p->ps_cur, (long)nbl * N,
-                       (double)N);
+// what one run of `niter` iterations reads and writes (hpx_gibbs_run's arguments)
+struct RunArgs {
+  const double *ps0, *ps_forced;
+  double *ps_out, *lnpost_out, *cr_out, *fg_out, *chisq_out, *ps_last;
+  int iter0, niter, thin;
+  hipStream_t st;
+};
+
+static int run_check(const hpx_plan* p, const RunArgs& A, const char* who) {
+  const char* why = nullptr;
+  if (!(p && p->have_static)) why = "plan has no static inputs";
+  else if (!(A.ps_out && A.lnpost_out && A.niter > 0 && A.iter0 >= 0)) why = "bad argument";
+  else if (!(p->uni && A.iter0 + A.niter <= p->niter_tab)) why = "random tables too short";
+  else if (!(A.ps0 || p->have_ps)) why = "no starting bandpowers (ps0 is NULL on a plan that has not run yet)";
+  if (why) {
+    hpx_set_error("%s: %s", who, why);
+    return HPX_EINVAL;
+  }
+  return HPX_OK;
+}
+
+static int run_begin(hpx_plan* p, const RunArgs& A) {
+  hipStream_t st = A.st;
+  if (A.ps0) {
+    hipLaunchKernelGGL(k_set_a, dim3(256), dim3(256), 0, st, A.ps0, p->ia, p->ps_cur, (long)p->nbl * p->N,
+                       (double)p->N);
     HPX_HIP(hipGetLastError());
   }
-  HPX_HIP(hipMemsetAsync(p->info, 0, (size_t)nbl * sizeof(int32_t), st));
+  HPX_HIP(hipMemsetAsync(p->info, 0, (size_t)p->nbl * sizeof(int32_t), st));
   if (p->child) HPX_HIP(hipMemsetAsync(p->child->info, 0, (size_t)p->child->nbl * sizeof(int32_t), st));
   p->ev_used = 0;
-  for (int it = 0; it < niter; ++it) {
+  return HPX_OK;
+}
+
+// iteration `it` (0-based within the run) of plan p: everything is enqueued on A.st, nothing waits
+static int run_iteration(hpx_plan* p, const RunArgs& A, int it) {
+  hipStream_t st = A.st;
+  const int nbl = p->nbl, N = p->N, M = p->M, T = p->T, TP = p->TP;
+  const int iter0 = A.iter0, niter = A.niter, thin = A.thin;
+  const int nkeep = (niter + thin - 1) / thin;
+  {
     HPX_TRY(mark(p, st));
     // Only the edge rows (foreground modes, padding, right-hand sides: rows >= rmin) are
     // assembled; the signal x signal part of the matrix is generated inside the factor kernel.
@@ -2339,19 +2359,56 @@ extern "C" int hpx_gibbs_run(hpx_plan* p, const double* ps0, int iter0, int nite
     const bool keep = (it % thin) == 0;
     const long slot = it / thin;
     IterOut O;
-    O.ps_forced = ps_forced ? ps_forced + (long)it * N : nullptr;
+    O.ps_forced = A.ps_forced ? A.ps_forced + (long)it * N : nullptr;
     O.forced_bstride = (long)niter * N;
-    O.ps_out = ps_out + (long)it * N; O.ps_bstride = (long)niter * N;
-    O.lnpost_out = lnpost_out + it; O.lnpost_pitch = niter;
+    O.ps_out = A.ps_out + (long)it * N; O.ps_bstride = (long)niter * N;
+    O.lnpost_out = A.lnpost_out + it; O.lnpost_pitch = niter;
     O.cr_bstride = (long)nkeep * T * N * 2;
     O.fg_bstride = (long)nkeep * T * M * 2;
     O.chisq_bstride = (long)nkeep * T * N;
-    O.cr_out = (cr_out && keep) ? cr_out + slot * T * N * 2 : nullptr;
-    O.fg_out = (fg_out && keep) ? fg_out + slot * T * M * 2 : nullptr;
-    O.chisq_out = (chisq_out && keep) ? chisq_out + slot * T * N : nullptr;
+    O.cr_out = (A.cr_out && keep) ? A.cr_out + slot * T * N * 2 : nullptr;
+    O.fg_out = (A.fg_out && keep) ? A.fg_out + slot * T * M * 2 : nullptr;
+    O.chisq_out = (A.chisq_out && keep) ? A.chisq_out + slot * T * N : nullptr;
     HPX_TRY(post_solve(p, iter0 + it, O, st));
   }
-  return finish_run(p, niter, ps_last, st);
+  return HPX_OK;
+}
+
+extern "C" int hpx_gibbs_run(hpx_plan* p, const double* ps0, int iter0, int niter,
+                             const double* ps_forced, double* ps_out, double* lnpost_out,
+                             double* cr_out, double* fg_out, double* chisq_out, int thin,
+                             double* ps_last, void* stream) {
+  const RunArgs A = {ps0, ps_forced, ps_out, lnpost_out, cr_out, fg_out, chisq_out, ps_last,
+                     iter0, niter, thin < 1 ? 1 : thin, (hipStream_t)stream};
+  HPX_TRY(run_check(p, A, "hpx_gibbs_run"));
+  HPX_TRY(run_begin(p, A));
+  for (int it = 0; it < niter; ++it) HPX_TRY(run_iteration(p, A, it));
+  return finish_run(p, niter, ps_last, A.st);
+}
+
+// Several plans advanced together, each on its own stream, iteration by iteration from this one host thread:
+// one part's back substitution, transforms and draw then run beside another part's factorisation (hpx.h).
+extern "C" int hpx_gibbs_run_parts(const hpx_run_part* parts, int nparts, int iter0, int niter, int thin) {
+  HPX_REQUIRE(parts && nparts > 0 && nparts <= 64, "hpx_gibbs_run_parts: bad argument");
+  std::vector<RunArgs> A(nparts);
+  for (int q = 0; q < nparts; ++q) {
+    const hpx_run_part& P = parts[q];
+    A[q] = {P.ps0, P.ps_forced, P.ps_out, P.lnpost_out, P.cr_out, P.fg_out, P.chisq_out, P.ps_last,
+            iter0, niter, thin < 1 ? 1 : thin, (hipStream_t)P.stream};
+    HPX_TRY(run_check(P.plan, A[q], "hpx_gibbs_run_parts"));
+    for (int r = 0; r < q; ++r)
+      HPX_REQUIRE(parts[r].plan != P.plan && (nparts == 1 || parts[r].stream != P.stream),
+                  "hpx_gibbs_run_parts: every part needs a plan and a stream of its own");
+  }
+  for (int q = 0; q < nparts; ++q) HPX_TRY(run_begin(parts[q].plan, A[q]));
+  for (int it = 0; it < niter; ++it)
+    for (int q = 0; q < nparts; ++q) HPX_TRY(run_iteration(parts[q].plan, A[q], it));
+  int rc = HPX_OK;
+  for (int q = 0; q < nparts; ++q) {         // every stream is drained even when an earlier part failed
+    const int r = finish_run(parts[q].plan, niter, parts[q].ps_last, A[q].st);
+    if (rc == HPX_OK) rc = r;
+  }
+  return rc;
 }
 
 // ---- general first iteration ---------------------------------------------------------------
