@@ -639,7 +639,8 @@ def main():
     # the same batch as several plans on several streams (GibbsParts / hpx_gibbs_run_parts): reported beside the
     # headline value, which stays the one-plan run that the roofline and the per-stage events describe
     multi = None
-    if rank == 0 and world == 1 and args.parts > 1 and nbl >= 2 * args.parts and args.config != "N4":
+    if rank == 0 and world == 1 and args.parts > 1 and nbl >= 128 * args.parts and args.config != "N4":
+        # (worth it only when one plan's kernels already fill the GPU: >= 128 baselines per part)
         gp = pspec.GibbsParts(d["vis"], flags_in, d["fgmodes"], ninv_in, d["ps_prior"], W + K, parts=args.parts,
                               seed=d["seed"], solver=args.solver)
         if W > 0:

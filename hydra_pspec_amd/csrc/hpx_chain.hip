@@ -2401,6 +2401,8 @@ extern "C" int hpx_gibbs_run_parts(const hpx_run_part* parts, int nparts, int it
                   "hpx_gibbs_run_parts: every part needs a plan and a stream of its own");
   }
   for (int q = 0; q < nparts; ++q) HPX_TRY(run_begin(parts[q].plan, A[q]));
+  // (a phase offset between the parts' first iterations was tried: no effect once the streams are fed from one
+  // thread -- the parts drift into place by themselves)
   for (int it = 0; it < niter; ++it)
     for (int q = 0; q < nparts; ++q) HPX_TRY(run_iteration(parts[q].plan, A[q], it));
   int rc = HPX_OK;

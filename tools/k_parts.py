@@ -14,17 +14,19 @@ ps0 = np.broadcast_to(d["ps0"], (nbl, N)).copy()
 def make(lo, hi, stream):
     with torch.cuda.stream(stream):
         gb = pspec.GibbsBatch(d["vis"][lo:hi], d["flags"][lo:hi], d["fgmodes"], d["ninv_diag"][lo:hi], d["ps_prior"],
-                              W + 2 * K, seed=d["seed"], solver="dense")
+                              W + K, seed=d["seed"], solver="dense")
         gb.run(W, ps0=ps0[lo:hi])
     return gb
 
 
-def timed(parts):
+def timed(parts, delay=0.0):
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     th = []
-    for gb, stream in parts:
-        def work(gb=gb, stream=stream):
+    for q, (gb, stream) in enumerate(parts):
+        def work(gb=gb, stream=stream, q=q):
+            if delay:
+                time.sleep(q * delay)          # a phase offset between the parts' iterations
             with torch.cuda.stream(stream):
                 gb.run(K)
         th.append(threading.Thread(target=work))
@@ -42,8 +44,11 @@ for P in [int(a) for a in sys.argv[1:]] or [1, 2, 3, 4]:
         s = torch.cuda.Stream()
         parts.append((make(cuts[i], cuts[i + 1], s), s))
     timed(parts)
-    dt = timed(parts)
-    print(f"{P} stream(s), sizes {[cuts[i + 1] - cuts[i] for i in range(P)]}: {dt / K * 1e3:.3f} ms/step = "
-          f"{nbl * K / dt:.4g} baseline*iter/s", flush=True)
+    for delay in (0.0, 0.0007, 0.0014) if P > 1 else (0.0,):
+        for gb, _ in parts:
+            gb.iter_done = W
+        dt = timed(parts, delay) - (P - 1) * delay
+        print(f"{P} stream(s), sizes {[cuts[i + 1] - cuts[i] for i in range(P)]}, start offset {delay * 1e3:.1f} ms: "
+              f"{dt / K * 1e3:.3f} ms/step = {nbl * K / dt:.4g} baseline*iter/s", flush=True)
     for gb, _ in parts:
         gb.close()
