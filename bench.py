@@ -507,9 +507,11 @@ def main():
     ap.add_argument("--config", default="C3", choices=sorted(CONFIGS) + ["dpss", "oqe", "fgmodes"])
     ap.add_argument("--nbl", type=int, default=None, help="baselines per GPU (default: config)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--parts", type=int, default=4,
-                    help="also run the batch as this many plans on as many streams and report it as `multi_stream` "
-                         "(0 / 1: skip)")
+    ap.add_argument("--parts", type=int, default=0,
+                    help="also run the batch as this many plans on as many streams (GibbsParts) and report it as "
+                         "`multi_stream`; off by default: the outcome depends on how the HIP runtime maps the streams "
+                         "onto its hardware queues (5.16 - 5.84 ms per iteration at C3 with 4 parts against 5.43 - 5.53 "
+                         "for one plan, DESIGN.md section 10.8)")
     ap.add_argument("--no-full-length", action="store_true",
                     help="skip the full-length leg (the config's 1000 / 2000 iterations, ~10 s at C3)")
     ap.add_argument("--solver", default="dense", choices=["dense", "auto"],

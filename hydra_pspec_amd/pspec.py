@@ -482,10 +482,10 @@ class GibbsBatch:
 class GibbsParts:
     """A batch cut into ``parts`` contiguous baseline ranges, one :class:`GibbsBatch` (plan) and one HIP stream each,
     advanced together by ``hpx_gibbs_run_parts``: the iterations of all parts are enqueued in turn, so one part's back
-    substitution, transforms and draw run on the GPU beside another part's factorisation (C3, 1024 baselines: 4 parts
-    -- two parts' factor workgroups then just fill the GPU's 512 workgroup slots -- are 5 % faster than one plan, 3 or 5
-    parts are slower: DESIGN.md section 10.8; pointless below a few hundred baselines, where one plan's kernels do
-    not fill the GPU anyway).  Same chains as one :class:`GibbsBatch`, bit for
+    substitution, transforms and draw run on the GPU beside another part's factorisation.  An OPTION, not a default:
+    at C3 (1024 baselines) 4 parts ran from 5 % faster to 6 % slower than one plan depending on how the HIP runtime
+    mapped the streams onto its hardware queues, 3 or 5 parts always slower; pointless below a
+    few hundred baselines, where one plan's kernels do not fill the GPU anyway.  Same chains as one :class:`GibbsBatch`, bit for
     bit; same ``run`` / ``close`` / ``iter_done`` interface (``shp0``, a general starting covariance, is not taken)."""
 
     def __init__(self, vis, flags, fgmodes, ninv_diag, ps_prior, Niter, parts=4, seed=None, map_estimate=False,
@@ -639,8 +639,8 @@ def gibbs_sample_with_fg_batched(vis, flags, fgmodes, Ninv, ps_prior, S_initial=
     ``"fg_amps"``, ``"chisq"``; every ``thin``-th iteration).
 
     ``parts`` > 1 cuts the batch into that many baseline ranges, each with a plan and a stream of its own, advanced
-    together (:class:`GibbsParts`): same chains bit for bit, 5 % more throughput at 1024 baselines with 4 parts
-    (256 baselines per part, the number of CUs).
+    together (:class:`GibbsParts`): same chains bit for bit; up to 5 % more throughput at 1024 baselines with 4 parts,
+    but not dependably (see there).
 
     ``solver``: ``"auto"`` (default) solves baselines whose unflagged channels share one ``Ninv``
     value through the diagonal + border structure of the system (hpx_flat.hip without flags,

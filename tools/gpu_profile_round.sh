@@ -29,8 +29,8 @@ kt() {   # kernel-trace stats: kt <name> <bench args...>
   grep -o '{"metric.*' $O/kt_$name.log > $O/${TAG}_bench_${name}_under_rocprof.json
   echo "kernel stats $name done"
 }
-kt c3 --steps 10 --warmup 2 --no-cpu-baseline --no-full-length --parts 0
-kt c5_auto --config C5 --solver auto --steps 10 --warmup 2 --no-cpu-baseline --no-full-length --parts 0
+kt c3 --steps 10 --warmup 2 --no-cpu-baseline --no-full-length
+kt c5_auto --config C5 --solver auto --steps 10 --warmup 2 --no-cpu-baseline --no-full-length
 kt fgmodes --config fgmodes --steps 5 --warmup 1
 kt dpss --config dpss --steps 10 --warmup 2
 kt oqe --config oqe --steps 3 --warmup 1
@@ -38,7 +38,7 @@ i=0
 for set in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" "TCC_HIT_sum TCC_MISS_sum"; do
   i=$((i+1))
   cd /tmp
-  timeout -k 10 300 rocprofv3 --pmc $set --output-format csv -d $O/pmc$i -- python3 $R/bench.py --steps 2 --warmup 0 --no-cpu-baseline --no-full-length --parts 0 > $O/pmc$i.log 2>&1
+  timeout -k 10 300 rocprofv3 --pmc $set --output-format csv -d $O/pmc$i -- python3 $R/bench.py --steps 2 --warmup 0 --no-cpu-baseline --no-full-length > $O/pmc$i.log 2>&1
   cd $R
   echo "pmc pass $i done"
 done
