@@ -5,6 +5,7 @@
 #include <stdarg.h>
 #include <string.h>
 #include "hpx_internal.h"
+#include <string>
 #include <stdlib.h>
 #include "hpx_fft.h"
 
@@ -2408,7 +2409,11 @@ extern "C" int hpx_gibbs_run_parts(const hpx_run_part* parts, int nparts, int it
   int rc = HPX_OK;
   for (int q = 0; q < nparts; ++q) {         // every stream is drained even when an earlier part failed
     const int r = finish_run(parts[q].plan, niter, parts[q].ps_last, A[q].st);
-    if (rc == HPX_OK) rc = r;
+    if (r != HPX_OK && rc == HPX_OK) {       // (baseline numbers in the message count within the part)
+      const std::string why = hpx_last_error();
+      hpx_set_error("part %d: %s", q, why.c_str());
+      rc = r;
+    }
   }
   return rc;
 }

@@ -639,3 +639,11 @@ def test_parts_on_streams_reproduce_the_single_plan_chain():
     with pytest.raises(NotImplementedError):
         pspec.GibbsParts(d["vis"], d["flags"], d["fgmodes"], d["ninv_diag"], d["ps_prior"], 2, parts=2,
                          seed=1).run(1, shp0=np.zeros((nbl, N, N), complex))
+    # a part whose system is not positive definite is reported with its part number; the other parts still finish
+    bad = d["ninv_diag"].copy()
+    bad[5] = np.nan                                         # baseline 5 = the first of part 2 (baselines 5, 6)
+    gp = pspec.GibbsParts(d["vis"], d["flags"], d["fgmodes"], bad, d["ps_prior"], 2, parts=3, seed=1, solver="dense")
+    with pytest.raises(FloatingPointError, match=r"part 2: non-positive pivot: baseline 0"):
+        gp.run(2, ps0=ps0)
+    gp.close()
+
