@@ -227,3 +227,26 @@ def test_time_dependent_flags_at_c3_shape():
     assert np.max(np.abs(out["signal_ps"][1] / ref[2] - 1)) < 1e-6
     assert np.max(np.abs(out["signal_cr"][1] - ref[0])) < 1e-6 * np.max(np.abs(ref[0]))
     assert np.allclose(out["ln_post"][1], ref[5], rtol=1e-6)
+
+
+def test_full_noise_matrices_per_time_at_256_channels():
+    """Non-diagonal time-dependent Ninv (Ntimes, Nfreqs, Nfreqs) at (Ntimes, Nfreq, Nmodes) = (6, 256, 8) with
+    time-dependent flags (FFT transforms in the per-unit set-up, up to ~30 Woodbury columns per unit), one
+    iteration against the per-time exact-solve oracle."""
+    from hydra_pspec_amd import pspec, synthetic
+    from oracle import pspec_ref
+    nbl, T, N, M = 2, 6, 256, 8
+    d = synthetic.make_baselines(N, T, M, k0=4, nbl=nbl, flag_frac=0.05, dense=True)
+    rng = np.random.default_rng(3)
+    flt = np.broadcast_to(d["flags"][:, None, :], (nbl, T, N)).copy()
+    flt &= rng.uniform(size=(nbl, T, N)) > 0.04
+    sig2 = 1.0 / d["Ninv"][0, 0].real
+    Ninv_t = np.stack([[_banded_ninv(N, sig2 * rng.uniform(0.7, 1.3)) for _ in range(T)] for _ in range(nbl)])
+    out = pspec.gibbs_sample_with_fg_batched(d["vis"], flt, d["fgmodes"], Ninv_t, d["ps_prior"], ps_initial=d["ps0"],
+                                             Niter=1, seed=4, keep=("signal_cr", "chisq"))
+    ref = pspec_ref.gibbs_sample_with_fg_pertime(d["vis"][1], flt[1], d["S_initial"], d["fgmodes"], Ninv_t[1],
+                                                 d["ps_prior"], Niter=1, seed=4)
+    assert np.max(np.abs(out["signal_ps"][1] / ref[2] - 1)) < 1e-6
+    assert np.max(np.abs(out["signal_cr"][1] - ref[0])) < 1e-6 * np.max(np.abs(ref[0]))
+    assert np.max(np.abs(out["chisq"][1] - ref[4])) < 1e-6 * np.max(np.abs(ref[4]))
+    assert np.allclose(out["ln_post"][1], ref[5], rtol=1e-6)
