@@ -8,8 +8,7 @@ TAG=${1:-r03}
 export TMPDIR=/tmp
 R=$PWD; O=$R/gpurun_out/prof; mkdir -p $O
 line() { grep -o '{"metric.*' $1 > $2; }
-timeout -k 10 500 python3 bench.py > $O/bench_c3.log 2>&1 || { tail -5 $O/bench_c3.log; exit 1; }
-line $O/bench_c3.log $O/${TAG}_bench_c3.json; echo "C3 done"
+# (the C3 line itself is taken LAST, after the PMC passes have re-stamped profiles/pmc_traffic.json for these sources)
 timeout -k 10 300 python3 bench.py --steps 5 --warmup 1 --config C5 --no-cpu-baseline > $O/bench_c5.log 2>&1 && line $O/bench_c5.log $O/${TAG}_bench_c5.json; echo "C5 done"
 timeout -k 10 300 python3 bench.py --steps 20 --warmup 2 --config C2 --no-cpu-baseline > $O/bench_c2.log 2>&1 && line $O/bench_c2.log $O/${TAG}_bench_c2.json; echo "C2 done"
 timeout -k 10 300 python3 bench.py --steps 10 --warmup 2 --config N4 --no-cpu-baseline > $O/bench_n4.log 2>&1 && line $O/bench_n4.log $O/${TAG}_bench_n4.json; echo "N4 done"
@@ -104,6 +103,9 @@ if out:
     json.dump({"source_hash": bench.kernel_source_hash(), "C3": out}, open(O + "/pmc_traffic.json", "w"), indent=1)   # traffic figure for any other build)
 print("\n".join(l for l in lines if "k_factor" in l or "k_backsolve" in l or "k_shape" in l))
 PY
+cp $O/pmc_traffic.json $R/profiles/pmc_traffic.json
+timeout -k 10 500 python3 bench.py > $O/bench_c3.log 2>&1 || { tail -5 $O/bench_c3.log; exit 1; }
+line $O/bench_c3.log $O/${TAG}_bench_c3.json; echo "C3 done"
 head -12 $O/${TAG}_kernel_stats_c3.csv | cut -c1-160
 python3 -c "
 import json
