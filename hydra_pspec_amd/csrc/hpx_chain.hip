@@ -1986,7 +1986,7 @@ __global__ __launch_bounds__(256) void k_wb_system(const double* __restrict__ Sr
 }
 // Gaussian elimination with partial pivoting on the f x (f + T) system of one baseline (global memory,
 // one workgroup), then the back substitution: the coefficients c[kf][t] end up in the right-hand-side
-// columns fmax .. fmax+T-1.  A zero pivot marks the baseline in info.
+// columns fmax .. fmax+T-1.  A vanishing pivot marks the baseline in info.
 __global__ __launch_bounds__(256) void k_wb_solve(double* __restrict__ W_all, const int32_t* __restrict__ fcount,
                                                   const int fmax, const int T, int32_t* __restrict__ info,
                                                   const int iter_tag) {
@@ -2017,7 +2017,9 @@ __global__ __launch_bounds__(256) void k_wb_solve(double* __restrict__ W_all, co
       for (int q = 1; q < 4; ++q)
         if (redv[q] > redv[w] || (redv[q] == redv[w] && redi[q] < redi[w])) w = q;
       piv_s = redi[w];
-      if (!(redv[w] > 0.0)) atomicCAS(&info[b], 0, iter_tag);
+      // (the system is I - Q^H Y_P, entries O(1): a pivot below 1e-12 means the flags leave it singular, e.g. a unit
+      // with every channel flagged, whose foreground amplitudes nothing constrains)
+      if (!(redv[w] > 1e-24)) atomicCAS(&info[b], 0, iter_tag);
     }
     __syncthreads();
     const int pv = piv_s;

@@ -150,3 +150,35 @@ def test_full_noise_matrices_per_time_vs_oracle():
     same = pspec.gibbs_sample_with_fg_batched(d["vis"], flt, d["fgmodes"], np.broadcast_to(Ninv_t[0, 0], (T, N, N)),
                                               d["ps_prior"], ps_initial=d["ps0"], Niter=2, seed=9)
     assert np.array_equal(one["signal_ps"], same["signal_ps"])
+
+
+def test_full_noise_matrices_per_time_edge_cases():
+    """Non-diagonal per-time Ninv at the edges: a time sample with HALF its channels flagged (12 Woodbury columns
+    beside one data column), two time samples, per-baseline matrices (Nbl, Ntimes, N, N) with a channel count that
+    is not a multiple of 16 -- against the per-time exact-solve oracle; a time sample with EVERY channel flagged
+    (singular in the reference too: nothing constrains the foreground amplitudes) is reported, not solved."""
+    from hydra_pspec_amd import pspec, synthetic
+    from oracle import pspec_ref
+    rng = np.random.default_rng(7)
+    for nbl, T, N, M, kill in ((2, 3, 24, 3, 1), (1, 2, 40, 4, None)):
+        d = synthetic.make_baselines(N, T, M, k0=2, nbl=nbl, flag_frac=0.1, dense=True)
+        flt = np.broadcast_to(d["flags"][:, None, :], (nbl, T, N)).copy()
+        if kill is not None:
+            flt[0, kill, ::2] = False                                        # every other channel gone at that time
+        sig2 = 1.0 / d["Ninv"][0, 0].real
+        Ninv_t = np.stack([[_banded_ninv(N, sig2 * rng.uniform(0.8, 1.2), phase=rng.uniform(-1, 1)) for _ in range(T)]
+                           for _ in range(nbl)])
+        out = pspec.gibbs_sample_with_fg_batched(d["vis"], flt, d["fgmodes"], Ninv_t, d["ps_prior"],
+                                                 ps_initial=d["ps0"], Niter=2, seed=3, keep=("signal_cr", "fg_amps"))
+        for b in range(nbl):
+            ref = pspec_ref.gibbs_sample_with_fg_pertime(d["vis"][b], flt[b], d["S_initial"], d["fgmodes"], Ninv_t[b],
+                                                         d["ps_prior"], Niter=2, seed=3)
+            assert np.max(np.abs(out["signal_ps"][b] / ref[2] - 1)) < RTOL, (nbl, T, N, b)
+            assert relerr(out["signal_cr"][b], ref[0]) < RTOL and np.allclose(out["ln_post"][b], ref[5], rtol=1e-7)
+    d = synthetic.make_baselines(24, 3, 3, k0=2, nbl=1, flag_frac=0.0, dense=True)
+    flt = np.ones((1, 3, 24), dtype=bool)
+    flt[0, 1, :] = False
+    Ninv_t = np.broadcast_to(_banded_ninv(24, 1.0 / d["Ninv"][0, 0].real), (3, 24, 24)).copy()
+    with pytest.raises(FloatingPointError):
+        pspec.gibbs_sample_with_fg_batched(d["vis"], flt, d["fgmodes"], Ninv_t, d["ps_prior"], ps_initial=d["ps0"],
+                                           Niter=1, seed=3)
