@@ -100,7 +100,7 @@ if sb > 0:
 if out:
     sys.path.insert(0, ".")
     import bench           # (the hash of the kernel sources these counters were measured on: bench.py drops the
-    json.dump({"source_hash": bench.kernel_source_hash(), "C3": out}, open(O + "/pmc_traffic.json", "w"), indent=1)   # traffic figure for any other build)
+    json.dump({"source_hash": bench.kernel_source_hash(), "C3": out, "source_hash_files": list(bench.DENSE_STEP_SOURCES)}, open(O + "/pmc_traffic.json", "w"), indent=1)   # traffic figure for any other build)
 print("\n".join(l for l in lines if "k_factor" in l or "k_backsolve" in l or "k_shape" in l))
 PY
 cp $O/pmc_traffic.json $R/profiles/pmc_traffic.json
