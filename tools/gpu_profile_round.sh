@@ -41,6 +41,7 @@ for set in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_G
   cd $R
   echo "pmc pass $i done"
 done
+[ -x $R/tools/fetch_calib_probe ] || /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -o $R/tools/fetch_calib_probe $R/tools/fetch_calib.hip
 cd /tmp
 timeout -k 10 200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/calib -- $R/tools/fetch_calib_probe > $O/calib.log 2>&1; echo "calib rc=$?"
 cd $R
