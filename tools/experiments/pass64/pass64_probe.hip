@@ -18,7 +18,7 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s -> %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 __device__ __forceinline__ d4 mfma64(double a, double b, d4 c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
 
-template <int CT, int RT>
+template <int CT, int RT, int KC>
 __device__ __forceinline__ void sweep(double* __restrict__ Lre, double* __restrict__ Lim, const int npad, const int c0,
                                       const int r0, const int rstride, const int lane) {
   const int li = lane & 15, g = lane >> 4;
@@ -27,31 +27,32 @@ __device__ __forceinline__ void sweep(double* __restrict__ Lre, double* __restri
   for (int t = 0; t < RT; ++t)
 #pragma unroll
     for (int ci = 0; ci < CT; ++ci) a1[t][ci] = a2[t][ci] = a3[t][ci] = (d4){0., 0., 0., 0.};
-  const int nch = c0 >> 2;                       // k-steps (c0 is a multiple of 32: even)
+  const int nch = (c0 >> 2) / KC;                // chunks of KC k-steps (c0 is a multiple of 32: even for KC | 4)
   const double* pre = Lre + (long)g * 32;
   const double* pim = Lim + (long)g * 32;
   const long kstep = 128, ptile = (long)npad * 32;
   const long boff = (long)(r0 >> 4) * ptile + li, bstr = (long)(rstride >> 4) * ptile;
   const long aoff = (long)(c0 >> 4) * ptile + li;
-  double b0r[RT], b0i[RT], b1r[RT], b1i[RT], p0r[CT], p0i[CT], p1r[CT], p1i[CT];
+  double b0r[KC][RT], b0i[KC][RT], b1r[KC][RT], b1i[KC][RT], p0r[KC][CT], p0i[KC][CT], p1r[KC][CT], p1i[KC][CT];
 #define LOADC(br_, bi_, pr_, pi_, base_re, base_im)                                         \
+  _Pragma("unroll") for (int s = 0; s < KC; ++s) {                                          \
   _Pragma("unroll") for (int t = 0; t < RT; ++t) {                                          \
-    br_[t] = __builtin_nontemporal_load(&(base_re)[boff + t * bstr]);                       \
-    bi_[t] = __builtin_nontemporal_load(&(base_im)[boff + t * bstr]);                       \
+    br_[s][t] = __builtin_nontemporal_load(&(base_re)[s * kstep + boff + t * bstr]);        \
+    bi_[s][t] = __builtin_nontemporal_load(&(base_im)[s * kstep + boff + t * bstr]);        \
   }                                                                                         \
   _Pragma("unroll") for (int ci = 0; ci < CT; ++ci) {                                       \
-    pr_[ci] = (base_re)[aoff + ci * ptile];                                                 \
-    pi_[ci] = (base_im)[aoff + ci * ptile];                                                 \
-  }
+    pr_[s][ci] = (base_re)[s * kstep + aoff + ci * ptile];                                  \
+    pi_[s][ci] = (base_im)[s * kstep + aoff + ci * ptile];                                  \
+  } }
 #define MMAC(br_, bi_, pr_, pi_)                                                            \
-  {                                                                                         \
+  _Pragma("unroll") for (int s = 0; s < KC; ++s) {                                          \
     double bd_[RT];                                                                         \
-    _Pragma("unroll") for (int t = 0; t < RT; ++t) bd_[t] = br_[t] - bi_[t];                \
+    _Pragma("unroll") for (int t = 0; t < RT; ++t) bd_[t] = br_[s][t] - bi_[s][t];          \
     _Pragma("unroll") for (int ci = 0; ci < CT; ++ci) {                                     \
-      const double npr = -pr_[ci], npi = -pi_[ci], psm = pr_[ci] + pi_[ci];                 \
+      const double npr = -pr_[s][ci], npi = -pi_[s][ci], psm = pr_[s][ci] + pi_[s][ci];     \
       _Pragma("unroll") for (int t = 0; t < RT; ++t) {                                      \
-        a1[t][ci] = mfma64(npr, br_[t], a1[t][ci]);                                         \
-        a2[t][ci] = mfma64(npi, bi_[t], a2[t][ci]);                                         \
+        a1[t][ci] = mfma64(npr, br_[s][t], a1[t][ci]);                                      \
+        a2[t][ci] = mfma64(npi, bi_[s][t], a2[t][ci]);                                      \
         a3[t][ci] = mfma64(psm, bd_[t], a3[t][ci]);                                         \
       }                                                                                     \
     }                                                                                       \
@@ -59,13 +60,13 @@ __device__ __forceinline__ void sweep(double* __restrict__ Lre, double* __restri
   if (nch > 0) {
     LOADC(b0r, b0i, p0r, p0i, pre, pim)
     for (int ch = 0; ch < nch; ch += 2) {
-      const double* qre = pre + kstep;
-      const double* qim = pim + kstep;
+      const double* qre = pre + KC * kstep;
+      const double* qim = pim + KC * kstep;
       LOADC(b1r, b1i, p1r, p1i, qre, qim)
       __builtin_amdgcn_sched_barrier(0);
       MMAC(b0r, b0i, p0r, p0i)
       __builtin_amdgcn_sched_barrier(0);
-      const long adv = (ch + 2 < nch) ? 2 * kstep : 0;
+      const long adv = (ch + 2 < nch) ? 2 * KC * kstep : 0;
       pre += adv;
       pim += adv;
       LOADC(b0r, b0i, p0r, p0i, pre, pim)
@@ -86,7 +87,7 @@ __device__ __forceinline__ void sweep(double* __restrict__ Lre, double* __restri
       }
 }
 
-template <int CT, int RT, int WPC>
+template <int CT, int RT, int WPC, int KC>
 __global__ __launch_bounds__(256, WPC) void k_pass(double* __restrict__ L_all, const int npad, const int ld) {
   extern __shared__ double lds_[];
   const int b = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -99,7 +100,7 @@ __global__ __launch_bounds__(256, WPC) void k_pass(double* __restrict__ L_all, c
     if (nrt <= rt) cnt = 0;
     while (cnt > 0) {                          // groups of RT strided tiles (a shorter last group sweeps RT too,
       const int r0 = min(rt, nrt - 4 * (RT - 1) - 1) << 4;    //  clamped into range: timing only)
-      sweep<CT, RT>(Lre, Lim, npad, c0, r0, 64, lane);
+      sweep<CT, RT, KC>(Lre, Lim, npad, c0, r0, 64, lane);
       rt += 4 * RT;
       cnt -= RT;
     }
@@ -134,9 +135,12 @@ int main(int argc, char** argv) {
              rep, ms, nbl, fl, fl * nbl / ms * 1e-9);
     }
   };
-  run("W32 (3 x 2 tiles, 2 workgroups / CU)", k_pass<2, 3, 2>, 60 * 1024, 32);
-  run("W64 (3 x 4 tiles, 1 workgroup / CU) ", k_pass<4, 3, 1>, 100 * 1024, 64);
-  run("W64 (2 x 4 tiles, 1 workgroup / CU) ", k_pass<4, 2, 1>, 100 * 1024, 64);
-  run("W32 (3 x 2 tiles, 1 workgroup / CU) ", k_pass<2, 3, 2>, 100 * 1024, 32);
+  run("W32 (3 x 2 tiles, 2 workgroups / CU, 1 k-step ahead)", k_pass<2, 3, 2, 1>, 60 * 1024, 32);
+  run("W32 (3 x 2 tiles, 2 workgroups / CU, 2 k-steps ahead)", k_pass<2, 3, 2, 2>, 60 * 1024, 32);
+  run("W32 (3 x 2 tiles, 1 workgroup / CU, 1 k-step ahead) ", k_pass<2, 3, 2, 1>, 100 * 1024, 32);
+  run("W64 (2 x 4 tiles, 1 workgroup / CU, 1 k-step ahead) ", k_pass<4, 2, 1, 1>, 100 * 1024, 64);
+  run("W64 (2 x 4 tiles, 1 workgroup / CU, 2 k-steps ahead)", k_pass<4, 2, 1, 2>, 100 * 1024, 64);
+  run("W64 (2 x 4 tiles, 1 workgroup / CU, 4 k-steps ahead)", k_pass<4, 2, 1, 4>, 100 * 1024, 64);
+  run("W32 (3 x 2 tiles, 1 workgroup / CU, 512 regs, 4 k-steps ahead)", k_pass<2, 3, 1, 4>, 100 * 1024, 32);
   return 0;
 }
