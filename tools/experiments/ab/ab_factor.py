@@ -13,7 +13,7 @@ ROOT = pathlib.Path(__file__).resolve().parents[3]
 sys.path.insert(0, str(ROOT))
 OUT = ROOT / "gpurun_out"
 CFG = {"C2": (64, 32, 256, 12, 0.0), "C3": (1024, 32, 512, 12, 0.0), "C5": (1024, 32, 1024, 12, 0.15),
-       "C3F": (1024, 32, 512, 12, 0.1), "S": (8, 16, 112, 6, 0.1), "S2": (5, 8, 100, 4, 0.0)}
+       "C3F": (1024, 32, 512, 12, 0.1), "C2L": (1024, 32, 256, 12, 0.0), "N64": (2048, 32, 64, 6, 0.0), "S": (8, 16, 112, 6, 0.1), "S2": (5, 8, 100, 4, 0.0)}
 
 
 def run(tag, name):
