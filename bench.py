@@ -507,11 +507,6 @@ def main():
     ap.add_argument("--config", default="C3", choices=sorted(CONFIGS) + ["dpss", "oqe", "fgmodes"])
     ap.add_argument("--nbl", type=int, default=None, help="baselines per GPU (default: config)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--parts", type=int, default=0,
-                    help="also run the batch as this many plans on as many streams (GibbsParts) and report it as "
-                         "`multi_stream`; off by default: the outcome depends on how the HIP runtime maps the streams "
-                         "onto its hardware queues (5.16 - 5.84 ms per iteration at C3 with 4 parts against 5.43 - 5.53 "
-                         "for one plan, DESIGN.md section 10.8)")
     ap.add_argument("--no-full-length", action="store_true",
                     help="skip the full-length leg (the config's 1000 / 2000 iterations, ~10 s at C3)")
     ap.add_argument("--solver", default="dense", choices=["dense", "auto"],
@@ -638,28 +633,6 @@ def main():
         del ofull
         gfull.close()
 
-    # the same batch as several plans on several streams (GibbsParts / hpx_gibbs_run_parts): reported beside the
-    # headline value, which stays the one-plan run that the roofline and the per-stage events describe
-    multi = None
-    if rank == 0 and world == 1 and args.parts > 1 and nbl >= 128 * args.parts and args.config != "N4":
-        # (worth it only when one plan's kernels already fill the GPU: >= 128 baselines per part)
-        gp = pspec.GibbsParts(d["vis"], flags_in, d["fgmodes"], ninv_in, d["ps_prior"], W + K, parts=args.parts,
-                              seed=d["seed"], solver=args.solver)
-        if W > 0:
-            gp.run(W, ps0=ps0)
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        po = gp.run(K, ps0=ps0 if W == 0 else None)
-        torch.cuda.synchronize()
-        dtp = time.perf_counter() - t1
-        multi = {"parts": args.parts, "value": nbl * K / dtp, "unit": "baseline*iter/s", "ms_per_step": dtp / K * 1e3,
-                 "same_chain_as_one_plan": bool(torch.equal(po["signal_ps"], out["signal_ps"])),
-                 "note": "the same batch as `parts` baseline ranges, one plan and one HIP stream each, iterations "
-                         "enqueued in turn (hpx_gibbs_run_parts): one part's back substitution / transforms / draw "
-                         "run beside another part's factorisation; not the headline value"}
-        del po
-        gp.close()
-
     # the same batch through solver="auto" (outside the timed region): unflagged flat-noise inputs
     # such as C3's then take the O(N M (M+T)) structured solve instead of the dense factorisation
     flat_extra = None
@@ -757,8 +730,6 @@ def main():
                                     "differs): no traffic figure for this build")
         if full_len:
             res["full_length"] = full_len
-        if multi:
-            res["multi_stream"] = multi
         if flat_extra:
             res["flat_noise_structured_solve"] = flat_extra     # (key kept from the unflagged case)
         if args.config == "N4":

@@ -1210,6 +1210,7 @@ static int plan_create_impl(hpx_plan** out, int nbl, int T, int N, int M, int ex
 #define A_(ptr, cnt) if (rc == HPX_OK) rc = dev_alloc(p, &p->ptr, (cnt))
   A_(L, nb * lsz * 2);
   A_(Wre, nb * p->nblk * 1024); A_(Wim, nb * p->nblk * 1024);
+  A_(Vt, nb * (size_t)p->npad * 32);
   A_(Xre, nb * xsz); A_(Xim, nb * xsz);
   A_(info, nb);
   A_(ia, nb * N); A_(ps_cur, nb * N); A_(beta, nb * N); A_(betam, nb * N); A_(lnp1, nb);
@@ -1875,6 +1876,7 @@ extern "C" int hpx_plan_set_solver(hpx_plan* p, int mode) {
     HPX_TRY(dev_alloc(p, &p->lr_L, nb * ns * lds_ * 2));
     HPX_TRY(dev_alloc(p, &p->lr_Wre, nb * nblkS * 1024));
     HPX_TRY(dev_alloc(p, &p->lr_Wim, nb * nblkS * 1024));
+    HPX_TRY(dev_alloc(p, &p->lr_Vt, nb * ns * 32));
     HPX_TRY(dev_alloc(p, &p->lr_Yre, nb * ns * p->TP));
     HPX_TRY(dev_alloc(p, &p->lr_Yim, nb * ns * p->TP));
     HPX_HIP(hipMemcpy(p->lr_flist, list.data(), list.size() * sizeof(int32_t), hipMemcpyHostToDevice));
@@ -2319,7 +2321,7 @@ static int run_iteration(hpx_plan* p, const RunArgs& A, int it) {
         else hipLaunchKernelGGL(k_assemble_edge, dim3(c->nbl, 1), dim3(256), 0, st, gc, c->L, c->npad, c->ld);
         HPX_HIP(hipGetLastError());
         HPX_TRY(mark(p, st));
-        HPX_TRY(hpx_launch_factor(c->nbl, c->npad, c->ld, c->L, c->Wre, c->Wim, c->info, iter0 + it + 1,
+        HPX_TRY(hpx_launch_factor(c->nbl, c->npad, c->ld, c->L, c->Wre, c->Wim, c->Vt, c->info, iter0 + it + 1,
                                   c->dense_noise ? nullptr : &gc, st));
         HPX_TRY(mark(p, st));
         HPX_TRY(hpx_launch_backsolve(c->nbl, c->npad, c->TP, c->ld, c->L, c->Wre, c->Wim, c->Xre, c->Xim, st));
@@ -2345,12 +2347,12 @@ static int run_iteration(hpx_plan* p, const RunArgs& A, int it) {
         // general Hermitian C: the whole augmented matrix is laid out, then factored in place
         HPX_TRY(launch_assemble(p, st, 0));
         HPX_TRY(mark(p, st));
-        HPX_TRY(hpx_launch_factor(nbl, p->npad, p->ld, p->L, p->Wre, p->Wim, p->info, iter0 + it + 1,
+        HPX_TRY(hpx_launch_factor(nbl, p->npad, p->ld, p->L, p->Wre, p->Wim, p->Vt, p->info, iter0 + it + 1,
                                   nullptr, st));
       } else {
         HPX_TRY(launch_assemble_edge(p, st));
         HPX_TRY(mark(p, st));
-        HPX_TRY(hpx_launch_factor(nbl, p->npad, p->ld, p->L, p->Wre, p->Wim, p->info, iter0 + it + 1,
+        HPX_TRY(hpx_launch_factor(nbl, p->npad, p->ld, p->L, p->Wre, p->Wim, p->Vt, p->info, iter0 + it + 1,
                                   &gen, st));
       }
       if (!p->per_time) {
@@ -2387,37 +2389,6 @@ extern "C" int hpx_gibbs_run(hpx_plan* p, const double* ps0, int iter0, int nite
   HPX_TRY(run_begin(p, A));
   for (int it = 0; it < niter; ++it) HPX_TRY(run_iteration(p, A, it));
   return finish_run(p, niter, ps_last, A.st);
-}
-
-// Several plans advanced together, each on its own stream, iteration by iteration from this one host thread:
-// one part's back substitution, transforms and draw then run beside another part's factorisation (hpx.h).
-extern "C" int hpx_gibbs_run_parts(const hpx_run_part* parts, int nparts, int iter0, int niter, int thin) {
-  HPX_REQUIRE(parts && nparts > 0 && nparts <= 64, "hpx_gibbs_run_parts: bad argument");
-  std::vector<RunArgs> A(nparts);
-  for (int q = 0; q < nparts; ++q) {
-    const hpx_run_part& P = parts[q];
-    A[q] = {P.ps0, P.ps_forced, P.ps_out, P.lnpost_out, P.cr_out, P.fg_out, P.chisq_out, P.ps_last,
-            iter0, niter, thin < 1 ? 1 : thin, (hipStream_t)P.stream};
-    HPX_TRY(run_check(P.plan, A[q], "hpx_gibbs_run_parts"));
-    for (int r = 0; r < q; ++r)
-      HPX_REQUIRE(parts[r].plan != P.plan && (nparts == 1 || parts[r].stream != P.stream),
-                  "hpx_gibbs_run_parts: every part needs a plan and a stream of its own");
-  }
-  for (int q = 0; q < nparts; ++q) HPX_TRY(run_begin(parts[q].plan, A[q]));
-  // (a phase offset between the parts' first iterations was tried: no effect once the streams are fed from one
-  // thread -- the parts drift into place by themselves)
-  for (int it = 0; it < niter; ++it)
-    for (int q = 0; q < nparts; ++q) HPX_TRY(run_iteration(parts[q].plan, A[q], it));
-  int rc = HPX_OK;
-  for (int q = 0; q < nparts; ++q) {         // every stream is drained even when an earlier part failed
-    const int r = finish_run(parts[q].plan, niter, parts[q].ps_last, A[q].st);
-    if (r != HPX_OK && rc == HPX_OK) {       // (baseline numbers in the message count within the part)
-      const std::string why = hpx_last_error();
-      hpx_set_error("part %d: %s", q, why.c_str());
-      rc = r;
-    }
-  }
-  return rc;
 }
 
 // ---- general first iteration ---------------------------------------------------------------
@@ -2554,7 +2525,7 @@ extern "C" int hpx_gibbs_step_general(hpx_plan* p, const double* shp, int iter0,
                      p->XTre, p->XTim, p->RSre, p->RSim, p->L, p->npad, p->ld);
   HPX_HIP(hipGetLastError());
   HPX_TRY(mark(p, st));
-  HPX_TRY(hpx_launch_factor(nbl, p->npad, p->ld, p->L, p->Wre, p->Wim, p->info, iter0 + 1, nullptr, st));
+  HPX_TRY(hpx_launch_factor(nbl, p->npad, p->ld, p->L, p->Wre, p->Wim, p->Vt, p->info, iter0 + 1, nullptr, st));
   HPX_TRY(mark(p, st));
   HPX_TRY(hpx_launch_backsolve(nbl, p->npad, TP, p->ld, p->L, p->Wre, p->Wim, p->Xre, p->Xim, st));
   HPX_TRY(mark(p, st));

@@ -970,8 +970,14 @@ static int launch_factor_t(int nbl, size_t lds, int npad, int ld, double* L, dou
   return HPX_OK;
 }
 
-int hpx_launch_factor(int nbl, int npad, int ld, double* L, double* Wre, double* Wim,
+// Which form runs: the wide one (hpx_factor_wide.hip) from HPX_WIDE_MIN columns on, this file's 32-wide one below.
+#ifndef HPX_WIDE_MIN
+#define HPX_WIDE_MIN (1 << 30)      /* off by default while it is being tuned: -DHPX_WIDE_MIN=16 turns it on */
+#endif
+int hpx_launch_factor(int nbl, int npad, int ld, double* L, double* Wre, double* Wim, double* Vt,
                       int32_t* info, int iter_tag, const hpx_gen_batch* gen, hipStream_t st) {
+  if (Vt && npad >= HPX_WIDE_MIN)
+    return hpx_launch_factor_wide(nbl, npad, ld, L, Wre, Wim, Vt, info, iter_tag, gen, st);
   const size_t base = sizeof(FactorShared);
   if (!gen) {
     hpx_gen_batch none = {};
@@ -994,9 +1000,9 @@ int hpx_launch_backsolve(int nbl, int npad, int TP, int ld, const double* L, con
 // ---- stand-alone C-ABI entry points (tests, other callers) -----------------
 namespace {
 struct Scratch {
-  double *L = nullptr, *Wre = nullptr, *Wim = nullptr, *Xre = nullptr, *Xim = nullptr;
+  double *L = nullptr, *Wre = nullptr, *Wim = nullptr, *Vt = nullptr, *Xre = nullptr, *Xim = nullptr;
   ~Scratch() {
-    (void)hipFree(L); (void)hipFree(Wre); (void)hipFree(Wim); (void)hipFree(Xre); (void)hipFree(Xim);
+    (void)hipFree(L); (void)hipFree(Wre); (void)hipFree(Wim); (void)hipFree(Vt); (void)hipFree(Xre); (void)hipFree(Xim);
   }
 };
 }  // namespace
@@ -1011,10 +1017,11 @@ static int potr_common(int nb, int n, int nrhs, const double* a, const double* r
   HPX_HIP(hipMalloc(&s.L, 2 * lbytes));
   HPX_HIP(hipMalloc(&s.Wre, (size_t)nb * nblk * 1024 * sizeof(double)));
   HPX_HIP(hipMalloc(&s.Wim, (size_t)nb * nblk * 1024 * sizeof(double)));
+  HPX_HIP(hipMalloc(&s.Vt, (size_t)nb * npad * 32 * sizeof(double)));
   if (info) HPX_HIP(hipMemsetAsync(info, 0, (size_t)nb * sizeof(int32_t), st));
   hipLaunchKernelGGL(k_pack_herm, dim3(64, nb), dim3(256), 0, st, a, rhs, s.L, n, nrhs, npad, ld);
   HPX_HIP(hipGetLastError());
-  HPX_TRY(hpx_launch_factor(nb, npad, ld, s.L, s.Wre, s.Wim, info, 1, nullptr, st));
+  HPX_TRY(hpx_launch_factor(nb, npad, ld, s.L, s.Wre, s.Wim, s.Vt, info, 1, nullptr, st));
   if (l_out) {
     hipLaunchKernelGGL(k_unpack_lower, dim3(64, nb), dim3(256), 0, st, s.L, l_out, n, npad, ld);
     HPX_HIP(hipGetLastError());

@@ -1,0 +1,867 @@
+// Batched complex-Hermitian Cholesky, wide form: left-looking by SUPER-BLOCKS of 128 columns with the
+// panel operand of every k-loop staged ONCE per workgroup through LDS (LDS-DMA, global_load_lds).
+//
+// Why (DESIGN.md sections 9.3, 10.9, 10.10, 11): the 32-wide kernel of hpx_factor.hip re-reads every
+// element of L once per 32-wide block column to its right (12 MB per baseline at C3) and sits on the HBM
+// roof at that traffic.  With 128-wide block columns the row-tile operand is read n/128 instead of n/32
+// times, and the 128 x k panel operand, which every wave of the workgroup needs, is brought in once per
+// group of four row strips instead of once per wave.
+//
+// One workgroup (4 waves) per baseline, two workgroups per CU.  Per super-block J (columns c0 .. c0+127):
+//   S  the 36 lower 16 x 16 tiles of the diagonal block  D = K[J,J] - sum_{k<c0} L[J,k] L[J,k]^H,
+//      nine per wave, both MFMA operands from the staged chunks of the block's own rows;
+//   F  D = L_JJ L_JJ^H in registers, right-looking by 16-wide tile columns: 16 x 16 fused Cholesky +
+//      inverse on the vector ALU (the elimination of hpx_factor.hip), tiles below by one MFMA product with
+//      the inverse, trailing tiles updated through an LDS exchange of the new column;
+//   P  the row strips below, four at a time (one 16 x 128 strip = 8 accumulator tiles per wave):
+//      k-loop over the staged chunks of the block's rows (row operand straight from global memory,
+//      non-temporal, one chunk ahead), then the triangular solve as a CONTINUATION of the same stream:
+//      tail chunk cj holds inv(L_cjcj) and the tiles L[ci][cj] below it, X_cj = inv(L_cjcj) acc_cj is
+//      stored and becomes the B operand (in registers) of the later column tiles' updates.
+// The npad/16 mod 8 tile columns left over after the last full super-block (one at every BASELINE shape:
+// npad = N + 16) go one at a time through a register-only path (narrow_column).
+// Complex products in S and P are three real MFMAs (hpx_factor.hip, top); F uses the four-product form
+// on (re, im) tiles.
+//
+// Storage: the factor's 16-row panel-major layout (HPX_LIDX); Vt[b][tile][16 cols][re16|im16] holds the
+// inverses of the diagonal 16 x 16 tiles in the same tile layout (the tail chunks' first operand);
+// W[b][block][32][32] the inverses of the diagonal 32 x 32 blocks for k_backsolve, as before.
+#include "hpx_internal.h"
+
+#define HPX_INL __forceinline__
+
+namespace {
+
+typedef __attribute__((address_space(3))) double lds_f64;
+typedef double cplx __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) cplx lds_cplx;
+
+template <int KC>
+struct WCfg {
+  static constexpr int PP = KC / 4;            // 1 KB pieces (4 columns) per tile and chunk
+  static constexpr int TILE_D = KC * 32;       // doubles of one tile's chunk
+  static constexpr int BUF_D = 8 * TILE_D;     // eight tiles per buffer
+  static constexpr int NBUF = (KC == 16) ? 2 : 3;
+  static constexpr int DIST = NBUF - 1;        // chunks in flight ahead of the one being consumed
+  static constexpr int H = 16 / KC;            // chunks per 16-column tile (tail steps per column tile)
+  static constexpr int STAGE_D = NBUF * BUF_D; // doubles of the staging area (also F's scratch)
+  static_assert(KC == 8 || KC == 16, "chunks of 8 or 16 columns");
+};
+// F's scratch inside the staging area (doubles): Xs[8 tiles][512] (slot 0: the diagonal tile handed to the
+// elimination), one inverse tile, the elimination's matrices
+constexpr int FX_OFF = 0, FV_OFF = 8 * 512, FD_OFF = FV_OFF + 512, F_END = FD_OFF + 2 * 2 * 16 * 17 + 16;
+static_assert(F_END <= WCfg<8>::STAGE_D && F_END <= WCfg<16>::STAGE_D, "F scratch must fit the staging area");
+
+// 16 bytes per lane from (uniform base) + (32-bit lane offset) to dst + 16 lane.  The base goes through
+// readfirstlane so that the address stays "scalar + zero-extended vector offset" and the scalar-base form
+// of the instruction is selected: one offset register for every piece instead of a 64-bit address each
+// (which, eight per stage and hoisted out of the loops, were spilled).
+__device__ HPX_INL const double* uniform_ptr(const double* p) {
+  const unsigned long a = (unsigned long)p;
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a);
+  const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+  return (const double*)(((unsigned long)hi << 32) | lo);
+}
+__device__ HPX_INL void glds16(const double* ubase, const unsigned lane_off, double* dst) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(uniform_ptr(ubase) + lane_off),
+                                   (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+}
+template <int N>
+__device__ HPX_INL void wait_vm() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+__device__ HPX_INL double rsqrt_nr(const double d) {
+  double q = __builtin_amdgcn_rsq(d);
+  q = fma(q * 0.5, fma(-d * q, q, 1.0), q);
+  q = fma(q * 0.5, fma(-d * q, q, 1.0), q);
+  return q;
+}
+#define HPX_NTLD(p_) __builtin_nontemporal_load(p_)
+
+struct WideCtx {
+  double* Lb;          // this baseline's factor
+  double* Vt;          // this baseline's inverse diagonal tiles
+  double* Wgre;        // this baseline's 32 x 32 inverse blocks
+  double* Wgim;
+  double* lds;         // staging area
+  long ptile;          // doubles per 16-row panel
+  int npad, nct, nrt, wave, lane, tid;
+};
+
+// entry (r, c), r >= c, of the augmented matrix before the factorisation: closed form, edge tiles or
+// the factor buffer (hpx_internal.h)
+template <bool GEN>
+__device__ HPX_INL void entry_init(const hpx_gen& G, const double* __restrict__ Lb, const int r, const int c,
+                                   const int npad, double& vr, double& vi) {
+  if (GEN && c < G.rmin) {
+    if (r < G.rmin) {
+      if (r > c) { vr = G.cre[r - c]; vi = G.cim[r - c]; }
+      else if (r == c) { const double ic = G.ia[c]; vr = fma(ic, ic, G.cre[0]); vi = 0.0; }
+      else { vr = 0.0; vi = 0.0; }
+    } else {
+      hpx_edge_init<GEN>(G, Lb, Lb + 16, r, c, npad, G.ere != nullptr, vr, vi);
+    }
+  } else {
+    const long off = HPX_LIDX(r, c, npad);
+    vr = Lb[off];
+    vi = Lb[off + 16];
+  }
+}
+// the 16 x 16 tile at (r0, c0), r0 >= c0, as acc^T: lane li <-> row r0 + li, register v <-> column c0 + g + 4 v.
+// rmin is a multiple of 32, so a tile lies on one side of it and the source is chosen per tile.
+template <bool GEN>
+__device__ HPX_INL void tile_init(const hpx_gen& G, const double* __restrict__ Lb, const int r0, const int c0,
+                                  const int npad, const int li, const int g, d4& vr, d4& vi) {
+  if (GEN && c0 < G.rmin) {
+    if (r0 < G.rmin) {
+      if (r0 > c0) {
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          const int d = r0 - c0 + li - HPX_ACC_ROW(g, v);
+          vr[v] = G.cre[d];
+          vi[v] = G.cim[d];
+        }
+      } else {
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          const int d = li - HPX_ACC_ROW(g, v);
+          const int dd = d > 0 ? d : 0;
+          const double ic = G.ia[c0 + li];
+          const double cr = G.cre[dd], cm = G.cim[dd];
+          vr[v] = d > 0 ? cr : (d == 0 ? fma(ic, ic, cr) : 0.0);
+          vi[v] = d > 0 ? cm : 0.0;
+        }
+      }
+    } else {
+      const bool use_e = G.ere != nullptr;
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        double a, b;
+        hpx_edge_init<GEN>(G, Lb, Lb + 16, r0 + li, c0 + HPX_ACC_ROW(g, v), npad, use_e, a, b);
+        vr[v] = a;
+        vi[v] = b;
+      }
+    }
+  } else {
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const long off = HPX_LIDX(r0 + li, c0 + HPX_ACC_ROW(g, v), npad);
+      vr[v] = Lb[off];
+      vi[v] = Lb[off + 16];
+    }
+  }
+}
+
+// ---- staging ---------------------------------------------------------------------------------------
+// Every wave stages two tile slots (2 wave, 2 wave + 1) of every chunk, PP pieces each: a constant
+// number of LDS-DMA operations per wave and stage, so that the counted vmcnt waits below hold for
+// every wave.
+template <int KC>
+__device__ HPX_INL void stage_k(const WideCtx& X, const int ct0, const int chunk, const int bi,
+                                const unsigned src_lane) {
+  typedef WCfg<KC> C;
+  double* bb = X.lds + bi * C::BUF_D;
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int ci = 2 * X.wave + u;
+    // (uniform base) + (32-bit lane offset): the scalar-base form of the load, no 64-bit address registers
+    const double* src = X.Lb + (long)(ct0 + ci) * X.ptile + (long)chunk * C::TILE_D;
+#pragma unroll
+    for (int pp = 0; pp < C::PP; ++pp) glds16(src + pp * 128, src_lane, bb + ci * C::TILE_D + pp * 128);
+  }
+}
+// tail step t = cj * H + h: slot cj <- columns [KC h, KC h + KC) of inv(L_cjcj) (Vt), slots ci > cj <- the same
+// columns of L[ci][cj]; the slots above re-stage the inverse (never read)
+template <int KC>
+__device__ HPX_INL void stage_t(const WideCtx& X, const int ct0, const int t, const int bi,
+                                const unsigned src_lane) {
+  typedef WCfg<KC> C;
+  double* bb = X.lds + bi * C::BUF_D;
+  const int cj = t / C::H, h = t % C::H;
+  const double* vsrc = X.Vt + (long)(ct0 + cj) * 512 + h * C::TILE_D;
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int ci = 2 * X.wave + u;
+    const double* src = vsrc;
+    if (ci > cj) src = X.Lb + (long)(ct0 + ci) * X.ptile + (long)((ct0 + cj) * 16 + h * KC) * 32;
+#pragma unroll
+    for (int pp = 0; pp < C::PP; ++pp) glds16(src + pp * 128, src_lane, bb + ci * C::TILE_D + pp * 128);
+  }
+}
+
+// ---- 16 x 16 fused Cholesky + inverse (all 256 threads; hpx_factor.hip diag_panel, steps A / D) -----
+// in: Ein (re | im, row-major [r][c], leading dimension 16) lower part incl. diagonal, written by THIS
+//     thread or in front of a barrier.
+// out: L tile -> global; inv(L) tile -> Vt (global, tile layout, zero above the diagonal), LDS copy `Vs`
+//      (tile layout with the odd-column swizzle), and the 16 x 16 sub-block of the 32 x 32 inverse block.
+__device__ HPX_INL bool elim16(const WideCtx& X, const int tcol /* global tile column */, const bool last_tile) {
+  lds_f64* const Ein = (lds_f64*)(X.lds + FX_OFF);            // slot 0 of Xs: re 256 | im 256
+  lds_f64* const Vs = (lds_f64*)(X.lds + FV_OFF);
+  lds_cplx* const Dm = (lds_cplx*)(X.lds + FD_OFF);
+  lds_cplx* const Ym = Dm + 16 * 17;
+  lds_f64* const dg = (lds_f64*)(Ym + 16 * 17);
+  const int tid = X.tid, q = tid & 15, ib = tid >> 4;
+  const bool dia = (q == ib), low = (q < ib);
+  double dr = Ein[ib * 16 + q], di = Ein[256 + ib * 16 + q];
+  if (!low) Dm[ib * 17 + q] = (cplx){0.0, 0.0};               // diagonal and above stay zero in LDS
+  double yr = dia ? 1.0 : 0.0, yi = 0.0;
+  __builtin_amdgcn_s_setprio(2);
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    if (dia) dg[ib] = dr; else if (low) Dm[ib * 17 + q] = (cplx){dr, di};
+    Ym[ib * 17 + q] = (cplx){yr, yi};
+    __syncthreads();
+    const double dkk = dg[k];
+    const cplx c = Dm[ib * 17 + k], cq = Dm[q * 17 + k], sy = Ym[k * 17 + q];
+    const double r0 = __builtin_amdgcn_rcp(dkk);
+    const double rinv = fma(r0, fma(-dkk, r0, 1.0), r0);
+    const double lr = c.x * rinv, lm = c.y * rinv;
+    yr = fma(-lr, sy.x, yr);
+    yr = fma(lm, sy.y, yr);
+    yi = fma(-lr, sy.y, yi);
+    yi = fma(-lm, sy.x, yi);
+    dr = fma(-lr, cq.x, dr);
+    dr = fma(-lm, cq.y, dr);
+    di = fma(-lm, cq.x, di);
+    di = fma(lr, cq.y, di);
+  }
+  __syncthreads();
+  __builtin_amdgcn_s_setprio(0);
+  bool bad = false;
+  double wr = 0.0, wi = 0.0;
+  if (q <= ib) {
+    const double pq = dg[q], pib = dg[ib];
+    if (!(pq > 0.0) || !(pib > 0.0)) bad = true;
+    const double sq = rsqrt_nr(pq);
+    const long off = HPX_LIDX(tcol * 16 + ib, tcol * 16 + q, X.npad);
+    X.Lb[off] = dr * sq;
+    X.Lb[off + 16] = dia ? 0.0 : di * sq;
+    const double sv = rsqrt_nr(pib);
+    wr = yr * sv;
+    wi = yi * sv;
+  }
+  // inv(L)[ib][q]: tile layout = column q, row ib
+  double* vt = X.Vt + (long)tcol * 512 + q * 32 + ib;
+  vt[0] = wr;
+  vt[16] = wi;
+  Vs[q * 32 + ib + 16 * (q & 1)] = wr;
+  Vs[q * 32 + ib + 16 * (1 - (q & 1))] = wi;
+  const int o = 16 * (tcol & 1);
+  double* wgr = X.Wgre + (long)(tcol >> 1) * 1024;
+  double* wgi = X.Wgim + (long)(tcol >> 1) * 1024;
+  wgr[(o + ib) * 32 + o + q] = wr;
+  wgi[(o + ib) * 32 + o + q] = wi;
+  if (o == 0) {
+    wgr[ib * 32 + 16 + q] = 0.0;                               // upper-right block of the inverse is zero
+    wgi[ib * 32 + 16 + q] = 0.0;
+    if (last_tile) {                                           // 16-wide last block: nothing below either
+      wgr[(16 + ib) * 32 + q] = 0.0; wgi[(16 + ib) * 32 + q] = 0.0;
+      wgr[(16 + ib) * 32 + 16 + q] = 0.0; wgi[(16 + ib) * 32 + 16 + q] = 0.0;
+    }
+  }
+  __syncthreads();
+  return bad;
+}
+
+// ---- S: the diagonal block's update.  Wave W owns tile rows 7 - W and W of the block's lower triangle
+//      (8 - W and W + 1 tiles: nine each): slot s < 8 - W is tile (7 - W, s), the others (W, s - (8 - W)).
+//      Per k-step the two row operands are read once and the column operands one tile ahead of their
+//      MFMAs; compile-time tile indices, so every LDS offset is an immediate.
+//      On return a1 = re, a2 = im of D^T[c][r] per tile.
+template <int W> struct DiagDeal {
+  static constexpr int row(const int s) { return s < 8 - W ? 7 - W : W; }
+  static constexpr int col(const int s) { return s < 8 - W ? s : s - (8 - W); }
+};
+template <int KC, bool GEN, int W>
+__device__ HPX_INL void diag_update(const WideCtx& X, const hpx_gen& G, const int ct0, d4 (&a1)[9], d4 (&a2)[9]) {
+  typedef WCfg<KC> C;
+  typedef DiagDeal<W> TD;
+  constexpr int RA = 7 - W, RB = W;                 // the wave's two tile rows
+  const int lane = X.lane, li = lane & 15, g = lane >> 4;
+  const unsigned src_lane = g * 32 + 2 * ((li + 8 * (g & 1)) & 15);
+  const int rd_re = g * 32 + li + 16 * (g & 1), rd_im = g * 32 + li + 16 * (1 - (g & 1));
+  const int c0 = ct0 * 16;
+  d4 a3[9];
+#pragma unroll
+  for (int s = 0; s < 9; ++s) {
+    d4 vr, vi;
+    tile_init<GEN>(G, X.Lb, c0 + 16 * TD::row(s), c0 + 16 * TD::col(s), X.npad, li, g, vr, vi);
+    a1[s] = -0.5 * vr;
+    a2[s] = -0.5 * vr;
+    a3[s] = vi;
+  }
+  const int nk = c0 / KC;
+  if (nk > 0) {
+#pragma unroll
+    for (int d = 0; d < C::DIST; ++d) stage_k<KC>(X, ct0, min(d, nk - 1), d, src_lane);
+    int bi = 0;
+    for (int ch = 0; ch < nk; ++ch) {
+      // nothing but LDS-DMA is in flight here: all but the (DIST - 1) younger stages must have landed
+      wait_vm<(C::DIST - 1) * 2 * C::PP>();
+      __builtin_amdgcn_s_barrier();
+      {
+        int bn = bi + C::DIST;
+        if (bn >= C::NBUF) bn -= C::NBUF;
+        stage_k<KC>(X, ct0, min(ch + C::DIST, nk - 1), bn, src_lane);     // branch-free tail: a harmless re-stage
+      }
+      const lds_f64* B = (const lds_f64*)(X.lds + bi * C::BUF_D);
+#pragma unroll
+      for (int p = 0; p < C::PP; ++p) {
+        const double bra = B[RA * C::TILE_D + p * 128 + rd_re], bma = B[RA * C::TILE_D + p * 128 + rd_im];
+        const double brb = B[RB * C::TILE_D + p * 128 + rd_re], bmb = B[RB * C::TILE_D + p * 128 + rd_im];
+        const double bda = bra - bma, bdb = brb - bmb;
+        double pr = B[p * 128 + rd_re], pi = B[p * 128 + rd_im];
+#pragma unroll
+        for (int c = 0; c <= RA; ++c) {          // column tile c: slot c (row RA) and, for c <= RB, slot 8 - W + c (row RB)
+          const double cr = pr, cm = pi, psm = pr + pi;
+          if (c + 1 <= RA) {
+            pr = B[(c + 1) * C::TILE_D + p * 128 + rd_re];
+            pi = B[(c + 1) * C::TILE_D + p * 128 + rd_im];
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          a1[c] = mfma64(cr, bra, a1[c]);
+          a2[c] = mfma64(cm, bma, a2[c]);
+          a3[c] = mfma64(psm, bda, a3[c]);
+          if (c <= RB) {
+            a1[8 - W + c] = mfma64(cr, brb, a1[8 - W + c]);
+            a2[8 - W + c] = mfma64(cm, bmb, a2[8 - W + c]);
+            a3[8 - W + c] = mfma64(psm, bdb, a3[8 - W + c]);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      bi = (bi + 1 == C::NBUF) ? 0 : bi + 1;
+    }
+    wait_vm<0>();                       // the re-staged chunks: nothing may land after F starts using the area
+  }
+#pragma unroll
+  for (int s = 0; s < 9; ++s) {
+    const d4 re_ = -(a1[s] + a2[s]);
+    const d4 im_ = a3[s] - a1[s] + a2[s];
+    a1[s] = re_;
+    a2[s] = im_;
+  }
+}
+
+// ---- F: D = L_JJ L_JJ^H on the (re, im) tiles; D^T[c][r] per tile: register v <-> column g + 4 v, lane li <-> row
+__device__ HPX_INL bool diag_factor(const WideCtx& X, const int ct0, d4 (&a1)[9], d4 (&a2)[9]) {
+  const int lane = X.lane, li = lane & 15, g = lane >> 4;
+  const int rd_re = g * 32 + li + 16 * (g & 1), rd_im = g * 32 + li + 16 * (1 - (g & 1));
+  int tr[9], tc[9];
+#pragma unroll
+  for (int s = 0; s < 9; ++s) {
+    // (uniform: wave is a scalar) the deal of diag_update
+    tr[s] = (s < 8 - X.wave) ? 7 - X.wave : X.wave;
+    tc[s] = (s < 8 - X.wave) ? s : s - (8 - X.wave);
+  }
+  lds_f64* const Xs = (lds_f64*)(X.lds + FX_OFF);
+  lds_f64* const Vs = (lds_f64*)(X.lds + FV_OFF);
+  bool bad = false;
+  d4 t_re = {0., 0., 0., 0.}, t_im = {0., 0., 0., 0.};     // L10 inv(L00) of the current pair of tiles (one wave)
+  __syncthreads();                                          // the staging area is free
+  for (int i = 0; i < 8; ++i) {
+    // (1) the diagonal tile goes to the elimination
+#pragma unroll
+    for (int s = 0; s < 9; ++s)
+      if (tr[s] == i && tc[s] == i) {
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          Xs[li * 16 + HPX_ACC_ROW(g, v)] = a1[s][v];
+          Xs[256 + li * 16 + HPX_ACC_ROW(g, v)] = a2[s][v];
+        }
+      }
+    __syncthreads();
+    // (2) L_ii and its inverse
+    bad |= elim16(X, ct0 + i, false);
+    // (2b) odd tile of a pair: W10 = -inv(L11) (L10 inv(L00))
+    if ((i & 1) && X.wave == ((i >> 1) & 3)) {
+      d4 zr = {0., 0., 0., 0.}, zi = {0., 0., 0., 0.};
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const double ar = Vs[v * 128 + rd_re], ai = Vs[v * 128 + rd_im];     // inv(L11)[i' = li][r = 4 v + g]
+        zr = mfma64(-ar, t_re[v], zr);
+        zr = mfma64(ai, t_im[v], zr);
+        zi = mfma64(-ar, t_im[v], zi);
+        zi = mfma64(-ai, t_re[v], zi);
+      }
+      double* wgr = X.Wgre + (long)((ct0 + i) >> 1) * 1024;
+      double* wgi = X.Wgim + (long)((ct0 + i) >> 1) * 1024;
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        wgr[(16 + HPX_ACC_ROW(g, v)) * 32 + li] = zr[v];
+        wgi[(16 + HPX_ACC_ROW(g, v)) * 32 + li] = zi[v];
+      }
+    }
+    // (3) tiles below: X^T[c'][r'] = sum_c conj(inv(L)[c'][c]) D^T[c][r'], stored and handed to the others
+#pragma unroll
+    for (int s = 0; s < 9; ++s)
+      if (tc[s] == i && tr[s] > i) {
+        d4 xr = {0., 0., 0., 0.}, xi = {0., 0., 0., 0.};
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          const double pr = Vs[v * 128 + rd_re], pi = Vs[v * 128 + rd_im];
+          xr = mfma64(pr, a1[s][v], xr);
+          xr = mfma64(pi, a2[s][v], xr);
+          xi = mfma64(pr, a2[s][v], xi);
+          xi = mfma64(-pi, a1[s][v], xi);
+        }
+        double* o_ = X.Lb + HPX_LIDX((ct0 + tr[s]) * 16 + li, (ct0 + i) * 16 + g, X.npad);
+        lds_f64* xs = Xs + tr[s] * 512;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          o_[(4 * v) * 32] = xr[v];
+          o_[(4 * v) * 32 + 16] = xi[v];
+          const int k = g + 4 * v;                         // column of the tile; row li
+          xs[k * 32 + li + 16 * (k & 1)] = xr[v];
+          xs[k * 32 + li + 16 * (1 - (k & 1))] = xi[v];
+        }
+      }
+    __syncthreads();
+    // (3b) even tile of a pair: T = L10 inv(L00), kept in registers until the pair's second inverse exists
+    if (!(i & 1) && X.wave == ((i >> 1) & 3)) {
+      t_re = (d4){0., 0., 0., 0.};
+      t_im = t_re;
+      const lds_f64* l10 = Xs + (i + 1) * 512;
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const double ar = l10[v * 128 + rd_re], ai = l10[v * 128 + rd_im];      // L10[r = li][k = 4 v + g]
+        const int k = 4 * v + g;                                                   // inv(L00)[k][c' = li]
+        const double br = Vs[li * 32 + k + 16 * (li & 1)], bm = Vs[li * 32 + k + 16 * (1 - (li & 1))];
+        t_re = mfma64(ar, br, t_re);
+        t_re = mfma64(-ai, bm, t_re);
+        t_im = mfma64(ar, bm, t_im);
+        t_im = mfma64(ai, br, t_im);
+      }
+    }
+    // (4) trailing tiles: D^T[c'][r'] -= sum_k conj(X(c,i)[c'][k]) X(r,i)[r'][k]
+#pragma unroll
+    for (int s = 0; s < 9; ++s)
+      if (tc[s] > i) {
+        const lds_f64* pa = Xs + tc[s] * 512;
+        const lds_f64* pb = Xs + tr[s] * 512;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          const double pr = pa[v * 128 + rd_re], pi = pa[v * 128 + rd_im];
+          const double br = pb[v * 128 + rd_re], bm = pb[v * 128 + rd_im];
+          a1[s] = mfma64(-pr, br, a1[s]);
+          a1[s] = mfma64(-pi, bm, a1[s]);
+          a2[s] = mfma64(-pr, bm, a2[s]);
+          a2[s] = mfma64(pi, br, a2[s]);
+        }
+      }
+  }
+  __syncthreads();        // F's stores (L_JJ, Vt) are complete before the passes stage them
+  return bad;
+}
+
+// ---- P: the row strips below the full super-block at ct0, four at a time ----------------------------
+template <int KC, bool GEN>
+__device__ HPX_INL void strip_passes(const WideCtx& X, const hpx_gen& G, const int ct0) {
+  typedef WCfg<KC> C;
+  constexpr int PP = C::PP, H = C::H, DIST = C::DIST;
+  constexpr int NA = DIST * 2 * PP + (DIST - 1) * 2 * PP;     // active wave: its own loads / stores + younger stages
+  constexpr int NI = (DIST - 1) * 2 * PP;                     // idle wave: younger stages only
+  const int lane = X.lane, li = lane & 15, g = lane >> 4;
+  const unsigned src_lane = g * 32 + 2 * ((li + 8 * (g & 1)) & 15);
+  const int rd_re = g * 32 + li + 16 * (g & 1), rd_im = g * 32 + li + 16 * (1 - (g & 1));
+  const int c0 = ct0 * 16;
+  const int first = ct0 + 8;
+  const int nk = c0 / KC, nt = 8 * H, total = nk + nt;
+  for (int rt0 = first; rt0 < X.nrt; rt0 += 4) {
+    const int rt = rt0 + X.wave;
+    const bool active = rt < X.nrt;
+    d4 a1[8], a2[8], a3[8];
+    if (active) {
+#pragma unroll
+      for (int ci = 0; ci < 8; ++ci) {
+        d4 vr, vi;
+        tile_init<GEN>(G, X.Lb, rt * 16, c0 + 16 * ci, X.npad, li, g, vr, vi);
+        a1[ci] = -0.5 * vr;
+        a2[ci] = -0.5 * vr;
+        a3[ci] = vi;
+      }
+    }
+    // row operand: columns 4 p + g of chunk `ch`, this strip
+    const double* brow = X.Lb + (long)(active ? rt : first) * X.ptile;      // (uniform) + lane offset `blane`
+    const unsigned blane = g * 32 + li;
+    double rb[PP], rm[PP];
+    // ---- prologue: the first DIST stages, the first chunk's row operand
+#pragma unroll
+    for (int d = 0; d < DIST; ++d) {
+      const int st = min(d, total - 1);
+      if (st < nk) stage_k<KC>(X, ct0, st, d, src_lane);
+      else stage_t<KC>(X, ct0, st - nk, d, src_lane);
+    }
+    if (active && nk > 0) {
+#pragma unroll
+      for (int p = 0; p < PP; ++p) {
+        rb[p] = HPX_NTLD(brow + p * 128 + blane);
+        rm[p] = HPX_NTLD(brow + p * 128 + 16 + blane);
+      }
+    }
+    int bi = 0;
+    // ---- k-loop
+    for (int st = 0; st < nk; ++st) {
+      if (st < DIST) wait_vm<0>();
+      else if (active) wait_vm<NA>();
+      else wait_vm<NI>();
+      __builtin_amdgcn_s_barrier();
+      {
+        int bn = bi + DIST;
+        if (bn >= C::NBUF) bn -= C::NBUF;
+        const int sn = min(st + DIST, total - 1);
+        if (sn < nk) stage_k<KC>(X, ct0, sn, bn, src_lane);
+        else stage_t<KC>(X, ct0, sn - nk, bn, src_lane);
+      }
+      if (active) {
+        const lds_f64* B = (const lds_f64*)(X.lds + bi * C::BUF_D);
+        const double* bnext = brow + (long)min(st + 1, nk - 1) * C::TILE_D;     // last chunk: a harmless re-read
+#pragma unroll
+        for (int p = 0; p < PP; ++p) {
+          const double br = rb[p], bm = rm[p], bd = br - bm;
+          double pr = B[p * 128 + rd_re], pi = B[p * 128 + rd_im];
+#pragma unroll
+          for (int ci = 0; ci < 8; ++ci) {
+            const double cr = pr, cm = pi, psm = pr + pi;
+            if (ci + 1 < 8) {
+              pr = B[(ci + 1) * C::TILE_D + p * 128 + rd_re];
+              pi = B[(ci + 1) * C::TILE_D + p * 128 + rd_im];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            a1[ci] = mfma64(cr, br, a1[ci]);
+            a2[ci] = mfma64(cm, bm, a2[ci]);
+            a3[ci] = mfma64(psm, bd, a3[ci]);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+          rb[p] = HPX_NTLD(bnext + p * 128 + blane);
+          rm[p] = HPX_NTLD(bnext + p * 128 + 16 + blane);
+        }
+      }
+      bi = (bi + 1 == C::NBUF) ? 0 : bi + 1;
+    }
+    // ---- tail: the triangular solve as further chunks of the same stream
+#define HPX_TAIL_STEP(CJ_, HH_)                                                                      \
+  {                                                                                                  \
+    const int st_ = nk + (CJ_) * H + (HH_);                                                          \
+    if (st_ < DIST) wait_vm<0>();                                                                    \
+    else if (active) wait_vm<NA>();                                                                  \
+    else wait_vm<NI>();                                                                              \
+    __builtin_amdgcn_s_barrier();                                                                    \
+    {                                                                                                \
+      int bn_ = bi + DIST;                                                                           \
+      if (bn_ >= C::NBUF) bn_ -= C::NBUF;                                                            \
+      const int sn_ = min(st_ + DIST, total - 1);                                                    \
+      stage_t<KC>(X, ct0, sn_ - nk, bn_, src_lane);                                                  \
+    }                                                                                                \
+    if (active) {                                                                                    \
+      const lds_f64* B = (const lds_f64*)(X.lds + bi * C::BUF_D);                                    \
+      if ((HH_) == 0) {                                                                              \
+        const d4 re_ = -(a1[CJ_] + a2[CJ_]);                                                         \
+        const d4 im_ = a3[CJ_] - a1[CJ_] + a2[CJ_];                                                  \
+        a1[CJ_] = re_; a2[CJ_] = im_; a3[CJ_] = re_ - im_;                                           \
+        x1 = (d4){0., 0., 0., 0.}; x2 = x1; x3 = x1;                                                 \
+      }                                                                                              \
+      {                                                                                              \
+        double pr[PP], pi[PP];                                                                       \
+        _Pragma("unroll") for (int p = 0; p < PP; ++p) {                                             \
+          pr[p] = B[(CJ_) * C::TILE_D + p * 128 + rd_re];                                            \
+          pi[p] = B[(CJ_) * C::TILE_D + p * 128 + rd_im];                                            \
+        }                                                                                            \
+        __builtin_amdgcn_sched_barrier(0);                                                           \
+        _Pragma("unroll") for (int p = 0; p < PP; ++p) {                                             \
+          x1 = mfma64(pr[p], a1[CJ_][(HH_) * PP + p], x1);                                           \
+          x2 = mfma64(pi[p], a2[CJ_][(HH_) * PP + p], x2);                                           \
+          x3 = mfma64(pr[p] + pi[p], a3[CJ_][(HH_) * PP + p], x3);                                   \
+        }                                                                                            \
+        __builtin_amdgcn_sched_barrier(0);                                                           \
+      }                                                                                              \
+      double* o_ = X.Lb + HPX_LIDX(rt * 16 + li, (ct0 + (CJ_)) * 16 + g, X.npad);                    \
+      _Pragma("unroll") for (int p = 0; p < PP; ++p) {                                               \
+        const int v = (HH_) * PP + p;                                                                \
+        const double xr = x1[v] + x2[v], xi = x1[v] - x2[v] - x3[v];                                 \
+        o_[(4 * v) * 32] = xr;                                                                       \
+        o_[(4 * v) * 32 + 16] = xi;                                                                  \
+        a1[CJ_][v] = xr; a2[CJ_][v] = xi; a3[CJ_][v] = xr - xi;                                      \
+      }                                                                                              \
+      __builtin_amdgcn_sched_barrier(0);                                                             \
+      _Pragma("unroll") for (int ci = (CJ_) + 1; ci < 8; ++ci) {                                     \
+        double pr[PP], pi[PP];                                                                       \
+        _Pragma("unroll") for (int p = 0; p < PP; ++p) {                                             \
+          pr[p] = B[ci * C::TILE_D + p * 128 + rd_re];                                               \
+          pi[p] = B[ci * C::TILE_D + p * 128 + rd_im];                                               \
+        }                                                                                            \
+        __builtin_amdgcn_sched_barrier(0);                                                           \
+        _Pragma("unroll") for (int p = 0; p < PP; ++p) {                                             \
+          const int v = (HH_) * PP + p;                                                              \
+          a1[ci] = mfma64(pr[p], a1[CJ_][v], a1[ci]);                                                \
+          a2[ci] = mfma64(pi[p], a2[CJ_][v], a2[ci]);                                                \
+          a3[ci] = mfma64(pr[p] + pi[p], a3[CJ_][v], a3[ci]);                                        \
+        }                                                                                            \
+        __builtin_amdgcn_sched_barrier(0);                                                           \
+      }                                                                                              \
+    }                                                                                                \
+    bi = (bi + 1 == C::NBUF) ? 0 : bi + 1;                                                           \
+  }
+#define HPX_TAIL_TILE(CJ_)                          \
+  {                                                 \
+    d4 x1, x2, x3;                                  \
+    HPX_TAIL_STEP(CJ_, 0)                           \
+    if constexpr (H == 2) { HPX_TAIL_STEP(CJ_, 1) } \
+  }
+    HPX_TAIL_TILE(0)
+    HPX_TAIL_TILE(1)
+    HPX_TAIL_TILE(2)
+    HPX_TAIL_TILE(3)
+    HPX_TAIL_TILE(4)
+    HPX_TAIL_TILE(5)
+    HPX_TAIL_TILE(6)
+    HPX_TAIL_TILE(7)
+#undef HPX_TAIL_TILE
+#undef HPX_TAIL_STEP
+    // the group's stores and re-staged chunks are done, every wave has finished reading the buffers
+    wait_vm<0>();
+    __builtin_amdgcn_s_barrier();
+  }
+}
+
+// ---- a single 16-wide tile column t (those after the last full super-block): register-only ----------
+//   diagonal tile: K-split of the update over the four waves, partial sums through LDS, elimination;
+//   tiles below: one per wave at a time, both operands straight from global memory (double buffered).
+template <bool GEN>
+__device__ HPX_INL bool narrow_column(const WideCtx& X, const hpx_gen& G, const int t) {
+  const int lane = X.lane, li = lane & 15, g = lane >> 4;
+  const int rd_re = g * 32 + li + 16 * (g & 1), rd_im = g * 32 + li + 16 * (1 - (g & 1));
+  lds_f64* const Xs = (lds_f64*)(X.lds + FX_OFF);
+  lds_f64* const Vs = (lds_f64*)(X.lds + FV_OFF);
+  const int c0 = 16 * t;
+  // ---- diagonal tile: partial sums over this wave's 16-column chunks (operand p = b = L[t rows][k])
+  {
+    d4 q1 = {0., 0., 0., 0.}, q2 = q1, q3 = q1;
+    const double* prow = X.Lb + (long)t * X.ptile + g * 32 + li;
+    for (int ch = X.wave; ch < t; ch += 4) {
+      double pr[4], pi[4];
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        pr[p] = prow[(long)ch * 512 + p * 128];
+        pi[p] = prow[(long)ch * 512 + p * 128 + 16];
+      }
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        q1 = mfma64(pr[p], pr[p], q1);
+        q2 = mfma64(pi[p], pi[p], q2);
+        q3 = mfma64(pr[p] + pi[p], pr[p] - pi[p], q3);
+      }
+    }
+    // sum_k conj(p) b as [row li][column g + 4 v] into this wave's slot (slots 1..4 of Xs)
+    lds_f64* part = Xs + (1 + X.wave) * 512;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      part[li * 16 + HPX_ACC_ROW(g, v)] = q1[v] + q2[v];
+      part[256 + li * 16 + HPX_ACC_ROW(g, v)] = q1[v] - q2[v] - q3[v];
+    }
+  }
+  __syncthreads();
+  {
+    const int q = X.tid & 15, ib = X.tid >> 4;
+    double kr = 0.0, ki = 0.0;
+    if (q <= ib) entry_init<GEN>(G, X.Lb, c0 + ib, c0 + q, X.npad, kr, ki);
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      kr -= Xs[(1 + w) * 512 + ib * 16 + q];
+      ki -= Xs[(1 + w) * 512 + 256 + ib * 16 + q];
+    }
+    Xs[ib * 16 + q] = kr;                   // Ein: read back by this thread
+    Xs[256 + ib * 16 + q] = ki;
+  }
+  bool bad = elim16(X, t, (t + 1 == X.nct));
+  // ---- odd tile of a pair: W10 = -inv(L11) L10 inv(L00), operands from global memory
+  if ((t & 1) && X.wave == 0) {
+    d4 tre = {0., 0., 0., 0.}, tim = tre;
+    const double* l10 = X.Lb + HPX_LIDX(c0 + li, c0 - 16 + g, X.npad);        // L10[r = li][k = 4 v + g]
+    const double* v00 = X.Vt + (long)(t - 1) * 512 + li * 32 + g;             // inv(L00)[k = 4 v + g][c' = li]
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const double ar = l10[(4 * v) * 32], ai = l10[(4 * v) * 32 + 16];
+      const double br = v00[4 * v], bm = v00[4 * v + 16];
+      tre = mfma64(ar, br, tre);
+      tre = mfma64(-ai, bm, tre);
+      tim = mfma64(ar, bm, tim);
+      tim = mfma64(ai, br, tim);
+    }
+    d4 zr = {0., 0., 0., 0.}, zi = zr;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const double ar = Vs[v * 128 + rd_re], ai = Vs[v * 128 + rd_im];
+      zr = mfma64(-ar, tre[v], zr);
+      zr = mfma64(ai, tim[v], zr);
+      zi = mfma64(-ar, tim[v], zi);
+      zi = mfma64(-ai, tre[v], zi);
+    }
+    double* wgr = X.Wgre + (long)(t >> 1) * 1024;
+    double* wgi = X.Wgim + (long)(t >> 1) * 1024;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      wgr[(16 + HPX_ACC_ROW(g, v)) * 32 + li] = zr[v];
+      wgi[(16 + HPX_ACC_ROW(g, v)) * 32 + li] = zi[v];
+    }
+  }
+  // ---- tiles below: X = (K[r, t] - sum_k L[r, k] L[t, k]^H) inv(L_tt)^H
+  for (int rt = t + 1 + X.wave; rt < X.nrt; rt += 4) {
+    d4 a1, a2, a3;
+    {
+      d4 vr, vi;
+      tile_init<GEN>(G, X.Lb, rt * 16, c0, X.npad, li, g, vr, vi);
+      a1 = -0.5 * vr;
+      a2 = -0.5 * vr;
+      a3 = vi;
+    }
+    const double* prow = X.Lb + (long)t * X.ptile + g * 32 + li;
+    const double* brow = X.Lb + (long)rt * X.ptile + g * 32 + li;
+    double pr0[4], pi0[4], br0[4], bm0[4], pr1[4], pi1[4], br1[4], bm1[4];
+#define HPX_NC_LOAD(pr_, pi_, br_, bm_, ch_)                                   \
+  _Pragma("unroll") for (int p = 0; p < 4; ++p) {                              \
+    pr_[p] = prow[(long)(ch_) * 512 + p * 128];                                \
+    pi_[p] = prow[(long)(ch_) * 512 + p * 128 + 16];                           \
+    br_[p] = HPX_NTLD(brow + (long)(ch_) * 512 + p * 128);                     \
+    bm_[p] = HPX_NTLD(brow + (long)(ch_) * 512 + p * 128 + 16);                \
+  }
+#define HPX_NC_MMA(pr_, pi_, br_, bm_)                                         \
+  _Pragma("unroll") for (int p = 0; p < 4; ++p) {                              \
+    a1 = mfma64(pr_[p], br_[p], a1);                                           \
+    a2 = mfma64(pi_[p], bm_[p], a2);                                           \
+    a3 = mfma64(pr_[p] + pi_[p], br_[p] - bm_[p], a3);                         \
+  }
+    if (t > 0) {
+      HPX_NC_LOAD(pr0, pi0, br0, bm0, 0)
+      for (int ch = 0; ch < t; ch += 2) {
+        const int c1 = min(ch + 1, t - 1);
+        HPX_NC_LOAD(pr1, pi1, br1, bm1, c1)
+        __builtin_amdgcn_sched_barrier(0);
+        HPX_NC_MMA(pr0, pi0, br0, bm0)
+        __builtin_amdgcn_sched_barrier(0);
+        const int c2 = min(ch + 2, t - 1);
+        HPX_NC_LOAD(pr0, pi0, br0, bm0, c2)
+        __builtin_amdgcn_sched_barrier(0);
+        if (ch + 1 < t) { HPX_NC_MMA(pr1, pi1, br1, bm1) }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+#undef HPX_NC_LOAD
+#undef HPX_NC_MMA
+    const d4 re_ = -(a1 + a2), im_ = a3 - a1 + a2, dd_ = re_ - im_;
+    d4 x1 = {0., 0., 0., 0.}, x2 = x1, x3 = x1;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const double pr = Vs[v * 128 + rd_re], pi = Vs[v * 128 + rd_im];
+      x1 = mfma64(pr, re_[v], x1);
+      x2 = mfma64(pi, im_[v], x2);
+      x3 = mfma64(pr + pi, dd_[v], x3);
+    }
+    double* o_ = X.Lb + HPX_LIDX(rt * 16 + li, c0 + g, X.npad);
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      o_[(4 * v) * 32] = x1[v] + x2[v];
+      o_[(4 * v) * 32 + 16] = x1[v] - x2[v] - x3[v];
+    }
+  }
+  __syncthreads();        // this column's stores are complete before the next one reads them
+  return bad;
+}
+
+template <int KC, bool GEN, bool GLDS>
+__global__ __launch_bounds__(256, 2) void k_factor_wide(double* __restrict__ L_all, double* __restrict__ Wre_all,
+                                                        double* __restrict__ Wim_all, double* __restrict__ Vt_all,
+                                                        int32_t* __restrict__ info, const int npad, const int ld,
+                                                        const int iter_tag, const hpx_gen_batch GB) {
+  typedef WCfg<KC> C;
+  extern __shared__ double lds_raw[];
+  const int b = blockIdx.x;
+  const int tid = threadIdx.x;
+  hpx_gen G = {};
+  if (GEN) G = hpx_gen_for(GB, b);
+  WideCtx X;
+  X.tid = tid;
+  X.wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  X.lane = tid & 63;
+  X.npad = npad;
+  X.nct = npad >> 4;
+  X.nrt = ld >> 4;
+  X.ptile = (long)npad * 32;
+  X.Lb = L_all + (long)b * npad * ld * 2;
+  X.Vt = Vt_all + (long)b * npad * 32;
+  const int nblk = (npad + HPX_NB - 1) / HPX_NB;
+  X.Wgre = Wre_all + (long)b * nblk * 1024;
+  X.Wgim = Wim_all + (long)b * nblk * 1024;
+  X.lds = lds_raw;
+  if (GEN && GLDS) {
+    double* ga = lds_raw + C::STAGE_D;
+    double* gcr = ga + G.N;
+    double* gci = gcr + G.N;
+    for (int i = tid; i < G.N; i += 256) {
+      ga[i] = G.ia[i];
+      gcr[i] = G.cre[i];
+      gci[i] = G.cim[i];
+    }
+    G.ia = ga;
+    G.cre = gcr;
+    G.cim = gci;
+    __syncthreads();
+  }
+  bool bad = false;
+  int ct0 = 0;
+  for (; ct0 + 8 <= X.nct; ct0 += 8) {
+    d4 a1[9], a2[9];
+#ifndef HPX_DBG_NO_S
+    if (X.wave == 0) diag_update<KC, GEN, 0>(X, G, ct0, a1, a2);
+    else if (X.wave == 1) diag_update<KC, GEN, 1>(X, G, ct0, a1, a2);
+    else if (X.wave == 2) diag_update<KC, GEN, 2>(X, G, ct0, a1, a2);
+    else diag_update<KC, GEN, 3>(X, G, ct0, a1, a2);
+#else
+    for (int s = 0; s < 9; ++s) { a1[s] = (d4){1.0 * tid, 0., 0., 0.}; a2[s] = a1[s]; }
+#endif
+#ifndef HPX_DBG_NO_F
+    bad |= diag_factor(X, ct0, a1, a2);
+#else
+    for (int s = 0; s < 9; ++s) X.Lb[s * 64 + tid] = a1[s][0] + a2[s][1];
+#endif
+#ifndef HPX_DBG_NO_P
+    strip_passes<KC, GEN>(X, G, ct0);
+#endif
+  }
+#ifndef HPX_DBG_NO_N
+  for (; ct0 < X.nct; ++ct0) bad |= narrow_column<GEN>(X, G, ct0);
+#endif
+  if (bad && info) atomicCAS(&info[b], 0, iter_tag);
+}
+
+template <int KC, bool GEN, bool GLDS>
+int launch_wide_t(int nbl, size_t lds, int npad, int ld, double* L, double* Wre, double* Wim, double* Vt,
+                  int32_t* info, int iter_tag, const hpx_gen_batch& gen, hipStream_t st) {
+  static hpx_lds_limit limit;      // per instantiation
+  HPX_TRY(limit.ensure(reinterpret_cast<const void*>(&k_factor_wide<KC, GEN, GLDS>), lds));
+  hipLaunchKernelGGL((k_factor_wide<KC, GEN, GLDS>), dim3(nbl), dim3(256), lds, st, L, Wre, Wim, Vt, info, npad, ld,
+                     iter_tag, gen);
+  HPX_HIP(hipGetLastError());
+  return HPX_OK;
+}
+
+}  // namespace
+
+#ifndef HPX_WIDE_KC
+#define HPX_WIDE_KC 16
+#endif
+
+int hpx_launch_factor_wide(int nbl, int npad, int ld, double* L, double* Wre, double* Wim, double* Vt,
+                           int32_t* info, int iter_tag, const hpx_gen_batch* gen, hipStream_t st) {
+  constexpr int KC = HPX_WIDE_KC;
+  const size_t base = (size_t)WCfg<KC>::STAGE_D * sizeof(double);
+  if (!gen) {
+    hpx_gen_batch none = {};
+    return launch_wide_t<KC, false, false>(nbl, base, npad, ld, L, Wre, Wim, Vt, info, iter_tag, none, st);
+  }
+  // 1 / a and the circulant in LDS while two workgroups still fit on a CU
+  const size_t staged = base + (size_t)3 * gen->N * sizeof(double);
+  if (staged <= (size_t)80 * 1024)
+    return launch_wide_t<KC, true, true>(nbl, staged, npad, ld, L, Wre, Wim, Vt, info, iter_tag, *gen, st);
+  return launch_wide_t<KC, true, false>(nbl, base, npad, ld, L, Wre, Wim, Vt, info, iter_tag, *gen, st);
+}

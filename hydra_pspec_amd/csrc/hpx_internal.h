@@ -86,6 +86,7 @@ struct hpx_plan {
   // HPX_SOLVER_LOWRANK: flagged channels per baseline, the small Schur system and its solution
   int lr_fmax, lr_npad;
   int32_t *lr_flist, *lr_fcount;
+  double *lr_Vt;
   double *lr_c, *lr_L, *lr_Wre, *lr_Wim, *lr_Yre, *lr_Yim, *lr_Bre, *lr_Bim, *lr_Tre, *lr_Tim;
   // FFT form of the low-rank solver (hpx_lowrank.hip): transform input / output, foreground
   // blocks, channel -> flagged index
@@ -96,6 +97,7 @@ struct hpx_plan {
   // factor / solution
   double *L;               // [nbl][ld/16 panels][npad][re16|im16]  (HPX_LIDX)
   double *Wre, *Wim;       // [nbl][nblk][32][32] inverse diagonal blocks
+  double *Vt;              // [nbl][npad/16 tiles][16][re16|im16] inverse diagonal 16 x 16 tiles (wide factor)
   double *Xre, *Xim;       // [nbl][npad][TP] solution [y' ; f]
   int32_t *info;           // [nbl]
   // chain state
@@ -305,8 +307,12 @@ struct hpx_lds_limit {
 // ---- launchers (each returns HPX_OK / HPX_EHIP) -----------------------------
 // gen == nullptr: factor the matrix stored in L in place; otherwise the augmented matrix is generated on the
 // fly from *gen and L is write-only.
-int hpx_launch_factor(int nbl, int npad, int ld, double* L, double* Wre, double* Wim,
+// Vt [nbl][npad * 32]: inverses of the diagonal 16 x 16 tiles in tile layout (workspace of the wide form).
+int hpx_launch_factor(int nbl, int npad, int ld, double* L, double* Wre, double* Wim, double* Vt,
                       int32_t* info, int iter_tag, const hpx_gen_batch* gen, hipStream_t st);
+// the wide (128-column super-block, LDS-staged) form, hpx_factor_wide.hip
+int hpx_launch_factor_wide(int nbl, int npad, int ld, double* L, double* Wre, double* Wim, double* Vt,
+                           int32_t* info, int iter_tag, const hpx_gen_batch* gen, hipStream_t st);
 // structured solve for flat noise with flags (hpx_lowrank.hip): writes X = [z; f]
 int hpx_launch_solve_lowrank(hpx_plan* p, int iter_tag, hipStream_t st);
 size_t hpx_lowrank_lds_bytes(const hpx_plan* p);

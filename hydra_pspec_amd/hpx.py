@@ -38,7 +38,6 @@ SIGNATURES = {
     "hpx_plan_set_static_pertime_dense": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _i, _vp]),
     "hpx_plan_set_rng": (_i, [_vp, _vp, _vp, _i, _vp]),
     "hpx_gibbs_run": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
-    "hpx_gibbs_run_parts": (_i, [_vp, _i, _i, _i, _i]),
     "hpx_gibbs_step_general": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "hpx_plan_info": (_i, [_vp, _vp]),
     "hpx_plan_set_profiling": (_i, [_vp, _i]),
@@ -134,13 +133,6 @@ def to_dev(torch, x, dtype, device):
             x = x.copy()
         x = torch.from_numpy(x)
     return x.to(device=device, dtype=dtype, non_blocking=False).contiguous()
-
-
-class RunPart(C.Structure):
-    """``hpx_run_part`` of include/hpx.h: one plan of an ``hpx_gibbs_run_parts`` call."""
-    _fields_ = [("plan", C.c_void_p), ("ps0", C.c_void_p), ("ps_forced", C.c_void_p), ("ps_out", C.c_void_p),
-                ("lnpost_out", C.c_void_p), ("cr_out", C.c_void_p), ("fg_out", C.c_void_p),
-                ("chisq_out", C.c_void_p), ("ps_last", C.c_void_p), ("stream", C.c_void_p)]
 
 
 class Plan:

@@ -479,111 +479,8 @@ class GibbsBatch:
             return out
 
 
-class GibbsParts:
-    """A batch cut into ``parts`` contiguous baseline ranges, one :class:`GibbsBatch` (plan) and one HIP stream each,
-    advanced together by ``hpx_gibbs_run_parts``: the iterations of all parts are enqueued in turn, so one part's back
-    substitution, transforms and draw run on the GPU beside another part's factorisation.  An OPTION, not a default:
-    at C3 (1024 baselines) 4 parts ran from 5 % faster to 6 % slower than one plan depending on how the HIP runtime
-    mapped the streams onto its hardware queues, 3 or 5 parts always slower; pointless below a
-    few hundred baselines, where one plan's kernels do not fill the GPU anyway.  Same chains as one :class:`GibbsBatch`, bit for
-    bit; same ``run`` / ``close`` / ``iter_done`` interface (``shp0``, a general starting covariance, is not taken)."""
-
-    def __init__(self, vis, flags, fgmodes, ninv_diag, ps_prior, Niter, parts=4, seed=None, map_estimate=False,
-                 device=None, tables=None, omega=None, solver="auto", ninv_dense=None):
-        torch = hpx.require_gpu()
-        self.torch = torch
-        nbl, T, N = tuple(vis.shape)
-        parts = max(1, min(int(parts), nbl))
-        self.nbl, self.T, self.N, self.M = nbl, T, N, tuple(fgmodes.shape)[-1]
-        self.map_estimate = bool(map_estimate)
-        self.Niter = 1 if map_estimate else int(Niter)
-        if tables is None:           # one set of random tables for every part (the chains share the seed)
-            tables = draw_tables(T, N, self.Niter, seed, reseed=not map_estimate)
-        if omega is None:
-            omega = omega_table(T, N)
-        self.cuts = [round(i * nbl / parts) for i in range(parts + 1)]
-
-        def cut(a, lo, hi, shared_ndim):
-            if a is None:
-                return None
-            return a if len(tuple(a.shape)) == shared_ndim else a[lo:hi]
-
-        self.batches = []
-        for lo, hi in zip(self.cuts[:-1], self.cuts[1:]):
-            nd = None if ninv_dense is None else cut(ninv_dense, lo, hi, 2)
-            self.batches.append(GibbsBatch(vis[lo:hi], flags[lo:hi], cut(fgmodes, lo, hi, 2),
-                                           None if ninv_diag is None else ninv_diag[lo:hi], cut(ps_prior, lo, hi, 2),
-                                           Niter, seed=seed, map_estimate=map_estimate, device=device, tables=tables,
-                                           omega=omega, solver=solver, ninv_dense=nd))
-        self.device = self.batches[0].device
-        self.solver = self.batches[0].solver
-        self.per_time = self.batches[0].per_time
-        with torch.cuda.device(self.device):
-            self.streams = [torch.cuda.Stream() for _ in self.batches]
-
-    @property
-    def iter_done(self):
-        return self.batches[0].iter_done
-
-    @iter_done.setter
-    def iter_done(self, v):
-        for gb in self.batches:
-            gb.iter_done = v
-
-    def close(self):
-        for gb in self.batches:
-            gb.close()
-
-    def run(self, niter, ps0=None, ps_forced=None, keep=("ps", "ln_post"), thin=1, shp0=None):
-        """As :meth:`GibbsBatch.run`, for all parts together."""
-        if shp0 is not None:
-            raise NotImplementedError("a general starting covariance needs a single GibbsBatch (parts=1)")
-        torch = self.torch
-        nbl, T, N, M = self.nbl, self.T, self.N, self.M
-        assert self.iter_done + niter <= self.Niter, "random tables exhausted"
-        assert ps0 is not None or self.iter_done > 0, "ps0 is required for the first run"
-        nkeep = (niter + thin - 1) // thin
-        with torch.cuda.device(self.device):
-            f64, c128, dev = torch.float64, torch.complex128, self.device
-            d_ps0 = None if ps0 is None else hpx.to_dev(torch, ps0, f64, dev)
-            d_forced = None if ps_forced is None else hpx.to_dev(torch, ps_forced, f64, dev)
-            if d_ps0 is not None:
-                assert tuple(d_ps0.shape) == (nbl, N)
-            if d_forced is not None:
-                assert tuple(d_forced.shape) == (nbl, niter, N)
-            out = dict(signal_ps=torch.empty((nbl, niter, N), dtype=f64, device=dev),
-                       ln_post=torch.empty((nbl, niter), dtype=f64, device=dev),
-                       ps_last=torch.empty((nbl, N), dtype=f64, device=dev))
-            if "signal_cr" in keep:
-                out["signal_cr"] = torch.empty((nbl, nkeep, T, N), dtype=c128, device=dev)
-            if "fg_amps" in keep:
-                out["fg_amps"] = torch.zeros((nbl, nkeep, T, M), dtype=c128, device=dev)
-            if "chisq" in keep:
-                out["chisq"] = torch.empty((nbl, nkeep, T, N), dtype=f64, device=dev)
-            arr = (hpx.RunPart * len(self.batches))()
-
-            def sub(t, lo, hi):
-                return None if t is None else hpx.ptr(t[lo:hi])
-
-            for q, (gb, st) in enumerate(zip(self.batches, self.streams)):
-                lo, hi = self.cuts[q], self.cuts[q + 1]
-                arr[q].plan = gb.plan.handle
-                arr[q].ps0, arr[q].ps_forced = sub(d_ps0, lo, hi), sub(d_forced, lo, hi)
-                arr[q].ps_out, arr[q].lnpost_out = sub(out["signal_ps"], lo, hi), sub(out["ln_post"], lo, hi)
-                arr[q].cr_out, arr[q].fg_out = sub(out.get("signal_cr"), lo, hi), sub(out.get("fg_amps"), lo, hi)
-                arr[q].chisq_out, arr[q].ps_last = sub(out.get("chisq"), lo, hi), sub(out["ps_last"], lo, hi)
-                arr[q].stream = st.cuda_stream
-            # the parts' streams do not wait for the current one: everything enqueued on it so far (uploads, and
-            # whatever last used the memory the outputs were carved from) has to be complete first
-            torch.cuda.current_stream().synchronize()
-            rc = hpx.lib().hpx_gibbs_run_parts(arr, len(self.batches), self.iter_done, niter, thin)
-            hpx.check(rc, "hpx_gibbs_run_parts")
-        self.iter_done = self.iter_done + niter
-        return out
-
-
 def make_batch(vis, flags, fgmodes, Ninv, ps_prior, Niter, seed=None, map_estimate=False, device=None,
-               solver="auto", tables=None, parts=1):
+               solver="auto", tables=None):
     """A :class:`GibbsBatch` from the inverse noise covariance in any form the path accepts:
     diagonals ``(Nfreqs,)`` / ``(Nbl,Nfreqs)`` or matrices ``(Nfreqs,Nfreqs)`` / ``(Nbl,Nfreqs,Nfreqs)``
     (reference run-hydra-pspec.py:427-438 passes ``inv(noise_cov)``)."""
@@ -600,12 +497,6 @@ def make_batch(vis, flags, fgmodes, Ninv, ps_prior, Niter, seed=None, map_estima
         nd = np.ascontiguousarray(np.broadcast_to(nd[:, None], (nbl, T, N, N)))    # time-dependent flags only
     elif nd is not None and nd.ndim == 2 and len(tuple(flags.shape)) == 3:
         nd = np.ascontiguousarray(np.broadcast_to(nd, (nbl, T, N, N)))
-    if parts > 1:      # several plans on several streams (GibbsParts); per-baseline noise matrices are cut with them
-        if nd is not None and nd.ndim == 2:
-            nd = np.ascontiguousarray(np.broadcast_to(nd, (nbl, N, N)))
-        return GibbsParts(vis, flags, fgmodes, None if nd is not None else _ninv_diag(Ninv, nbl, T, N), ps_prior, Niter,
-                          parts=parts, seed=seed, map_estimate=map_estimate, device=device, solver=solver,
-                          ninv_dense=nd, tables=tables)
     if nd is not None:
         return GibbsBatch(vis, flags, fgmodes, None, ps_prior, Niter, seed=seed, map_estimate=map_estimate,
                           device=device, solver=solver, ninv_dense=nd, tables=tables)
@@ -616,7 +507,7 @@ def make_batch(vis, flags, fgmodes, Ninv, ps_prior, Niter, seed=None, map_estima
 def gibbs_sample_with_fg_batched(vis, flags, fgmodes, Ninv, ps_prior, S_initial=None,
                                  ps_initial=None, Niter=100, seed=None, map_estimate=False,
                                  keep=("ps", "ln_post"), thin=1, ps_forced=None, device=None,
-                                 as_numpy=True, iter0=0, solver="auto", parts=1):
+                                 as_numpy=True, iter0=0, solver="auto"):
     """Run the Gibbs chain of ``gibbs_sample_with_fg`` for ``Nbl`` baselines at once.
 
     Parameters mirror the reference (pspec.py:493-571) with a leading baseline
@@ -638,10 +529,6 @@ def gibbs_sample_with_fg_batched(vis, flags, fgmodes, Ninv, ps_prior, S_initial=
     ``ps_last`` and the histories named in ``keep`` (``"signal_cr"``,
     ``"fg_amps"``, ``"chisq"``; every ``thin``-th iteration).
 
-    ``parts`` > 1 cuts the batch into that many baseline ranges, each with a plan and a stream of its own, advanced
-    together (:class:`GibbsParts`): same chains bit for bit; up to 5 % more throughput at 1024 baselines with 4 parts,
-    but not dependably (see there).
-
     ``solver``: ``"auto"`` (default) solves baselines whose unflagged channels share one ``Ninv``
     value through the diagonal + border structure of the system (hpx_flat.hip without flags,
     hpx_lowrank.hip with flags) and everything else with the batched dense Cholesky; ``"dense"``
@@ -661,7 +548,7 @@ def gibbs_sample_with_fg_batched(vis, flags, fgmodes, Ninv, ps_prior, S_initial=
         if np.any(resid > FOURIER_FORM_TOL):     # general covariance: first iteration via Sh'
             shp0 = np.ascontiguousarray(np.broadcast_to(sqrt_cov_delay_basis(S0), (nbl, N, N)))
     gb = make_batch(vis, flags, fgmodes, Ninv, ps_prior, Niter, seed=seed, map_estimate=map_estimate,
-                    device=device, solver=solver, parts=1 if shp0 is not None else parts)
+                    device=device, solver=solver)
     try:
         if shp0 is not None:
             assert iter0 == 0, "a general S_initial cannot be combined with iter0 > 0"

@@ -176,27 +176,6 @@ int hpx_gibbs_run(hpx_plan* p, const double* ps0, int iter0, int niter,
                   double* cr_out, double* fg_out, double* chisq_out, int thin,
                   double* ps_last, void* stream);
 
-/* Several plans advanced together: part q is hpx_gibbs_run(parts[q].plan, ...) on parts[q].stream, but the
- * iterations of all parts are enqueued in turn from the calling thread (iteration i of every part before
- * iteration i + 1 of any), so that one part's back substitution, transforms and bandpower draw run on the GPU
- * beside another part's factorisation.  The parts are independent batches (e.g. contiguous baseline ranges of
- * one batch, their output pointers offsets into the same arrays: every output is laid out baseline-major);
- * each needs a plan and a stream of its own.  Results are those of separate hpx_gibbs_run calls, bit for bit.
- * Returns after every stream has drained; the first error, if any. */
-typedef struct hpx_run_part {
-  hpx_plan* plan;
-  const double* ps0;          /* as hpx_gibbs_run, per part */
-  const double* ps_forced;
-  double* ps_out;
-  double* lnpost_out;
-  double* cr_out;
-  double* fg_out;
-  double* chisq_out;
-  double* ps_last;
-  void* stream;
-} hpx_run_part;
-int hpx_gibbs_run_parts(const hpx_run_part* parts, int nparts, int iter0, int niter, int thin);
-
 /* Iteration 0 for an initial covariance that is NOT of the form
  * F^H diag(.) F (pspec.py:599 accepts any matrix): the caller supplies
  * Sh' = U^H sqrtm(S_initial) U, (nbl,N,N) c128.  Runs exactly one iteration

@@ -129,14 +129,15 @@ def write_json_atomic(path, obj):
     os.replace(tmp, path)
 
 
-def wait_for_file(path, newer_than, timeout=900.0, what=""):
-    """Poll for a JSON file written (atomically) after `newer_than` by another rank of this launch."""
+def wait_for_file(path, newer_than, timeout=900.0, what="", nonce=None):
+    """Poll for a JSON file written (atomically) after `newer_than` by another rank of this launch; with `nonce`,
+    only a file that echoes this launch's nonce (handed out by rank 0 through the marker file) counts."""
     t_end = time.time() + timeout
     while time.time() < t_end:
         try:
             with open(path) as f:
                 obj = json.load(f)
-            if obj.get("created", 0.0) >= newer_than:
+            if obj.get("created", 0.0) >= newer_than and (nonce is None or obj.get("nonce") == nonce):
                 return obj
         except (FileNotFoundError, json.JSONDecodeError):
             pass
@@ -280,6 +281,10 @@ def main(argv=None):
         dirname = f"results-{freq_str}-Niter-{args.Niter}"
     else:
         dirname = f"results-seed-{args.seed}-Niter-{args.Niter}"
+    if args.dry_run:
+        # a dry run writes all-zero chains: it gets a tree of its own, so that neither --clobber nor --resume can
+        # ever mix them with real results (and `dry_run` is one of the arguments a --resume must match)
+        dirname = "dryrun-" + dirname
     results = out_dir / dirname
     # Rank 0 alone prepares the tree (moves an earlier one aside, creates the directory) and reads the earlier
     # run's args.json for --resume; the other ranks wait for its marker file before they touch the tree and take
@@ -287,7 +292,17 @@ def main(argv=None):
     # with MPI barriers / bcast (run-hydra-pspec.py:343-366); here the ranks of a launch meet through files.
     marker = out_dir / f".{dirname}.{launch_token()}.ranks.json"
     old_args = None
+    nonce = None
     if rank == 0:
+        # leftovers of a launch that died (same token: torchrun's default run id and port repeat): gone before
+        # anything of this launch can be mistaken for them
+        import uuid
+        nonce = uuid.uuid4().hex
+        for stale in [marker] + (sorted(results.glob(".timings-*.json")) if results.exists() else []):
+            try:
+                os.remove(stale)
+            except FileNotFoundError:
+                pass
         if args.resume and (results / "args.json").exists():
             with open(results / "args.json") as f:
                 old_args = json.load(f)
@@ -300,11 +315,28 @@ def main(argv=None):
             shutil.move(str(results), str(results.with_name(f"{results.name}-{mtime}")))
         results.mkdir(parents=True, exist_ok=True)
         if world > 1:
-            write_json_atomic(marker, {"created": time.time(), "old_args": old_args})
+            write_json_atomic(marker, {"created": time.time(), "old_args": old_args, "nonce": nonce})
     else:
-        old_args = wait_for_file(marker, t_launch - 300.0, what="rank 0 to prepare the output tree")["old_args"]
+        met = wait_for_file(marker, t_launch - 300.0, what="rank 0 to prepare the output tree")
+        old_args, nonce = met["old_args"], met.get("nonce")
 
     # ---- sampling -----------------------------------------------------------------------
+    try:
+        return sample_and_write(args, rank, world, local_rank, results, marker, nonce, old_args, locals())
+    except SystemExit as e:
+        if rank > 0:        # rank 0 waits for this rank's timings file: tell it not to
+            write_json_atomic(results / f".timings-{rank}.json",
+                              {"created": time.time(), "nonce": nonce, "rank": rank, "failed": str(e)})
+        raise
+
+
+def sample_and_write(args, rank, world, local_rank, results, marker, nonce, old_args, env):
+    """Everything after the output tree exists: the chains, the periodic writes, the merged timings."""
+    from hydra_pspec_amd import pspec, utils
+    (vis, flags_any, flags_pt, fg, ninv, ninv_dense, ps_prior, ps0, S_general, antpairs, nbl, nbl_all, N, T, t_load,
+     t_start, t_launch) = (env[k] for k in ("vis", "flags_any", "flags_pt", "fg", "ninv", "ninv_dense", "ps_prior",
+                                            "ps0", "S_general", "antpairs", "nbl", "nbl_all", "N", "T", "t_load",
+                                            "t_start", "t_launch"))
     import torch
     if not args.dry_run:
         torch.cuda.set_device(local_rank)
@@ -329,7 +361,7 @@ def main(argv=None):
     if args.resume:
         if old_args is None:
             raise SystemExit(f"--resume: no args.json of an earlier run in {results}")
-        run_only = {"Niter", "resume", "clobber", "verbose", "write_Niter", "Nproc", "config", "outputs", "dry_run"}
+        run_only = {"Niter", "resume", "clobber", "verbose", "write_Niter", "Nproc", "config", "outputs"}
         diff = sorted(k for k in vars(args) if k not in run_only and old_args.get(k) != getattr(args, k))
         if diff:
             raise SystemExit("--resume: the earlier run in " + str(results) + " used different "
@@ -421,14 +453,17 @@ def main(argv=None):
 
     # every rank's write times reach rank 0 (the reference gathers them, run-hydra-pspec.py:557, and writes
     # one timings.json, :570-581): per-rank files, merged and removed by rank 0
-    mine = {"created": time.time(), "rank": rank, "ant_pairs": ant_strs, "write_times": write_times}
+    mine = {"created": time.time(), "nonce": nonce, "rank": rank, "ant_pairs": ant_strs, "write_times": write_times}
     if rank > 0:
         write_json_atomic(results / f".timings-{rank}.json", mine)
     if rank == 0:
         t_bar = time.perf_counter()
         write_data = [{k: mine[k] for k in ("rank", "ant_pairs", "write_times")}]
         for r in range(1, world):
-            other = wait_for_file(results / f".timings-{r}.json", t_launch - 300.0, what=f"rank {r} to finish")
+            other = wait_for_file(results / f".timings-{r}.json", t_launch - 300.0, what=f"rank {r} to finish",
+                                  nonce=nonce)
+            if "failed" in other:
+                raise SystemExit(f"rank {r} stopped: {other['failed']}")
             write_data.append({k: other[k] for k in ("rank", "ant_pairs", "write_times")})
             os.remove(results / f".timings-{r}.json")
         if world > 1:

@@ -282,7 +282,8 @@ def test_driver_two_ranks_dry_run(tmp_path):
               "--outputs", "ps", "--write_Niter", "2"]
     rcs, outs = _spawn_ranks(2, common + ["--Niter", "4", "--dirname", "run"])
     assert rcs == [0, 0], outs
-    res = tmp_path / "run"
+    res = tmp_path / "dryrun-run"                                    # a dry run never shares a tree with real results
+    assert not (tmp_path / "run").exists()
     for k in range(1, 6):                                            # 5 baselines: rank 0 owns 3, rank 1 owns 2
         assert np.load(res / f"0-{k}" / "dps-eor.npy").shape == (4, 32)
     tm = json.load(open(res / "timings.json"))
@@ -305,6 +306,6 @@ def test_driver_two_ranks_dry_run(tmp_path):
     # a second plain run moves the first tree aside (rank 0, before rank 1 proceeds) and writes a fresh one
     rcs, outs = _spawn_ranks(2, common + ["--Niter", "2", "--dirname", "run"])
     assert rcs == [0, 0], outs
-    moved = [p for p in tmp_path.iterdir() if p.name.startswith("run-")]
+    moved = [p for p in tmp_path.iterdir() if p.name.startswith("dryrun-run-")]
     assert len(moved) == 1 and np.load(moved[0] / "0-5" / "dps-eor.npy").shape == (6, 32)
     assert np.load(res / "0-5" / "dps-eor.npy").shape == (2, 32) and np.load(res / "0-1" / "dps-eor.npy").shape == (2, 32)

@@ -603,47 +603,3 @@ def test_dense_noise_with_flags_general_S_and_map_estimate(golden):
     assert res[0].shape[0] == 1 and np.max(np.abs(res[2] / ref[2] - 1)) < RTOL and relerr(res[0], ref[0]) < RTOL
 
 
-def test_parts_on_streams_reproduce_the_single_plan_chain():
-    """hpx_gibbs_run_parts (GibbsParts): the batch cut into baseline ranges, one plan and one stream each, iterations
-    enqueued in turn -- the same chains as one plan, bit for bit, for uneven cuts, flags, kept histories and a
-    continued run; and through the batched entry point."""
-    from hydra_pspec_amd import pspec, synthetic
-    nbl, T, N, M = 7, 8, 64, 5
-    d = synthetic.make_baselines(N, T, M, k0=3, nbl=nbl, flag_frac=0.1, dense=False)
-    ps0 = np.broadcast_to(d["ps0"], (nbl, N)).copy()
-    keep = ("signal_cr", "fg_amps", "chisq")
-    one = pspec.GibbsBatch(d["vis"], d["flags"], d["fgmodes"], d["ninv_diag"], d["ps_prior"], 6, seed=11, solver="dense")
-    a1 = one.run(4, ps0=ps0, keep=keep, thin=2)
-    a2 = one.run(2, keep=keep)
-    par = pspec.GibbsParts(d["vis"], d["flags"], d["fgmodes"], d["ninv_diag"], d["ps_prior"], 6, parts=3, seed=11,
-                           solver="dense")
-    assert [hi - lo for lo, hi in zip(par.cuts[:-1], par.cuts[1:])] == [2, 3, 2]
-    b1 = par.run(4, ps0=ps0, keep=keep, thin=2)
-    b2 = par.run(2, keep=keep)
-    for x, y in ((a1, b1), (a2, b2)):
-        for k in ("signal_ps", "ln_post", "ps_last") + keep:
-            assert np.array_equal(x[k].cpu().numpy(), y[k].cpu().numpy()), k
-    assert par.iter_done == 6
-    one.close()
-    par.close()
-    # the batched entry point, structured solver (flat noise, no flags), per-baseline fgmodes and priors
-    d2 = synthetic.make_baselines(N, T, M, k0=1, nbl=5, flag_frac=0.0, dense=False)
-    fg = np.broadcast_to(d2["fgmodes"], (5, N, M)).copy()
-    pri = np.broadcast_to(d2["ps_prior"], (5, 2, N)).copy()
-    ninv = np.full((5, N), d2["ninv_diag"][0, 0])
-    kw = dict(ps_initial=d2["ps0"], Niter=4, seed=2, keep=("signal_cr",))
-    s1 = pspec.gibbs_sample_with_fg_batched(d2["vis"], d2["flags"], fg, ninv, pri, **kw)
-    s4 = pspec.gibbs_sample_with_fg_batched(d2["vis"], d2["flags"], fg, ninv, pri, parts=4, **kw)
-    for k in s1:
-        assert np.array_equal(s1[k], s4[k]), k
-    with pytest.raises(NotImplementedError):
-        pspec.GibbsParts(d["vis"], d["flags"], d["fgmodes"], d["ninv_diag"], d["ps_prior"], 2, parts=2,
-                         seed=1).run(1, shp0=np.zeros((nbl, N, N), complex))
-    # a part whose system is not positive definite is reported with its part number; the other parts still finish
-    bad = d["ninv_diag"].copy()
-    bad[5] = np.nan                                         # baseline 5 = the first of part 2 (baselines 5, 6)
-    gp = pspec.GibbsParts(d["vis"], d["flags"], d["fgmodes"], bad, d["ps_prior"], 2, parts=3, seed=1, solver="dense")
-    with pytest.raises(FloatingPointError, match=r"part 2: non-positive pivot: baseline 0"):
-        gp.run(2, ps0=ps0)
-    gp.close()
-
