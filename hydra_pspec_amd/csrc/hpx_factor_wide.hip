@@ -77,6 +77,19 @@ __device__ HPX_INL double rsqrt_nr(const double d) {
   return q;
 }
 #define HPX_NTLD(p_) __builtin_nontemporal_load(p_)
+// Workgroup barrier for data handed over through LDS only: the wave's LDS operations are complete, its global
+// stores need not be (__syncthreads() also drains vmcnt, i.e. waits ~1-2 us for every store issued just before).
+// The lane / thread index through an empty asm: what is derived from it afterwards (LDS addresses, masks)
+// cannot be hoisted out of the phase it is used in.  Otherwise dozens of such per-thread invariants are
+// computed once at kernel entry, live across the register-bound S and P loops, are spilled there and reloaded
+// inside F -- each reload behind an s_waitcnt vmcnt(0) that drains the stores of the step before (~2 us a time).
+__device__ HPX_INL int opaque(int v) {
+  asm volatile("" : "+v"(v));
+  return v;
+}
+__device__ HPX_INL void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
 
 struct WideCtx {
   double* Lb;          // this baseline's factor
@@ -200,17 +213,20 @@ __device__ HPX_INL bool elim16(const WideCtx& X, const int tcol /* global tile c
   lds_cplx* const Dm = (lds_cplx*)(X.lds + FD_OFF);
   lds_cplx* const Ym = Dm + 16 * 17;
   lds_f64* const dg = (lds_f64*)(Ym + 16 * 17);
-  const int tid = X.tid, q = tid & 15, ib = tid >> 4;
+  const int tid = opaque(X.tid), q = tid & 15, ib = tid >> 4;
   const bool dia = (q == ib), low = (q < ib);
   double dr = Ein[ib * 16 + q], di = Ein[256 + ib * 16 + q];
   if (!low) Dm[ib * 17 + q] = (cplx){0.0, 0.0};               // diagonal and above stay zero in LDS
   double yr = dia ? 1.0 : 0.0, yi = 0.0;
   __builtin_amdgcn_s_setprio(2);
+#ifdef HPX_DBG_F_NOELIM
+  if (dia) dg[ib] = dr;
+#else
 #pragma unroll
   for (int k = 0; k < 16; ++k) {
     if (dia) dg[ib] = dr; else if (low) Dm[ib * 17 + q] = (cplx){dr, di};
     Ym[ib * 17 + q] = (cplx){yr, yi};
-    __syncthreads();
+    lds_barrier();
     const double dkk = dg[k];
     const cplx c = Dm[ib * 17 + k], cq = Dm[q * 17 + k], sy = Ym[k * 17 + q];
     const double r0 = __builtin_amdgcn_rcp(dkk);
@@ -225,7 +241,8 @@ __device__ HPX_INL bool elim16(const WideCtx& X, const int tcol /* global tile c
     di = fma(-lm, cq.x, di);
     di = fma(lr, cq.y, di);
   }
-  __syncthreads();
+#endif
+  lds_barrier();
   __builtin_amdgcn_s_setprio(0);
   bool bad = false;
   double wr = 0.0, wi = 0.0;
@@ -259,7 +276,7 @@ __device__ HPX_INL bool elim16(const WideCtx& X, const int tcol /* global tile c
       wgr[(16 + ib) * 32 + 16 + q] = 0.0; wgi[(16 + ib) * 32 + 16 + q] = 0.0;
     }
   }
-  __syncthreads();
+  lds_barrier();
   return bad;
 }
 
@@ -277,7 +294,7 @@ __device__ HPX_INL void diag_update(const WideCtx& X, const hpx_gen& G, const in
   typedef WCfg<KC> C;
   typedef DiagDeal<W> TD;
   constexpr int RA = 7 - W, RB = W;                 // the wave's two tile rows
-  const int lane = X.lane, li = lane & 15, g = lane >> 4;
+  const int lane = opaque(X.lane), li = lane & 15, g = lane >> 4;
   const unsigned src_lane = g * 32 + 2 * ((li + 8 * (g & 1)) & 15);
   const int rd_re = g * 32 + li + 16 * (g & 1), rd_im = g * 32 + li + 16 * (1 - (g & 1));
   const int c0 = ct0 * 16;
@@ -345,8 +362,6 @@ __device__ HPX_INL void diag_update(const WideCtx& X, const hpx_gen& G, const in
 
 // ---- F: D = L_JJ L_JJ^H on the (re, im) tiles; D^T[c][r] per tile: register v <-> column g + 4 v, lane li <-> row
 __device__ HPX_INL bool diag_factor(const WideCtx& X, const int ct0, d4 (&a1)[9], d4 (&a2)[9]) {
-  const int lane = X.lane, li = lane & 15, g = lane >> 4;
-  const int rd_re = g * 32 + li + 16 * (g & 1), rd_im = g * 32 + li + 16 * (1 - (g & 1));
   int tr[9], tc[9];
 #pragma unroll
   for (int s = 0; s < 9; ++s) {
@@ -358,8 +373,10 @@ __device__ HPX_INL bool diag_factor(const WideCtx& X, const int ct0, d4 (&a1)[9]
   lds_f64* const Vs = (lds_f64*)(X.lds + FV_OFF);
   bool bad = false;
   d4 t_re = {0., 0., 0., 0.}, t_im = {0., 0., 0., 0.};     // L10 inv(L00) of the current pair of tiles (one wave)
-  __syncthreads();                                          // the staging area is free
+  lds_barrier();                                          // the staging area is free
   for (int i = 0; i < 8; ++i) {
+    const int lane = opaque(X.lane), li = lane & 15, g = lane >> 4;
+    const int rd_re = g * 32 + li + 16 * (g & 1), rd_im = g * 32 + li + 16 * (1 - (g & 1));
     // (1) the diagonal tile goes to the elimination
 #pragma unroll
     for (int s = 0; s < 9; ++s)
@@ -370,10 +387,11 @@ __device__ HPX_INL bool diag_factor(const WideCtx& X, const int ct0, d4 (&a1)[9]
           Xs[256 + li * 16 + HPX_ACC_ROW(g, v)] = a2[s][v];
         }
       }
-    __syncthreads();
+    lds_barrier();
     // (2) L_ii and its inverse
     bad |= elim16(X, ct0 + i, false);
     // (2b) odd tile of a pair: W10 = -inv(L11) (L10 inv(L00))
+#ifndef HPX_DBG_F_NOW
     if ((i & 1) && X.wave == ((i >> 1) & 3)) {
       d4 zr = {0., 0., 0., 0.}, zi = {0., 0., 0., 0.};
 #pragma unroll
@@ -392,7 +410,9 @@ __device__ HPX_INL bool diag_factor(const WideCtx& X, const int ct0, d4 (&a1)[9]
         wgi[(16 + HPX_ACC_ROW(g, v)) * 32 + li] = zi[v];
       }
     }
+#endif
     // (3) tiles below: X^T[c'][r'] = sum_c conj(inv(L)[c'][c]) D^T[c][r'], stored and handed to the others
+#ifndef HPX_DBG_F_NOX
 #pragma unroll
     for (int s = 0; s < 9; ++s)
       if (tc[s] == i && tr[s] > i) {
@@ -416,8 +436,10 @@ __device__ HPX_INL bool diag_factor(const WideCtx& X, const int ct0, d4 (&a1)[9]
           xs[k * 32 + li + 16 * (1 - (k & 1))] = xi[v];
         }
       }
-    __syncthreads();
+#endif
+    lds_barrier();
     // (3b) even tile of a pair: T = L10 inv(L00), kept in registers until the pair's second inverse exists
+#ifndef HPX_DBG_F_NOW
     if (!(i & 1) && X.wave == ((i >> 1) & 3)) {
       t_re = (d4){0., 0., 0., 0.};
       t_im = t_re;
@@ -433,7 +455,9 @@ __device__ HPX_INL bool diag_factor(const WideCtx& X, const int ct0, d4 (&a1)[9]
         t_im = mfma64(ai, br, t_im);
       }
     }
+#endif
     // (4) trailing tiles: D^T[c'][r'] -= sum_k conj(X(c,i)[c'][k]) X(r,i)[r'][k]
+#ifndef HPX_DBG_F_NOUPD
 #pragma unroll
     for (int s = 0; s < 9; ++s)
       if (tc[s] > i) {
@@ -449,27 +473,54 @@ __device__ HPX_INL bool diag_factor(const WideCtx& X, const int ct0, d4 (&a1)[9]
           a2[s] = mfma64(pi, br, a2[s]);
         }
       }
+#endif
   }
   __syncthreads();        // F's stores (L_JJ, Vt) are complete before the passes stage them
   return bad;
 }
 
 // ---- P: the row strips below the full super-block at ct0, four at a time ----------------------------
+// The chunks of all groups form ONE stream through the ring of staging buffers: every step waits for its own
+// chunk, passes the barrier, issues the chunk DIST steps ahead (of the next group when this one is nearly done)
+// and computes; nothing is drained between the groups.  Counted waits: every wave issues 2 PP LDS-DMA operations
+// per stage, and an active wave 2 PP loads (row operand of the next chunk) or stores (its solved columns) per
+// step, so with the vmcnt counter in issue order "all but the NA (NI) youngest" covers the chunk being waited for.
 template <int KC, bool GEN>
 __device__ HPX_INL void strip_passes(const WideCtx& X, const hpx_gen& G, const int ct0) {
   typedef WCfg<KC> C;
   constexpr int PP = C::PP, H = C::H, DIST = C::DIST;
   constexpr int NA = DIST * 2 * PP + (DIST - 1) * 2 * PP;     // active wave: its own loads / stores + younger stages
   constexpr int NI = (DIST - 1) * 2 * PP;                     // idle wave: younger stages only
-  const int lane = X.lane, li = lane & 15, g = lane >> 4;
+  const int lane = opaque(X.lane), li = lane & 15, g = lane >> 4;
   const unsigned src_lane = g * 32 + 2 * ((li + 8 * (g & 1)) & 15);
   const int rd_re = g * 32 + li + 16 * (g & 1), rd_im = g * 32 + li + 16 * (1 - (g & 1));
+  const unsigned blane = g * 32 + li;
   const int c0 = ct0 * 16;
   const int first = ct0 + 8;
+  if (first >= X.nrt) return;
   const int nk = c0 / KC, nt = 8 * H, total = nk + nt;
+  double rb[PP], rm[PP];
+  // ---- prologue of the pass: the first DIST stages, the first group's first row operand
+#pragma unroll
+  for (int d = 0; d < DIST; ++d) {
+    const int st = min(d, total - 1);
+    if (st < nk) stage_k<KC>(X, ct0, st, d, src_lane);
+    else stage_t<KC>(X, ct0, st - nk, d, src_lane);
+  }
+  if (first + X.wave < X.nrt && nk > 0) {
+    const double* b0 = X.Lb + (long)(first + X.wave) * X.ptile;
+#pragma unroll
+    for (int p = 0; p < PP; ++p) {
+      rb[p] = HPX_NTLD(b0 + p * 128 + blane);
+      rm[p] = HPX_NTLD(b0 + p * 128 + 16 + blane);
+    }
+  }
+  int bi = 0, q = 0;                     // ring position, steps since the pass began
   for (int rt0 = first; rt0 < X.nrt; rt0 += 4) {
     const int rt = rt0 + X.wave;
     const bool active = rt < X.nrt;
+    const bool last_group = rt0 + 4 >= X.nrt;
+    const bool next_active = rt + 4 < X.nrt;
     d4 a1[8], a2[8], a3[8];
     if (active) {
 #pragma unroll
@@ -481,38 +532,25 @@ __device__ HPX_INL void strip_passes(const WideCtx& X, const hpx_gen& G, const i
         a3[ci] = vi;
       }
     }
-    // row operand: columns 4 p + g of chunk `ch`, this strip
     const double* brow = X.Lb + (long)(active ? rt : first) * X.ptile;      // (uniform) + lane offset `blane`
-    const unsigned blane = g * 32 + li;
-    double rb[PP], rm[PP];
-    // ---- prologue: the first DIST stages, the first chunk's row operand
-#pragma unroll
-    for (int d = 0; d < DIST; ++d) {
-      const int st = min(d, total - 1);
-      if (st < nk) stage_k<KC>(X, ct0, st, d, src_lane);
-      else stage_t<KC>(X, ct0, st - nk, d, src_lane);
-    }
-    if (active && nk > 0) {
-#pragma unroll
-      for (int p = 0; p < PP; ++p) {
-        rb[p] = HPX_NTLD(brow + p * 128 + blane);
-        rm[p] = HPX_NTLD(brow + p * 128 + 16 + blane);
-      }
-    }
-    int bi = 0;
+    // step `st_` of this group: wait for its chunk, barrier, issue the chunk DIST steps ahead
+#define HPX_STEP_HEAD(st_)                                                                           \
+    if (q < DIST) wait_vm<0>();                                                                      \
+    else if (active) wait_vm<NA>();                                                                  \
+    else wait_vm<NI>();                                                                              \
+    __builtin_amdgcn_s_barrier();                                                                    \
+    {                                                                                                \
+      int bn_ = bi + DIST;                                                                           \
+      if (bn_ >= C::NBUF) bn_ -= C::NBUF;                                                            \
+      int sn_ = (st_) + DIST;                                                                        \
+      if (sn_ >= total) sn_ = last_group ? total - 1 : sn_ - total;      /* next group's / a harmless re-stage */ \
+      if (sn_ < nk) stage_k<KC>(X, ct0, sn_, bn_, src_lane);                                         \
+      else stage_t<KC>(X, ct0, sn_ - nk, bn_, src_lane);                                             \
+    }                                                                                                \
+    ++q;
     // ---- k-loop
     for (int st = 0; st < nk; ++st) {
-      if (st < DIST) wait_vm<0>();
-      else if (active) wait_vm<NA>();
-      else wait_vm<NI>();
-      __builtin_amdgcn_s_barrier();
-      {
-        int bn = bi + DIST;
-        if (bn >= C::NBUF) bn -= C::NBUF;
-        const int sn = min(st + DIST, total - 1);
-        if (sn < nk) stage_k<KC>(X, ct0, sn, bn, src_lane);
-        else stage_t<KC>(X, ct0, sn - nk, bn, src_lane);
-      }
+      HPX_STEP_HEAD(st)
       if (active) {
         const lds_f64* B = (const lds_f64*)(X.lds + bi * C::BUF_D);
         const double* bnext = brow + (long)min(st + 1, nk - 1) * C::TILE_D;     // last chunk: a harmless re-read
@@ -542,17 +580,7 @@ __device__ HPX_INL void strip_passes(const WideCtx& X, const hpx_gen& G, const i
     // ---- tail: the triangular solve as further chunks of the same stream
 #define HPX_TAIL_STEP(CJ_, HH_)                                                                      \
   {                                                                                                  \
-    const int st_ = nk + (CJ_) * H + (HH_);                                                          \
-    if (st_ < DIST) wait_vm<0>();                                                                    \
-    else if (active) wait_vm<NA>();                                                                  \
-    else wait_vm<NI>();                                                                              \
-    __builtin_amdgcn_s_barrier();                                                                    \
-    {                                                                                                \
-      int bn_ = bi + DIST;                                                                           \
-      if (bn_ >= C::NBUF) bn_ -= C::NBUF;                                                            \
-      const int sn_ = min(st_ + DIST, total - 1);                                                    \
-      stage_t<KC>(X, ct0, sn_ - nk, bn_, src_lane);                                                  \
-    }                                                                                                \
+    HPX_STEP_HEAD(nk + (CJ_) * H + (HH_))                                                            \
     if (active) {                                                                                    \
       const lds_f64* B = (const lds_f64*)(X.lds + bi * C::BUF_D);                                    \
       if ((HH_) == 0) {                                                                              \
@@ -562,18 +590,27 @@ __device__ HPX_INL void strip_passes(const WideCtx& X, const hpx_gen& G, const i
         x1 = (d4){0., 0., 0., 0.}; x2 = x1; x3 = x1;                                                 \
       }                                                                                              \
       {                                                                                              \
-        double pr[PP], pi[PP];                                                                       \
+        double pr = B[(CJ_) * C::TILE_D + rd_re], pi = B[(CJ_) * C::TILE_D + rd_im];                 \
         _Pragma("unroll") for (int p = 0; p < PP; ++p) {                                             \
-          pr[p] = B[(CJ_) * C::TILE_D + p * 128 + rd_re];                                            \
-          pi[p] = B[(CJ_) * C::TILE_D + p * 128 + rd_im];                                            \
+          const double cr = pr, cm = pi, psm = pr + pi;                                              \
+          if (p + 1 < PP) {                                                                          \
+            pr = B[(CJ_) * C::TILE_D + (p + 1) * 128 + rd_re];                                       \
+            pi = B[(CJ_) * C::TILE_D + (p + 1) * 128 + rd_im];                                       \
+          }                                                                                          \
+          __builtin_amdgcn_sched_barrier(0);                                                         \
+          x1 = mfma64(cr, a1[CJ_][(HH_) * PP + p], x1);                                              \
+          x2 = mfma64(cm, a2[CJ_][(HH_) * PP + p], x2);                                              \
+          x3 = mfma64(psm, a3[CJ_][(HH_) * PP + p], x3);                                             \
+          __builtin_amdgcn_sched_barrier(0);                                                         \
         }                                                                                            \
-        __builtin_amdgcn_sched_barrier(0);                                                           \
+      }                                                                                              \
+      if ((CJ_) == 7 && (HH_) == H - 1 && next_active && nk > 0) {                                   \
+        /* the next group's first row operand, in front of this step's stores (the youngest 2 PP) */ \
+        const double* bn0_ = X.Lb + (long)(rt + 4) * X.ptile;                                        \
         _Pragma("unroll") for (int p = 0; p < PP; ++p) {                                             \
-          x1 = mfma64(pr[p], a1[CJ_][(HH_) * PP + p], x1);                                           \
-          x2 = mfma64(pi[p], a2[CJ_][(HH_) * PP + p], x2);                                           \
-          x3 = mfma64(pr[p] + pi[p], a3[CJ_][(HH_) * PP + p], x3);                                   \
+          rb[p] = HPX_NTLD(bn0_ + p * 128 + blane);                                                  \
+          rm[p] = HPX_NTLD(bn0_ + p * 128 + 16 + blane);                                             \
         }                                                                                            \
-        __builtin_amdgcn_sched_barrier(0);                                                           \
       }                                                                                              \
       double* o_ = X.Lb + HPX_LIDX(rt * 16 + li, (ct0 + (CJ_)) * 16 + g, X.npad);                    \
       _Pragma("unroll") for (int p = 0; p < PP; ++p) {                                               \
@@ -584,20 +621,26 @@ __device__ HPX_INL void strip_passes(const WideCtx& X, const hpx_gen& G, const i
         a1[CJ_][v] = xr; a2[CJ_][v] = xi; a3[CJ_][v] = xr - xi;                                      \
       }                                                                                              \
       __builtin_amdgcn_sched_barrier(0);                                                             \
-      _Pragma("unroll") for (int ci = (CJ_) + 1; ci < 8; ++ci) {                                     \
-        double pr[PP], pi[PP];                                                                       \
-        _Pragma("unroll") for (int p = 0; p < PP; ++p) {                                             \
-          pr[p] = B[ci * C::TILE_D + p * 128 + rd_re];                                               \
-          pi[p] = B[ci * C::TILE_D + p * 128 + rd_im];                                               \
+      if ((CJ_) < 7) {                                                                               \
+        double pr = B[((CJ_) + 1) * C::TILE_D + rd_re], pi = B[((CJ_) + 1) * C::TILE_D + rd_im];     \
+        _Pragma("unroll") for (int ci = (CJ_) + 1; ci < 8; ++ci) {                                   \
+          _Pragma("unroll") for (int p = 0; p < PP; ++p) {                                           \
+            const int v = (HH_) * PP + p;                                                            \
+            const double cr = pr, cm = pi, psm = pr + pi;                                            \
+            if (p + 1 < PP) {                                                                        \
+              pr = B[ci * C::TILE_D + (p + 1) * 128 + rd_re];                                        \
+              pi = B[ci * C::TILE_D + (p + 1) * 128 + rd_im];                                        \
+            } else if (ci + 1 < 8) {                                                                 \
+              pr = B[(ci + 1) * C::TILE_D + rd_re];                                                  \
+              pi = B[(ci + 1) * C::TILE_D + rd_im];                                                  \
+            }                                                                                        \
+            __builtin_amdgcn_sched_barrier(0);                                                       \
+            a1[ci] = mfma64(cr, a1[CJ_][v], a1[ci]);                                                 \
+            a2[ci] = mfma64(cm, a2[CJ_][v], a2[ci]);                                                 \
+            a3[ci] = mfma64(psm, a3[CJ_][v], a3[ci]);                                                \
+            __builtin_amdgcn_sched_barrier(0);                                                       \
+          }                                                                                          \
         }                                                                                            \
-        __builtin_amdgcn_sched_barrier(0);                                                           \
-        _Pragma("unroll") for (int p = 0; p < PP; ++p) {                                             \
-          const int v = (HH_) * PP + p;                                                              \
-          a1[ci] = mfma64(pr[p], a1[CJ_][v], a1[ci]);                                                \
-          a2[ci] = mfma64(pi[p], a2[CJ_][v], a2[ci]);                                                \
-          a3[ci] = mfma64(pr[p] + pi[p], a3[CJ_][v], a3[ci]);                                        \
-        }                                                                                            \
-        __builtin_amdgcn_sched_barrier(0);                                                           \
       }                                                                                              \
     }                                                                                                \
     bi = (bi + 1 == C::NBUF) ? 0 : bi + 1;                                                           \
@@ -618,10 +661,11 @@ __device__ HPX_INL void strip_passes(const WideCtx& X, const hpx_gen& G, const i
     HPX_TAIL_TILE(7)
 #undef HPX_TAIL_TILE
 #undef HPX_TAIL_STEP
-    // the group's stores and re-staged chunks are done, every wave has finished reading the buffers
-    wait_vm<0>();
-    __builtin_amdgcn_s_barrier();
+#undef HPX_STEP_HEAD
   }
+  // the pass's stores and re-staged chunks are done, every wave has finished reading the buffers
+  wait_vm<0>();
+  __builtin_amdgcn_s_barrier();
 }
 
 // ---- a single 16-wide tile column t (those after the last full super-block): register-only ----------
@@ -629,7 +673,7 @@ __device__ HPX_INL void strip_passes(const WideCtx& X, const hpx_gen& G, const i
 //   tiles below: one per wave at a time, both operands straight from global memory (double buffered).
 template <bool GEN>
 __device__ HPX_INL bool narrow_column(const WideCtx& X, const hpx_gen& G, const int t) {
-  const int lane = X.lane, li = lane & 15, g = lane >> 4;
+  const int lane = opaque(X.lane), li = lane & 15, g = lane >> 4;
   const int rd_re = g * 32 + li + 16 * (g & 1), rd_im = g * 32 + li + 16 * (1 - (g & 1));
   lds_f64* const Xs = (lds_f64*)(X.lds + FX_OFF);
   lds_f64* const Vs = (lds_f64*)(X.lds + FV_OFF);
@@ -660,9 +704,9 @@ __device__ HPX_INL bool narrow_column(const WideCtx& X, const hpx_gen& G, const 
       part[256 + li * 16 + HPX_ACC_ROW(g, v)] = q1[v] - q2[v] - q3[v];
     }
   }
-  __syncthreads();
+  lds_barrier();
   {
-    const int q = X.tid & 15, ib = X.tid >> 4;
+    const int tid = opaque(X.tid), q = tid & 15, ib = tid >> 4;
     double kr = 0.0, ki = 0.0;
     if (q <= ib) entry_init<GEN>(G, X.Lb, c0 + ib, c0 + q, X.npad, kr, ki);
 #pragma unroll
