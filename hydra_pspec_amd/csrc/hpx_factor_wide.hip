@@ -26,6 +26,14 @@
 // Storage: the factor's 16-row panel-major layout (HPX_LIDX); Vt[b][tile][16 cols][re16|im16] holds the
 // inverses of the diagonal 16 x 16 tiles in the same tile layout (the tail chunks' first operand);
 // W[b][block][32][32] the inverses of the diagonal 32 x 32 blocks for k_backsolve, as before.
+//
+// Staging: chunks of 16 columns x 8 tiles (32 KB) alternate between TWO SEPARATE LDS arrays, and the
+// buffer a step reads / fills is a compile-time constant (every loop is unrolled by two; a super-block's chunk
+// counts are even).  This matters: the compiler makes a ds_read wait for every pending LDS-DMA whose target it
+// cannot prove distinct from the read's -- with one array and a run-time buffer index that is an
+// s_waitcnt vmcnt(0) after every stage, i.e. no chunk in flight behind the computation at all.  For the same
+// reason the counted waits are the s_waitcnt builtin (visible to that analysis), fenced against compiler
+// motion by empty asm statements.
 #include "hpx_internal.h"
 
 #define HPX_INL __forceinline__
@@ -36,39 +44,86 @@ typedef __attribute__((address_space(3))) double lds_f64;
 typedef double cplx __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) cplx lds_cplx;
 
-template <int KC>
-struct WCfg {
-  static constexpr int PP = KC / 4;            // 1 KB pieces (4 columns) per tile and chunk
-  static constexpr int TILE_D = KC * 32;       // doubles of one tile's chunk
-  static constexpr int BUF_D = 8 * TILE_D;     // eight tiles per buffer
-  static constexpr int NBUF = (KC == 16) ? 2 : 3;
-  static constexpr int DIST = NBUF - 1;        // chunks in flight ahead of the one being consumed
-  static constexpr int H = 16 / KC;            // chunks per 16-column tile (tail steps per column tile)
-  static constexpr int STAGE_D = NBUF * BUF_D; // doubles of the staging area (also F's scratch)
-  static_assert(KC == 8 || KC == 16, "chunks of 8 or 16 columns");
-};
-// F's scratch inside the staging area (doubles): Xs[8 tiles][512] (slot 0: the diagonal tile handed to the
-// elimination), one inverse tile, the elimination's matrices
-constexpr int FX_OFF = 0, FV_OFF = 8 * 512, FD_OFF = FV_OFF + 512, F_END = FD_OFF + 2 * 2 * 16 * 17 + 16;
-static_assert(F_END <= WCfg<8>::STAGE_D && F_END <= WCfg<16>::STAGE_D, "F scratch must fit the staging area");
+constexpr int KC = 16;             // columns per chunk
+constexpr int PP = KC / 4;         // 1 KB pieces (4 columns) per tile and chunk = k-steps per chunk
+constexpr int TILE_D = KC * 32;    // doubles of one tile's chunk
+constexpr int BUF_D = 8 * TILE_D;  // eight tiles per buffer
 
-// 16 bytes per lane from (uniform base) + (32-bit lane offset) to dst + 16 lane.  The base goes through
-// readfirstlane so that the address stays "scalar + zero-extended vector offset" and the scalar-base form
-// of the instruction is selected: one offset register for every piece instead of a 64-bit address each
-// (which, eight per stage and hoisted out of the loops, were spilled).
-__device__ HPX_INL const double* uniform_ptr(const double* p) {
-  const unsigned long a = (unsigned long)p;
-  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a);
-  const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
-  return (const double*)(((unsigned long)hi << 32) | lo);
+__shared__ double hpx_stage0[BUF_D];
+__shared__ double hpx_stage1[BUF_D];
+template <int PAR> __device__ HPX_INL double* stage_buf() { return PAR ? hpx_stage1 : hpx_stage0; }
+// F's scratch over the staging buffers: Xs[8 tiles][512] = buffer 0 (slot 0: the diagonal tile handed to the
+// elimination; the K-split partial sums of narrow_column in slots 1..4); in buffer 1 one inverse tile and the
+// elimination's matrices
+constexpr int FV_OFF = 0, FD_OFF = 512, F_END = FD_OFF + 2 * 2 * 16 * 17 + 16;
+static_assert(F_END <= BUF_D, "F scratch must fit a staging buffer");
+
+// ---- vector-memory traffic of the staged loops: ALL of it through inline asm, waits included ----------------
+// The compiler's own s_waitcnt insertion cannot be used here: once an LDS-DMA and an ordinary global load are
+// both in flight it waits with vmcnt(0) at the first use of the loaded register (measured: the next chunk's
+// DMA, just issued, then had to land before the step could compute), and it adds a vmcnt(0) in front of any
+// ds_read that might alias a pending DMA.  Operations issued from asm statements are invisible to it; the
+// counted waits below are placed by hand, on the facts that the counter retires in issue order and that every
+// wave issues the same number of operations per step.  Whatever else the compiler issues in between (the loads
+// of a strip's initial values, a spill) only makes a counted wait stricter, never wrong.
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+// one tile's chunk (16 columns = four 1 KB pieces) from (uniform base) + (lane offset, bytes) to the LDS byte
+// address `lds` + 16 lane: the instruction offset moves the global and the LDS address together
+__device__ HPX_INL void glds_tile(const double* ubase, const unsigned lane_bytes, const unsigned lds) {
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\t"
+               "global_load_lds_dwordx4 %0, %1\n\t"
+               "global_load_lds_dwordx4 %0, %1 offset:1024\n\t"
+               "global_load_lds_dwordx4 %0, %1 offset:2048\n\t"
+               "global_load_lds_dwordx4 %0, %1 offset:3072"
+               :: "v"(lane_bytes), "s"(ubase), "s"(lds) : "memory", "m0");
 }
-__device__ HPX_INL void glds16(const double* ubase, const unsigned lane_off, double* dst) {
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(uniform_ptr(ubase) + lane_off),
-                                   (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+#pragma clang diagnostic pop
+// non-temporal 8-byte load from (uniform base) + (lane offset, bytes) + OFF; the value may be used only behind a
+// wait_vm_keep that names it
+template <int OFF>
+__device__ HPX_INL double ld_nt(const double* ubase, const unsigned lane_bytes) {
+  double r;
+  asm volatile("global_load_dwordx2 %0, %1, %2 offset:%3 nt" : "=v"(r) : "v"(lane_bytes), "s"(ubase), "n"(OFF) : "memory");
+  return r;
 }
+template <int OFF>
+__device__ HPX_INL void st_g(double* ubase, const unsigned lane_bytes, const double v) {
+  asm volatile("global_store_dwordx2 %0, %1, %2 offset:%3" :: "v"(lane_bytes), "v"(v), "s"(ubase), "n"(OFF) : "memory");
+}
+#ifdef HPX_DBG_WAIT0
+#define HPX_WAITN(n_) 0
+#else
+#define HPX_WAITN(n_) (n_)
+#endif
 template <int N>
 __device__ HPX_INL void wait_vm() {
-  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+  asm volatile("s_waitcnt vmcnt(%0)" :: "n"(HPX_WAITN(N)) : "memory");
+}
+// The eight row-operand registers were written by ld_nt asm statements the compiler knows nothing about: it must
+// not touch them before the wait that covers their loads.  The wait itself has no operands (tied operands
+// let the register allocator put copies of the not-yet-loaded registers IN FRONT of it: observed, as
+// timing-dependent garbage); this anchor follows it, ties all eight, and everything that uses them depends on it.
+__device__ HPX_INL void anchor_rows(double (&rb)[4], double (&rm)[4]) {
+  asm volatile("" : "+v"(rb[0]), "+v"(rb[1]), "+v"(rb[2]), "+v"(rb[3]), "+v"(rm[0]), "+v"(rm[1]), "+v"(rm[2]),
+               "+v"(rm[3]));
+}
+__device__ HPX_INL void wg_barrier() {
+  asm volatile("s_barrier" ::: "memory");
+}
+// The compiler's own loads (a tile's initial values from the edge tiles or the factor buffer) are complete, and
+// the compiler knows it: otherwise it waits for them at their first use, a static s_waitcnt vmcnt(0) INSIDE the
+// step loops that drains the hand-placed traffic there on every trip.
+__device__ HPX_INL void wait_compiler_loads() {
+  __builtin_amdgcn_s_waitcnt(0x0f70);
+}
+__device__ HPX_INL unsigned lds_addr(const double* p) {
+  return (unsigned)(unsigned long)(const __attribute__((address_space(3))) double*)p;
+}
+// Workgroup barrier for data handed over through LDS only: the wave's LDS operations are complete, its global
+// stores need not be (__syncthreads() also drains vmcnt, i.e. waits ~1-2 us for every store issued just before).
+__device__ HPX_INL void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 __device__ HPX_INL double rsqrt_nr(const double d) {
   double q = __builtin_amdgcn_rsq(d);
@@ -77,8 +132,6 @@ __device__ HPX_INL double rsqrt_nr(const double d) {
   return q;
 }
 #define HPX_NTLD(p_) __builtin_nontemporal_load(p_)
-// Workgroup barrier for data handed over through LDS only: the wave's LDS operations are complete, its global
-// stores need not be (__syncthreads() also drains vmcnt, i.e. waits ~1-2 us for every store issued just before).
 // The lane / thread index through an empty asm: what is derived from it afterwards (LDS addresses, masks)
 // cannot be hoisted out of the phase it is used in.  Otherwise dozens of such per-thread invariants are
 // computed once at kernel entry, live across the register-bound S and P loops, are spilled there and reloaded
@@ -87,29 +140,33 @@ __device__ HPX_INL int opaque(int v) {
   asm volatile("" : "+v"(v));
   return v;
 }
-__device__ HPX_INL void lds_barrier() {
-  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-}
+
+// 1 / a and the circulant's first column with their address space in the type (LDS copies when GLDS): through
+// the generic pointers of hpx_gen they become FLAT loads, which count on vmcnt as well and make the compiler
+// wait for everything in flight at their first use
+typedef __attribute__((address_space(1))) double glb_f64;
+template <bool GLDS> struct GenVec;
+template <> struct GenVec<true> { const lds_f64 *ia, *cre, *cim; };
+template <> struct GenVec<false> { const glb_f64 *ia, *cre, *cim; };
 
 struct WideCtx {
   double* Lb;          // this baseline's factor
   double* Vt;          // this baseline's inverse diagonal tiles
   double* Wgre;        // this baseline's 32 x 32 inverse blocks
   double* Wgim;
-  double* lds;         // staging area
   long ptile;          // doubles per 16-row panel
   int npad, nct, nrt, wave, lane, tid;
 };
 
 // entry (r, c), r >= c, of the augmented matrix before the factorisation: closed form, edge tiles or
 // the factor buffer (hpx_internal.h)
-template <bool GEN>
-__device__ HPX_INL void entry_init(const hpx_gen& G, const double* __restrict__ Lb, const int r, const int c,
-                                   const int npad, double& vr, double& vi) {
+template <bool GEN, bool GLDS>
+__device__ HPX_INL void entry_init(const hpx_gen& G, const GenVec<GLDS>& V, const double* __restrict__ Lb, const int r,
+                                   const int c, const int npad, double& vr, double& vi) {
   if (GEN && c < G.rmin) {
     if (r < G.rmin) {
-      if (r > c) { vr = G.cre[r - c]; vi = G.cim[r - c]; }
-      else if (r == c) { const double ic = G.ia[c]; vr = fma(ic, ic, G.cre[0]); vi = 0.0; }
+      if (r > c) { vr = V.cre[r - c]; vi = V.cim[r - c]; }
+      else if (r == c) { const double ic = V.ia[c]; vr = fma(ic, ic, V.cre[0]); vi = 0.0; }
       else { vr = 0.0; vi = 0.0; }
     } else {
       hpx_edge_init<GEN>(G, Lb, Lb + 16, r, c, npad, G.ere != nullptr, vr, vi);
@@ -120,27 +177,51 @@ __device__ HPX_INL void entry_init(const hpx_gen& G, const double* __restrict__ 
     vi = Lb[off + 16];
   }
 }
+// the closed-form part of tile_init alone (signal x signal tile, r0 >= c0, both below rmin): no vector-memory
+// instruction on this path when the vectors are in LDS
+template <bool GLDS>
+__device__ HPX_INL void tile_init_closed(const GenVec<GLDS>& V, const int r0, const int c0, const int li, const int g,
+                                         d4& vr, d4& vi) {
+  if (r0 > c0) {
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const int d = r0 - c0 + li - HPX_ACC_ROW(g, v);
+      vr[v] = V.cre[d];
+      vi[v] = V.cim[d];
+    }
+  } else {
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const int d = li - HPX_ACC_ROW(g, v);
+      const int dd = d > 0 ? d : 0;
+      const double ic = V.ia[c0 + li];
+      const double cr = V.cre[dd], cm = V.cim[dd];
+      vr[v] = d > 0 ? cr : (d == 0 ? fma(ic, ic, cr) : 0.0);
+      vi[v] = d > 0 ? cm : 0.0;
+    }
+  }
+}
 // the 16 x 16 tile at (r0, c0), r0 >= c0, as acc^T: lane li <-> row r0 + li, register v <-> column c0 + g + 4 v.
 // rmin is a multiple of 32, so a tile lies on one side of it and the source is chosen per tile.
-template <bool GEN>
-__device__ HPX_INL void tile_init(const hpx_gen& G, const double* __restrict__ Lb, const int r0, const int c0,
-                                  const int npad, const int li, const int g, d4& vr, d4& vi) {
+template <bool GEN, bool GLDS>
+__device__ HPX_INL void tile_init(const hpx_gen& G, const GenVec<GLDS>& V, const double* __restrict__ Lb, const int r0,
+                                  const int c0, const int npad, const int li, const int g, d4& vr, d4& vi) {
   if (GEN && c0 < G.rmin) {
     if (r0 < G.rmin) {
       if (r0 > c0) {
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
           const int d = r0 - c0 + li - HPX_ACC_ROW(g, v);
-          vr[v] = G.cre[d];
-          vi[v] = G.cim[d];
+          vr[v] = V.cre[d];
+          vi[v] = V.cim[d];
         }
       } else {
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
           const int d = li - HPX_ACC_ROW(g, v);
           const int dd = d > 0 ? d : 0;
-          const double ic = G.ia[c0 + li];
-          const double cr = G.cre[dd], cm = G.cim[dd];
+          const double ic = V.ia[c0 + li];
+          const double cr = V.cre[dd], cm = V.cim[dd];
           vr[v] = d > 0 ? cr : (d == 0 ? fma(ic, ic, cr) : 0.0);
           vi[v] = d > 0 ? cm : 0.0;
         }
@@ -167,39 +248,38 @@ __device__ HPX_INL void tile_init(const hpx_gen& G, const double* __restrict__ L
 
 // ---- staging ---------------------------------------------------------------------------------------
 // Every wave stages two tile slots (2 wave, 2 wave + 1) of every chunk, PP pieces each: a constant
-// number of LDS-DMA operations per wave and stage, so that the counted vmcnt waits below hold for
-// every wave.
-template <int KC>
-__device__ HPX_INL void stage_k(const WideCtx& X, const int ct0, const int chunk, const int bi,
-                                const unsigned src_lane) {
-  typedef WCfg<KC> C;
-  double* bb = X.lds + bi * C::BUF_D;
+// number (2 PP = 8) of LDS-DMA operations per wave and stage, so that the counted vmcnt waits hold for every wave.
+// Lane's 16 bytes inside a 1 KB piece (4 columns x [re16 | im16]): odd columns are stored [im | re] so that the
+// two halves of a wave read disjoint banks (src_lane / rd_re / rd_im below).
+template <int PAR>
+__device__ HPX_INL void stage_k(const WideCtx& X, const int ct0, const int chunk, const unsigned src_lane) {
+  const unsigned bb = lds_addr(stage_buf<PAR>());
 #pragma unroll
   for (int u = 0; u < 2; ++u) {
     const int ci = 2 * X.wave + u;
-    // (uniform base) + (32-bit lane offset): the scalar-base form of the load, no 64-bit address registers
-    const double* src = X.Lb + (long)(ct0 + ci) * X.ptile + (long)chunk * C::TILE_D;
-#pragma unroll
-    for (int pp = 0; pp < C::PP; ++pp) glds16(src + pp * 128, src_lane, bb + ci * C::TILE_D + pp * 128);
+    glds_tile(X.Lb + (long)(ct0 + ci) * X.ptile + (long)chunk * TILE_D, 8 * src_lane, bb + ci * TILE_D * 8);
   }
 }
-// tail step t = cj * H + h: slot cj <- columns [KC h, KC h + KC) of inv(L_cjcj) (Vt), slots ci > cj <- the same
-// columns of L[ci][cj]; the slots above re-stage the inverse (never read)
-template <int KC>
-__device__ HPX_INL void stage_t(const WideCtx& X, const int ct0, const int t, const int bi,
-                                const unsigned src_lane) {
-  typedef WCfg<KC> C;
-  double* bb = X.lds + bi * C::BUF_D;
-  const int cj = t / C::H, h = t % C::H;
-  const double* vsrc = X.Vt + (long)(ct0 + cj) * 512 + h * C::TILE_D;
+// tail step cj: slot cj <- inv(L_cjcj) (Vt), slots ci > cj <- L[ci][cj]; the slots above re-stage the inverse
+// (never read)
+template <int PAR>
+__device__ HPX_INL void stage_t(const WideCtx& X, const int ct0, const int cj, const unsigned src_lane) {
+  const unsigned bb = lds_addr(stage_buf<PAR>());
+  const double* vsrc = X.Vt + (long)(ct0 + cj) * 512;
 #pragma unroll
   for (int u = 0; u < 2; ++u) {
     const int ci = 2 * X.wave + u;
     const double* src = vsrc;
-    if (ci > cj) src = X.Lb + (long)(ct0 + ci) * X.ptile + (long)((ct0 + cj) * 16 + h * KC) * 32;
-#pragma unroll
-    for (int pp = 0; pp < C::PP; ++pp) glds16(src + pp * 128, src_lane, bb + ci * C::TILE_D + pp * 128);
+    if (ci > cj) src = X.Lb + (long)(ct0 + ci) * X.ptile + (long)((ct0 + cj) * 16) * 32;
+    glds_tile(src, 8 * src_lane, bb + ci * TILE_D * 8);
   }
+}
+// step `st` of a pass (k-chunks 0 .. nk-1, then the eight tail steps) into buffer PAR
+template <int PAR>
+__device__ HPX_INL void stage_step(const WideCtx& X, const int ct0, const int st, const int nk,
+                                   const unsigned src_lane) {
+  if (st < nk) stage_k<PAR>(X, ct0, st, src_lane);
+  else stage_t<PAR>(X, ct0, st - nk, src_lane);
 }
 
 // ---- 16 x 16 fused Cholesky + inverse (all 256 threads; hpx_factor.hip diag_panel, steps A / D) -----
@@ -208,9 +288,9 @@ __device__ HPX_INL void stage_t(const WideCtx& X, const int ct0, const int t, co
 // out: L tile -> global; inv(L) tile -> Vt (global, tile layout, zero above the diagonal), LDS copy `Vs`
 //      (tile layout with the odd-column swizzle), and the 16 x 16 sub-block of the 32 x 32 inverse block.
 __device__ HPX_INL bool elim16(const WideCtx& X, const int tcol /* global tile column */, const bool last_tile) {
-  lds_f64* const Ein = (lds_f64*)(X.lds + FX_OFF);            // slot 0 of Xs: re 256 | im 256
-  lds_f64* const Vs = (lds_f64*)(X.lds + FV_OFF);
-  lds_cplx* const Dm = (lds_cplx*)(X.lds + FD_OFF);
+  lds_f64* const Ein = (lds_f64*)hpx_stage0;                  // slot 0 of Xs: re 256 | im 256
+  lds_f64* const Vs = (lds_f64*)(hpx_stage1 + FV_OFF);
+  lds_cplx* const Dm = (lds_cplx*)(hpx_stage1 + FD_OFF);
   lds_cplx* const Ym = Dm + 16 * 17;
   lds_f64* const dg = (lds_f64*)(Ym + 16 * 17);
   const int tid = opaque(X.tid), q = tid & 15, ib = tid >> 4;
@@ -219,9 +299,6 @@ __device__ HPX_INL bool elim16(const WideCtx& X, const int tcol /* global tile c
   if (!low) Dm[ib * 17 + q] = (cplx){0.0, 0.0};               // diagonal and above stay zero in LDS
   double yr = dia ? 1.0 : 0.0, yi = 0.0;
   __builtin_amdgcn_s_setprio(2);
-#ifdef HPX_DBG_F_NOELIM
-  if (dia) dg[ib] = dr;
-#else
 #pragma unroll
   for (int k = 0; k < 16; ++k) {
     if (dia) dg[ib] = dr; else if (low) Dm[ib * 17 + q] = (cplx){dr, di};
@@ -241,7 +318,6 @@ __device__ HPX_INL bool elim16(const WideCtx& X, const int tcol /* global tile c
     di = fma(-lm, cq.x, di);
     di = fma(lr, cq.y, di);
   }
-#endif
   lds_barrier();
   __builtin_amdgcn_s_setprio(0);
   bool bad = false;
@@ -289,9 +365,9 @@ template <int W> struct DiagDeal {
   static constexpr int row(const int s) { return s < 8 - W ? 7 - W : W; }
   static constexpr int col(const int s) { return s < 8 - W ? s : s - (8 - W); }
 };
-template <int KC, bool GEN, int W>
-__device__ HPX_INL void diag_update(const WideCtx& X, const hpx_gen& G, const int ct0, d4 (&a1)[9], d4 (&a2)[9]) {
-  typedef WCfg<KC> C;
+template <bool GEN, bool GLDS, int W>
+__device__ HPX_INL void diag_update(const WideCtx& X, const hpx_gen& G, const GenVec<GLDS>& V, const int ct0,
+                                    d4 (&a1)[9], d4 (&a2)[9]) {
   typedef DiagDeal<W> TD;
   constexpr int RA = 7 - W, RB = W;                 // the wave's two tile rows
   const int lane = opaque(X.lane), li = lane & 15, g = lane >> 4;
@@ -299,57 +375,68 @@ __device__ HPX_INL void diag_update(const WideCtx& X, const hpx_gen& G, const in
   const int rd_re = g * 32 + li + 16 * (g & 1), rd_im = g * 32 + li + 16 * (1 - (g & 1));
   const int c0 = ct0 * 16;
   d4 a3[9];
+  if (GEN && GLDS && c0 + 128 <= G.rmin) {       // closed form from LDS: no vector-memory instruction on this path
 #pragma unroll
-  for (int s = 0; s < 9; ++s) {
-    d4 vr, vi;
-    tile_init<GEN>(G, X.Lb, c0 + 16 * TD::row(s), c0 + 16 * TD::col(s), X.npad, li, g, vr, vi);
-    a1[s] = -0.5 * vr;
-    a2[s] = -0.5 * vr;
-    a3[s] = vi;
-  }
-  const int nk = c0 / KC;
-  if (nk > 0) {
-#pragma unroll
-    for (int d = 0; d < C::DIST; ++d) stage_k<KC>(X, ct0, min(d, nk - 1), d, src_lane);
-    int bi = 0;
-    for (int ch = 0; ch < nk; ++ch) {
-      // nothing but LDS-DMA is in flight here: all but the (DIST - 1) younger stages must have landed
-      wait_vm<(C::DIST - 1) * 2 * C::PP>();
-      __builtin_amdgcn_s_barrier();
-      {
-        int bn = bi + C::DIST;
-        if (bn >= C::NBUF) bn -= C::NBUF;
-        stage_k<KC>(X, ct0, min(ch + C::DIST, nk - 1), bn, src_lane);     // branch-free tail: a harmless re-stage
-      }
-      const lds_f64* B = (const lds_f64*)(X.lds + bi * C::BUF_D);
-#pragma unroll
-      for (int p = 0; p < C::PP; ++p) {
-        const double bra = B[RA * C::TILE_D + p * 128 + rd_re], bma = B[RA * C::TILE_D + p * 128 + rd_im];
-        const double brb = B[RB * C::TILE_D + p * 128 + rd_re], bmb = B[RB * C::TILE_D + p * 128 + rd_im];
-        const double bda = bra - bma, bdb = brb - bmb;
-        double pr = B[p * 128 + rd_re], pi = B[p * 128 + rd_im];
-#pragma unroll
-        for (int c = 0; c <= RA; ++c) {          // column tile c: slot c (row RA) and, for c <= RB, slot 8 - W + c (row RB)
-          const double cr = pr, cm = pi, psm = pr + pi;
-          if (c + 1 <= RA) {
-            pr = B[(c + 1) * C::TILE_D + p * 128 + rd_re];
-            pi = B[(c + 1) * C::TILE_D + p * 128 + rd_im];
-          }
-          __builtin_amdgcn_sched_barrier(0);
-          a1[c] = mfma64(cr, bra, a1[c]);
-          a2[c] = mfma64(cm, bma, a2[c]);
-          a3[c] = mfma64(psm, bda, a3[c]);
-          if (c <= RB) {
-            a1[8 - W + c] = mfma64(cr, brb, a1[8 - W + c]);
-            a2[8 - W + c] = mfma64(cm, bmb, a2[8 - W + c]);
-            a3[8 - W + c] = mfma64(psm, bdb, a3[8 - W + c]);
-          }
-          __builtin_amdgcn_sched_barrier(0);
-        }
-      }
-      bi = (bi + 1 == C::NBUF) ? 0 : bi + 1;
+    for (int s = 0; s < 9; ++s) {
+      d4 vr, vi;
+      tile_init_closed<GLDS>(V, c0 + 16 * TD::row(s), c0 + 16 * TD::col(s), li, g, vr, vi);
+      a1[s] = -0.5 * vr;
+      a2[s] = -0.5 * vr;
+      a3[s] = vi;
     }
-    wait_vm<0>();                       // the re-staged chunks: nothing may land after F starts using the area
+  } else {
+#pragma unroll
+    for (int s = 0; s < 9; ++s) {
+      d4 vr, vi;
+      tile_init<GEN, GLDS>(G, V, X.Lb, c0 + 16 * TD::row(s), c0 + 16 * TD::col(s), X.npad, li, g, vr, vi);
+      a1[s] = -0.5 * vr;
+      a2[s] = -0.5 * vr;
+      a3[s] = vi;
+    }
+    wait_compiler_loads();
+  }
+  const int nk = c0 / KC;                  // (a multiple of 8)
+  if (nk > 0) {
+    stage_k<0>(X, ct0, 0, src_lane);
+    // one chunk: wait for it (nothing but LDS-DMA is in flight), barrier, issue the next one into the other
+    // buffer (after the last chunk: a harmless re-stage of it), compute
+#define HPX_S_STEP(PAR_, ch_)                                                                        \
+    {                                                                                                \
+      wait_vm<0>();                                                                                  \
+      wg_barrier();                                                                                  \
+      stage_k<1 - (PAR_)>(X, ct0, min((ch_) + 1, nk - 1), src_lane);                                 \
+      const lds_f64* B = (const lds_f64*)stage_buf<PAR_>();                                          \
+      _Pragma("unroll") for (int p = 0; p < PP; ++p) {                                               \
+        const double bra = B[RA * TILE_D + p * 128 + rd_re], bma = B[RA * TILE_D + p * 128 + rd_im]; \
+        const double brb = B[RB * TILE_D + p * 128 + rd_re], bmb = B[RB * TILE_D + p * 128 + rd_im]; \
+        const double bda = bra - bma, bdb = brb - bmb;                                               \
+        double pr = B[p * 128 + rd_re], pi = B[p * 128 + rd_im];                                     \
+        _Pragma("unroll") for (int c = 0; c <= RA; ++c) {                                            \
+          /* column tile c: slot c (row RA) and, for c <= RB, slot 8 - W + c (row RB) */             \
+          const double cr = pr, cm = pi, psm = pr + pi;                                              \
+          if (c + 1 <= RA) {                                                                         \
+            pr = B[(c + 1) * TILE_D + p * 128 + rd_re];                                              \
+            pi = B[(c + 1) * TILE_D + p * 128 + rd_im];                                              \
+          }                                                                                          \
+          __builtin_amdgcn_sched_barrier(0);                                                         \
+          a1[c] = mfma64(cr, bra, a1[c]);                                                            \
+          a2[c] = mfma64(cm, bma, a2[c]);                                                            \
+          a3[c] = mfma64(psm, bda, a3[c]);                                                           \
+          if (c <= RB) {                                                                             \
+            a1[8 - W + c] = mfma64(cr, brb, a1[8 - W + c]);                                          \
+            a2[8 - W + c] = mfma64(cm, bmb, a2[8 - W + c]);                                          \
+            a3[8 - W + c] = mfma64(psm, bdb, a3[8 - W + c]);                                         \
+          }                                                                                          \
+          __builtin_amdgcn_sched_barrier(0);                                                         \
+        }                                                                                            \
+      }                                                                                              \
+    }
+    for (int ch = 0; ch < nk; ch += 2) {
+      HPX_S_STEP(0, ch)
+      HPX_S_STEP(1, ch + 1)
+    }
+#undef HPX_S_STEP
+    wait_vm<0>();                       // the re-staged chunk: nothing may land after F starts using the area
   }
 #pragma unroll
   for (int s = 0; s < 9; ++s) {
@@ -369,8 +456,8 @@ __device__ HPX_INL bool diag_factor(const WideCtx& X, const int ct0, d4 (&a1)[9]
     tr[s] = (s < 8 - X.wave) ? 7 - X.wave : X.wave;
     tc[s] = (s < 8 - X.wave) ? s : s - (8 - X.wave);
   }
-  lds_f64* const Xs = (lds_f64*)(X.lds + FX_OFF);
-  lds_f64* const Vs = (lds_f64*)(X.lds + FV_OFF);
+  lds_f64* const Xs = (lds_f64*)hpx_stage0;
+  lds_f64* const Vs = (lds_f64*)(hpx_stage1 + FV_OFF);
   bool bad = false;
   d4 t_re = {0., 0., 0., 0.}, t_im = {0., 0., 0., 0.};     // L10 inv(L00) of the current pair of tiles (one wave)
   lds_barrier();                                          // the staging area is free
@@ -391,7 +478,6 @@ __device__ HPX_INL bool diag_factor(const WideCtx& X, const int ct0, d4 (&a1)[9]
     // (2) L_ii and its inverse
     bad |= elim16(X, ct0 + i, false);
     // (2b) odd tile of a pair: W10 = -inv(L11) (L10 inv(L00))
-#ifndef HPX_DBG_F_NOW
     if ((i & 1) && X.wave == ((i >> 1) & 3)) {
       d4 zr = {0., 0., 0., 0.}, zi = {0., 0., 0., 0.};
 #pragma unroll
@@ -410,9 +496,7 @@ __device__ HPX_INL bool diag_factor(const WideCtx& X, const int ct0, d4 (&a1)[9]
         wgi[(16 + HPX_ACC_ROW(g, v)) * 32 + li] = zi[v];
       }
     }
-#endif
     // (3) tiles below: X^T[c'][r'] = sum_c conj(inv(L)[c'][c]) D^T[c][r'], stored and handed to the others
-#ifndef HPX_DBG_F_NOX
 #pragma unroll
     for (int s = 0; s < 9; ++s)
       if (tc[s] == i && tr[s] > i) {
@@ -436,10 +520,8 @@ __device__ HPX_INL bool diag_factor(const WideCtx& X, const int ct0, d4 (&a1)[9]
           xs[k * 32 + li + 16 * (1 - (k & 1))] = xi[v];
         }
       }
-#endif
     lds_barrier();
     // (3b) even tile of a pair: T = L10 inv(L00), kept in registers until the pair's second inverse exists
-#ifndef HPX_DBG_F_NOW
     if (!(i & 1) && X.wave == ((i >> 1) & 3)) {
       t_re = (d4){0., 0., 0., 0.};
       t_im = t_re;
@@ -455,9 +537,7 @@ __device__ HPX_INL bool diag_factor(const WideCtx& X, const int ct0, d4 (&a1)[9]
         t_im = mfma64(ai, br, t_im);
       }
     }
-#endif
     // (4) trailing tiles: D^T[c'][r'] -= sum_k conj(X(c,i)[c'][k]) X(r,i)[r'][k]
-#ifndef HPX_DBG_F_NOUPD
 #pragma unroll
     for (int s = 0; s < 9; ++s)
       if (tc[s] > i) {
@@ -473,24 +553,21 @@ __device__ HPX_INL bool diag_factor(const WideCtx& X, const int ct0, d4 (&a1)[9]
           a2[s] = mfma64(pi, br, a2[s]);
         }
       }
-#endif
   }
   __syncthreads();        // F's stores (L_JJ, Vt) are complete before the passes stage them
   return bad;
 }
 
 // ---- P: the row strips below the full super-block at ct0, four at a time ----------------------------
-// The chunks of all groups form ONE stream through the ring of staging buffers: every step waits for its own
-// chunk, passes the barrier, issues the chunk DIST steps ahead (of the next group when this one is nearly done)
-// and computes; nothing is drained between the groups.  Counted waits: every wave issues 2 PP LDS-DMA operations
-// per stage, and an active wave 2 PP loads (row operand of the next chunk) or stores (its solved columns) per
-// step, so with the vmcnt counter in issue order "all but the NA (NI) youngest" covers the chunk being waited for.
-template <int KC, bool GEN>
-__device__ HPX_INL void strip_passes(const WideCtx& X, const hpx_gen& G, const int ct0) {
-  typedef WCfg<KC> C;
-  constexpr int PP = C::PP, H = C::H, DIST = C::DIST;
-  constexpr int NA = DIST * 2 * PP + (DIST - 1) * 2 * PP;     // active wave: its own loads / stores + younger stages
-  constexpr int NI = (DIST - 1) * 2 * PP;                     // idle wave: younger stages only
+// The chunks of all groups form ONE stream through the two staging buffers: every step waits for its own
+// chunk, passes the barrier, issues the next chunk (the next group's first when this one is done) into the other
+// buffer and computes; nothing is drained between the groups.  Counted waits: every wave issues 8 LDS-DMA
+// operations per stage, and an active wave 8 loads (row operand of the next chunk) or 8 stores (its solved
+// columns) per step AFTER them, so with the vmcnt counter in issue order "all but the 8 youngest" covers the
+// chunk being waited for.  A super-block's steps per group (c0 / 16 + 8) are even: the buffer of a step is its
+// parity within the group.
+template <bool GEN, bool GLDS>
+__device__ HPX_INL void strip_passes(const WideCtx& X, const hpx_gen& G, const GenVec<GLDS>& V, const int ct0) {
   const int lane = opaque(X.lane), li = lane & 15, g = lane >> 4;
   const unsigned src_lane = g * 32 + 2 * ((li + 8 * (g & 1)) & 15);
   const int rd_re = g * 32 + li + 16 * (g & 1), rd_im = g * 32 + li + 16 * (1 - (g & 1));
@@ -498,24 +575,19 @@ __device__ HPX_INL void strip_passes(const WideCtx& X, const hpx_gen& G, const i
   const int c0 = ct0 * 16;
   const int first = ct0 + 8;
   if (first >= X.nrt) return;
-  const int nk = c0 / KC, nt = 8 * H, total = nk + nt;
+  const int nk = c0 / KC, total = nk + 8;
   double rb[PP], rm[PP];
-  // ---- prologue of the pass: the first DIST stages, the first group's first row operand
-#pragma unroll
-  for (int d = 0; d < DIST; ++d) {
-    const int st = min(d, total - 1);
-    if (st < nk) stage_k<KC>(X, ct0, st, d, src_lane);
-    else stage_t<KC>(X, ct0, st - nk, d, src_lane);
+  // ---- prologue of the pass: the first stage, the first group's first row operand
+  stage_step<0>(X, ct0, 0, nk, src_lane);
+#define HPX_ROW_LOAD(base_)                                                      \
+  {                                                                              \
+    rb[0] = ld_nt<0>(base_, 8 * blane);    rm[0] = ld_nt<128>(base_, 8 * blane);   \
+    rb[1] = ld_nt<1024>(base_, 8 * blane); rm[1] = ld_nt<1152>(base_, 8 * blane);  \
+    rb[2] = ld_nt<2048>(base_, 8 * blane); rm[2] = ld_nt<2176>(base_, 8 * blane);  \
+    rb[3] = ld_nt<3072>(base_, 8 * blane); rm[3] = ld_nt<3200>(base_, 8 * blane);  \
   }
-  if (first + X.wave < X.nrt && nk > 0) {
-    const double* b0 = X.Lb + (long)(first + X.wave) * X.ptile;
-#pragma unroll
-    for (int p = 0; p < PP; ++p) {
-      rb[p] = HPX_NTLD(b0 + p * 128 + blane);
-      rm[p] = HPX_NTLD(b0 + p * 128 + 16 + blane);
-    }
-  }
-  int bi = 0, q = 0;                     // ring position, steps since the pass began
+  if (first + X.wave < X.nrt && nk > 0) HPX_ROW_LOAD(X.Lb + (long)(first + X.wave) * X.ptile)
+  bool first_step = true;
   for (int rt0 = first; rt0 < X.nrt; rt0 += 4) {
     const int rt = rt0 + X.wave;
     const bool active = rt < X.nrt;
@@ -523,160 +595,166 @@ __device__ HPX_INL void strip_passes(const WideCtx& X, const hpx_gen& G, const i
     const bool next_active = rt + 4 < X.nrt;
     d4 a1[8], a2[8], a3[8];
     if (active) {
+      if (GEN && GLDS && rt * 16 < G.rmin && c0 + 128 <= G.rmin) {     // no vector-memory instruction on this path
 #pragma unroll
-      for (int ci = 0; ci < 8; ++ci) {
-        d4 vr, vi;
-        tile_init<GEN>(G, X.Lb, rt * 16, c0 + 16 * ci, X.npad, li, g, vr, vi);
-        a1[ci] = -0.5 * vr;
-        a2[ci] = -0.5 * vr;
-        a3[ci] = vi;
+        for (int ci = 0; ci < 8; ++ci) {
+          d4 vr, vi;
+          tile_init_closed<GLDS>(V, rt * 16, c0 + 16 * ci, li, g, vr, vi);
+          a1[ci] = -0.5 * vr;
+          a2[ci] = -0.5 * vr;
+          a3[ci] = vi;
+        }
+      } else {
+#pragma unroll
+        for (int ci = 0; ci < 8; ++ci) {
+          d4 vr, vi;
+          tile_init<GEN, GLDS>(G, V, X.Lb, rt * 16, c0 + 16 * ci, X.npad, li, g, vr, vi);
+          a1[ci] = -0.5 * vr;
+          a2[ci] = -0.5 * vr;
+          a3[ci] = vi;
+        }
+        wait_compiler_loads();
       }
     }
     const double* brow = X.Lb + (long)(active ? rt : first) * X.ptile;      // (uniform) + lane offset `blane`
-    // step `st_` of this group: wait for its chunk, barrier, issue the chunk DIST steps ahead
-#define HPX_STEP_HEAD(st_)                                                                           \
-    if (q < DIST) wait_vm<0>();                                                                      \
-    else if (active) wait_vm<NA>();                                                                  \
-    else wait_vm<NI>();                                                                              \
-    __builtin_amdgcn_s_barrier();                                                                    \
+    // step `st_` of this group (buffer PAR_): wait for its chunk, barrier, issue the next one
+#define HPX_STEP_HEAD(PAR_, st_)                                                                     \
+    if (first_step || !active) wait_vm<0>();            /* the chunk of this step has landed ... */  \
+    else wait_vm<8>();              /* ... behind this wave's 8 row-operand loads or 8 stores */     \
+    first_step = false;                                                                              \
+    wg_barrier();                                                                                    \
     {                                                                                                \
-      int bn_ = bi + DIST;                                                                           \
-      if (bn_ >= C::NBUF) bn_ -= C::NBUF;                                                            \
-      int sn_ = (st_) + DIST;                                                                        \
-      if (sn_ >= total) sn_ = last_group ? total - 1 : sn_ - total;      /* next group's / a harmless re-stage */ \
-      if (sn_ < nk) stage_k<KC>(X, ct0, sn_, bn_, src_lane);                                         \
-      else stage_t<KC>(X, ct0, sn_ - nk, bn_, src_lane);                                             \
-    }                                                                                                \
-    ++q;
-    // ---- k-loop
-    for (int st = 0; st < nk; ++st) {
-      HPX_STEP_HEAD(st)
-      if (active) {
-        const lds_f64* B = (const lds_f64*)(X.lds + bi * C::BUF_D);
-        const double* bnext = brow + (long)min(st + 1, nk - 1) * C::TILE_D;     // last chunk: a harmless re-read
-#pragma unroll
-        for (int p = 0; p < PP; ++p) {
-          const double br = rb[p], bm = rm[p], bd = br - bm;
-          double pr = B[p * 128 + rd_re], pi = B[p * 128 + rd_im];
-#pragma unroll
-          for (int ci = 0; ci < 8; ++ci) {
-            const double cr = pr, cm = pi, psm = pr + pi;
-            if (ci + 1 < 8) {
-              pr = B[(ci + 1) * C::TILE_D + p * 128 + rd_re];
-              pi = B[(ci + 1) * C::TILE_D + p * 128 + rd_im];
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            a1[ci] = mfma64(cr, br, a1[ci]);
-            a2[ci] = mfma64(cm, bm, a2[ci]);
-            a3[ci] = mfma64(psm, bd, a3[ci]);
-            __builtin_amdgcn_sched_barrier(0);
-          }
-          rb[p] = HPX_NTLD(bnext + p * 128 + blane);
-          rm[p] = HPX_NTLD(bnext + p * 128 + 16 + blane);
-        }
-      }
-      bi = (bi + 1 == C::NBUF) ? 0 : bi + 1;
+      int sn_ = (st_) + 1;                                                                           \
+      if (sn_ >= total) sn_ = last_group ? total - 1 : 0;        /* a harmless re-stage / the next group's first */ \
+      stage_step<1 - (PAR_)>(X, ct0, sn_, nk, src_lane);                                             \
     }
-    // ---- tail: the triangular solve as further chunks of the same stream
-#define HPX_TAIL_STEP(CJ_, HH_)                                                                      \
+    // ---- k-loop
+#define HPX_K_STEP(PAR_, st_)                                                                        \
+    {                                                                                                \
+      HPX_STEP_HEAD(PAR_, st_)                                                                       \
+      if (active) {                                                                                  \
+        /* the row operand (issued a step ago) is in: all but the 8 DMA just issued have retired */  \
+        wait_vm<8>();                                                                                \
+        anchor_rows(rb, rm);                                                                         \
+        const lds_f64* B = (const lds_f64*)stage_buf<PAR_>();                                        \
+        const double* bnext = brow + (long)min((st_) + 1, nk - 1) * TILE_D;   /* last: a harmless re-read */ \
+        _Pragma("unroll") for (int p = 0; p < PP; ++p) {                                             \
+          const double br = rb[p], bm = rm[p], bd = br - bm;                                         \
+          double pr = B[p * 128 + rd_re], pi = B[p * 128 + rd_im];                                   \
+          _Pragma("unroll") for (int ci = 0; ci < 8; ++ci) {                                         \
+            const double cr = pr, cm = pi, psm = pr + pi;                                            \
+            if (ci + 1 < 8) {                                                                        \
+              pr = B[(ci + 1) * TILE_D + p * 128 + rd_re];                                           \
+              pi = B[(ci + 1) * TILE_D + p * 128 + rd_im];                                           \
+            }                                                                                        \
+            __builtin_amdgcn_sched_barrier(0);                                                       \
+            a1[ci] = mfma64(cr, br, a1[ci]);                                                         \
+            a2[ci] = mfma64(cm, bm, a2[ci]);                                                         \
+            a3[ci] = mfma64(psm, bd, a3[ci]);                                                        \
+            __builtin_amdgcn_sched_barrier(0);                                                       \
+          }                                                                                          \
+          if (p == 0) { rb[0] = ld_nt<0>(bnext, 8 * blane);    rm[0] = ld_nt<128>(bnext, 8 * blane); }   \
+          if (p == 1) { rb[1] = ld_nt<1024>(bnext, 8 * blane); rm[1] = ld_nt<1152>(bnext, 8 * blane); }  \
+          if (p == 2) { rb[2] = ld_nt<2048>(bnext, 8 * blane); rm[2] = ld_nt<2176>(bnext, 8 * blane); }  \
+          if (p == 3) { rb[3] = ld_nt<3072>(bnext, 8 * blane); rm[3] = ld_nt<3200>(bnext, 8 * blane); }  \
+        }                                                                                            \
+      }                                                                                              \
+    }
+    for (int st = 0; st < nk; st += 2) {
+      HPX_K_STEP(0, st)
+      HPX_K_STEP(1, st + 1)
+    }
+    // ---- tail: the triangular solve as further chunks of the same stream (step nk + CJ: buffer CJ & 1)
+#define HPX_TAIL_STEP(CJ_)                                                                           \
   {                                                                                                  \
-    HPX_STEP_HEAD(nk + (CJ_) * H + (HH_))                                                            \
+    d4 x1 = {0., 0., 0., 0.}, x2 = x1, x3 = x1;                                                      \
+    HPX_STEP_HEAD((CJ_) & 1, nk + (CJ_))                                                             \
     if (active) {                                                                                    \
-      const lds_f64* B = (const lds_f64*)(X.lds + bi * C::BUF_D);                                    \
-      if ((HH_) == 0) {                                                                              \
+      const lds_f64* B = (const lds_f64*)stage_buf<(CJ_) & 1>();                                     \
+      {                                                                                              \
         const d4 re_ = -(a1[CJ_] + a2[CJ_]);                                                         \
         const d4 im_ = a3[CJ_] - a1[CJ_] + a2[CJ_];                                                  \
         a1[CJ_] = re_; a2[CJ_] = im_; a3[CJ_] = re_ - im_;                                           \
-        x1 = (d4){0., 0., 0., 0.}; x2 = x1; x3 = x1;                                                 \
       }                                                                                              \
       {                                                                                              \
-        double pr = B[(CJ_) * C::TILE_D + rd_re], pi = B[(CJ_) * C::TILE_D + rd_im];                 \
+        double pr = B[(CJ_) * TILE_D + rd_re], pi = B[(CJ_) * TILE_D + rd_im];                       \
         _Pragma("unroll") for (int p = 0; p < PP; ++p) {                                             \
           const double cr = pr, cm = pi, psm = pr + pi;                                              \
           if (p + 1 < PP) {                                                                          \
-            pr = B[(CJ_) * C::TILE_D + (p + 1) * 128 + rd_re];                                       \
-            pi = B[(CJ_) * C::TILE_D + (p + 1) * 128 + rd_im];                                       \
+            pr = B[(CJ_) * TILE_D + (p + 1) * 128 + rd_re];                                          \
+            pi = B[(CJ_) * TILE_D + (p + 1) * 128 + rd_im];                                          \
           }                                                                                          \
           __builtin_amdgcn_sched_barrier(0);                                                         \
-          x1 = mfma64(cr, a1[CJ_][(HH_) * PP + p], x1);                                              \
-          x2 = mfma64(cm, a2[CJ_][(HH_) * PP + p], x2);                                              \
-          x3 = mfma64(psm, a3[CJ_][(HH_) * PP + p], x3);                                             \
+          x1 = mfma64(cr, a1[CJ_][p], x1);                                                           \
+          x2 = mfma64(cm, a2[CJ_][p], x2);                                                           \
+          x3 = mfma64(psm, a3[CJ_][p], x3);                                                          \
           __builtin_amdgcn_sched_barrier(0);                                                         \
         }                                                                                            \
       }                                                                                              \
-      if ((CJ_) == 7 && (HH_) == H - 1 && next_active && nk > 0) {                                   \
-        /* the next group's first row operand, in front of this step's stores (the youngest 2 PP) */ \
-        const double* bn0_ = X.Lb + (long)(rt + 4) * X.ptile;                                        \
-        _Pragma("unroll") for (int p = 0; p < PP; ++p) {                                             \
-          rb[p] = HPX_NTLD(bn0_ + p * 128 + blane);                                                  \
-          rm[p] = HPX_NTLD(bn0_ + p * 128 + 16 + blane);                                             \
-        }                                                                                            \
+      if ((CJ_) == 7 && next_active && nk > 0) {                                                     \
+        /* the next group's first row operand, in front of this step's stores (the youngest 8) */    \
+        HPX_ROW_LOAD(X.Lb + (long)(rt + 4) * X.ptile)                                                \
       }                                                                                              \
-      double* o_ = X.Lb + HPX_LIDX(rt * 16 + li, (ct0 + (CJ_)) * 16 + g, X.npad);                    \
-      _Pragma("unroll") for (int p = 0; p < PP; ++p) {                                               \
-        const int v = (HH_) * PP + p;                                                                \
+      /* (uniform base) + lane offset: no 64-bit address registers per column tile */               \
+      double* o_ = X.Lb + ((long)rt * X.npad + (ct0 + (CJ_)) * 16) * 32;                             \
+      _Pragma("unroll") for (int v = 0; v < 4; ++v) {                                                \
         const double xr = x1[v] + x2[v], xi = x1[v] - x2[v] - x3[v];                                 \
-        o_[(4 * v) * 32] = xr;                                                                       \
-        o_[(4 * v) * 32 + 16] = xi;                                                                  \
         a1[CJ_][v] = xr; a2[CJ_][v] = xi; a3[CJ_][v] = xr - xi;                                      \
       }                                                                                              \
+      st_g<0>(o_, 8 * blane, a1[CJ_][0]);    st_g<128>(o_, 8 * blane, a2[CJ_][0]);                   \
+      st_g<1024>(o_, 8 * blane, a1[CJ_][1]); st_g<1152>(o_, 8 * blane, a2[CJ_][1]);                  \
+      st_g<2048>(o_, 8 * blane, a1[CJ_][2]); st_g<2176>(o_, 8 * blane, a2[CJ_][2]);                  \
+      st_g<3072>(o_, 8 * blane, a1[CJ_][3]); st_g<3200>(o_, 8 * blane, a2[CJ_][3]);                  \
       __builtin_amdgcn_sched_barrier(0);                                                             \
       if ((CJ_) < 7) {                                                                               \
-        double pr = B[((CJ_) + 1) * C::TILE_D + rd_re], pi = B[((CJ_) + 1) * C::TILE_D + rd_im];     \
+        double pr = B[((CJ_) + 1) * TILE_D + rd_re], pi = B[((CJ_) + 1) * TILE_D + rd_im];           \
         _Pragma("unroll") for (int ci = (CJ_) + 1; ci < 8; ++ci) {                                   \
           _Pragma("unroll") for (int p = 0; p < PP; ++p) {                                           \
-            const int v = (HH_) * PP + p;                                                            \
             const double cr = pr, cm = pi, psm = pr + pi;                                            \
             if (p + 1 < PP) {                                                                        \
-              pr = B[ci * C::TILE_D + (p + 1) * 128 + rd_re];                                        \
-              pi = B[ci * C::TILE_D + (p + 1) * 128 + rd_im];                                        \
+              pr = B[ci * TILE_D + (p + 1) * 128 + rd_re];                                           \
+              pi = B[ci * TILE_D + (p + 1) * 128 + rd_im];                                           \
             } else if (ci + 1 < 8) {                                                                 \
-              pr = B[(ci + 1) * C::TILE_D + rd_re];                                                  \
-              pi = B[(ci + 1) * C::TILE_D + rd_im];                                                  \
+              pr = B[(ci + 1) * TILE_D + rd_re];                                                     \
+              pi = B[(ci + 1) * TILE_D + rd_im];                                                     \
             }                                                                                        \
             __builtin_amdgcn_sched_barrier(0);                                                       \
-            a1[ci] = mfma64(cr, a1[CJ_][v], a1[ci]);                                                 \
-            a2[ci] = mfma64(cm, a2[CJ_][v], a2[ci]);                                                 \
-            a3[ci] = mfma64(psm, a3[CJ_][v], a3[ci]);                                                \
+            a1[ci] = mfma64(cr, a1[CJ_][p], a1[ci]);                                                 \
+            a2[ci] = mfma64(cm, a2[CJ_][p], a2[ci]);                                                 \
+            a3[ci] = mfma64(psm, a3[CJ_][p], a3[ci]);                                                \
             __builtin_amdgcn_sched_barrier(0);                                                       \
           }                                                                                          \
         }                                                                                            \
       }                                                                                              \
     }                                                                                                \
-    bi = (bi + 1 == C::NBUF) ? 0 : bi + 1;                                                           \
   }
-#define HPX_TAIL_TILE(CJ_)                          \
-  {                                                 \
-    d4 x1, x2, x3;                                  \
-    HPX_TAIL_STEP(CJ_, 0)                           \
-    if constexpr (H == 2) { HPX_TAIL_STEP(CJ_, 1) } \
-  }
-    HPX_TAIL_TILE(0)
-    HPX_TAIL_TILE(1)
-    HPX_TAIL_TILE(2)
-    HPX_TAIL_TILE(3)
-    HPX_TAIL_TILE(4)
-    HPX_TAIL_TILE(5)
-    HPX_TAIL_TILE(6)
-    HPX_TAIL_TILE(7)
-#undef HPX_TAIL_TILE
+    HPX_TAIL_STEP(0)
+    HPX_TAIL_STEP(1)
+    HPX_TAIL_STEP(2)
+    HPX_TAIL_STEP(3)
+    HPX_TAIL_STEP(4)
+    HPX_TAIL_STEP(5)
+    HPX_TAIL_STEP(6)
+    HPX_TAIL_STEP(7)
 #undef HPX_TAIL_STEP
+#undef HPX_K_STEP
 #undef HPX_STEP_HEAD
+#undef HPX_ROW_LOAD
   }
-  // the pass's stores and re-staged chunks are done, every wave has finished reading the buffers
+  // the pass's stores and the re-staged chunk are done, every wave has finished reading the buffers
   wait_vm<0>();
-  __builtin_amdgcn_s_barrier();
+  wg_barrier();
 }
 
 // ---- a single 16-wide tile column t (those after the last full super-block): register-only ----------
 //   diagonal tile: K-split of the update over the four waves, partial sums through LDS, elimination;
 //   tiles below: one per wave at a time, both operands straight from global memory (double buffered).
-template <bool GEN>
-__device__ HPX_INL bool narrow_column(const WideCtx& X, const hpx_gen& G, const int t) {
+template <bool GEN, bool GLDS>
+__device__ HPX_INL bool narrow_column(const WideCtx& X, const hpx_gen& G, const GenVec<GLDS>& V, const int t) {
   const int lane = opaque(X.lane), li = lane & 15, g = lane >> 4;
   const int rd_re = g * 32 + li + 16 * (g & 1), rd_im = g * 32 + li + 16 * (1 - (g & 1));
-  lds_f64* const Xs = (lds_f64*)(X.lds + FX_OFF);
-  lds_f64* const Vs = (lds_f64*)(X.lds + FV_OFF);
+  lds_f64* const Xs = (lds_f64*)hpx_stage0;
+  lds_f64* const Vs = (lds_f64*)(hpx_stage1 + FV_OFF);
   const int c0 = 16 * t;
   // ---- diagonal tile: partial sums over this wave's 16-column chunks (operand p = b = L[t rows][k])
   {
@@ -708,7 +786,7 @@ __device__ HPX_INL bool narrow_column(const WideCtx& X, const hpx_gen& G, const 
   {
     const int tid = opaque(X.tid), q = tid & 15, ib = tid >> 4;
     double kr = 0.0, ki = 0.0;
-    if (q <= ib) entry_init<GEN>(G, X.Lb, c0 + ib, c0 + q, X.npad, kr, ki);
+    if (q <= ib) entry_init<GEN, GLDS>(G, V, X.Lb, c0 + ib, c0 + q, X.npad, kr, ki);
 #pragma unroll
     for (int w = 0; w < 4; ++w) {
       kr -= Xs[(1 + w) * 512 + ib * 16 + q];
@@ -754,7 +832,7 @@ __device__ HPX_INL bool narrow_column(const WideCtx& X, const hpx_gen& G, const 
     d4 a1, a2, a3;
     {
       d4 vr, vi;
-      tile_init<GEN>(G, X.Lb, rt * 16, c0, X.npad, li, g, vr, vi);
+      tile_init<GEN, GLDS>(G, V, X.Lb, rt * 16, c0, X.npad, li, g, vr, vi);
       a1 = -0.5 * vr;
       a2 = -0.5 * vr;
       a3 = vi;
@@ -812,13 +890,12 @@ __device__ HPX_INL bool narrow_column(const WideCtx& X, const hpx_gen& G, const 
   return bad;
 }
 
-template <int KC, bool GEN, bool GLDS>
+template <bool GEN, bool GLDS>
 __global__ __launch_bounds__(256, 2) void k_factor_wide(double* __restrict__ L_all, double* __restrict__ Wre_all,
                                                         double* __restrict__ Wim_all, double* __restrict__ Vt_all,
                                                         int32_t* __restrict__ info, const int npad, const int ld,
                                                         const int iter_tag, const hpx_gen_batch GB) {
-  typedef WCfg<KC> C;
-  extern __shared__ double lds_raw[];
+  extern __shared__ double lds_dyn[];      // 1 / a and the circulant (GLDS), behind the two static staging buffers
   const int b = blockIdx.x;
   const int tid = threadIdx.x;
   hpx_gen G = {};
@@ -836,9 +913,9 @@ __global__ __launch_bounds__(256, 2) void k_factor_wide(double* __restrict__ L_a
   const int nblk = (npad + HPX_NB - 1) / HPX_NB;
   X.Wgre = Wre_all + (long)b * nblk * 1024;
   X.Wgim = Wim_all + (long)b * nblk * 1024;
-  X.lds = lds_raw;
-  if (GEN && GLDS) {
-    double* ga = lds_raw + C::STAGE_D;
+  GenVec<GLDS> V = {};
+  if constexpr (GEN && GLDS) {
+    double* ga = lds_dyn;
     double* gcr = ga + G.N;
     double* gci = gcr + G.N;
     for (int i = tid; i < G.N; i += 256) {
@@ -846,20 +923,24 @@ __global__ __launch_bounds__(256, 2) void k_factor_wide(double* __restrict__ L_a
       gcr[i] = G.cre[i];
       gci[i] = G.cim[i];
     }
-    G.ia = ga;
-    G.cre = gcr;
-    G.cim = gci;
+    V.ia = (const lds_f64*)ga;
+    V.cre = (const lds_f64*)gcr;
+    V.cim = (const lds_f64*)gci;
     __syncthreads();
+  } else if constexpr (GEN) {
+    V.ia = (const glb_f64*)G.ia;
+    V.cre = (const glb_f64*)G.cre;
+    V.cim = (const glb_f64*)G.cim;
   }
   bool bad = false;
   int ct0 = 0;
   for (; ct0 + 8 <= X.nct; ct0 += 8) {
     d4 a1[9], a2[9];
 #ifndef HPX_DBG_NO_S
-    if (X.wave == 0) diag_update<KC, GEN, 0>(X, G, ct0, a1, a2);
-    else if (X.wave == 1) diag_update<KC, GEN, 1>(X, G, ct0, a1, a2);
-    else if (X.wave == 2) diag_update<KC, GEN, 2>(X, G, ct0, a1, a2);
-    else diag_update<KC, GEN, 3>(X, G, ct0, a1, a2);
+    if (X.wave == 0) diag_update<GEN, GLDS, 0>(X, G, V, ct0, a1, a2);
+    else if (X.wave == 1) diag_update<GEN, GLDS, 1>(X, G, V, ct0, a1, a2);
+    else if (X.wave == 2) diag_update<GEN, GLDS, 2>(X, G, V, ct0, a1, a2);
+    else diag_update<GEN, GLDS, 3>(X, G, V, ct0, a1, a2);
 #else
     for (int s = 0; s < 9; ++s) { a1[s] = (d4){1.0 * tid, 0., 0., 0.}; a2[s] = a1[s]; }
 #endif
@@ -869,21 +950,21 @@ __global__ __launch_bounds__(256, 2) void k_factor_wide(double* __restrict__ L_a
     for (int s = 0; s < 9; ++s) X.Lb[s * 64 + tid] = a1[s][0] + a2[s][1];
 #endif
 #ifndef HPX_DBG_NO_P
-    strip_passes<KC, GEN>(X, G, ct0);
+    strip_passes<GEN, GLDS>(X, G, V, ct0);
 #endif
   }
 #ifndef HPX_DBG_NO_N
-  for (; ct0 < X.nct; ++ct0) bad |= narrow_column<GEN>(X, G, ct0);
+  for (; ct0 < X.nct; ++ct0) bad |= narrow_column<GEN, GLDS>(X, G, V, ct0);
 #endif
   if (bad && info) atomicCAS(&info[b], 0, iter_tag);
 }
 
-template <int KC, bool GEN, bool GLDS>
+template <bool GEN, bool GLDS>
 int launch_wide_t(int nbl, size_t lds, int npad, int ld, double* L, double* Wre, double* Wim, double* Vt,
                   int32_t* info, int iter_tag, const hpx_gen_batch& gen, hipStream_t st) {
   static hpx_lds_limit limit;      // per instantiation
-  HPX_TRY(limit.ensure(reinterpret_cast<const void*>(&k_factor_wide<KC, GEN, GLDS>), lds));
-  hipLaunchKernelGGL((k_factor_wide<KC, GEN, GLDS>), dim3(nbl), dim3(256), lds, st, L, Wre, Wim, Vt, info, npad, ld,
+  if (lds > 0) HPX_TRY(limit.ensure(reinterpret_cast<const void*>(&k_factor_wide<GEN, GLDS>), lds));
+  hipLaunchKernelGGL((k_factor_wide<GEN, GLDS>), dim3(nbl), dim3(256), lds, st, L, Wre, Wim, Vt, info, npad, ld,
                      iter_tag, gen);
   HPX_HIP(hipGetLastError());
   return HPX_OK;
@@ -891,21 +972,15 @@ int launch_wide_t(int nbl, size_t lds, int npad, int ld, double* L, double* Wre,
 
 }  // namespace
 
-#ifndef HPX_WIDE_KC
-#define HPX_WIDE_KC 16
-#endif
-
 int hpx_launch_factor_wide(int nbl, int npad, int ld, double* L, double* Wre, double* Wim, double* Vt,
                            int32_t* info, int iter_tag, const hpx_gen_batch* gen, hipStream_t st) {
-  constexpr int KC = HPX_WIDE_KC;
-  const size_t base = (size_t)WCfg<KC>::STAGE_D * sizeof(double);
   if (!gen) {
     hpx_gen_batch none = {};
-    return launch_wide_t<KC, false, false>(nbl, base, npad, ld, L, Wre, Wim, Vt, info, iter_tag, none, st);
+    return launch_wide_t<false, false>(nbl, 0, npad, ld, L, Wre, Wim, Vt, info, iter_tag, none, st);
   }
-  // 1 / a and the circulant in LDS while two workgroups still fit on a CU
-  const size_t staged = base + (size_t)3 * gen->N * sizeof(double);
-  if (staged <= (size_t)80 * 1024)
-    return launch_wide_t<KC, true, true>(nbl, staged, npad, ld, L, Wre, Wim, Vt, info, iter_tag, *gen, st);
-  return launch_wide_t<KC, true, false>(nbl, base, npad, ld, L, Wre, Wim, Vt, info, iter_tag, *gen, st);
+  // 1 / a and the circulant in LDS while two workgroups still fit on a CU (64 KB of staging buffers each)
+  const size_t staged = (size_t)3 * gen->N * sizeof(double);
+  if (2 * BUF_D * sizeof(double) + staged <= (size_t)80 * 1024)
+    return launch_wide_t<true, true>(nbl, staged, npad, ld, L, Wre, Wim, Vt, info, iter_tag, *gen, st);
+  return launch_wide_t<true, false>(nbl, 0, npad, ld, L, Wre, Wim, Vt, info, iter_tag, *gen, st);
 }
