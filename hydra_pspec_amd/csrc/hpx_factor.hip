@@ -970,9 +970,12 @@ static int launch_factor_t(int nbl, size_t lds, int npad, int ld, double* L, dou
   return HPX_OK;
 }
 
-// Which form runs: the wide one (hpx_factor_wide.hip) from HPX_WIDE_MIN columns on, this file's 32-wide one below.
+// Which form runs: the wide one (hpx_factor_wide.hip: 128-column super-blocks, LDS-staged panels) from HPX_WIDE_MIN
+// columns on, this file's 32-wide one below.  Measured on one MI355X, 1024 systems: order 1040
+// 24.7 against 27.9 ms, order 528 4.06 against 4.19 ms, order 272 1.05 against 0.99 ms, order 144 0.92 against 0.73 ms
+// -- the wide form pays from four super-blocks on.
 #ifndef HPX_WIDE_MIN
-#define HPX_WIDE_MIN (1 << 30)      /* off by default while it is being tuned: -DHPX_WIDE_MIN=16 turns it on */
+#define HPX_WIDE_MIN 400
 #endif
 int hpx_launch_factor(int nbl, int npad, int ld, double* L, double* Wre, double* Wim, double* Vt,
                       int32_t* info, int iter_tag, const hpx_gen_batch* gen, hipStream_t st) {

@@ -100,13 +100,12 @@ template <int N>
 __device__ HPX_INL void wait_vm() {
   asm volatile("s_waitcnt vmcnt(%0)" :: "n"(HPX_WAITN(N)) : "memory");
 }
-// The eight row-operand registers were written by ld_nt asm statements the compiler knows nothing about: it must
+// The row-operand registers were written by ld_nt asm statements the compiler knows nothing about: it must
 // not touch them before the wait that covers their loads.  The wait itself has no operands (tied operands
 // let the register allocator put copies of the not-yet-loaded registers IN FRONT of it: observed, as
-// timing-dependent garbage); this anchor follows it, ties all eight, and everything that uses them depends on it.
-__device__ HPX_INL void anchor_rows(double (&rb)[4], double (&rm)[4]) {
-  asm volatile("" : "+v"(rb[0]), "+v"(rb[1]), "+v"(rb[2]), "+v"(rb[3]), "+v"(rm[0]), "+v"(rm[1]), "+v"(rm[2]),
-               "+v"(rm[3]));
+// timing-dependent garbage); this anchor follows it, ties the pair, and everything that uses it depends on it.
+__device__ HPX_INL void anchor_pair(double& a, double& b) {
+  asm volatile("" : "+v"(a), "+v"(b));
 }
 __device__ HPX_INL void wg_barrier() {
   asm volatile("s_barrier" ::: "memory");
@@ -633,12 +632,14 @@ __device__ HPX_INL void strip_passes(const WideCtx& X, const hpx_gen& G, const G
     {                                                                                                \
       HPX_STEP_HEAD(PAR_, st_)                                                                       \
       if (active) {                                                                                  \
-        /* the row operand (issued a step ago) is in: all but the 8 DMA just issued have retired */  \
-        wait_vm<8>();                                                                                \
-        anchor_rows(rb, rm);                                                                         \
         const lds_f64* B = (const lds_f64*)stage_buf<PAR_>();                                        \
         const double* bnext = brow + (long)min((st_) + 1, nk - 1) * TILE_D;   /* last: a harmless re-read */ \
         _Pragma("unroll") for (int p = 0; p < PP; ++p) {                                             \
+          /* k-step p's pair was loaded right after k-step p of the step before: behind it are the  \
+             pairs p+1 .. 3 of that step, the 8 DMA of this step's head and the pairs 0 .. p-1 of   \
+             this step -- 14 operations whatever p is */                                            \
+          wait_vm<14>();                                                                             \
+          anchor_pair(rb[p], rm[p]);                                                                 \
           const double br = rb[p], bm = rm[p], bd = br - bm;                                         \
           double pr = B[p * 128 + rd_re], pi = B[p * 128 + rd_im];                                   \
           _Pragma("unroll") for (int ci = 0; ci < 8; ++ci) {                                         \

@@ -43,7 +43,7 @@ def _hpd(rng, nb, n, cond=1e3):
     return (q * ev[None, None, :]) @ np.conj(np.swapaxes(q, 1, 2))
 
 
-@pytest.mark.parametrize("n", [5, 16, 35, 64, 132, 524])
+@pytest.mark.parametrize("n", [5, 16, 35, 64, 132, 400, 524, 652, 1036])
 def test_zpotrf(T, n):
     from hydra_pspec_amd import hpx
     rng = np.random.default_rng(n)
@@ -72,7 +72,7 @@ def test_zpotrf_not_positive_definite(T):
     assert info.cpu().numpy().tolist() == [0, 1]
 
 
-@pytest.mark.parametrize("n,nrhs", [(16, 16), (35, 3), (132, 203), (524, 32), (150, 48)])
+@pytest.mark.parametrize("n,nrhs", [(16, 16), (35, 3), (132, 203), (524, 32), (150, 48), (780, 48), (513, 1)])
 def test_zpotrs(T, n, nrhs):
     from hydra_pspec_amd import hpx
     rng = np.random.default_rng(n + nrhs)
