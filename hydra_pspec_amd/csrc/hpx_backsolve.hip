@@ -1,0 +1,298 @@
+// Backward substitution L^H X = Z with the whole solution block in registers (orders up to 640).
+//
+// k_backsolve of hpx_factor.hip reads every tile of L once but re-reads the solution X once per 128-column
+// super-block and runs at two 4-wave workgroups per CU; at C3 it moved 3.9 GB per launch for 2.8 GB of
+// algorithmic traffic and took 0.85 ms (DESIGN.md sections 9.4, 10.9).  Here ONE workgroup of eight waves owns a
+// baseline and keeps all of X -- (n/16) row tiles x the t-tiles of a pass, as f64 MFMA accumulators -- in its
+// registers, right-looking from the last tile row to the first:
+//
+//   step J:  X_J = inv(L_JJ)^H acc_J   (the wave that owns row tile J; published through LDS and stored)
+//            acc_I -= L[J, I]^H X_J    for every row tile I < J, on the wave that owns I
+//
+// so that L is read exactly once (tile (J, I) by the owner of I, 32 bytes per lane and load), Z once and X is
+// only written.  Row tiles are dealt to the waves boustrophedon (tile 8 q + p to wave p for even q, 7 - p for odd
+// q): every wave gets the same number of tile updates.  The finalisation of X_{J-1} is taken off the critical
+// path: its owner updates that tile first, finalises and publishes it, then does its other updates, so the next
+// step's operand is in LDS (two slots) when the barrier opens.  Each wave re-loads its L operand registers for
+// step J - 1 as soon as step J has used them (a whole step of latency cover).
+//
+// inv(L_JJ) is read from the diagonal 16 x 16 sub-blocks of W (the 32 x 32 inverse blocks both factor kernels
+// write).  Complex products are four real MFMAs on (re, im) accumulators: the three-product form would need 24
+// instead of 16 registers per tile, and the tiles no longer fit.
+#include "hpx_internal.h"
+
+#define HPX_INL __forceinline__
+
+namespace {
+
+typedef __attribute__((address_space(3))) double lds_f64;
+
+__device__ HPX_INL void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+// (uniform base) + (32-bit lane offset in bytes): the scalar-base addressing form, one offset register for all
+// accesses instead of a 64-bit address pair each (which, hoisted out of the step loop, filled the register file)
+template <typename T>
+__device__ HPX_INL const T* lane_ptr(const double* ubase, const unsigned lane_bytes) {
+  return reinterpret_cast<const T*>(reinterpret_cast<const char*>(ubase) + lane_bytes);
+}
+__device__ HPX_INL double* lane_ptr_w(double* ubase, const unsigned lane_bytes) {
+  return reinterpret_cast<double*>(reinterpret_cast<char*>(ubase) + lane_bytes);
+}
+// row tile of block q owned by `wave`
+__device__ HPX_INL int tile_of(const int q, const int wave) { return 8 * q + ((q & 1) ? 7 - wave : wave); }
+__device__ HPX_INL int owner_of(const int I) { return ((I >> 3) & 1) ? 7 - (I & 7) : (I & 7); }
+
+// NS: row tiles (accumulator + L operand slots) per wave, ceil((n/16 - 1) / 8): the last tile row has nothing
+// below it and is finalised straight from Z when it is alone in its block of eight (n/16 = 8 m + 1, every
+// BASELINE shape), without a slot; NT: t-tiles of this pass
+template <int NS, int NT>
+__device__ HPX_INL void bs_reg_pass(const double* __restrict__ Lre, const double* __restrict__ Wgre,
+                                    const double* __restrict__ Wgim, double* __restrict__ Xre,
+                                    double* __restrict__ Xim, double* xs, const int npad, const int TP, const int t0,
+                                    const int wave, const int lane) {
+  const int nct = npad >> 4;
+  const int li = lane & 15, g = lane >> 4;
+  constexpr int NL = NS;
+  const unsigned lz = 8u * (g * 32 + li);          // lane offsets (bytes): Z / X tiles, L operand, inverse tile
+  const unsigned ll = 8u * (li * 32 + 4 * g);
+  const unsigned lw = 8u * (g * 32 + li);
+  d4 ar[NS > 0 ? NS : 1][NT], ai[NS > 0 ? NS : 1][NT];
+  // ---- Z[c][t] = conj(Laug[npad + t][c]) as acc[m = c][n = t]
+#pragma unroll
+  for (int q = 0; q < NS; ++q) {
+    const int I = tile_of(q, wave);
+#pragma unroll
+    for (int tt = 0; tt < NT; ++tt)
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        double zr = 0.0, zi = 0.0;
+        if (I < nct) {      // row npad + t0 + 16 tt + li (a tile row of its own), column 16 I + g + 4 v
+          const double* zb = Lre + (((long)((npad + t0) >> 4) + tt) * npad + 16 * I + 4 * v) * 32;
+          zr = *lane_ptr<double>(zb, lz);
+          zi = -*lane_ptr<double>(zb + 16, lz);
+        }
+        ar[q][tt][v] = zr;
+        ai[q][tt][v] = zi;
+      }
+  }
+  // ---- L operand of a step: rows 4 g .. 4 g + 3 (k index (g, s)) of column li of tile (J, I)
+  double lr[NL > 0 ? NL : 1][4], lm[NL > 0 ? NL : 1][4];
+#define HPX_BS_LOADL(q_, J_)                                                             \
+  {                                                                                      \
+    const int I_ = tile_of(q_, wave);                                                    \
+    if (I_ < (J_)) {                                                                     \
+      const double* lb_ = Lre + ((long)(J_) * npad + 16 * I_) * 32;                      \
+      const double2 a0_ = *lane_ptr<double2>(lb_, ll);                                   \
+      const double2 a1_ = *lane_ptr<double2>(lb_ + 2, ll);                               \
+      const double2 b0_ = *lane_ptr<double2>(lb_ + 16, ll);                              \
+      const double2 b1_ = *lane_ptr<double2>(lb_ + 18, ll);                              \
+      lr[q_][0] = a0_.x; lr[q_][1] = a0_.y; lr[q_][2] = a1_.x; lr[q_][3] = a1_.y;       \
+      lm[q_][0] = b0_.x; lm[q_][1] = b0_.y; lm[q_][2] = b1_.x; lm[q_][3] = b1_.y;       \
+    }                                                                                    \
+  }
+  // acc_I -= L[J, I]^H X_J with X_J from LDS slot `sl`:  conj(l) x = (lr xr + lm xi) + i (lr xi - lm xr)
+#define HPX_BS_UPDATE(q_, sl_)                                                           \
+  {                                                                                      \
+    const lds_f64* xb_ = (const lds_f64*)(xs + (sl_) * (NT * 512));                      \
+    _Pragma("unroll") for (int s = 0; s < 4; ++s) {                                      \
+      __builtin_amdgcn_sched_barrier(0);                                                 \
+      const double nlr_ = -lr[q_][s], nlm_ = -lm[q_][s], plm_ = lm[q_][s];               \
+      _Pragma("unroll") for (int tt = 0; tt < NT; ++tt) {                                \
+        const double xr_ = xb_[tt * 512 + (4 * g + s) * 16 + li];                        \
+        const double xi_ = xb_[tt * 512 + 256 + (4 * g + s) * 16 + li];                  \
+        ar[q_][tt] = mfma64(nlr_, xr_, ar[q_][tt]);                                      \
+        ar[q_][tt] = mfma64(nlm_, xi_, ar[q_][tt]);                                      \
+        ai[q_][tt] = mfma64(nlr_, xi_, ai[q_][tt]);                                      \
+        ai[q_][tt] = mfma64(plm_, xr_, ai[q_][tt]);                                      \
+      }                                                                                  \
+    }                                                                                    \
+  }
+  // X_J = inv(L_JJ)^H acc_J: stored, and published in LDS slot J & 1 as [t-tile][re 16 x 16 | im 16 x 16], row-major
+  // inv(L_JJ) for the tile this wave finalises NEXT, fetched a whole round of steps ahead (its latency would
+  // otherwise sit on the critical path of every step): inv(L)[c' = 4 s + g][c = li]
+  double w_r[4], w_i[4];
+#define HPX_BS_LOADW(J_)                                                                 \
+  if ((J_) >= 0) {                                                                       \
+    const double* wr_ = Wgre + (long)((J_) >> 1) * 1024 + (16 * ((J_) & 1)) * 33;        \
+    const double* wi_ = Wgim + (long)((J_) >> 1) * 1024 + (16 * ((J_) & 1)) * 33;        \
+    _Pragma("unroll") for (int s = 0; s < 4; ++s) {                                      \
+      w_r[s] = *lane_ptr<double>(wr_ + (4 * s) * 32, lw);                                \
+      w_i[s] = *lane_ptr<double>(wi_ + (4 * s) * 32, lw);                                \
+    }                                                                                    \
+  }
+#define HPX_BS_FINAL_OF(J_)                                                              \
+  {                                                                                      \
+    double* xb_ = xs + ((J_) & 1) * (NT * 512);                                          \
+    _Pragma("unroll") for (int tt = 0; tt < NT; ++tt) {                                  \
+      d4 xr_ = {0., 0., 0., 0.}, xi_ = {0., 0., 0., 0.};                                 \
+      _Pragma("unroll") for (int s = 0; s < 4; ++s) {                                    \
+        xr_ = mfma64(w_r[s], HPX_BS_ACC_R(tt)[s], xr_);                                  \
+        xr_ = mfma64(w_i[s], HPX_BS_ACC_I(tt)[s], xr_);                                  \
+        xi_ = mfma64(w_r[s], HPX_BS_ACC_I(tt)[s], xi_);                                  \
+        xi_ = mfma64(-w_i[s], HPX_BS_ACC_R(tt)[s], xi_);                                 \
+      }                                                                                  \
+      _Pragma("unroll") for (int v = 0; v < 4; ++v) {                                    \
+        const int c_ = HPX_ACC_ROW(g, v);                                                \
+        xb_[tt * 512 + c_ * 16 + li] = xr_[v];                                           \
+        xb_[tt * 512 + 256 + c_ * 16 + li] = xi_[v];                                     \
+        const long xo_ = (long)(16 * (J_) + 4 * v) * TP + t0 + 16 * tt;                  \
+        *lane_ptr_w(Xre + xo_, 8u * (g * TP + li)) = xr_[v];                             \
+        *lane_ptr_w(Xim + xo_, 8u * (g * TP + li)) = xi_[v];                             \
+      }                                                                                  \
+    }                                                                                    \
+  }
+  const int Jlast = nct - 1;
+  // the highest tile this wave owns (it finalises its tiles from there downwards, one per block of eight)
+  int mynext = tile_of((Jlast >> 3), wave);
+  if (mynext > Jlast) mynext = tile_of((Jlast >> 3) - 1, wave);       // (-1 .. : tile_of of a negative block is < 0)
+  HPX_BS_LOADW(mynext)
+#pragma unroll
+  for (int q = 0; q < NL; ++q) HPX_BS_LOADL(q, Jlast)
+  if (wave == owner_of(Jlast)) {
+    if ((Jlast >> 3) >= NS) {                 // alone in its block: no slot, Z straight from memory
+      d4 zr[NT], zi[NT];
+#pragma unroll
+      for (int tt = 0; tt < NT; ++tt)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          const double* zb = Lre + (((long)((npad + t0) >> 4) + tt) * npad + 16 * Jlast + 4 * v) * 32;
+          zr[tt][v] = *lane_ptr<double>(zb, lz);
+          zi[tt][v] = -*lane_ptr<double>(zb + 16, lz);
+        }
+#define HPX_BS_ACC_R(tt_) zr[tt_]
+#define HPX_BS_ACC_I(tt_) zi[tt_]
+      HPX_BS_FINAL_OF(Jlast)
+#undef HPX_BS_ACC_R
+#undef HPX_BS_ACC_I
+    } else {
+#pragma unroll
+      for (int q = 0; q < NS; ++q)
+        if (q == (Jlast >> 3)) {
+#define HPX_BS_ACC_R(tt_) ar[q][tt_]
+#define HPX_BS_ACC_I(tt_) ai[q][tt_]
+          HPX_BS_FINAL_OF(Jlast)
+#undef HPX_BS_ACC_R
+#undef HPX_BS_ACC_I
+        }
+    }
+  }
+  if (wave == owner_of(Jlast)) {               // its next tile: one block further down
+    mynext = tile_of((Jlast >> 3) - 1, wave);
+    HPX_BS_LOADW(mynext)
+  }
+  for (int J = Jlast; J >= 1; --J) {
+    lds_barrier();                              // X_J is in its slot; the other slot is free again
+    const int sl = J & 1;
+    const int qn = (J - 1) >> 3;                // the next tile to finalise lives in this slot of its owner
+    const bool next_mine = (wave == owner_of(J - 1));
+    if (next_mine) {
+#pragma unroll
+      for (int q = 0; q < NS; ++q)
+        if (q == qn) {
+          HPX_BS_UPDATE(q, sl)
+#define HPX_BS_ACC_R(tt_) ar[q][tt_]
+#define HPX_BS_ACC_I(tt_) ai[q][tt_]
+          HPX_BS_FINAL_OF(J - 1)
+#undef HPX_BS_ACC_R
+#undef HPX_BS_ACC_I
+          mynext = tile_of(q - 1, wave);
+          HPX_BS_LOADW(mynext)
+          HPX_BS_LOADL(q, J - 1)
+        }
+    }
+    // the other tiles, k-step by k-step with the X operand of one k-step in registers at a time
+    {
+      const lds_f64* xb = (const lds_f64*)(xs + sl * (NT * 512));
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        __builtin_amdgcn_sched_barrier(0);
+        double xr[NT], xi[NT];
+#pragma unroll
+        for (int tt = 0; tt < NT; ++tt) {
+          xr[tt] = xb[tt * 512 + (4 * g + s) * 16 + li];
+          xi[tt] = xb[tt * 512 + 256 + (4 * g + s) * 16 + li];
+        }
+#pragma unroll
+        for (int q = 0; q < NL; ++q)
+          if (!(next_mine && q == qn) && tile_of(q, wave) < J) {
+            const double nlr = -lr[q][s], nlm = -lm[q][s], plm = lm[q][s];
+#pragma unroll
+            for (int tt = 0; tt < NT; ++tt) {
+              ar[q][tt] = mfma64(nlr, xr[tt], ar[q][tt]);
+              ar[q][tt] = mfma64(nlm, xi[tt], ar[q][tt]);
+              ai[q][tt] = mfma64(nlr, xi[tt], ai[q][tt]);
+              ai[q][tt] = mfma64(plm, xr[tt], ai[q][tt]);
+            }
+          }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int q = 0; q < NL; ++q)
+        if (!(next_mine && q == qn) && tile_of(q, wave) < J) HPX_BS_LOADL(q, J - 1)
+    }
+  }
+#undef HPX_BS_LOADL
+#undef HPX_BS_UPDATE
+#undef HPX_BS_FINAL_OF
+#undef HPX_BS_LOADW
+}
+
+template <int NS>
+__global__ __launch_bounds__(512, 2) void k_backsolve_reg(const double* __restrict__ L_all,
+                                                          const double* __restrict__ Wre_all,
+                                                          const double* __restrict__ Wim_all,
+                                                          double* __restrict__ Xre_all, double* __restrict__ Xim_all,
+                                                          const int npad, const int TP, const int ld) {
+  __shared__ double xs[2 * 2 * 512];      // two slots x two t-tiles x (re | im) 16 x 16
+  const int b = blockIdx.x;
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const double* Lre = L_all + (long)b * npad * ld * 2;
+  const int nblk = (npad + HPX_NB - 1) / HPX_NB;
+  const double* Wgre = Wre_all + (long)b * nblk * 1024;
+  const double* Wgim = Wim_all + (long)b * nblk * 1024;
+  double* Xre = Xre_all + (long)b * npad * TP;
+  double* Xim = Xim_all + (long)b * npad * TP;
+  const int TT = TP >> 4;
+  constexpr int NTMAX = (NS >= 5) ? 1 : 2;      // accumulators + L operands within the register file
+  for (int tp = 0; tp < TT; tp += NTMAX) {
+    if (NTMAX == 2 && tp + 1 < TT) bs_reg_pass<NS, 2>(Lre, Wgre, Wgim, Xre, Xim, xs, npad, TP, tp << 4, wave, lane);
+    else bs_reg_pass<NS, 1>(Lre, Wgre, Wgim, Xre, Xim, xs, npad, TP, tp << 4, wave, lane);
+    __syncthreads();                       // the slots are free for the next pass
+  }
+}
+
+template <int NS>
+int launch_reg(int nbl, int npad, int TP, int ld, const double* L, const double* Wre, const double* Wim, double* Xre,
+               double* Xim, hipStream_t st) {
+  hipLaunchKernelGGL((k_backsolve_reg<NS>), dim3(nbl), dim3(512), 0, st, L, Wre, Wim, Xre, Xim, npad, TP, ld);
+  HPX_HIP(hipGetLastError());
+  return HPX_OK;
+}
+
+}  // namespace
+
+// 1 where the register-resident form is the faster one.  It is correct for orders up to 656 (41 tiles) and any
+// number of right-hand sides, but: from 18 tiles on (three or more accumulator slots per wave) the accumulators,
+// the L operands of the next step and the temporaries no longer fit 256 registers without spills, and every spill
+// reload waits for the operand prefetch in flight -- 1.57 ms against 0.84 ms at C3 (33 tiles) on MI355X; with more
+// than two t-tiles the factor is read once per pair of them.  At 17 tiles (N = 256): 0.077 against 0.095 ms for 64
+// baselines, 0.32 against 0.32 ms for 1024.
+int hpx_backsolve_reg_ok(int npad, int TP) { return (npad >> 4) <= 17 && TP <= 32; }
+
+int hpx_launch_backsolve_reg(int nbl, int npad, int TP, int ld, const double* L, const double* Wre, const double* Wim,
+                             double* Xre, double* Xim, hipStream_t st) {
+  const int nct = npad >> 4;
+  const int ns = (nct - 1 + 7) / 8;                   // tile rows with a tile row below them, per wave
+  switch (ns) {
+    case 0: return launch_reg<0>(nbl, npad, TP, ld, L, Wre, Wim, Xre, Xim, st);
+    case 1: return launch_reg<1>(nbl, npad, TP, ld, L, Wre, Wim, Xre, Xim, st);
+    case 2: return launch_reg<2>(nbl, npad, TP, ld, L, Wre, Wim, Xre, Xim, st);
+    case 3: return launch_reg<3>(nbl, npad, TP, ld, L, Wre, Wim, Xre, Xim, st);
+    case 4: return launch_reg<4>(nbl, npad, TP, ld, L, Wre, Wim, Xre, Xim, st);
+    case 5: return launch_reg<5>(nbl, npad, TP, ld, L, Wre, Wim, Xre, Xim, st);
+    default: break;
+  }
+  hpx_set_error("hpx_launch_backsolve_reg: order %d not handled", npad);
+  return HPX_EINVAL;
+}

@@ -995,6 +995,9 @@ int hpx_launch_factor(int nbl, int npad, int ld, double* L, double* Wre, double*
 
 int hpx_launch_backsolve(int nbl, int npad, int TP, int ld, const double* L, const double* Wre,
                          const double* Wim, double* Xre, double* Xim, hipStream_t st) {
+#ifndef HPX_BACKSOLVE_OLD
+  if (hpx_backsolve_reg_ok(npad, TP)) return hpx_launch_backsolve_reg(nbl, npad, TP, ld, L, Wre, Wim, Xre, Xim, st);
+#endif
   hipLaunchKernelGGL(k_backsolve, dim3(nbl), dim3(256), 0, st, L, Wre, Wim, Xre, Xim, npad, TP, ld);
   HPX_HIP(hipGetLastError());
   return HPX_OK;

@@ -324,6 +324,10 @@ int hpx_launch_solve_flat(hpx_plan* p, int iter_tag, hipStream_t st);
 size_t hpx_flat_lds_bytes(const hpx_plan* p);
 int hpx_launch_backsolve(int nbl, int npad, int TP, int ld, const double* L, const double* Wre,
                          const double* Wim, double* Xre, double* Xim, hipStream_t st);
+// the register-resident form (hpx_backsolve.hip): small orders, up to 32 right-hand sides
+int hpx_backsolve_reg_ok(int npad, int TP);
+int hpx_launch_backsolve_reg(int nbl, int npad, int TP, int ld, const double* L, const double* Wre, const double* Wim,
+                             double* Xre, double* Xim, hipStream_t st);
 // out[b][x][c] = scale * sum_k W[x][k] in[b][k][c] (W = fop or conj(fop)), optional
 // row scaling of the input by rs[b][k]; ncol multiple of 16; matrices [NP][NP].
 extern int hpx_dft_use_fft;
