@@ -145,7 +145,8 @@ def cpu_baseline_multiproc(N, T, M, flag_frac, niter=8, max_procs=None):
                        f"slowest {max(secs):.1f} s, wall incl. start-up {wall:.1f} s")
 
 
-DENSE_STEP_SOURCES = ("hpx_factor.hip", "hpx_chain.hip", "hpx_transform.hip", "hpx_internal.h", "hpx_fft.h", "Makefile")
+DENSE_STEP_SOURCES = ("hpx_factor.hip", "hpx_factor_wide.hip", "hpx_backsolve.hip", "hpx_chain.hip", "hpx_transform.hip",
+                      "hpx_internal.h", "hpx_fft.h", "Makefile")
 
 
 def kernel_source_hash():
@@ -192,7 +193,8 @@ def roofline_for(solver, stage, nbl, N, M, T, fmax, K, traffic, peak_meas):
         ms = stage["factor"] / K
         fl = flops_factor(N, M, T)
         ach = nbl * fl / (ms * 1e-3) / 1e12
-        return {"kernel": "k_factor (batched complex Cholesky + forward solve, FP64 MFMA)", "bound": "mfma",
+        return {"kernel": "k_factor_wide / k_factor (batched complex Cholesky + forward solve, FP64 MFMA; the wide form from "
+                          "order 400 on)", "bound": "mfma",
                 "achieved": ach, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": ach / FP64_MFMA_PEAK_TFLOPS, "traffic": traffic,
                 "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; see profiles/pmc_traffic.json "
@@ -572,17 +574,35 @@ def main():
 
     if W > 0:
         first = gb.run(W, ps0=ps0)
+    # ---- the timed region (the metric): exactly K steps, no profiling events, barrier + synchronize on both sides
     barrier()
-    gb.plan.set_profiling(True)
+    gb.plan.set_profiling(False)
     t0 = time.perf_counter()
     out = gb.run(K, ps0=ps0 if W == 0 else None)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    stage = gb.plan.stage_ms()
     if dist is not None:
         tt = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
+        dist.barrier()
+    torch.cuda.synchronize()
+    # ---- the same K steps again with a HIP event between the stages of every iteration (hpx_plan_stage_ms):
+    # where `stage_ms_per_step` and `roofline.avg_launch_ms` come from; ~2 % slower than the metric's run
+    gb.iter_done = W
+    barrier()
+    gb.plan.set_profiling(True)
+    t0 = time.perf_counter()
+    out_ev = gb.run(K, ps0=(first["ps_last"] if W > 0 else ps0))
+    torch.cuda.synchronize()
+    dt_events = time.perf_counter() - t0
+    stage = gb.plan.stage_ms()
+    events_same_chain = bool(torch.equal(out_ev["signal_ps"], out["signal_ps"]))
+    del out_ev
+    if dist is not None:
+        tt = torch.tensor([dt_events], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt_events = float(tt.item())
         dist.barrier()
     torch.cuda.synchronize()
 
@@ -661,13 +681,20 @@ def main():
                                   "on the general dense path"}
         gf.close()
 
-    # which physical device every rank ran on (a rehearsal pins all ranks to one: HPX_BENCH_DEVICE)
-    devices = [dev_index]
-    if dist is not None:      # one-hot over the device index, summed over the ranks (a plain all-reduce, as for the times)
-        onehot = torch.zeros(64, dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
-        onehot[dev_index % 64] = 1.0
-        dist.all_reduce(onehot, op=dist.ReduceOp.SUM)
-        devices = [i for i in range(64) if float(onehot[i].item()) > 0]
+    # which physical device every rank ran on (a rehearsal pins all ranks to one: HPX_BENCH_DEVICE).  The
+    # identity is (host name, device uuid / PCI bus id), not the local index: ranks on two nodes, or ranks
+    # that each see their card as device 0 through HIP_VISIBLE_DEVICES, must not collapse into one device.
+    import hashlib, socket
+    prop = torch.cuda.get_device_properties(dev_index)
+    ident = f"{socket.gethostname()}|{getattr(prop, 'uuid', '')}|{getattr(prop, 'pci_bus_id', '')}|" \
+            f"{getattr(prop, 'pci_device_id', '')}|{os.environ.get('HIP_VISIBLE_DEVICES', '')}|{dev_index}"
+    my_id = int.from_bytes(hashlib.sha1(ident.encode()).digest()[:6], "big")      # 48 bits: exact in a float64
+    devices = [my_id]
+    if dist is not None:      # every rank's id in its own slot, summed over the ranks (a plain all-reduce, as for the times)
+        ids = torch.zeros(world, dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+        ids[rank] = float(my_id)
+        dist.all_reduce(ids, op=dist.ReduceOp.SUM)
+        devices = [int(v) for v in ids.tolist()]
     if rank == 0:
         total_units = sum(counts) * K
         value = total_units / dt
@@ -712,6 +739,12 @@ def main():
                                    "7-bin prior, fp64",
                        "baselines_total": int(sum(counts)), "sharding": "contiguous blocks by baseline index, "
                        "no collective"},
+            "value_no_events": value,
+            "value_with_stage_events": total_units / dt_events,
+            "events_note": "`value` is the event-free run (exactly K steps between barrier + synchronize); "
+                           "`value_with_stage_events` is the same K steps again with a HIP event between the stages of "
+                           "every iteration -- the run `stage_ms_per_step` and `roofline.avg_launch_ms` come from; same "
+                           f"chain bit for bit: {events_same_chain}",
             "value_incl_transfers": total_units / dt_incl,
             "incl_transfers_note": f"the same {K} steps with the (Niter, Nfreq) random tables uploaded from host memory "
                                    f"and P(k) + ln-posterior ({(ps_host.numel() + ln_host.numel()) * 8 / 1e6:.0f} MB per GPU) "

@@ -298,8 +298,13 @@ __device__ HPX_INL bool elim16(const WideCtx& X, const int tcol /* global tile c
   if (!low) Dm[ib * 17 + q] = (cplx){0.0, 0.0};               // diagonal and above stay zero in LDS
   double yr = dia ? 1.0 : 0.0, yi = 0.0;
   __builtin_amdgcn_s_setprio(2);
+#ifdef HPX_DBG_F_NOELIM
+  if (dia) dg[ib] = dr;
+  for (int k = 0; k < 0; ++k) {
+#else
 #pragma unroll
   for (int k = 0; k < 16; ++k) {
+#endif
     if (dia) dg[ib] = dr; else if (low) Dm[ib * 17 + q] = (cplx){dr, di};
     Ym[ib * 17 + q] = (cplx){yr, yi};
     lds_barrier();
@@ -496,6 +501,7 @@ __device__ HPX_INL bool diag_factor(const WideCtx& X, const int ct0, d4 (&a1)[9]
       }
     }
     // (3) tiles below: X^T[c'][r'] = sum_c conj(inv(L)[c'][c]) D^T[c][r'], stored and handed to the others
+#ifndef HPX_DBG_F_NOX
 #pragma unroll
     for (int s = 0; s < 9; ++s)
       if (tc[s] == i && tr[s] > i) {
@@ -519,6 +525,7 @@ __device__ HPX_INL bool diag_factor(const WideCtx& X, const int ct0, d4 (&a1)[9]
           xs[k * 32 + li + 16 * (1 - (k & 1))] = xi[v];
         }
       }
+#endif
     lds_barrier();
     // (3b) even tile of a pair: T = L10 inv(L00), kept in registers until the pair's second inverse exists
     if (!(i & 1) && X.wave == ((i >> 1) & 3)) {
@@ -537,6 +544,7 @@ __device__ HPX_INL bool diag_factor(const WideCtx& X, const int ct0, d4 (&a1)[9]
       }
     }
     // (4) trailing tiles: D^T[c'][r'] -= sum_k conj(X(c,i)[c'][k]) X(r,i)[r'][k]
+#ifndef HPX_DBG_F_NOUPD
 #pragma unroll
     for (int s = 0; s < 9; ++s)
       if (tc[s] > i) {
@@ -552,6 +560,7 @@ __device__ HPX_INL bool diag_factor(const WideCtx& X, const int ct0, d4 (&a1)[9]
           a2[s] = mfma64(pi, br, a2[s]);
         }
       }
+#endif
   }
   __syncthreads();        // F's stores (L_JJ, Vt) are complete before the passes stage them
   return bad;

@@ -4,7 +4,7 @@
 #   stats of the C3 / C5-auto / dpss / oqe benches; PMC passes (FETCH_SIZE, WRITE_SIZE, MFMA busy, L2 hits)
 #   of the C3 bench, one counter set per pass; the FETCH_SIZE calibration probe.
 # usage: tools/gpu_profile_round.sh <tag>      e.g. r02
-TAG=${1:-r03}
+TAG=${1:-r04}
 export TMPDIR=/tmp
 R=$PWD; O=$R/gpurun_out/prof; mkdir -p $O
 line() { grep -o '{"metric.*' $1 > $2; }
@@ -63,7 +63,9 @@ for i, f in enumerate(sorted(glob.glob(O + "/pmc*/*/*counter_collection.csv")), 
         n = len(next(iter(acc[k].values())))
         lines.append("pass%d %-34s n=%2d dur_ms=%7.3f %s" % (i, k[:34], n, sum(dur[k]) / len(dur[k]) / 1e6,
                                                            " ".join("%s=%.4g" % kv for kv in cs.items())))
-        tot.setdefault(k.split("<")[0], {}).update(cs)
+        kk = k.split("<")[0]
+        kk = {"k_factor_wide": "k_factor", "k_backsolve_reg": "k_backsolve"}.get(kk, kk)     # (one name per stage)
+        tot.setdefault(kk, {}).update(cs)
 lines += ["", "FETCH_SIZE calibration (tools/fetch_calib.hip: 1 GiB = 1048576 KB streamed once per shape):"]
 for f in glob.glob(O + "/calib/*/*counter_collection.csv"):
     acc = collections.defaultdict(list)
