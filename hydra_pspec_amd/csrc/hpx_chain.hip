@@ -1210,7 +1210,8 @@ static int plan_create_impl(hpx_plan** out, int nbl, int T, int N, int M, int ex
 #define A_(ptr, cnt) if (rc == HPX_OK) rc = dev_alloc(p, &p->ptr, (cnt))
   A_(L, nb * lsz * 2);
   A_(Wre, nb * p->nblk * 1024); A_(Wim, nb * p->nblk * 1024);
-  A_(Vt, nb * (size_t)p->npad * 32);
+  A_(Vt, nb * HPX_VT_STRIDE(p->npad));
+  if (rc == HPX_OK && hipMemset(p->Vt, 0, nb * HPX_VT_STRIDE(p->npad) * sizeof(double)) != hipSuccess) rc = HPX_EHIP;
   A_(Xre, nb * xsz); A_(Xim, nb * xsz);
   A_(info, nb);
   A_(ia, nb * N); A_(ps_cur, nb * N); A_(beta, nb * N); A_(betam, nb * N); A_(lnp1, nb);
@@ -1876,7 +1877,8 @@ extern "C" int hpx_plan_set_solver(hpx_plan* p, int mode) {
     HPX_TRY(dev_alloc(p, &p->lr_L, nb * ns * lds_ * 2));
     HPX_TRY(dev_alloc(p, &p->lr_Wre, nb * nblkS * 1024));
     HPX_TRY(dev_alloc(p, &p->lr_Wim, nb * nblkS * 1024));
-    HPX_TRY(dev_alloc(p, &p->lr_Vt, nb * ns * 32));
+    HPX_TRY(dev_alloc(p, &p->lr_Vt, nb * HPX_VT_STRIDE(ns)));
+    HPX_HIP(hipMemset(p->lr_Vt, 0, nb * HPX_VT_STRIDE(ns) * sizeof(double)));
     HPX_TRY(dev_alloc(p, &p->lr_Yre, nb * ns * p->TP));
     HPX_TRY(dev_alloc(p, &p->lr_Yim, nb * ns * p->TP));
     HPX_HIP(hipMemcpy(p->lr_flist, list.data(), list.size() * sizeof(int32_t), hipMemcpyHostToDevice));

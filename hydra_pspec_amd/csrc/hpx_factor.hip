@@ -979,6 +979,10 @@ static int launch_factor_t(int nbl, size_t lds, int npad, int ld, double* L, dou
 #endif
 int hpx_launch_factor(int nbl, int npad, int ld, double* L, double* Wre, double* Wim, double* Vt,
                       int32_t* info, int iter_tag, const hpx_gen_batch* gen, hipStream_t st) {
+  if (Vt) {      // a batch too small for one workgroup per CU: several workgroups per system (hpx_factor_split.hip)
+    const int parts = hpx_factor_split_parts(nbl, npad, ld);
+    if (parts) return hpx_launch_factor_split(nbl, parts, npad, ld, L, Wre, Wim, Vt, info, iter_tag, gen, st);
+  }
   if (Vt && npad >= HPX_WIDE_MIN)
     return hpx_launch_factor_wide(nbl, npad, ld, L, Wre, Wim, Vt, info, iter_tag, gen, st);
   const size_t base = sizeof(FactorShared);
@@ -1023,7 +1027,8 @@ static int potr_common(int nb, int n, int nrhs, const double* a, const double* r
   HPX_HIP(hipMalloc(&s.L, 2 * lbytes));
   HPX_HIP(hipMalloc(&s.Wre, (size_t)nb * nblk * 1024 * sizeof(double)));
   HPX_HIP(hipMalloc(&s.Wim, (size_t)nb * nblk * 1024 * sizeof(double)));
-  HPX_HIP(hipMalloc(&s.Vt, (size_t)nb * npad * 32 * sizeof(double)));
+  HPX_HIP(hipMalloc(&s.Vt, (size_t)nb * HPX_VT_STRIDE(npad) * sizeof(double)));
+  HPX_HIP(hipMemsetAsync(s.Vt, 0, (size_t)nb * HPX_VT_STRIDE(npad) * sizeof(double), st));
   if (info) HPX_HIP(hipMemsetAsync(info, 0, (size_t)nb * sizeof(int32_t), st));
   hipLaunchKernelGGL(k_pack_herm, dim3(64, nb), dim3(256), 0, st, a, rhs, s.L, n, nrhs, npad, ld);
   HPX_HIP(hipGetLastError());

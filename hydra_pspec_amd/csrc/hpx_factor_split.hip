@@ -1,0 +1,337 @@
+// Batched complex-Hermitian Cholesky, split form: SEVERAL workgroups per system, for batches too small to give
+// every CU a system of its own (BASELINE config 2: 64 systems of order 272 on 256 CUs).
+//
+// With one workgroup per system such a batch runs on a quarter of the chip and each system's 17 tile columns go
+// through one CU's latency chain (elimination -> tiles below -> trailing update) one after the other.  Here a
+// system's 16 x 16 tiles are dealt over `parts` workgroups x 8 waves and stay in REGISTERS for the whole
+// factorisation (right-looking): tile (r, c) belongs to workgroup r mod parts, wave (r / parts + c) mod 8 -- a
+// column's tiles of one workgroup sit in different waves.  Per tile column j
+//   E  the owner of the diagonal tile runs the fused 16 x 16 Cholesky + inverse (elim16), stores L_jj and
+//      inv(L_jj) (Vt) and releases flag A[j];
+//   B  every workgroup takes inv(L_jj) (from LDS if it is the owner, else from Vt once A[j] is up), forms its
+//      tiles of the column, X(r, j) = D(r, j) inv(L_jj)^H, stores them into the
+//      factor and counts itself in on B[j];
+//   D  once B[j] shows all parts, the column (rows j+1 .. nrt-1) is copied into LDS once per workgroup (LDS-DMA;
+//      the workgroup's own tiles were put there by B) and every wave updates its trailing tiles
+//      D(r, c) -= X(r, j) X(c, j)^H.
+// Look-ahead: the owner of diagonal tile j+1 also owns X(j+1, j), the only operand that tile's last update
+// needs, so it runs E(j+1) BEFORE its own D(j) -- the chain from one elimination to the next is one flag
+// hand-off plus one tile product, and the trailing updates of all parts run beside it.
+//
+// Hand-off: release / acquire at agent scope on counters in the system's Vt block (HPX_VT_SYNC), no grid
+// sync; the parts of a system are placed on one XCD (block index mod 8) so the data they exchange stays in one
+// L2.  The LAST part to finish zeroes the system's counters again.  The launch never exceeds one workgroup per CU
+// of the device, so every part is resident (or becomes so without any other part's help) and every spin ends;
+// a spin that does not (it never should) gives up after SPIN_LIMIT polls and flags the system in `info`.
+#include "hpx_factor_tiles.h"
+
+namespace {
+
+constexpr int SPLIT_NS = 10;            // register tile slots per wave
+constexpr int SPLIT_NW = 8;             // waves per workgroup
+constexpr int SPLIT_MAX_CT = 40;        // tile columns the counter block holds
+constexpr unsigned SPIN_LIMIT = 1u << 22;
+static_assert(2 * SPLIT_MAX_CT + 1 <= 2 * HPX_VT_SYNC, "counters must fit the Vt block's sync area");
+
+// wave-uniform wait for *flag >= target
+__device__ HPX_INL bool spin_until(int* flag, const int target) {
+  unsigned n = 0;
+  while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) {
+    __builtin_amdgcn_s_sleep(4);
+    if (++n > SPIN_LIMIT) return false;
+  }
+  return true;
+}
+
+template <bool GEN>
+__global__ __launch_bounds__(64 * SPLIT_NW, 2) void k_factor_split(double* __restrict__ L_all, double* __restrict__ Wre_all,
+                                                         double* __restrict__ Wim_all, double* __restrict__ Vt_all,
+                                                         int32_t* __restrict__ info, const int npad, const int ld,
+                                                         const int iter_tag, const hpx_gen_batch GB, const int nbl,
+                                                         const int parts) {
+  extern __shared__ double lds_panel[];        // [nrt][512]: the current column's tiles (odd-column swizzle)
+  const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+  const int b = (idx / parts) * 8 + xcd, w = idx % parts;
+  if (b >= nbl) return;
+  const int tid = threadIdx.x;
+  hpx_gen G = {};
+  if (GEN) G = hpx_gen_for(GB, b);
+  WideCtx X;
+  X.tid = tid;
+  X.wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  X.lane = tid & 63;
+  X.npad = npad;
+  X.nct = npad >> 4;
+  X.nrt = ld >> 4;
+  X.ptile = (long)npad * 32;
+  X.Lb = L_all + (long)b * npad * ld * 2;
+  X.Vt = Vt_all + (long)b * HPX_VT_STRIDE(npad);
+  const int nblk = (npad + HPX_NB - 1) / HPX_NB;
+  X.Wgre = Wre_all + (long)b * nblk * 1024;
+  X.Wgim = Wim_all + (long)b * nblk * 1024;
+  int* const flagA = (int*)(X.Vt + (long)npad * 32);
+  int* const cntB = flagA + SPLIT_MAX_CT;
+  int* const done = cntB + SPLIT_MAX_CT;
+  GenVec<false> V = {};
+  if constexpr (GEN) {
+    V.ia = (const glb_f64*)G.ia;
+    V.cre = (const glb_f64*)G.cre;
+    V.cim = (const glb_f64*)G.cim;
+  }
+  // the lane's indices, re-derived through an empty asm in every step: otherwise each slot's LDS addresses become
+  // loop invariants that outlive the registers (spilled, and reloaded in the middle of the hand-off chain)
+  int lane = X.lane, li = lane & 15, g = lane >> 4;
+  unsigned src_lane = 0;
+  int rd_re = 0, rd_im = 0;
+  lds_f64* const Pn = (lds_f64*)lds_panel;
+  lds_f64* const Ein = (lds_f64*)hpx_stage0;
+  lds_f64* const Vs = (lds_f64*)(hpx_stage1 + FV_OFF);
+
+  // ---- the wave's tiles: rows r = w + k parts; of row k the columns c = (wave - k) mod 8, + 8, ... (<= the diagonal)
+  int tr[SPLIT_NS], tc[SPLIT_NS];
+  d4 a1[SPLIT_NS], a2[SPLIT_NS];               // re, im of D^T[c][r]: lane li <-> row, register v <-> column g + 4 v
+  {
+    int r = w, k = 0, c = X.wave;
+#pragma unroll
+    for (int s = 0; s < SPLIT_NS; ++s) {
+      while (r < X.nrt && c > min(r, X.nct - 1)) { r += parts; ++k; c = (X.wave - k) & (SPLIT_NW - 1); }
+      if (r < X.nrt) {
+        tr[s] = r;
+        tc[s] = c;
+        tile_init<GEN, false>(G, V, X.Lb, r * 16, c * 16, npad, li, g, a1[s], a2[s]);
+        c += SPLIT_NW;
+        __builtin_amdgcn_sched_barrier(0);
+      } else {
+        tr[s] = 0;
+        tc[s] = -1;
+        a1[s] = (d4){0., 0., 0., 0.};
+        a2[s] = a1[s];
+      }
+    }
+  }
+  bool bad = false, timed_out = false;
+
+  // E: the diagonal tile t (held by one wave of this workgroup, fully updated) -> L_tt, inv(L_tt), W
+  auto eliminate = [&](const int t) {
+    {
+#pragma unroll
+      for (int s = 0; s < SPLIT_NS; ++s)
+        if (tr[s] == t && tc[s] == t) {
+#pragma unroll
+          for (int v = 0; v < 4; ++v) {
+            Ein[li * 16 + HPX_ACC_ROW(g, v)] = a1[s][v];
+            Ein[256 + li * 16 + HPX_ACC_ROW(g, v)] = a2[s][v];
+          }
+        }
+    }
+    lds_barrier();
+    if (X.wave < 4) bad |= elim16(X, t, t + 1 == X.nct);     // (written for 256 threads)
+    else elim16_idle();
+    // odd tile of a pair: W10 = -inv(L11) L10 inv(L00); L10 = X(t, t-1) was stored by this workgroup in B(t-1),
+    // inv(L00) by the owner of tile t-1 (flag A[t-1] acquired in step t-1)
+    if ((t & 1) && X.wave == 4) {
+      d4 tre = {0., 0., 0., 0.}, tim = tre;
+      const double* l10 = X.Lb + HPX_LIDX(t * 16 + li, t * 16 - 16 + g, X.npad);   // L10[r = li][k = 4 v + g]
+      const double* v00 = X.Vt + (long)(t - 1) * 512 + li * 32 + g;                // inv(L00)[k = 4 v + g][c' = li]
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const double ar = l10[(4 * v) * 32], ai = l10[(4 * v) * 32 + 16];
+        const double br = v00[4 * v], bm = v00[4 * v + 16];
+        tre = mfma64(ar, br, tre);
+        tre = mfma64(-ai, bm, tre);
+        tim = mfma64(ar, bm, tim);
+        tim = mfma64(ai, br, tim);
+      }
+      d4 zr = {0., 0., 0., 0.}, zi = zr;
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const double ar = Vs[v * 128 + rd_re], ai = Vs[v * 128 + rd_im];
+        zr = mfma64(-ar, tre[v], zr);
+        zr = mfma64(ai, tim[v], zr);
+        zi = mfma64(-ar, tim[v], zi);
+        zi = mfma64(-ai, tre[v], zi);
+      }
+      double* wgr = X.Wgre + (long)(t >> 1) * 1024;
+      double* wgi = X.Wgim + (long)(t >> 1) * 1024;
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        wgr[(16 + HPX_ACC_ROW(g, v)) * 32 + li] = zr[v];
+        wgi[(16 + HPX_ACC_ROW(g, v)) * 32 + li] = zi[v];
+      }
+    }
+    __syncthreads();                           // every wave's stores have left before the flag goes up
+    if (tid == 0) __hip_atomic_store(&flagA[t], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  };
+  // one trailing update D(r, c) -= X(r, j) X(c, j)^H from the column in LDS
+  auto update = [&](d4& re, d4& im, const int r, const int c) {
+    const lds_f64* pa = Pn + c * 512;
+    const lds_f64* pb = Pn + r * 512;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const double pr = pa[v * 128 + rd_re], pi = pa[v * 128 + rd_im];
+      const double br = pb[v * 128 + rd_re], bm = pb[v * 128 + rd_im];
+      re = mfma64(-pr, br, re);
+      re = mfma64(-pi, bm, re);
+      im = mfma64(-pr, bm, im);
+      im = mfma64(pi, br, im);
+    }
+  };
+
+  // step j = -1 is the first elimination alone: E(0) is "the look-ahead of the column before the first"
+  for (int j = -1; j < X.nct; ++j) {
+    lane = opaque(X.lane);
+    li = lane & 15;
+    g = lane >> 4;
+    src_lane = g * 32 + 2 * ((li + 8 * (g & 1)) & 15);
+    rd_re = g * 32 + li + 16 * (g & 1);
+    rd_im = g * 32 + li + 16 * (1 - (g & 1));
+    if (j >= 0) {
+      const int wj = j % parts;
+      // ---- inverse of the diagonal tile -> Vs
+      if (w != wj) {
+        if (X.wave == 0) {
+          if (!spin_until(&flagA[j], 1)) timed_out = true;
+          glds_tile(X.Vt + (long)j * 512, 8 * src_lane, lds_addr(hpx_stage1 + FV_OFF));
+          wait_vm<0>();
+        }
+        wg_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      }
+      // ---- B: the workgroup's tiles of column j, into the factor and into the LDS column
+#pragma unroll
+      for (int s = 0; s < SPLIT_NS; ++s)
+        if (tc[s] == j && tr[s] > j) {
+          d4 xr = {0., 0., 0., 0.}, xi = {0., 0., 0., 0.};
+#pragma unroll
+          for (int v = 0; v < 4; ++v) {
+            const double pr = Vs[v * 128 + rd_re], pi = Vs[v * 128 + rd_im];
+            xr = mfma64(pr, a1[s][v], xr);
+            xr = mfma64(pi, a2[s][v], xr);
+            xi = mfma64(pr, a2[s][v], xi);
+            xi = mfma64(-pi, a1[s][v], xi);
+          }
+          double* o_ = X.Lb + HPX_LIDX(tr[s] * 16 + li, j * 16 + g, X.npad);
+          lds_f64* xs = Pn + tr[s] * 512;
+#pragma unroll
+          for (int v = 0; v < 4; ++v) {
+            o_[(4 * v) * 32] = xr[v];
+            o_[(4 * v) * 32 + 16] = xi[v];
+            const int k = g + 4 * v;                         // column of the tile; row li
+            xs[k * 32 + li + 16 * (k & 1)] = xr[v];
+            xs[k * 32 + li + 16 * (1 - (k & 1))] = xi[v];
+          }
+        }
+      __syncthreads();                           // the column's stores have left (and its LDS copies are visible)
+      if (tid == 0) __hip_atomic_fetch_add(&cntB[j], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      if (j + 1 == X.nct) break;                 // last column: nothing to its right
+    }
+    // ---- look-ahead: the next diagonal tile's last update needs only this workgroup's own X(j+1, j)
+    const bool ahead = (w == (j + 1) % parts);
+    if (ahead) {
+      if (j >= 0) {
+#pragma unroll
+        for (int s = 0; s < SPLIT_NS; ++s)
+          if (tr[s] == j + 1 && tc[s] == j + 1) update(a1[s], a2[s], j + 1, j + 1);
+      }
+      eliminate(j + 1);
+    }
+    if (j < 0) continue;
+    // ---- D: the other parts' tiles of the column -> LDS, then the trailing updates
+    if (X.wave == 0 && !spin_until(&cntB[j], parts)) timed_out = true;
+    wg_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    {
+      int n = 0;
+      for (int r = j + 1; r < X.nrt; ++r) {
+        if (r % parts == w) continue;
+        if ((n++ & (SPLIT_NW - 1)) == X.wave)
+          glds_tile(X.Lb + HPX_LIDX(r * 16, j * 16, X.npad), 8 * src_lane, lds_addr(lds_panel + r * 512));
+      }
+      wait_vm<0>();
+      wg_barrier();
+    }
+#pragma unroll
+    for (int s = 0; s < SPLIT_NS; ++s) {
+      if (tc[s] > j && !(ahead && tr[s] == j + 1 && tc[s] == j + 1)) update(a1[s], a2[s], tr[s], tc[s]);
+      __builtin_amdgcn_sched_barrier(0);       // one tile's operands at a time: the accumulators need the registers
+    }
+    lds_barrier();                             // the LDS column and Vs are free again
+  }
+  __syncthreads();
+  if (tid == 0) {
+    const int old = __hip_atomic_fetch_add(done, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    if (old == parts - 1) {                    // every part is past its last wait: leave the counters zero
+      for (int i = 0; i < 2 * SPLIT_MAX_CT + 1; ++i) flagA[i] = 0;
+    }
+  }
+  if ((bad || timed_out) && info) atomicCAS(&info[b], 0, iter_tag);
+}
+
+struct SplitDevice {
+  int cus[32] = {};
+  int get() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 32) return 0;
+    if (!cus[dev]) {
+      int n = 0;
+      if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+      cus[dev] = n;
+    }
+    return cus[dev];
+  }
+};
+
+// most tiles any wave holds with `parts` workgroups per system
+int split_slots(const int parts, const int nct, const int nrt) {
+  int most = 0;
+  for (int w = 0; w < parts; ++w)
+    for (int v = 0; v < SPLIT_NW; ++v) {
+      int n = 0, k = 0;
+      for (int r = w; r < nrt; r += parts, ++k)
+        for (int c = (v - k) & (SPLIT_NW - 1); c <= (r < nct - 1 ? r : nct - 1); c += SPLIT_NW) ++n;
+      if (n > most) most = n;
+    }
+  return most;
+}
+
+template <bool GEN>
+int launch_split_t(int nbl, int parts, int npad, int ld, double* L, double* Wre, double* Wim, double* Vt, int32_t* info,
+                   int iter_tag, const hpx_gen_batch& gen, hipStream_t st) {
+  static hpx_lds_limit limit;
+  const size_t lds = (size_t)(ld >> 4) * 512 * sizeof(double);
+  HPX_TRY(limit.ensure(reinterpret_cast<const void*>(&k_factor_split<GEN>), lds));
+  const int grid = 8 * ((nbl + 7) / 8) * parts;
+  hipLaunchKernelGGL((k_factor_split<GEN>), dim3(grid), dim3(64 * SPLIT_NW), lds, st, L, Wre, Wim, Vt, info, npad, ld, iter_tag,
+                     gen, nbl, parts);
+  HPX_HIP(hipGetLastError());
+  return HPX_OK;
+}
+
+}  // namespace
+
+// Workgroups per system for a batch of nbl systems, or 0 when the split form does not apply: the batch must leave
+// at least half of the CUs without a system, every part must be resident at one workgroup per CU, a wave's tiles must
+// fit its registers and the column its LDS.
+int hpx_factor_split_parts(int nbl, int npad, int ld) {
+#ifdef HPX_NO_SPLIT
+  return 0;
+#endif
+  static SplitDevice dev;
+  const int cus = dev.get();
+  const int nct = npad >> 4, nrt = ld >> 4;
+  if (cus <= 0 || nbl <= 0 || nct < 2 || nct > SPLIT_MAX_CT) return 0;
+  if ((size_t)nrt * 4096 + 2 * BUF_D * sizeof(double) > (size_t)156 * 1024) return 0;
+  const int live = 8 * ((nbl + 7) / 8);        // block indices are dealt in eights (one system's parts on one XCD)
+  for (int parts = 8; parts >= 2; parts >>= 1)
+    if (live * parts <= cus) return split_slots(parts, nct, nrt) <= SPLIT_NS ? parts : 0;
+  return 0;
+}
+
+int hpx_launch_factor_split(int nbl, int parts, int npad, int ld, double* L, double* Wre, double* Wim, double* Vt,
+                            int32_t* info, int iter_tag, const hpx_gen_batch* gen, hipStream_t st) {
+  if (!gen) {
+    hpx_gen_batch none = {};
+    return launch_split_t<false>(nbl, parts, npad, ld, L, Wre, Wim, Vt, info, iter_tag, none, st);
+  }
+  return launch_split_t<true>(nbl, parts, npad, ld, L, Wre, Wim, Vt, info, iter_tag, *gen, st);
+}

@@ -34,216 +34,9 @@
 // s_waitcnt vmcnt(0) after every stage, i.e. no chunk in flight behind the computation at all.  For the same
 // reason the counted waits are the s_waitcnt builtin (visible to that analysis), fenced against compiler
 // motion by empty asm statements.
-#include "hpx_internal.h"
-
-#define HPX_INL __forceinline__
+#include "hpx_factor_tiles.h"
 
 namespace {
-
-typedef __attribute__((address_space(3))) double lds_f64;
-typedef double cplx __attribute__((ext_vector_type(2)));
-typedef __attribute__((address_space(3))) cplx lds_cplx;
-
-constexpr int KC = 16;             // columns per chunk
-constexpr int PP = KC / 4;         // 1 KB pieces (4 columns) per tile and chunk = k-steps per chunk
-constexpr int TILE_D = KC * 32;    // doubles of one tile's chunk
-constexpr int BUF_D = 8 * TILE_D;  // eight tiles per buffer
-
-__shared__ double hpx_stage0[BUF_D];
-__shared__ double hpx_stage1[BUF_D];
-template <int PAR> __device__ HPX_INL double* stage_buf() { return PAR ? hpx_stage1 : hpx_stage0; }
-// F's scratch over the staging buffers: Xs[8 tiles][512] = buffer 0 (slot 0: the diagonal tile handed to the
-// elimination; the K-split partial sums of narrow_column in slots 1..4); in buffer 1 one inverse tile and the
-// elimination's matrices
-constexpr int FV_OFF = 0, FD_OFF = 512, F_END = FD_OFF + 2 * 2 * 16 * 17 + 16;
-static_assert(F_END <= BUF_D, "F scratch must fit a staging buffer");
-
-// ---- vector-memory traffic of the staged loops: ALL of it through inline asm, waits included ----------------
-// The compiler's own s_waitcnt insertion cannot be used here: once an LDS-DMA and an ordinary global load are
-// both in flight it waits with vmcnt(0) at the first use of the loaded register (measured: the next chunk's
-// DMA, just issued, then had to land before the step could compute), and it adds a vmcnt(0) in front of any
-// ds_read that might alias a pending DMA.  Operations issued from asm statements are invisible to it; the
-// counted waits below are placed by hand, on the facts that the counter retires in issue order and that every
-// wave issues the same number of operations per step.  Whatever else the compiler issues in between (the loads
-// of a strip's initial values, a spill) only makes a counted wait stricter, never wrong.
-#pragma clang diagnostic push
-#pragma clang diagnostic ignored "-Winline-asm"
-// one tile's chunk (16 columns = four 1 KB pieces) from (uniform base) + (lane offset, bytes) to the LDS byte
-// address `lds` + 16 lane: the instruction offset moves the global and the LDS address together
-__device__ HPX_INL void glds_tile(const double* ubase, const unsigned lane_bytes, const unsigned lds) {
-  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\t"
-               "global_load_lds_dwordx4 %0, %1\n\t"
-               "global_load_lds_dwordx4 %0, %1 offset:1024\n\t"
-               "global_load_lds_dwordx4 %0, %1 offset:2048\n\t"
-               "global_load_lds_dwordx4 %0, %1 offset:3072"
-               :: "v"(lane_bytes), "s"(ubase), "s"(lds) : "memory", "m0");
-}
-#pragma clang diagnostic pop
-// non-temporal 8-byte load from (uniform base) + (lane offset, bytes) + OFF; the value may be used only behind a
-// wait_vm_keep that names it
-template <int OFF>
-__device__ HPX_INL double ld_nt(const double* ubase, const unsigned lane_bytes) {
-  double r;
-  asm volatile("global_load_dwordx2 %0, %1, %2 offset:%3 nt" : "=v"(r) : "v"(lane_bytes), "s"(ubase), "n"(OFF) : "memory");
-  return r;
-}
-template <int OFF>
-__device__ HPX_INL void st_g(double* ubase, const unsigned lane_bytes, const double v) {
-  asm volatile("global_store_dwordx2 %0, %1, %2 offset:%3" :: "v"(lane_bytes), "v"(v), "s"(ubase), "n"(OFF) : "memory");
-}
-#ifdef HPX_DBG_WAIT0
-#define HPX_WAITN(n_) 0
-#else
-#define HPX_WAITN(n_) (n_)
-#endif
-template <int N>
-__device__ HPX_INL void wait_vm() {
-  asm volatile("s_waitcnt vmcnt(%0)" :: "n"(HPX_WAITN(N)) : "memory");
-}
-// The row-operand registers were written by ld_nt asm statements the compiler knows nothing about: it must
-// not touch them before the wait that covers their loads.  The wait itself has no operands (tied operands
-// let the register allocator put copies of the not-yet-loaded registers IN FRONT of it: observed, as
-// timing-dependent garbage); this anchor follows it, ties the pair, and everything that uses it depends on it.
-__device__ HPX_INL void anchor_pair(double& a, double& b) {
-  asm volatile("" : "+v"(a), "+v"(b));
-}
-__device__ HPX_INL void wg_barrier() {
-  asm volatile("s_barrier" ::: "memory");
-}
-// The compiler's own loads (a tile's initial values from the edge tiles or the factor buffer) are complete, and
-// the compiler knows it: otherwise it waits for them at their first use, a static s_waitcnt vmcnt(0) INSIDE the
-// step loops that drains the hand-placed traffic there on every trip.
-__device__ HPX_INL void wait_compiler_loads() {
-  __builtin_amdgcn_s_waitcnt(0x0f70);
-}
-__device__ HPX_INL unsigned lds_addr(const double* p) {
-  return (unsigned)(unsigned long)(const __attribute__((address_space(3))) double*)p;
-}
-// Workgroup barrier for data handed over through LDS only: the wave's LDS operations are complete, its global
-// stores need not be (__syncthreads() also drains vmcnt, i.e. waits ~1-2 us for every store issued just before).
-__device__ HPX_INL void lds_barrier() {
-  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-}
-__device__ HPX_INL double rsqrt_nr(const double d) {
-  double q = __builtin_amdgcn_rsq(d);
-  q = fma(q * 0.5, fma(-d * q, q, 1.0), q);
-  q = fma(q * 0.5, fma(-d * q, q, 1.0), q);
-  return q;
-}
-#define HPX_NTLD(p_) __builtin_nontemporal_load(p_)
-// The lane / thread index through an empty asm: what is derived from it afterwards (LDS addresses, masks)
-// cannot be hoisted out of the phase it is used in.  Otherwise dozens of such per-thread invariants are
-// computed once at kernel entry, live across the register-bound S and P loops, are spilled there and reloaded
-// inside F -- each reload behind an s_waitcnt vmcnt(0) that drains the stores of the step before (~2 us a time).
-__device__ HPX_INL int opaque(int v) {
-  asm volatile("" : "+v"(v));
-  return v;
-}
-
-// 1 / a and the circulant's first column with their address space in the type (LDS copies when GLDS): through
-// the generic pointers of hpx_gen they become FLAT loads, which count on vmcnt as well and make the compiler
-// wait for everything in flight at their first use
-typedef __attribute__((address_space(1))) double glb_f64;
-template <bool GLDS> struct GenVec;
-template <> struct GenVec<true> { const lds_f64 *ia, *cre, *cim; };
-template <> struct GenVec<false> { const glb_f64 *ia, *cre, *cim; };
-
-struct WideCtx {
-  double* Lb;          // this baseline's factor
-  double* Vt;          // this baseline's inverse diagonal tiles
-  double* Wgre;        // this baseline's 32 x 32 inverse blocks
-  double* Wgim;
-  long ptile;          // doubles per 16-row panel
-  int npad, nct, nrt, wave, lane, tid;
-};
-
-// entry (r, c), r >= c, of the augmented matrix before the factorisation: closed form, edge tiles or
-// the factor buffer (hpx_internal.h)
-template <bool GEN, bool GLDS>
-__device__ HPX_INL void entry_init(const hpx_gen& G, const GenVec<GLDS>& V, const double* __restrict__ Lb, const int r,
-                                   const int c, const int npad, double& vr, double& vi) {
-  if (GEN && c < G.rmin) {
-    if (r < G.rmin) {
-      if (r > c) { vr = V.cre[r - c]; vi = V.cim[r - c]; }
-      else if (r == c) { const double ic = V.ia[c]; vr = fma(ic, ic, V.cre[0]); vi = 0.0; }
-      else { vr = 0.0; vi = 0.0; }
-    } else {
-      hpx_edge_init<GEN>(G, Lb, Lb + 16, r, c, npad, G.ere != nullptr, vr, vi);
-    }
-  } else {
-    const long off = HPX_LIDX(r, c, npad);
-    vr = Lb[off];
-    vi = Lb[off + 16];
-  }
-}
-// the closed-form part of tile_init alone (signal x signal tile, r0 >= c0, both below rmin): no vector-memory
-// instruction on this path when the vectors are in LDS
-template <bool GLDS>
-__device__ HPX_INL void tile_init_closed(const GenVec<GLDS>& V, const int r0, const int c0, const int li, const int g,
-                                         d4& vr, d4& vi) {
-  if (r0 > c0) {
-#pragma unroll
-    for (int v = 0; v < 4; ++v) {
-      const int d = r0 - c0 + li - HPX_ACC_ROW(g, v);
-      vr[v] = V.cre[d];
-      vi[v] = V.cim[d];
-    }
-  } else {
-#pragma unroll
-    for (int v = 0; v < 4; ++v) {
-      const int d = li - HPX_ACC_ROW(g, v);
-      const int dd = d > 0 ? d : 0;
-      const double ic = V.ia[c0 + li];
-      const double cr = V.cre[dd], cm = V.cim[dd];
-      vr[v] = d > 0 ? cr : (d == 0 ? fma(ic, ic, cr) : 0.0);
-      vi[v] = d > 0 ? cm : 0.0;
-    }
-  }
-}
-// the 16 x 16 tile at (r0, c0), r0 >= c0, as acc^T: lane li <-> row r0 + li, register v <-> column c0 + g + 4 v.
-// rmin is a multiple of 32, so a tile lies on one side of it and the source is chosen per tile.
-template <bool GEN, bool GLDS>
-__device__ HPX_INL void tile_init(const hpx_gen& G, const GenVec<GLDS>& V, const double* __restrict__ Lb, const int r0,
-                                  const int c0, const int npad, const int li, const int g, d4& vr, d4& vi) {
-  if (GEN && c0 < G.rmin) {
-    if (r0 < G.rmin) {
-      if (r0 > c0) {
-#pragma unroll
-        for (int v = 0; v < 4; ++v) {
-          const int d = r0 - c0 + li - HPX_ACC_ROW(g, v);
-          vr[v] = V.cre[d];
-          vi[v] = V.cim[d];
-        }
-      } else {
-#pragma unroll
-        for (int v = 0; v < 4; ++v) {
-          const int d = li - HPX_ACC_ROW(g, v);
-          const int dd = d > 0 ? d : 0;
-          const double ic = V.ia[c0 + li];
-          const double cr = V.cre[dd], cm = V.cim[dd];
-          vr[v] = d > 0 ? cr : (d == 0 ? fma(ic, ic, cr) : 0.0);
-          vi[v] = d > 0 ? cm : 0.0;
-        }
-      }
-    } else {
-      const bool use_e = G.ere != nullptr;
-#pragma unroll
-      for (int v = 0; v < 4; ++v) {
-        double a, b;
-        hpx_edge_init<GEN>(G, Lb, Lb + 16, r0 + li, c0 + HPX_ACC_ROW(g, v), npad, use_e, a, b);
-        vr[v] = a;
-        vi[v] = b;
-      }
-    }
-  } else {
-#pragma unroll
-    for (int v = 0; v < 4; ++v) {
-      const long off = HPX_LIDX(r0 + li, c0 + HPX_ACC_ROW(g, v), npad);
-      vr[v] = Lb[off];
-      vi[v] = Lb[off + 16];
-    }
-  }
-}
 
 // ---- staging ---------------------------------------------------------------------------------------
 // Every wave stages two tile slots (2 wave, 2 wave + 1) of every chunk, PP pieces each: a constant
@@ -281,84 +74,6 @@ __device__ HPX_INL void stage_step(const WideCtx& X, const int ct0, const int st
   else stage_t<PAR>(X, ct0, st - nk, src_lane);
 }
 
-// ---- 16 x 16 fused Cholesky + inverse (all 256 threads; hpx_factor.hip diag_panel, steps A / D) -----
-// in: Ein (re | im, row-major [r][c], leading dimension 16) lower part incl. diagonal, written by THIS
-//     thread or in front of a barrier.
-// out: L tile -> global; inv(L) tile -> Vt (global, tile layout, zero above the diagonal), LDS copy `Vs`
-//      (tile layout with the odd-column swizzle), and the 16 x 16 sub-block of the 32 x 32 inverse block.
-__device__ HPX_INL bool elim16(const WideCtx& X, const int tcol /* global tile column */, const bool last_tile) {
-  lds_f64* const Ein = (lds_f64*)hpx_stage0;                  // slot 0 of Xs: re 256 | im 256
-  lds_f64* const Vs = (lds_f64*)(hpx_stage1 + FV_OFF);
-  lds_cplx* const Dm = (lds_cplx*)(hpx_stage1 + FD_OFF);
-  lds_cplx* const Ym = Dm + 16 * 17;
-  lds_f64* const dg = (lds_f64*)(Ym + 16 * 17);
-  const int tid = opaque(X.tid), q = tid & 15, ib = tid >> 4;
-  const bool dia = (q == ib), low = (q < ib);
-  double dr = Ein[ib * 16 + q], di = Ein[256 + ib * 16 + q];
-  if (!low) Dm[ib * 17 + q] = (cplx){0.0, 0.0};               // diagonal and above stay zero in LDS
-  double yr = dia ? 1.0 : 0.0, yi = 0.0;
-  __builtin_amdgcn_s_setprio(2);
-#ifdef HPX_DBG_F_NOELIM
-  if (dia) dg[ib] = dr;
-  for (int k = 0; k < 0; ++k) {
-#else
-#pragma unroll
-  for (int k = 0; k < 16; ++k) {
-#endif
-    if (dia) dg[ib] = dr; else if (low) Dm[ib * 17 + q] = (cplx){dr, di};
-    Ym[ib * 17 + q] = (cplx){yr, yi};
-    lds_barrier();
-    const double dkk = dg[k];
-    const cplx c = Dm[ib * 17 + k], cq = Dm[q * 17 + k], sy = Ym[k * 17 + q];
-    const double r0 = __builtin_amdgcn_rcp(dkk);
-    const double rinv = fma(r0, fma(-dkk, r0, 1.0), r0);
-    const double lr = c.x * rinv, lm = c.y * rinv;
-    yr = fma(-lr, sy.x, yr);
-    yr = fma(lm, sy.y, yr);
-    yi = fma(-lr, sy.y, yi);
-    yi = fma(-lm, sy.x, yi);
-    dr = fma(-lr, cq.x, dr);
-    dr = fma(-lm, cq.y, dr);
-    di = fma(-lm, cq.x, di);
-    di = fma(lr, cq.y, di);
-  }
-  lds_barrier();
-  __builtin_amdgcn_s_setprio(0);
-  bool bad = false;
-  double wr = 0.0, wi = 0.0;
-  if (q <= ib) {
-    const double pq = dg[q], pib = dg[ib];
-    if (!(pq > 0.0) || !(pib > 0.0)) bad = true;
-    const double sq = rsqrt_nr(pq);
-    const long off = HPX_LIDX(tcol * 16 + ib, tcol * 16 + q, X.npad);
-    X.Lb[off] = dr * sq;
-    X.Lb[off + 16] = dia ? 0.0 : di * sq;
-    const double sv = rsqrt_nr(pib);
-    wr = yr * sv;
-    wi = yi * sv;
-  }
-  // inv(L)[ib][q]: tile layout = column q, row ib
-  double* vt = X.Vt + (long)tcol * 512 + q * 32 + ib;
-  vt[0] = wr;
-  vt[16] = wi;
-  Vs[q * 32 + ib + 16 * (q & 1)] = wr;
-  Vs[q * 32 + ib + 16 * (1 - (q & 1))] = wi;
-  const int o = 16 * (tcol & 1);
-  double* wgr = X.Wgre + (long)(tcol >> 1) * 1024;
-  double* wgi = X.Wgim + (long)(tcol >> 1) * 1024;
-  wgr[(o + ib) * 32 + o + q] = wr;
-  wgi[(o + ib) * 32 + o + q] = wi;
-  if (o == 0) {
-    wgr[ib * 32 + 16 + q] = 0.0;                               // upper-right block of the inverse is zero
-    wgi[ib * 32 + 16 + q] = 0.0;
-    if (last_tile) {                                           // 16-wide last block: nothing below either
-      wgr[(16 + ib) * 32 + q] = 0.0; wgi[(16 + ib) * 32 + q] = 0.0;
-      wgr[(16 + ib) * 32 + 16 + q] = 0.0; wgi[(16 + ib) * 32 + 16 + q] = 0.0;
-    }
-  }
-  lds_barrier();
-  return bad;
-}
 
 // ---- S: the diagonal block's update.  Wave W owns tile rows 7 - W and W of the block's lower triangle
 //      (8 - W and W + 1 tiles: nine each): slot s < 8 - W is tile (7 - W, s), the others (W, s - (8 - W)).
@@ -919,7 +634,7 @@ __global__ __launch_bounds__(256, 2) void k_factor_wide(double* __restrict__ L_a
   X.nrt = ld >> 4;
   X.ptile = (long)npad * 32;
   X.Lb = L_all + (long)b * npad * ld * 2;
-  X.Vt = Vt_all + (long)b * npad * 32;
+  X.Vt = Vt_all + (long)b * HPX_VT_STRIDE(npad);
   const int nblk = (npad + HPX_NB - 1) / HPX_NB;
   X.Wgre = Wre_all + (long)b * nblk * 1024;
   X.Wgim = Wim_all + (long)b * nblk * 1024;

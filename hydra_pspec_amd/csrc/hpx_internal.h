@@ -307,12 +307,20 @@ struct hpx_lds_limit {
 // ---- launchers (each returns HPX_OK / HPX_EHIP) -----------------------------
 // gen == nullptr: factor the matrix stored in L in place; otherwise the augmented matrix is generated on the
 // fly from *gen and L is write-only.
-// Vt [nbl][npad * 32]: inverses of the diagonal 16 x 16 tiles in tile layout (workspace of the wide form).
+// Vt [nbl][HPX_VT_STRIDE(npad)]: per system the inverses of the diagonal 16 x 16 tiles in tile layout (npad * 32
+// doubles; workspace of the wide and split forms) and HPX_VT_SYNC doubles of hand-off flags for the split form --
+// zero when allocated, and left zero by every launch.
+#define HPX_VT_SYNC 64
+#define HPX_VT_STRIDE(npad) ((size_t)(npad) * 32 + HPX_VT_SYNC)
 int hpx_launch_factor(int nbl, int npad, int ld, double* L, double* Wre, double* Wim, double* Vt,
                       int32_t* info, int iter_tag, const hpx_gen_batch* gen, hipStream_t st);
 // the wide (128-column super-block, LDS-staged) form, hpx_factor_wide.hip
 int hpx_launch_factor_wide(int nbl, int npad, int ld, double* L, double* Wre, double* Wim, double* Vt,
                            int32_t* info, int iter_tag, const hpx_gen_batch* gen, hipStream_t st);
+// the split form (hpx_factor_split.hip): several workgroups per system, for batches too small to fill the chip
+int hpx_factor_split_parts(int nbl, int npad, int ld);     // workgroups per system, 0 = not applicable
+int hpx_launch_factor_split(int nbl, int parts, int npad, int ld, double* L, double* Wre, double* Wim, double* Vt,
+                            int32_t* info, int iter_tag, const hpx_gen_batch* gen, hipStream_t st);
 // structured solve for flat noise with flags (hpx_lowrank.hip): writes X = [z; f]
 int hpx_launch_solve_lowrank(hpx_plan* p, int iter_tag, hipStream_t st);
 size_t hpx_lowrank_lds_bytes(const hpx_plan* p);
