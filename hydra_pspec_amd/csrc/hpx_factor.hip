@@ -978,8 +978,8 @@ static int launch_factor_t(int nbl, size_t lds, int npad, int ld, double* L, dou
 #define HPX_WIDE_MIN 400
 #endif
 int hpx_launch_factor(int nbl, int npad, int ld, double* L, double* Wre, double* Wim, double* Vt,
-                      int32_t* info, int iter_tag, const hpx_gen_batch* gen, hipStream_t st) {
-  if (Vt) {      // a batch too small for one workgroup per CU: several workgroups per system (hpx_factor_split.hip)
+                      int32_t* info, int iter_tag, const hpx_gen_batch* gen, hipStream_t st, int allow_split) {
+  if (Vt && allow_split) {      // a batch too small for one workgroup per CU: several workgroups per system (hpx_factor_split.hip)
     const int parts = hpx_factor_split_parts(nbl, npad, ld);
     if (parts) return hpx_launch_factor_split(nbl, parts, npad, ld, L, Wre, Wim, Vt, info, iter_tag, gen, st);
   }

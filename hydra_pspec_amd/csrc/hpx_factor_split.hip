@@ -3,10 +3,12 @@
 //
 // With one workgroup per system such a batch runs on a quarter of the chip and each system's 17 tile columns go
 // through one CU's latency chain (elimination -> tiles below -> trailing update) one after the other.  Here a
-// system's 16 x 16 tiles are dealt over `parts` workgroups x 8 waves and stay in REGISTERS for the whole
-// factorisation (right-looking): tile (r, c) belongs to workgroup r mod parts, wave (r / parts + c) mod 8 -- a
+// system's 16 x 16 tiles are dealt over `parts` workgroups and stay in REGISTERS for the whole factorisation
+// (right-looking): tile (r, c) belongs to workgroup r mod parts; there the diagonal tiles belong to wave 0 (the
+// ELIMINATOR, a code path of its own) and the others to the seven WORKER waves, wave 1 + (r / parts + c) mod 7 -- a
 // column's tiles of one workgroup sit in different waves.  Per tile column j
-//   E  the owner of the diagonal tile runs the fused 16 x 16 Cholesky + inverse (elim16), stores L_jj and
+//   E  the eliminator that owns the diagonal tile runs the fused 16 x 16 Cholesky + inverse on its own (elim16w:
+//      one wave, the tile in registers, no barrier), stores L_jj and
 //      inv(L_jj) (Vt) and releases flag A[j];
 //   B  every workgroup takes inv(L_jj) (from LDS if it is the owner, else from Vt once A[j] is up), forms its
 //      tiles of the column, X(r, j) = D(r, j) inv(L_jj)^H, stores them into the
@@ -23,32 +25,76 @@
 // L2.  The LAST part to finish zeroes the system's counters again.  The launch never exceeds one workgroup per CU
 // of the device, so every part is resident (or becomes so without any other part's help) and every spin ends;
 // a spin that does not (it never should) gives up after SPIN_LIMIT polls and flags the system in `info`.
+#define HPX_TILES_STAGE0_D 512            // (only the tile hand-over area of the first staging buffer is used here)
 #include "hpx_factor_tiles.h"
 
 namespace {
 
-constexpr int SPLIT_NS = 10;            // register tile slots per wave
-constexpr int SPLIT_NW = 8;             // waves per workgroup
+constexpr int SPLIT_NW = 8;             // waves per workgroup: the eliminator and seven workers
+constexpr int SPLIT_NSD = 5;            // diagonal tiles the eliminator can hold
+constexpr int SPLIT_NSW = 9;            // tiles a worker wave can hold
 constexpr int SPLIT_MAX_CT = 40;        // tile columns the counter block holds
 constexpr unsigned SPIN_LIMIT = 1u << 22;
-static_assert(2 * SPLIT_MAX_CT + 1 <= 2 * HPX_VT_SYNC, "counters must fit the Vt block's sync area");
+static_assert(2 * SPLIT_MAX_CT + 2 <= 2 * HPX_VT_SYNC, "counters must fit the Vt block's sync area");
 
-// wave-uniform wait for *flag >= target
-__device__ HPX_INL bool spin_until(int* flag, const int target) {
+// ---- hand-off between workgroups.  `heavy`: release / acquire fences at agent scope -- on this part a write-back
+// and an invalidate of the XCD's L2 (the L2s of different XCDs are not coherent with each other), microseconds
+// each and serialised between the CUs of an XCD.  Light: the parts of a system share one L2 (they sit on one XCD:
+// checked at run time, see xmask below), so all that is needed is that the producer's stores have reached L2
+// (vmcnt 0: the vector L1 is write-through) and that the consumer's L1 holds no stale line (buffer_inv sc0) --
+// the protocol the memory model uses between the CUs of a workgroup in threadgroup-split mode.
+__device__ HPX_INL void handoff_release(const bool heavy) {
+  if (heavy) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+__device__ HPX_INL void handoff_acquire(const bool heavy) {
+  if (heavy) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  else asm volatile("buffer_inv sc0" ::: "memory");
+}
+// wave-uniform wait for *flag >= target: relaxed polls (they go to L2 and invalidate nothing), the acquire follows
+__device__ HPX_INL bool spin_until(int* flag, const int target, const bool heavy) {
   unsigned n = 0;
-  while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) {
-    __builtin_amdgcn_s_sleep(4);
-    if (++n > SPIN_LIMIT) return false;
+  bool ok = true;
+  while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+    __builtin_amdgcn_s_sleep(1);
+    if (++n > SPIN_LIMIT) { ok = false; break; }
   }
-  return true;
+  handoff_acquire(heavy);
+  return ok;
+}
+// every wave's stores and LDS writes are complete, then the barrier
+__device__ HPX_INL void full_barrier() {
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+#ifdef HPX_SPLIT_TRACE
+// timing of system 0's steps (a debugging build): [part][column + 1][stamp] in 10 ns ticks
+__device__ long long hpx_split_trace[8 * (SPLIT_MAX_CT + 1) * 8];
+#define HPX_STAMP(k_, t_) if (b == 0 && tid == (t_)) hpx_split_trace[(w * (SPLIT_MAX_CT + 1) + j + 1) * 8 + (k_)] = wall_clock64()
+#else
+#define HPX_STAMP(k_, t_)
+#endif
+
+// one trailing update D(r, c) -= X(r, j) X(c, j)^H, the column's tiles in LDS
+__device__ HPX_INL void tile_update(d4& re, d4& im, const lds_f64* pa /* X(c, j) */, const lds_f64* pb /* X(r, j) */,
+                                    const int rd_re, const int rd_im) {
+#pragma unroll
+  for (int v = 0; v < 4; ++v) {
+    const double pr = pa[v * 128 + rd_re], pi = pa[v * 128 + rd_im];
+    const double br = pb[v * 128 + rd_re], bm = pb[v * 128 + rd_im];
+    re = mfma64(-pr, br, re);
+    re = mfma64(-pi, bm, re);
+    im = mfma64(-pr, bm, im);
+    im = mfma64(pi, br, im);
+  }
 }
 
 template <bool GEN>
 __global__ __launch_bounds__(64 * SPLIT_NW, 2) void k_factor_split(double* __restrict__ L_all, double* __restrict__ Wre_all,
-                                                         double* __restrict__ Wim_all, double* __restrict__ Vt_all,
-                                                         int32_t* __restrict__ info, const int npad, const int ld,
-                                                         const int iter_tag, const hpx_gen_batch GB, const int nbl,
-                                                         const int parts) {
+                                                                   double* __restrict__ Wim_all, double* __restrict__ Vt_all,
+                                                                   int32_t* __restrict__ info, const int npad, const int ld,
+                                                                   const int iter_tag, const hpx_gen_batch GB, const int nbl,
+                                                                   const int parts, const int force_heavy) {
   extern __shared__ double lds_panel[];        // [nrt][512]: the current column's tiles (odd-column swizzle)
   const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
   const int b = (idx / parts) * 8 + xcd, w = idx % parts;
@@ -72,135 +118,172 @@ __global__ __launch_bounds__(64 * SPLIT_NW, 2) void k_factor_split(double* __res
   int* const flagA = (int*)(X.Vt + (long)npad * 32);
   int* const cntB = flagA + SPLIT_MAX_CT;
   int* const done = cntB + SPLIT_MAX_CT;
+  int* const arrive = done + 1;                // parts that have started (low byte) and the XCDs they run on (one bit each)
   GenVec<false> V = {};
   if constexpr (GEN) {
     V.ia = (const glb_f64*)G.ia;
     V.cre = (const glb_f64*)G.cre;
     V.cim = (const glb_f64*)G.cim;
   }
+  lds_f64* const Pn = (lds_f64*)lds_panel;
+  lds_f64* const Vs = (lds_f64*)(hpx_stage1 + FV_OFF);
+  // Which protocol: every part enters its XCD and counts itself in (`arrive`); when all have (no data is exchanged
+  // yet, so no fence), a system whose parts share one XCD uses the light hand-off from the first column on.
+  if (tid == 0) {
+    const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 15u;        // HW_REG_XCC_ID, bits 3:0
+    // (one word: XCD bits above the count -- the same thread's OR and ADD on one location stay in order)
+    __hip_atomic_fetch_or(arrive, 256 << xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_fetch_add(arrive, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  bool heavy = true, bad = false, timed_out = false;
   // the lane's indices, re-derived through an empty asm in every step: otherwise each slot's LDS addresses become
   // loop invariants that outlive the registers (spilled, and reloaded in the middle of the hand-off chain)
   int lane = X.lane, li = lane & 15, g = lane >> 4;
   unsigned src_lane = 0;
   int rd_re = 0, rd_im = 0;
-  lds_f64* const Pn = (lds_f64*)lds_panel;
-  lds_f64* const Ein = (lds_f64*)hpx_stage0;
-  lds_f64* const Vs = (lds_f64*)(hpx_stage1 + FV_OFF);
+#define HPX_LANE_INDICES()                                   \
+  lane = opaque(X.lane);                                     \
+  li = lane & 15;                                            \
+  g = lane >> 4;                                             \
+  src_lane = g * 32 + 2 * ((li + 8 * (g & 1)) & 15);         \
+  rd_re = g * 32 + li + 16 * (g & 1);                        \
+  rd_im = g * 32 + li + 16 * (1 - (g & 1))
 
-  // ---- the wave's tiles: rows r = w + k parts; of row k the columns c = (wave - k) mod 8, + 8, ... (<= the diagonal)
-  int tr[SPLIT_NS], tc[SPLIT_NS];
-  d4 a1[SPLIT_NS], a2[SPLIT_NS];               // re, im of D^T[c][r]: lane li <-> row, register v <-> column g + 4 v
-  {
-    int r = w, k = 0, c = X.wave;
-#pragma unroll
-    for (int s = 0; s < SPLIT_NS; ++s) {
-      while (r < X.nrt && c > min(r, X.nct - 1)) { r += parts; ++k; c = (X.wave - k) & (SPLIT_NW - 1); }
-      if (r < X.nrt) {
-        tr[s] = r;
-        tc[s] = c;
-        tile_init<GEN, false>(G, V, X.Lb, r * 16, c * 16, npad, li, g, a1[s], a2[s]);
-        c += SPLIT_NW;
-        __builtin_amdgcn_sched_barrier(0);
-      } else {
-        tr[s] = 0;
-        tc[s] = -1;
-        a1[s] = (d4){0., 0., 0., 0.};
-        a2[s] = a1[s];
-      }
+  auto agree = [&] {                           // (every wave polls for itself: no barrier, the tiles are loaded meanwhile)
+    unsigned n = 0, word;
+    while (((word = (unsigned)__hip_atomic_load(arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) & 255u) < (unsigned)parts) {
+      __builtin_amdgcn_s_sleep(1);
+      if (++n > SPIN_LIMIT) { timed_out = true; break; }
     }
-  }
-  bool bad = false, timed_out = false;
-
-  // E: the diagonal tile t (held by one wave of this workgroup, fully updated) -> L_tt, inv(L_tt), W
-  auto eliminate = [&](const int t) {
-    {
+    const unsigned m = word >> 8;
+    heavy = force_heavy || (m & (m - 1)) != 0 || timed_out;
+  };
+  if (X.wave == 0) {
+    // =================== the eliminator: the workgroup's diagonal tiles (r = w + s parts) =====================
+    d4 e1[SPLIT_NSD], e2[SPLIT_NSD];           // re, im of D^T[c][r]: lane li <-> row, register v <-> column g + 4 v
 #pragma unroll
-      for (int s = 0; s < SPLIT_NS; ++s)
-        if (tr[s] == t && tc[s] == t) {
+    for (int s = 0; s < SPLIT_NSD; ++s) {
+      const int r = w + s * parts;
+      e1[s] = (d4){0., 0., 0., 0.};
+      e2[s] = e1[s];
+      if (r < X.nct) tile_init<GEN, false>(G, V, X.Lb, r * 16, r * 16, npad, li, g, e1[s], e2[s]);
+    }
+    agree();
+    // E: diagonal tile t, fully updated -> L_tt, inv(L_tt) (Vt, Vs), W; then flag A[t]
+    auto eliminate = [&](const int t, const d4 er, const d4 ei) {
+      // flag A[t] goes up as soon as the inverse tile is stored (this wave's own stores: nobody else wrote for it)
+      bad |= elim16w(X, t, t + 1 == X.nct, er, ei, [&] {
+        handoff_release(heavy);
+        if (lane == 0) __hip_atomic_store(&flagA[t], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      });
+      if (t & 1) {
+        // odd tile of a pair: W10 = -inv(L11) L10 inv(L00); L10 = X(t, t-1) was stored by this workgroup in B(t-1),
+        // inv(L00) by the owner of tile t-1 (flag A[t-1] acquired in step t-1); inv(L11) is in Vs (this wave's own
+        // LDS writes)
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        d4 tre = {0., 0., 0., 0.}, tim = tre;
+        const double* l10 = X.Lb + HPX_LIDX(t * 16 + li, t * 16 - 16 + g, X.npad);   // L10[r = li][k = 4 v + g]
+        const double* v00 = X.Vt + (long)(t - 1) * 512 + li * 32 + g;                // inv(L00)[k = 4 v + g][c' = li]
 #pragma unroll
-          for (int v = 0; v < 4; ++v) {
-            Ein[li * 16 + HPX_ACC_ROW(g, v)] = a1[s][v];
-            Ein[256 + li * 16 + HPX_ACC_ROW(g, v)] = a2[s][v];
-          }
+        for (int v = 0; v < 4; ++v) {
+          const double ar = l10[(4 * v) * 32], ai = l10[(4 * v) * 32 + 16];
+          const double br = v00[4 * v], bm = v00[4 * v + 16];
+          tre = mfma64(ar, br, tre);
+          tre = mfma64(-ai, bm, tre);
+          tim = mfma64(ar, bm, tim);
+          tim = mfma64(ai, br, tim);
         }
-    }
-    lds_barrier();
-    if (X.wave < 4) bad |= elim16(X, t, t + 1 == X.nct);     // (written for 256 threads)
-    else elim16_idle();
-    // odd tile of a pair: W10 = -inv(L11) L10 inv(L00); L10 = X(t, t-1) was stored by this workgroup in B(t-1),
-    // inv(L00) by the owner of tile t-1 (flag A[t-1] acquired in step t-1)
-    if ((t & 1) && X.wave == 4) {
-      d4 tre = {0., 0., 0., 0.}, tim = tre;
-      const double* l10 = X.Lb + HPX_LIDX(t * 16 + li, t * 16 - 16 + g, X.npad);   // L10[r = li][k = 4 v + g]
-      const double* v00 = X.Vt + (long)(t - 1) * 512 + li * 32 + g;                // inv(L00)[k = 4 v + g][c' = li]
+        d4 zr = {0., 0., 0., 0.}, zi = zr;
 #pragma unroll
-      for (int v = 0; v < 4; ++v) {
-        const double ar = l10[(4 * v) * 32], ai = l10[(4 * v) * 32 + 16];
-        const double br = v00[4 * v], bm = v00[4 * v + 16];
-        tre = mfma64(ar, br, tre);
-        tre = mfma64(-ai, bm, tre);
-        tim = mfma64(ar, bm, tim);
-        tim = mfma64(ai, br, tim);
+        for (int v = 0; v < 4; ++v) {
+          const double ar = Vs[v * 128 + rd_re], ai = Vs[v * 128 + rd_im];
+          zr = mfma64(-ar, tre[v], zr);
+          zr = mfma64(ai, tim[v], zr);
+          zi = mfma64(-ar, tim[v], zi);
+          zi = mfma64(-ai, tre[v], zi);
+        }
+        double* wgr = X.Wgre + (long)(t >> 1) * 1024;
+        double* wgi = X.Wgim + (long)(t >> 1) * 1024;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          wgr[(16 + HPX_ACC_ROW(g, v)) * 32 + li] = zr[v];
+          wgi[(16 + HPX_ACC_ROW(g, v)) * 32 + li] = zi[v];
+        }
       }
-      d4 zr = {0., 0., 0., 0.}, zi = zr;
-#pragma unroll
-      for (int v = 0; v < 4; ++v) {
-        const double ar = Vs[v * 128 + rd_re], ai = Vs[v * 128 + rd_im];
-        zr = mfma64(-ar, tre[v], zr);
-        zr = mfma64(ai, tim[v], zr);
-        zi = mfma64(-ar, tim[v], zi);
-        zi = mfma64(-ai, tre[v], zi);
-      }
-      double* wgr = X.Wgre + (long)(t >> 1) * 1024;
-      double* wgi = X.Wgim + (long)(t >> 1) * 1024;
-#pragma unroll
-      for (int v = 0; v < 4; ++v) {
-        wgr[(16 + HPX_ACC_ROW(g, v)) * 32 + li] = zr[v];
-        wgi[(16 + HPX_ACC_ROW(g, v)) * 32 + li] = zi[v];
-      }
-    }
-    __syncthreads();                           // every wave's stores have left before the flag goes up
-    if (tid == 0) __hip_atomic_store(&flagA[t], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-  };
-  // one trailing update D(r, c) -= X(r, j) X(c, j)^H from the column in LDS
-  auto update = [&](d4& re, d4& im, const int r, const int c) {
-    const lds_f64* pa = Pn + c * 512;
-    const lds_f64* pb = Pn + r * 512;
-#pragma unroll
-    for (int v = 0; v < 4; ++v) {
-      const double pr = pa[v * 128 + rd_re], pi = pa[v * 128 + rd_im];
-      const double br = pb[v * 128 + rd_re], bm = pb[v * 128 + rd_im];
-      re = mfma64(-pr, br, re);
-      re = mfma64(-pi, bm, re);
-      im = mfma64(-pr, bm, im);
-      im = mfma64(pi, br, im);
-    }
-  };
-
-  // step j = -1 is the first elimination alone: E(0) is "the look-ahead of the column before the first"
-  for (int j = -1; j < X.nct; ++j) {
-    lane = opaque(X.lane);
-    li = lane & 15;
-    g = lane >> 4;
-    src_lane = g * 32 + 2 * ((li + 8 * (g & 1)) & 15);
-    rd_re = g * 32 + li + 16 * (g & 1);
-    rd_im = g * 32 + li + 16 * (1 - (g & 1));
-    if (j >= 0) {
-      const int wj = j % parts;
-      // ---- inverse of the diagonal tile -> Vs
-      if (w != wj) {
-        if (X.wave == 0) {
-          if (!spin_until(&flagA[j], 1)) timed_out = true;
+    };
+    // step j = -1 is the first elimination alone: E(0) is "the look-ahead of the column before the first"
+    for (int j = -1; j < X.nct; ++j) {
+      HPX_LANE_INDICES();
+      HPX_STAMP(0, 0);
+      if (j >= 0) {
+        if (w != j % parts) {                  // the inverse of the diagonal tile -> Vs
+          if (!spin_until(&flagA[j], 1, heavy)) timed_out = true;
           glds_tile(X.Vt + (long)j * 512, 8 * src_lane, lds_addr(hpx_stage1 + FV_OFF));
           wait_vm<0>();
         }
-        wg_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        HPX_STAMP(1, 0);
+        lds_barrier();                         // (1) Vs is ready
+        full_barrier();                        // (2) the workers' tiles of column j are stored, and in LDS
+        HPX_STAMP(2, 0);
+        if (j + 1 == X.nct) break;
       }
-      // ---- B: the workgroup's tiles of column j, into the factor and into the LDS column
+      // this workgroup's diagonal tiles right of column j take their update from its own X(r, j); the next
+      // diagonal tile first, eliminated at once (look-ahead: the workers wait for the other parts meanwhile)
+      if ((j + 1) % parts == w) {
+        d4 er = {0., 0., 0., 0.}, ei = er;
 #pragma unroll
-      for (int s = 0; s < SPLIT_NS; ++s)
-        if (tc[s] == j && tr[s] > j) {
+        for (int s = 0; s < SPLIT_NSD; ++s)
+          if (w + s * parts == j + 1) { er = e1[s]; ei = e2[s]; }
+        if (j >= 0) tile_update(er, ei, Pn + (j + 1) * 512, Pn + (j + 1) * 512, rd_re, rd_im);
+        eliminate(j + 1, er, ei);
+      }
+      HPX_STAMP(3, 0);
+      if (j < 0) continue;
+#pragma unroll
+      for (int s = 0; s < SPLIT_NSD; ++s) {
+        const int r = w + s * parts;
+        if (r > j + 1 && r < X.nct) tile_update(e1[s], e2[s], Pn + r * 512, Pn + r * 512, rd_re, rd_im);
+      }
+      lds_barrier();                           // (3) the column is staged
+      HPX_STAMP(4, 0);
+      lds_barrier();                           // (4) the column and Vs are free again
+    }
+  } else {
+    // =================== the workers: tiles (r, c) below the diagonal and of the right-hand-side rows ==========
+    // rows r = w + k parts; of row k the columns c = (wv - k) mod 7, + 7, ... (< min(r, nct)): a column's tiles of one
+    // workgroup sit in different waves
+    constexpr int NWK = SPLIT_NW - 1;
+    const int wv = X.wave - 1;
+    int tr[SPLIT_NSW], tc[SPLIT_NSW];
+    d4 a1[SPLIT_NSW], a2[SPLIT_NSW];
+    {
+      int r = w, k = 0, c = wv;
+#pragma unroll
+      for (int s = 0; s < SPLIT_NSW; ++s) {
+        while (r < X.nrt && c >= min(r, X.nct)) { r += parts; ++k; c = (wv + NWK * SPLIT_MAX_CT - k) % NWK; }
+        if (r < X.nrt) {
+          tr[s] = r;
+          tc[s] = c;
+          tile_init<GEN, false>(G, V, X.Lb, r * 16, c * 16, npad, li, g, a1[s], a2[s]);
+          c += NWK;
+          __builtin_amdgcn_sched_barrier(0);
+        } else {
+          tr[s] = 0;
+          tc[s] = -1;
+          a1[s] = (d4){0., 0., 0., 0.};
+          a2[s] = a1[s];
+        }
+      }
+    }
+    agree();
+    for (int j = 0; j < X.nct; ++j) {
+      HPX_LANE_INDICES();
+      lds_barrier();                           // (1) Vs is ready
+      // ---- B: the wave's tiles of column j, X = D inv(L_jj)^H, into the factor and into the LDS column
+#pragma unroll
+      for (int s = 0; s < SPLIT_NSW; ++s)
+        if (tc[s] == j) {
           d4 xr = {0., 0., 0., 0.}, xi = {0., 0., 0., 0.};
 #pragma unroll
           for (int v = 0; v < 4; ++v) {
@@ -221,47 +304,41 @@ __global__ __launch_bounds__(64 * SPLIT_NW, 2) void k_factor_split(double* __res
             xs[k * 32 + li + 16 * (1 - (k & 1))] = xi[v];
           }
         }
-      __syncthreads();                           // the column's stores have left (and its LDS copies are visible)
-      if (tid == 0) __hip_atomic_fetch_add(&cntB[j], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-      if (j + 1 == X.nct) break;                 // last column: nothing to its right
-    }
-    // ---- look-ahead: the next diagonal tile's last update needs only this workgroup's own X(j+1, j)
-    const bool ahead = (w == (j + 1) % parts);
-    if (ahead) {
-      if (j >= 0) {
-#pragma unroll
-        for (int s = 0; s < SPLIT_NS; ++s)
-          if (tr[s] == j + 1 && tc[s] == j + 1) update(a1[s], a2[s], j + 1, j + 1);
+      full_barrier();                          // (2) the workgroup's tiles of the column are stored
+      if (tid == 64) {
+        handoff_release(heavy);
+        __hip_atomic_fetch_add(&cntB[j], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
-      eliminate(j + 1);
-    }
-    if (j < 0) continue;
-    // ---- D: the other parts' tiles of the column -> LDS, then the trailing updates
-    if (X.wave == 0 && !spin_until(&cntB[j], parts)) timed_out = true;
-    wg_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    {
-      int n = 0;
-      for (int r = j + 1; r < X.nrt; ++r) {
-        if (r % parts == w) continue;
-        if ((n++ & (SPLIT_NW - 1)) == X.wave)
-          glds_tile(X.Lb + HPX_LIDX(r * 16, j * 16, X.npad), 8 * src_lane, lds_addr(lds_panel + r * 512));
+      if (j + 1 == X.nct) break;               // last column: nothing to its right
+      // ---- D: the other parts' tiles of the column -> LDS, then the trailing updates
+      if (!spin_until(&cntB[j], parts, heavy)) timed_out = true;
+      HPX_STAMP(5, 64);
+      {
+        int n = 0;
+        for (int r = j + 1; r < X.nrt; ++r) {
+          if (r % parts == w) continue;
+          if (n++ % NWK == wv)
+            glds_tile(X.Lb + HPX_LIDX(r * 16, j * 16, X.npad), 8 * src_lane, lds_addr(lds_panel + r * 512));
+        }
+        wait_vm<0>();
       }
-      wait_vm<0>();
-      wg_barrier();
-    }
+      HPX_STAMP(6, 64);
+      lds_barrier();                           // (3) the column is staged
 #pragma unroll
-    for (int s = 0; s < SPLIT_NS; ++s) {
-      if (tc[s] > j && !(ahead && tr[s] == j + 1 && tc[s] == j + 1)) update(a1[s], a2[s], tr[s], tc[s]);
-      __builtin_amdgcn_sched_barrier(0);       // one tile's operands at a time: the accumulators need the registers
+      for (int s = 0; s < SPLIT_NSW; ++s) {
+        if (tc[s] > j) tile_update(a1[s], a2[s], Pn + tc[s] * 512, Pn + tr[s] * 512, rd_re, rd_im);
+        __builtin_amdgcn_sched_barrier(0);     // one tile's operands at a time: the accumulators need the registers
+      }
+      HPX_STAMP(7, 64);
+      lds_barrier();                           // (4) the column and Vs are free again
     }
-    lds_barrier();                             // the LDS column and Vs are free again
   }
+#undef HPX_LANE_INDICES
   __syncthreads();
   if (tid == 0) {
     const int old = __hip_atomic_fetch_add(done, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
     if (old == parts - 1) {                    // every part is past its last wait: leave the counters zero
-      for (int i = 0; i < 2 * SPLIT_MAX_CT + 1; ++i) flagA[i] = 0;
+      for (int i = 0; i < 2 * SPLIT_MAX_CT + 2; ++i) flagA[i] = 0;
     }
   }
   if ((bad || timed_out) && info) atomicCAS(&info[b], 0, iter_tag);
@@ -281,28 +358,29 @@ struct SplitDevice {
   }
 };
 
-// most tiles any wave holds with `parts` workgroups per system
-int split_slots(const int parts, const int nct, const int nrt) {
-  int most = 0;
+// do the tiles of a system fit the waves' registers with `parts` workgroups per system?
+bool split_fits(const int parts, const int nct, const int nrt) {
+  if ((nct + parts - 1) / parts > SPLIT_NSD) return false;
   for (int w = 0; w < parts; ++w)
-    for (int v = 0; v < SPLIT_NW; ++v) {
+    for (int v = 0; v < SPLIT_NW - 1; ++v) {
       int n = 0, k = 0;
       for (int r = w; r < nrt; r += parts, ++k)
-        for (int c = (v - k) & (SPLIT_NW - 1); c <= (r < nct - 1 ? r : nct - 1); c += SPLIT_NW) ++n;
-      if (n > most) most = n;
+        for (int c = (v + (SPLIT_NW - 1) * SPLIT_MAX_CT - k) % (SPLIT_NW - 1); c < (r < nct ? r : nct); c += SPLIT_NW - 1) ++n;
+      if (n > SPLIT_NSW) return false;
     }
-  return most;
+  return true;
 }
 
 template <bool GEN>
 int launch_split_t(int nbl, int parts, int npad, int ld, double* L, double* Wre, double* Wim, double* Vt, int32_t* info,
                    int iter_tag, const hpx_gen_batch& gen, hipStream_t st) {
   static hpx_lds_limit limit;
+  static const int force_heavy = getenv("HPX_SPLIT_HEAVY") ? 1 : 0;      // (testing: agent-scope fences throughout)
   const size_t lds = (size_t)(ld >> 4) * 512 * sizeof(double);
   HPX_TRY(limit.ensure(reinterpret_cast<const void*>(&k_factor_split<GEN>), lds));
   const int grid = 8 * ((nbl + 7) / 8) * parts;
   hipLaunchKernelGGL((k_factor_split<GEN>), dim3(grid), dim3(64 * SPLIT_NW), lds, st, L, Wre, Wim, Vt, info, npad, ld, iter_tag,
-                     gen, nbl, parts);
+                     gen, nbl, parts, force_heavy);
   HPX_HIP(hipGetLastError());
   return HPX_OK;
 }
@@ -320,12 +398,19 @@ int hpx_factor_split_parts(int nbl, int npad, int ld) {
   const int cus = dev.get();
   const int nct = npad >> 4, nrt = ld >> 4;
   if (cus <= 0 || nbl <= 0 || nct < 2 || nct > SPLIT_MAX_CT) return 0;
-  if ((size_t)nrt * 4096 + 2 * BUF_D * sizeof(double) > (size_t)156 * 1024) return 0;
+  if ((size_t)nrt * 4096 + (BUF_D + HPX_TILES_STAGE0_D) * sizeof(double) > (size_t)156 * 1024) return 0;
   const int live = 8 * ((nbl + 7) / 8);        // block indices are dealt in eights (one system's parts on one XCD)
   for (int parts = 8; parts >= 2; parts >>= 1)
-    if (live * parts <= cus) return split_slots(parts, nct, nrt) <= SPLIT_NS ? parts : 0;
+    if (live * parts <= cus) return split_fits(parts, nct, nrt) ? parts : 0;
   return 0;
 }
+
+#ifdef HPX_SPLIT_TRACE
+extern "C" int hpx_debug_split_trace(long long* out) {
+  HPX_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(hpx_split_trace), sizeof(long long) * 8 * (SPLIT_MAX_CT + 1) * 8));
+  return HPX_OK;
+}
+#endif
 
 int hpx_launch_factor_split(int nbl, int parts, int npad, int ld, double* L, double* Wre, double* Wim, double* Vt,
                             int32_t* info, int iter_tag, const hpx_gen_batch* gen, hipStream_t st) {

@@ -18,7 +18,10 @@ constexpr int PP = KC / 4;         // 1 KB pieces (4 columns) per tile and chunk
 constexpr int TILE_D = KC * 32;    // doubles of one tile's chunk
 constexpr int BUF_D = 8 * TILE_D;  // eight tiles per buffer
 
-__shared__ double hpx_stage0[BUF_D];
+#ifndef HPX_TILES_STAGE0_D
+#define HPX_TILES_STAGE0_D BUF_D
+#endif
+__shared__ double hpx_stage0[HPX_TILES_STAGE0_D];
 __shared__ double hpx_stage1[BUF_D];
 template <int PAR> __device__ HPX_INL double* stage_buf() { return PAR ? hpx_stage1 : hpx_stage0; }
 // F's scratch over the staging buffers: Xs[8 tiles][512] = buffer 0 (slot 0: the diagonal tile handed to the
@@ -292,6 +295,139 @@ __device__ HPX_INL bool elim16(const WideCtx& X, const int tcol /* global tile c
   lds_barrier();
   return bad;
 }
+// ---- the same elimination on ONE wave with the tile in registers: lane (li, g) holds row li, columns g + 4 v -- the
+// accumulator layout of a D^T tile, so the wave that owns the diagonal tile eliminates it where it lies.  No
+// workgroup barrier inside (elim16 has eighteen, and spends most of its time in them): per step the pivot column
+// and row k of the inverse go through LDS -- a wave's LDS operations execute in order, the reads behind the writes
+// see them -- and everything else stays in the lane.  Same operations in the same order per element as elim16.
+// out: as elim16; the CALLER puts a workgroup barrier between this and the first use of Vs by another wave.
+// `flag` (split form; else null): raised -- behind `publish()` -- as soon as the inverse tile is in Vt, the one thing
+// another workgroup waits for; the factor's own tile and the W blocks follow.
+template <class Publish>
+__device__ HPX_INL bool elim16w(const WideCtx& X, const int tcol, const bool last_tile, const d4 re, const d4 im,
+                             Publish publish) {
+  lds_f64* const Vs = (lds_f64*)(hpx_stage1 + FV_OFF);
+  lds_cplx* const col = (lds_cplx*)(hpx_stage1 + FD_OFF);      // [4 lane groups][16 rows]: column k below the pivot
+  lds_cplx* const yrw = col + 64;                               // [4 lane groups][4]: row k of the inverse
+  lds_f64* const raw = (lds_f64*)(yrw + 16);                    // [4 lane groups][16]: the column's real parts, unmasked
+  lds_f64* const dgs = raw + 64;                                // [16]: the pivots
+  const int lane = opaque(X.lane), li = lane & 15, g = lane >> 4;
+  double dr[4], di[4], yr[4], yi[4];
+#pragma unroll
+  for (int v = 0; v < 4; ++v) {
+    dr[v] = re[v];
+    di[v] = im[v];
+    yr[v] = (li == g + 4 * v) ? 1.0 : 0.0;
+    yi[v] = 0.0;
+  }
+  __builtin_amdgcn_s_setprio(2);
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    const int kv = k >> 2, kg = k & 3;
+    const bool below = li > k;
+    col[g * 16 + li] = (cplx){below ? dr[kv] : 0.0, below ? di[kv] : 0.0};     // (group kg's copy is the column)
+    raw[g * 16 + li] = dr[kv];
+    if (li == k) {
+#pragma unroll
+      for (int v = 0; v < 4; ++v) yrw[g * 4 + v] = (cplx){yr[v], yi[v]};
+    }
+    // the lanes exchange data here: without the fence the compiler may (and did) move a lane's reads in front of
+    // the OTHER lanes' writes -- per thread there is no dependence
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const double dkk = raw[kg * 16 + k];
+    const cplx c = col[kg * 16 + li];
+    cplx cq[4], sy[4];
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      cq[v] = col[kg * 16 + g + 4 * v];
+      sy[v] = yrw[g * 4 + v];
+    }
+    dgs[k] = dkk;
+    const double r0 = __builtin_amdgcn_rcp(dkk);
+    const double rinv = fma(r0, fma(-dkk, r0, 1.0), r0);
+    const double lr = c.x * rinv, lm = c.y * rinv;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      yr[v] = fma(-lr, sy[v].x, yr[v]);
+      yr[v] = fma(lm, sy[v].y, yr[v]);
+      yi[v] = fma(-lr, sy[v].y, yi[v]);
+      yi[v] = fma(-lm, sy[v].x, yi[v]);
+      dr[v] = fma(-lr, cq[v].x, dr[v]);
+      dr[v] = fma(-lm, cq[v].y, dr[v]);
+      di[v] = fma(-lm, cq[v].x, di[v]);
+      di[v] = fma(lr, cq[v].y, di[v]);
+      // (computed HERE: left alone, the compiler sinks the update chains of the elements that are only stored at the
+      // end into that final block and keeps every step's operands alive for it -- in scratch)
+      asm volatile("" : "+v"(dr[v]), "+v"(di[v]), "+v"(yr[v]), "+v"(yi[v]));
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");     // (the reads above are done before the next step's writes)
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_sched_barrier(0);       // a step's operands die with it (the caller's accumulators need the rest)
+  }
+  __builtin_amdgcn_s_setprio(0);
+  bool bad = false;
+  const double pib = dgs[li];
+  const double sv = rsqrt_nr(pib);
+  double wr[4], wi[4], sq[4];
+#pragma unroll
+  for (int v = 0; v < 4; ++v) {
+    const int q = g + 4 * v;                                   // column; row li
+    wr[v] = 0.0;
+    wi[v] = 0.0;
+    sq[v] = 0.0;
+    if (q <= li) {
+      const double pq = dgs[q];
+      if (!(pq > 0.0) || !(pib > 0.0)) bad = true;
+      sq[v] = rsqrt_nr(pq);
+      wr[v] = yr[v] * sv;
+      wi[v] = yi[v] * sv;
+    }
+    double* vt = X.Vt + (long)tcol * 512 + q * 32 + li;        // inv(L)[li][q]: tile layout = column q, row li
+    vt[0] = wr[v];
+    vt[16] = wi[v];
+    Vs[q * 32 + li + 16 * (q & 1)] = wr[v];
+    Vs[q * 32 + li + 16 * (1 - (q & 1))] = wi[v];
+  }
+  publish();
+  const int o = 16 * (tcol & 1);
+  double* wgr = X.Wgre + (long)(tcol >> 1) * 1024;
+  double* wgi = X.Wgim + (long)(tcol >> 1) * 1024;
+#pragma unroll
+  for (int v = 0; v < 4; ++v) {
+    const int q = g + 4 * v;
+    if (q <= li) {
+      const long off = HPX_LIDX(tcol * 16 + li, tcol * 16 + q, X.npad);
+      X.Lb[off] = dr[v] * sq[v];
+      X.Lb[off + 16] = (q == li) ? 0.0 : di[v] * sq[v];
+    }
+    wgr[(o + li) * 32 + o + q] = wr[v];
+    wgi[(o + li) * 32 + o + q] = wi[v];
+    if (o == 0) {
+      wgr[li * 32 + 16 + q] = 0.0;                             // upper-right block of the inverse is zero
+      wgi[li * 32 + 16 + q] = 0.0;
+      if (last_tile) {                                         // 16-wide last block: nothing below either
+        wgr[(16 + li) * 32 + q] = 0.0; wgi[(16 + li) * 32 + q] = 0.0;
+        wgr[(16 + li) * 32 + 16 + q] = 0.0; wgi[(16 + li) * 32 + 16 + q] = 0.0;
+      }
+    }
+  }
+  return bad;
+}
+__device__ HPX_INL bool elim16w(const WideCtx& X, const int tcol, const bool last_tile, const d4 re, const d4 im) {
+  return elim16w(X, tcol, last_tile, re, im, [] {});
+}
+// a tile handed over in LDS (Ein: re | im, row-major [r][c], written in front of a barrier) -> the lane's elements
+__device__ HPX_INL void ein_load(const WideCtx& X, d4& re, d4& im) {
+  const lds_f64* const Ein = (const lds_f64*)hpx_stage0;
+  const int lane = opaque(X.lane), li = lane & 15, g = lane >> 4;
+#pragma unroll
+  for (int v = 0; v < 4; ++v) {
+    re[v] = Ein[li * 16 + g + 4 * v];
+    im[v] = Ein[256 + li * 16 + g + 4 * v];
+  }
+}
+
 // what a wave that takes no part in elim16 executes beside it: the same barriers (16 steps, one after the loop, one
 // at the end)
 __device__ HPX_INL void elim16_idle() {

@@ -312,8 +312,11 @@ struct hpx_lds_limit {
 // zero when allocated, and left zero by every launch.
 #define HPX_VT_SYNC 64
 #define HPX_VT_STRIDE(npad) ((size_t)(npad) * 32 + HPX_VT_SYNC)
+// allow_split: batches too small for one workgroup per CU may take the split form (another order of operations:
+// a system's factor then depends, in its last bits, on the size of the batch it is in -- callers that promise
+// "alone == inside the batch" for batches of any size pass 0).
 int hpx_launch_factor(int nbl, int npad, int ld, double* L, double* Wre, double* Wim, double* Vt,
-                      int32_t* info, int iter_tag, const hpx_gen_batch* gen, hipStream_t st);
+                      int32_t* info, int iter_tag, const hpx_gen_batch* gen, hipStream_t st, int allow_split = 1);
 // the wide (128-column super-block, LDS-staged) form, hpx_factor_wide.hip
 int hpx_launch_factor_wide(int nbl, int npad, int ld, double* L, double* Wre, double* Wim, double* Vt,
                            int32_t* info, int iter_tag, const hpx_gen_batch* gen, hipStream_t st);

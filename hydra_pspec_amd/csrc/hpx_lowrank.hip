@@ -592,7 +592,7 @@ static int solve_lowrank_fft(hpx_plan* p, const LrArgs& A, int iter_tag, hipStre
   hipLaunchKernelGGL(k_lrf_gather, dim3(p->nbl), dim3(256), lds_g, st, A);
   HPX_HIP(hipGetLastError());
   HPX_TRY(hpx_launch_factor(p->nbl, p->lr_npad, p->lr_npad + TP, p->lr_L, p->lr_Wre, p->lr_Wim, p->lr_Vt, p->info,
-                            iter_tag, nullptr, st));
+                            iter_tag, nullptr, st, 0));
   HPX_TRY(hpx_launch_backsolve(p->nbl, p->lr_npad, TP, p->lr_npad + TP, p->lr_L, p->lr_Wre, p->lr_Wim,
                                p->lr_Yre, p->lr_Yim, st));
   hipLaunchKernelGGL(k_lrf_fill, dim3(32, p->nbl), dim3(256), 0, st, A);
@@ -622,7 +622,7 @@ int hpx_launch_solve_lowrank(hpx_plan* p, int iter_tag, hipStream_t st) {
   else if (per <= 8) HPX_TRY(launch_schur<8>(p, A, nwg, lds_s, st));
   else HPX_TRY(launch_schur<11>(p, A, nwg, lds_s, st));
   HPX_TRY(hpx_launch_factor(p->nbl, p->lr_npad, p->lr_npad + p->TP, p->lr_L, p->lr_Wre, p->lr_Wim, p->lr_Vt, p->info,
-                            iter_tag, nullptr, st));
+                            iter_tag, nullptr, st, 0));
   HPX_TRY(hpx_launch_backsolve(p->nbl, p->lr_npad, p->TP, p->lr_npad + p->TP, p->lr_L, p->lr_Wre, p->lr_Wim,
                                p->lr_Yre, p->lr_Yim, st));
   const size_t lds = (size_t)p->NP * sizeof(double);

@@ -159,6 +159,30 @@ def test_full_batch_at_the_baseline_configs(N, frac, solver):
         assert np.array_equal(one["ln_post"][0], big["ln_post"][k]), k
 
 
+def test_full_batch_at_baseline_config_2():
+    """BASELINE.json configs[1] at FULL size: 64 baselines x (32, 256, 12) on the dense path -- the batch that takes
+    the split factor (four workgroups per system; a baseline alone takes eight).  Baseline k alone gives bit for bit
+    the chain it gives inside the batch, the batch repeats itself bit for bit, and the first baseline agrees with the
+    exact-solve oracle."""
+    from oracle import pspec_ref
+    nbl, N = 64, 256
+    d, big = _run(nbl, N, frac=0.0, niter=3, solver="dense")
+    assert big["signal_ps"].shape == (nbl, 3, N)
+    assert np.isfinite(big["signal_ps"]).all() and (big["signal_ps"] > 0).all() and np.isfinite(big["ln_post"]).all()
+    _, again = _run(nbl, N, frac=0.0, niter=3, solver="dense")
+    assert np.array_equal(big["signal_ps"], again["signal_ps"]) and np.array_equal(big["ln_post"], again["ln_post"])
+    for k in (0, 31, 63):
+        _, one = _run(1, N, frac=0.0, niter=3, k0=k, solver="dense")
+        assert np.array_equal(one["signal_ps"][0], big["signal_ps"][k]), k
+        assert np.array_equal(one["ln_post"][0], big["ln_post"][k]), k
+    from hydra_pspec_amd import synthetic
+    dd = synthetic.make_baselines(N, 32, 12, k0=0, nbl=1, flag_frac=0.0, dense=True)
+    assert np.array_equal(dd["vis"][0], d["vis"][0])
+    ref = pspec_ref.gibbs_sample_with_fg(dd["vis"][0], dd["flags"][0], dd["S_initial"], dd["fgmodes"], dd["Ninv"],
+                                         dd["ps_prior"], Niter=2, seed=dd["seed"], solver="direct")
+    assert np.max(np.abs(big["signal_ps"][0, :2] / ref[2] - 1)) < 1e-6
+
+
 def _banded_ninv(N, sig2, seed=0):
     i = np.arange(N)
     band = np.zeros((N, N), dtype=complex)

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """zpotrf / zpotrs of a given library build (HPX_LIB_PATH) at a list of orders against numpy."""
-import sys, pathlib
+import os, sys, pathlib
 import numpy as np
 ROOT = pathlib.Path(__file__).resolve().parents[3]
 sys.path.insert(0, str(ROOT))
@@ -16,7 +16,7 @@ def hpd(rng, nb, n, cond=1e3):
 
 rng = np.random.default_rng(3)
 for n in [int(v) for v in sys.argv[1:]] or [132, 260, 524, 652, 780, 908, 1036]:
-    nb, nrhs = 2, 32
+    nb, nrhs = int(os.environ.get("POTRF_NB", "2")), int(os.environ.get("POTRF_NRHS", "32"))
     A = hpd(rng, nb, n)
     B = rng.standard_normal((nb, n, nrhs)) + 1j * rng.standard_normal((nb, n, nrhs))
     dA = torch.from_numpy(np.ascontiguousarray(A)).cuda().contiguous(); dB = torch.from_numpy(np.ascontiguousarray(B)).cuda().contiguous()
