@@ -44,5 +44,5 @@ for n in [int(v) for v in sys.argv[1:]] or [132, 260, 524, 652, 780, 908, 1036]:
         for i in range(nt):
             if tb[i].any():
                 print("  tile row %2d: " % i + "".join(".xN"[v] for v in tb[i, :i + 1]))
-    print(n, "L err %.2e" % eL, "info", info.cpu().numpy().tolist(), "first bad col", (cols[0] if len(cols) else None),
+    print(n, "L err %.2e" % eL, "X err", eX, "info", info.cpu().numpy().tolist()[:4], "first bad col", (cols[0] if len(cols) else None),
           "first bad row", (rows[0] if len(rows) else None), "X err", eX, flush=True)
