@@ -514,6 +514,12 @@ def main():
     ap.add_argument("--solver", default="dense", choices=["dense", "auto"],
                     help="dense (default): the general batched-Cholesky path the metric is about; auto: let "
                          "unflagged flat-noise batches take the structured solve (reported separately anyway)")
+    ap.add_argument("--noise", default="diag", choices=["diag", "dense", "pertime-dense"],
+                    help="diag (default): the configs' diagonal inverse noise variances.  dense: a Hermitian banded "
+                         "inverse noise covariance per baseline (correlated noise; with --flag-frac > 0 the Woodbury "
+                         "path).  pertime-dense: one such matrix per (baseline, time) with time-dependent flags "
+                         "(needs --nbl small: nbl x Ntimes full matrices)")
+    ap.add_argument("--flag-frac", type=float, default=None, help="override the config's flag fraction")
     ap.add_argument("--dry-run", action="store_true",
                     help="rank plumbing only (gloo, no GPU): print the blocks of baselines the ranks would own")
     args = ap.parse_args()
@@ -545,8 +551,12 @@ def main():
     from hydra_pspec_amd import hpx, pspec, synthetic
     from hydra_pspec_amd.sharding import split_counts
     nbl_gpu, T, N, M, frac = CONFIGS[args.config]
+    if args.flag_frac is not None:
+        frac = args.flag_frac
     if args.nbl:
         nbl_gpu = args.nbl
+    elif args.noise == "pertime-dense":
+        nbl_gpu = 8            # nbl x Ntimes matrices of N x N: 8 x 32 x 4 MiB at N = 512
     counts = split_counts(nbl_gpu * world, world)
     k0 = sum(counts[:rank])
     nbl = counts[rank]
@@ -560,11 +570,38 @@ def main():
         flags_in &= rng.uniform(size=(nbl, T, N)) > 0.05
         ninv_in = np.ascontiguousarray(np.broadcast_to(d["ninv_diag"][:, None, :] *
                                                        rng.uniform(0.7, 1.3, size=(nbl, T, 1)), (nbl, T, N)))
+    ninv_dense = None
+    if args.noise != "diag":
+        # Hermitian banded inverse noise covariance, one per baseline (scaled to the baseline's noise level), as
+        # tests/test_gpu_fullsize.py:_banded_ninv; pertime-dense: one per (baseline, time) with 5 % more flags per time
+        i = np.arange(N)
+        band = np.zeros((N, N), dtype=complex)
+        band[i, i] = 1.0 + 0.2 * np.cos(0.3 * i)
+        band[i[:-1], i[:-1] + 1] = 0.3 * np.exp(0.4j)
+        band[i[:-1] + 1, i[:-1]] = 0.3 * np.exp(-0.4j)
+        band[i[:-2], i[:-2] + 2] = 0.1
+        band[i[:-2] + 2, i[:-2]] = 0.1
+        binv = np.linalg.inv(band)
+        lev = np.asarray(d["ninv_diag"])[:, 0]
+        if args.noise == "dense":
+            ninv_dense = np.ascontiguousarray(binv[None] * lev[:, None, None])
+        else:
+            rng = np.random.default_rng(11 + k0)
+            flags_in = np.broadcast_to(d["flags"][:, None, :], (nbl, T, N)).copy()
+            flags_in &= rng.uniform(size=(nbl, T, N)) > 0.05
+            ninv_dense = np.ascontiguousarray(binv[None, None] * (lev[:, None, None, None] *
+                                                                  rng.uniform(0.7, 1.3, size=(nbl, T, 1, 1))))
+        ninv_in = None
+    torch.cuda.synchronize()
+    t_setup = time.perf_counter()
     gb = pspec.GibbsBatch(d["vis"], flags_in, d["fgmodes"], ninv_in, d["ps_prior"],
-                          W + K, seed=d["seed"], solver=args.solver)
+                          W + K, seed=d["seed"], solver=args.solver, ninv_dense=ninv_dense)
+    torch.cuda.synchronize()
+    t_setup = time.perf_counter() - t_setup
     ps0 = np.broadcast_to(d["ps0"], (nbl, N)).copy()
     fmax = int((~np.asarray(d["flags"]).astype(bool)).sum(axis=1).max())
-    units_per_bl = T if args.config == "N4" else 1      # factorisations per baseline and iteration
+    per_time = args.config == "N4" or args.noise == "pertime-dense"
+    units_per_bl = T if per_time else 1      # factorisations per baseline and iteration
 
     def barrier():
         torch.cuda.synchronize()
@@ -632,7 +669,8 @@ def main():
     # plan and tables; bracketed like the timed region, max over ranks)
     full_len = None
     n_full = FULL_ITERS.get(args.config)
-    if n_full and not args.no_full_length:
+    special = args.noise != "diag"     # (the extra legs below are the diagonal-noise metric's)
+    if n_full and not args.no_full_length and not special:
         gfull = pspec.GibbsBatch(d["vis"], flags_in, d["fgmodes"], ninv_in, d["ps_prior"], n_full, seed=d["seed"],
                                  solver=args.solver)
         barrier()
@@ -656,7 +694,7 @@ def main():
     # the same batch through solver="auto" (outside the timed region): unflagged flat-noise inputs
     # such as C3's then take the O(N M (M+T)) structured solve instead of the dense factorisation
     flat_extra = None
-    if rank == 0 and world == 1 and args.solver == "dense" and args.config != "N4":
+    if rank == 0 and world == 1 and args.solver == "dense" and args.config != "N4" and not special:
         gf = pspec.GibbsBatch(d["vis"], d["flags"], d["fgmodes"], d["ninv_diag"], d["ps_prior"],
                               W + K, seed=d["seed"], solver="auto")
         if gf.solver in ("flat", "lowrank"):
@@ -716,11 +754,21 @@ def main():
         peak_meas = np.zeros(1)
         import ctypes
         hpx.check(hpx.lib().hpx_mfma_f64_peak(20000, peak_meas.ctypes.data_as(ctypes.c_void_p)))
-        if args.config == "N4":      # nbl*T systems with one right-hand side each
-            roof = roofline_for("dense", stage, nbl * T, N, M, 1, fmax, K, None, float(peak_meas[0]))
-            roof["whole_step"] = whole_step_for("dense", value / world * T, N, M, 1, fmax)
+        wb_cols = fmax if (special and fmax > 0) else 0      # Woodbury columns next to the data columns (dense noise + flags)
+        if args.noise == "pertime-dense":
+            wb_cols = int((~flags_in).sum(axis=2).max()) if not flags_in.all() else 0
+        if per_time:      # nbl*T systems with one right-hand side each (+ the Woodbury columns)
+            roof = roofline_for("dense", stage, nbl * T, N, M, 1 + wb_cols, fmax, K, None, float(peak_meas[0]))
+            roof["whole_step"] = whole_step_for("dense", value / world * T, N, M, 1 + wb_cols, fmax)
             roof["note"] = ("time-dependent flags: one (N+M)-order system per (baseline, time) and iteration; "
-                            f"units_per_launch = {nbl} baselines x {T} times")
+                            f"units_per_launch = {nbl} baselines x {T} times"
+                            + (f"; {wb_cols} Woodbury right-hand sides per unit" if wb_cols else ""))
+        elif special:
+            roof = roofline_for("dense", stage, nbl, N, M, T + wb_cols, fmax, K, None, float(peak_meas[0]))
+            roof["whole_step"] = whole_step_for("dense", value / world, N, M, T + wb_cols, fmax)
+            roof["note"] = (f"Hermitian non-diagonal Ninv: the matrix is assembled in full every iteration (k_assemble), "
+                            f"{T} data columns + {wb_cols} Woodbury columns (one per flagged channel) go through the "
+                            "factorisation's forward solve")
         else:
             roof = roofline_for(gb.solver, stage, nbl, N, M, T, fmax, K, traffic, float(peak_meas[0]))
             roof["whole_step"] = whole_step_for(gb.solver, value / world, N, M, T, fmax)
@@ -765,11 +813,17 @@ def main():
             res["full_length"] = full_len
         if flat_extra:
             res["flat_noise_structured_solve"] = flat_extra     # (key kept from the unflagged case)
-        if args.config == "N4":
+        if per_time:
             res["config"]["workload"] += (f"; TIME-DEPENDENT flags (5 % per time on top) and noise levels: "
                                           f"{nbl_gpu * T} factorisations per iteration")
             res["systems_per_second"] = value * units_per_bl
-        if world == 1 and not args.no_cpu_baseline and args.config != "N4":
+        res["setup_seconds"] = t_setup
+        if special:
+            res["config"]["noise"] = ("a Hermitian banded inverse noise covariance per baseline" if args.noise == "dense" else
+                                      "a Hermitian banded inverse noise covariance per (baseline, time)")
+            res["setup_note"] = ("setup_seconds = GibbsBatch(...): upload, the noise matrices' square roots "
+                                 "(hpx_sqrtm_hpd_batched on the device), invariant operators; outside the timed region")
+        if world == 1 and not args.no_cpu_baseline and args.config != "N4" and not special:
             one, ref_ps, dd = cpu_baseline(N, T, M, frac)
             mp = cpu_baseline_multiproc(N, T, M, frac)
             if mp and mp["value"] > one["value"]:

@@ -93,6 +93,50 @@ def sqrtm_hermitian(A):
     return (V * np.sqrt(np.clip(lam, 0.0, None))[..., None, :]) @ np.conj(np.swapaxes(V, -1, -2))
 
 
+def sqrtm_masked_device(torch, nd, w, device, tol=1e-7, max_iter=60):
+    """``sqrtm(Ninv diag(w))`` for a stack of Hermitian positive-definite ``Ninv`` (K,N,N) and channel masks ``w``
+    (K,N) bool (True = use), on the device: what the reference gets from ``scipy.linalg.sqrtm(Ni)`` per baseline
+    (pspec.py:361-362).  With the unflagged channels ``u`` first, ``Ni = [[A, 0], [B, 0]]`` with ``A = Ninv[u, u]``
+    Hermitian positive definite, and the principal root is ``[[A^1/2, 0], [B A^-1/2, 0]]``: one call of
+    ``hpx_sqrtm_hpd_batched`` (Newton-Schulz on the batched FP64-MFMA product) on the ``A`` blocks -- each padded with
+    an identity block to a common multiple of 16 -- gives both factors.  Returns a (K,N,N) complex128 device tensor."""
+    c128 = torch.complex128
+    nd = nd if hasattr(nd, "device") and not isinstance(nd, np.ndarray) else hpx.to_dev(torch, np.ascontiguousarray(nd), c128, device)
+    K, N = int(nd.shape[0]), int(nd.shape[-1])
+    w_t = torch.as_tensor(np.ascontiguousarray(w), device=device).reshape(K, N).bool()
+    nu = w_t.sum(dim=1)
+    npad = 16 * ((int(nu.max().item()) + 15) // 16)
+    if npad == 0:
+        return torch.zeros_like(nd)
+    # unflagged channels first (stable), one permutation per matrix
+    order = torch.argsort((~w_t).to(torch.int8), dim=1, stable=True)                 # (K,N)
+    P = nd.gather(1, order[:, :, None].expand(K, N, N)).gather(2, order[:, None, :].expand(K, N, N))
+    A = torch.zeros((K, npad, npad), dtype=c128, device=device)
+    m = min(npad, N)
+    A[:, :m, :m] = P[:, :m, :m]
+    inside = (torch.arange(npad, device=device)[None, :] < nu[:, None])              # (K,npad): a column of A's block
+    blockmask = inside[:, :, None] & inside[:, None, :]
+    A = torch.where(blockmask, A, torch.zeros((), dtype=c128, device=device))
+    A = A + torch.diag_embed((~inside).to(c128))                                       # identity on the padding
+    A = A.contiguous()
+    sq, isq = torch.empty_like(A), torch.empty_like(A)
+    hpx.check(hpx.lib().hpx_sqrtm_hpd_batched(K, npad, hpx.ptr(A), hpx.ptr(sq), hpx.ptr(isq), float(tol), int(max_iter),
+                                              None, hpx.stream_ptr(torch)), "hpx_sqrtm_hpd_batched")
+    R = torch.zeros((K, N, N), dtype=c128, device=device)
+    R[:, :m, :m] = torch.where(blockmask[:, :m, :m], sq[:, :m, :m], torch.zeros((), dtype=c128, device=device))
+    if bool((nu < N).any()):
+        # rows of the flagged channels: B A^-1/2 with B = (permuted Ninv)[f, u]
+        Bfull = torch.zeros((K, N, npad), dtype=c128, device=device)
+        Bfull[:, :, :m] = P[:, :, :m]
+        rows_f = (torch.arange(N, device=device)[None, :] >= nu[:, None])           # (K,N)
+        Bfull = torch.where(rows_f[:, :, None] & inside[:, None, :], Bfull, torch.zeros((), dtype=c128, device=device))
+        low = torch.matmul(Bfull, torch.where(blockmask, isq, torch.zeros((), dtype=c128, device=device)))   # (K,N,npad)
+        R[:, :, :m] = R[:, :, :m] + low[:, :, :m]
+    # back to channel order
+    inv = torch.argsort(order, dim=1)
+    return R.gather(1, inv[:, :, None].expand(K, N, N)).gather(2, inv[:, None, :].expand(K, N, N)).contiguous()
+
+
 def _ninv_dense(Ninv, nbl, N):
     """``Ninv`` if it is a non-diagonal (N,N) / (Nbl,N,N) matrix (then it must be Hermitian), else None."""
     if not isinstance(Ninv, np.ndarray) and hasattr(Ninv, "detach"):
@@ -239,20 +283,15 @@ class GibbsBatch:
             if self.dense_noise and self.per_time:
                 # one full noise matrix per (baseline, time) (pspec.py:337-340): Ni = Ninv_t diag(w_t) and its
                 # scipy sqrtm per unit, as build_matrices would make them for that time (:361-362)
-                import scipy.linalg
                 nd = np.asarray(ninv_dense, dtype=complex)
                 if nd.ndim == 3:
                     nd = np.broadcast_to(nd[:, None], (nbl, T, N, N))
                 assert nd.shape == (nbl, T, N, N), "time-dependent Ninv must have shape (Nbl, Ntimes, Nfreqs, Nfreqs)"
                 nd = np.ascontiguousarray(nd)
                 w = fl_np.astype(bool)
-                nih = np.empty((nbl, T, N, N), dtype=complex)
-                for b in range(nbl):
-                    for t in range(T):
-                        nih[b, t] = scipy.linalg.sqrtm(nd[b, t] * w[b, t][None, :]) if not w[b, t].all() \
-                            else sqrtm_hermitian(nd[b, t])
                 d_nd = hpx.to_dev(torch, nd, c128, self.device)
-                d_nh = hpx.to_dev(torch, nih, c128, self.device)
+                d_nh = sqrtm_masked_device(torch, d_nd.reshape(nbl * T, N, N), w.reshape(nbl * T, N),
+                                           self.device).reshape(nbl, T, N, N)
                 d_ninv = None
             elif self.dense_noise:
                 nd = np.asarray(ninv_dense, dtype=complex)
@@ -260,15 +299,14 @@ class GibbsBatch:
                 d_nd = hpx.to_dev(torch, nd, c128, self.device)
                 if self.any_flags:
                     # the reference masks the COLUMNS of Ninv (Ni = flags.T * Ninv * flags, pspec.py:361) and takes
-                    # scipy's sqrtm of that general matrix (:362): the same call, per baseline, on the host
-                    import scipy.linalg
+                    # scipy's sqrtm of that general matrix (:362): the same principal root, on the device
                     w = fl_np.astype(bool)
-                    nih = np.stack([scipy.linalg.sqrtm((nd if nd.ndim == 2 else nd[b]) * w[b][None, :])
-                                    for b in range(nbl)]).astype(complex)
-                    d_nh = hpx.to_dev(torch, nih, c128, self.device)
+                    full = d_nd if nd.ndim == 3 else d_nd[None].expand(nbl, N, N)
+                    d_nh = sqrtm_masked_device(torch, full, w, self.device)
                     extra_rhs = int((~w).sum(axis=1).max())        # one more right-hand side per flagged channel
                 else:
-                    d_nh = hpx.to_dev(torch, sqrtm_hermitian(nd), c128, self.device)
+                    d_nh = sqrtm_masked_device(torch, d_nd.reshape(-1, N, N), np.ones((d_nd.numel() // (N * N), N), bool),
+                                               self.device).reshape(d_nd.shape)
                 d_ninv = None
             else:
                 d_ninv = hpx.to_dev(torch, ninv_diag, f64, self.device)
@@ -610,13 +648,33 @@ def build_matrices(Nparams, flags, signal_S, Ninv, fgmodes):
     F = np.asarray(fgmodes, dtype=complex)
     M = F.shape[1]
     assert Nparams == N + M, "Nparams must equal Nfreqs + Nmodes"
-    ninv = _ninv_diag(Ninv, 1, 1, N)[0]
+    dense = _ninv_dense(Ninv, 1, N)
     ops = np.zeros((4, N, N), dtype=complex)
     lam, V = np.linalg.eigh(0.5 * (S + S.conj().T))
     if lam.min() <= 1e-14 * lam.max():
         raise np.linalg.LinAlgError("build_matrices needs a positive-definite signal_S")
     ops[0] = (V * np.sqrt(lam)) @ V.conj().T
     ops[1] = S
+    if dense is not None:
+        # Hermitian non-diagonal Ninv: the reference's operators as it forms them (pspec.py:359-372, host
+        # linear algebra: this function is not on the sampler's path) -- Ni = Ninv with its flagged COLUMNS
+        # zeroed, Nih = scipy's sqrtm of that matrix, A the non-Hermitian system, Ai = pinv(A)
+        import scipy.linalg
+        nd = np.asarray(dense, dtype=complex).reshape(N, N)
+        w = fl.reshape(-1).astype(bool)
+        ops[2] = nd * w[None, :]
+        ops[3] = sqrtm_hermitian(nd) if w.all() else scipy.linalg.sqrtm(ops[2])
+        sys_ = np.zeros((2, Nparams, Nparams), dtype=complex)
+        A = sys_[0]
+        A[:N, :N] = np.eye(N) + S @ ops[2]
+        A[:N, N:] = S @ ops[2] @ F
+        A[N:, :N] = F.conj().T @ ops[2]
+        A[N:, N:] = F.conj().T @ ops[2] @ F
+        sys_[1] = np.linalg.pinv(A)
+        out = GcrMatrices([ops, sys_])
+        out.flags, out.signal_S, out.ninv_diag, out.fgmodes = fl, S, None, F
+        return out
+    ninv = _ninv_diag(Ninv, 1, 1, N)[0]
     ni = ninv * fl
     ops[2] = np.diag(ni)
     ops[3] = np.diag(np.sqrt(ni))
@@ -643,6 +701,29 @@ def build_matrices(Nparams, flags, signal_S, Ninv, fgmodes):
     return out
 
 
+def _hermitian_completion(Ni, fl):
+    """A Hermitian positive-definite ``H`` with ``H diag(fl) = Ni`` for the reference's column-masked
+    ``Ni = Ninv diag(fl)`` (pspec.py:361), when only ``Ni`` is at hand (the ``matrices`` argument of the GCR entry
+    points): the unflagged columns are Ni's, the flagged rows of those columns give the flagged-by-unflagged block and
+    its adjoint, and the flagged-by-flagged block -- which the system never sees -- is chosen to keep ``H`` positive
+    definite (Schur complement = the mean unflagged diagonal times the identity)."""
+    Ni = np.asarray(Ni, dtype=complex)
+    u = np.asarray(fl, dtype=bool)
+    A = Ni[np.ix_(u, u)]
+    if np.abs(A - A.conj().T).max() > 1e-12 * np.abs(A).max():
+        raise NotImplementedError("a non-Hermitian inverse noise covariance is not supported")
+    if u.all():
+        return 0.5 * (Ni + Ni.conj().T)
+    H = np.zeros_like(Ni)
+    B = Ni[np.ix_(~u, u)]
+    H[np.ix_(u, u)] = 0.5 * (A + A.conj().T)
+    H[np.ix_(~u, u)] = B
+    H[np.ix_(u, ~u)] = B.conj().T
+    C = B @ np.linalg.solve(H[np.ix_(u, u)], B.conj().T)
+    H[np.ix_(~u, ~u)] = 0.5 * (C + C.conj().T) + np.eye(int((~u).sum())) * np.real(np.diagonal(A)).mean()
+    return H
+
+
 def _gcr_solve(vis2d, w, matrices, fgmodes, map_estimate, idx):
     """Constrained realisations [s_t ; f_t] for the rows of ``vis2d`` on the GPU, with the
     reference's per-time noise streams for time indices ``idx``."""
@@ -655,14 +736,19 @@ def _gcr_solve(vis2d, w, matrices, fgmodes, map_estimate, idx):
     F = np.asarray(fgmodes, dtype=complex)
     M = F.shape[1]
     S = np.asarray(matrices[0][1])
-    ni = np.real(np.diagonal(np.asarray(matrices[0][2])))          # already column-masked
-    if np.abs(np.asarray(matrices[0][2]) - np.diag(np.diagonal(matrices[0][2]))).max() > 0:
-        raise NotImplementedError("only diagonal inverse noise covariances are supported")
+    Ni = np.asarray(matrices[0][2])
+    ni = np.real(np.diagonal(Ni))          # already column-masked
     fl = np.asarray(w).reshape(-1).astype(bool)
     ps0, resid = pspec_from_covariance(S)
     tables = (np.full((1, N), 0.5), np.ones((1, N)))     # the bandpower draw's output is discarded
-    gb = GibbsBatch(vis2d[None], fl[None], F, np.ascontiguousarray(ni)[None], np.zeros((2, N)), 1,
-                    map_estimate=map_estimate, tables=tables, omega=omega_table(T, N, idx=idx))
+    if np.abs(Ni - np.diag(np.diagonal(Ni))).max() > 0:
+        # a non-diagonal Ni: the chain's dense-noise path (GibbsBatch(ninv_dense=...): Hermitian noise factorisation
+        # + one Woodbury column per flagged channel) on a Hermitian matrix whose unflagged columns are Ni's
+        gb = GibbsBatch(vis2d[None], fl[None], F, None, np.zeros((2, N)), 1, map_estimate=map_estimate, tables=tables,
+                        omega=omega_table(T, N, idx=idx), ninv_dense=_hermitian_completion(Ni, fl)[None], solver="dense")
+    else:
+        gb = GibbsBatch(vis2d[None], fl[None], F, np.ascontiguousarray(ni)[None], np.zeros((2, N)), 1,
+                        map_estimate=map_estimate, tables=tables, omega=omega_table(T, N, idx=idx))
     try:
         if resid > FOURIER_FORM_TOL:
             out = gb.run(1, shp0=sqrt_cov_delay_basis(S)[None], keep=("signal_cr", "fg_amps"))
@@ -735,8 +821,10 @@ def inversion_sample_invgamma(alpha, beta, prior_min, prior_max, ngrid=1000):
         raise ValueError("prior_max must be finite")
     if prior_max <= prior_min:
         raise ValueError("prior_max must be greater than prior_min")
-    if float(alpha) != int(alpha) or alpha < 1:
-        raise NotImplementedError("the HIP inversion kernel needs a positive integer alpha")
+    if alpha <= 0:
+        raise ValueError("alpha must be greater than zero")
+    if float(alpha) != int(alpha):
+        return _inversion_sample_invgamma_host(float(alpha), float(beta), prior_min, prior_max, ngrid)
     torch = hpx.require_gpu()
     dev = torch.device("cuda", torch.cuda.current_device())
     x = np.logspace(np.log10(prior_min), np.log10(prior_max), ngrid)
@@ -750,6 +838,22 @@ def inversion_sample_invgamma(alpha, beta, prior_min, prior_max, ngrid=1000):
                                                hpx.ptr(d_x), ngrid, hpx.ptr(d_o),
                                                hpx.stream_ptr(torch)), "hpx_invgamma_inversion")
     return float(d_o.cpu()[0])
+
+
+def _inversion_sample_invgamma_host(alpha, beta, prior_min, prior_max, ngrid):
+    """The same draw for a NON-INTEGER shape parameter, evaluated on the host (reference pspec.py:49-62 step
+    by step: the inverse-gamma CDF Q(alpha, beta / x) on the log grid, shifted and rescaled to [0, 1],
+    duplicate values dropped, linear interpolation of the grid at one ``np.random.uniform()``).  The device kernel
+    sums the closed form of Q for integer alpha (all the Gibbs path ever passes: alpha = Ntimes); a general alpha
+    needs the incomplete gamma function itself, a scalar utility call outside the per-baseline path."""
+    from scipy.special import gammaincc
+    x = np.logspace(np.log10(prior_min), np.log10(prior_max), ngrid)
+    cdf = gammaincc(alpha, beta / x)
+    cdf = cdf - cdf.min()
+    cdf = cdf / cdf.max()
+    cdf_unique, idx = np.unique(cdf, return_index=True)
+    u = np.random.uniform()
+    return float(np.interp(u, cdf_unique, x[idx]))
 
 
 def sample_S(s=None, sk=None, prior=None):

@@ -333,6 +333,16 @@ int hpx_fgmodes_eig(int nb, int T, int N, int nmodes, const double* vis, double*
 int hpx_oqe_qauto(int nb, int nvis, int s, const double* R, const double* V, double* q_out,
                   void* work, int64_t work_bytes, void* stream);
 
+/* Principal square root and inverse square root of nb Hermitian positive-definite matrices on the device
+ * (coupled Newton-Schulz iteration on the batched FP64-MFMA product; csrc/hpx_sqrtm.hip).  Set-up of the
+ * correlated-noise paths: replaces the per-baseline host calls scipy.linalg.sqrtm(Ni) / eigh of reference
+ * pspec.py:361-362 (for flagged channels through Ni = P [[A, 0], [B, 0]] P^T -> P [[A^1/2, 0], [B A^-1/2, 0]] P^T).
+ * a (nb,n,n) c128 row-major, n a multiple of 16 (pad with an identity block); sq, isq (nb,n,n) c128, either may be
+ * NULL; stops when ||I - Z Y||_F < tol * n (tol ~ 1e-7: the step taken after that squares it), HPX_EINVAL if that
+ * takes more than max_iter steps or a matrix is not positive definite; iters_out (host int, optional). */
+int hpx_sqrtm_hpd_batched(int nb, int n, const double* a, double* sq, double* isq, double tol,
+                          int max_iter, int* iters_out, void* stream);
+
 /* Empirical lane map of v_mfma_f64_16x16x4_f64 (diagnostic used by the tests):
  * computes D = A(16x4) * B(4x16) and writes, for lane l and register v, the
  * value D holds; host (64*4) doubles. */

@@ -272,6 +272,40 @@ def test_build_matrices_and_gcr_vs_reference(golden, tag):
     assert relerr(smp[0], xs[0]) < RTOL and relerr(smp[3], xs[1]) < RTOL
 
 
+@pytest.mark.parametrize("flagged", [False, True])
+def test_gcr_entry_points_with_dense_noise(flagged):
+    """build_matrices / gcr_fgmodes_1d / gcr_fgmodes with a Hermitian NON-DIAGONAL inverse noise covariance, with and
+    without flagged channels (reference pspec.py:325-374, :151-235, :238-310): the operators against
+    the oracle's, the constrained realisations against the oracle's exact solve of the reference's own system --
+    through the chain's dense-noise path (Hermitian factorisation + one Woodbury column per flagged channel)."""
+    from hydra_pspec_amd import pspec, synthetic
+    from oracle import pspec_ref
+    N, T, M = 30, 5, 4
+    d = synthetic.make_baselines(N, T, M, k0=3, nbl=1, flag_frac=0.2 if flagged else 0.0, dense=True)
+    fl = d["flags"][0]
+    assert (not fl.all()) == flagged
+    i = np.arange(N)
+    band = np.zeros((N, N), dtype=complex)
+    band[i, i] = 1.0 + 0.2 * np.cos(0.3 * i)
+    band[i[:-1], i[:-1] + 1] = 0.3 * np.exp(0.4j)
+    band[i[:-1] + 1, i[:-1]] = 0.3 * np.exp(-0.4j)
+    Ninv = np.linalg.inv(band / d["Ninv"][0, 0].real)
+    vis, F, S = d["vis"][0], d["fgmodes"], d["S_initial"]
+    mats = pspec.build_matrices(N + M, fl, S, Ninv, F)
+    ref = pspec_ref.build_matrices(N + M, fl, S, Ninv, F)
+    for k in range(4):
+        assert relerr(mats[0][k], ref[0][k]) < 1e-9, k
+    assert relerr(mats[1][0], ref[1][0]) < 1e-12
+    for idx in (0, 3):
+        x, res, info = pspec.gcr_fgmodes_1d(idx, (vis * fl)[idx], fl, mats, F, verbose=True)
+        xr, _, _ = pspec_ref.gcr_fgmodes_1d(idx, (vis * fl)[idx], fl, ref, F, solver="direct")
+        assert info == 0 and relerr(x, xr) < 1e-8, idx
+        assert res < 1e-8 * np.abs(x).max() * np.abs(ref[1][0]).max()
+    smp = pspec.gcr_fgmodes(vis * fl, fl, ref, F)          # (the oracle's list of arrays works as `matrices`)
+    sr = pspec_ref.gcr_fgmodes(vis * fl, fl, ref, F, solver="direct")
+    assert relerr(smp, sr) < 1e-8
+
+
 @pytest.mark.parametrize("shape", [(3, 8, 64, 6), (2, 32, 512, 12), (2, 203, 120, 12), (2, 5, 30, 0), (2, 40, 64, 6),
                                    (2, 70, 128, 16)])
 def test_flat_noise_solver_matches_dense(shape):

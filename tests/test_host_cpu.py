@@ -168,6 +168,24 @@ def test_reference_call_surface_is_importable():
             assert callable(getattr(mod, n)), (mod.__name__, n)
 
 
+def test_inversion_sample_invgamma_non_integer_alpha():
+    """A non-integer shape parameter takes the host evaluation (reference pspec.py:11-64): same uniform, same draw as
+    the oracle, and the reference's argument checks hold on that path too.  No GPU touched."""
+    from hydra_pspec_amd import pspec
+    from oracle import pspec_ref
+    for alpha, beta, lo, hi in ((2.5, 3.0, 1e-2, 1e3), (31.7, 40.0, 0.1, 50.0), (0.6, 1e-3, 1e-6, 1.0)):
+        for seed in (1, 2, 3):
+            np.random.seed(seed)
+            got = pspec.inversion_sample_invgamma(alpha, beta, lo, hi)
+            np.random.seed(seed)
+            ref = float(pspec_ref.inversion_sample_invgamma(alpha, beta, lo, hi))
+            assert abs(got / ref - 1) < 1e-12, (alpha, beta, got, ref)
+    with pytest.raises(ValueError):
+        pspec.inversion_sample_invgamma(2.5, 1.0, 0.0, 1.0)
+    with pytest.raises(ValueError):
+        pspec.inversion_sample_invgamma(-0.5, 1.0, 0.1, 1.0)
+
+
 def test_dense_noise_detection_rules():
     """Which `Ninv` inputs select the dense-noise path (host logic only; no GPU touched)."""
     from hydra_pspec_amd import pspec
