@@ -1321,6 +1321,16 @@ static int set_static_impl(hpx_plan* p, const double* vis, const uint8_t* flags,
       HPX_REQUIRE(T + fmax <= TP, "hpx_plan_set_static_dense_flagged: the plan has too few right-hand-side columns "
                                   "(hpx_plan_create_ex with extra_rhs >= the largest number of flagged channels)");
       HPX_REQUIRE(fmax <= 512, "hpx_plan_set_static_dense_flagged: at most 512 flagged channels per baseline");
+      {   // the residual kernel keeps (2 M + N / 16) x TP doubles in LDS (k_resid): say so HERE, not at the first run
+        const size_t lds = (size_t)(2 * M * TP + N * (TP / 16)) * sizeof(double);
+        if (lds > (size_t)160 * 1024) {
+          hpx_set_error("hpx_plan_set_static_dense_flagged: %d right-hand-side columns (%d times + %d flagged channels, "
+                        "padded) need %zu bytes of LDS in the residual kernel, the CU has 160 KiB: at Nfreqs = %d and "
+                        "%d modes at most %d columns", TP, T, fmax, lds, N, M,
+                        (int)((160 * 1024 / sizeof(double)) / (2 * M + N / 16.0)) / 16 * 16);
+          return HPX_EINVAL;
+        }
+      }
       p->wb_fmax = fmax > 0 ? fmax : 1;
       std::vector<int32_t> list((size_t)nbl * p->wb_fmax, 0);
       for (int b = 0; b < nbl; ++b) {
