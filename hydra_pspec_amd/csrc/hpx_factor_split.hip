@@ -13,7 +13,8 @@
 //   B  every workgroup takes inv(L_jj) (from LDS if it is the owner, else from Vt once A[j] is up), forms its
 //      tiles of the column, X(r, j) = D(r, j) inv(L_jj)^H, stores them into the
 //      factor and counts itself in on B[j];
-//   D  once B[j] shows all parts, the column (rows j+1 .. nrt-1) is copied into LDS once per workgroup (LDS-DMA;
+//   D  once B[j] shows all parts, the column (rows j+1 .. nrt-1) is copied into LDS once per workgroup (LDS-DMA; the
+//      workers meet on a counter in LDS for this, the eliminator is not held up;
 //      the workgroup's own tiles were put there by B) and every wave updates its trailing tiles
 //      D(r, c) -= X(r, j) X(c, j)^H.
 // Look-ahead: the owner of diagonal tile j+1 also owns X(j+1, j), the only operand that tile's last update
@@ -67,6 +68,15 @@ __device__ HPX_INL void full_barrier() {
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
+// The seven worker waves meet without the eliminator (s_barrier counts every wave of the workgroup, and the
+// eliminator is busy with the next diagonal tile just then): a counter in LDS, one increment per wave and step.
+__device__ HPX_INL void worker_barrier(int* cnt, const int target, const int lane) {
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");       // this wave's LDS-DMA and LDS writes have landed
+  if (lane == 0) __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target) __builtin_amdgcn_s_sleep(0);
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
 #ifdef HPX_SPLIT_TRACE
 // timing of system 0's steps (a debugging build): [part][column + 1][stamp] in 10 ns ticks
 __device__ long long hpx_split_trace[8 * (SPLIT_MAX_CT + 1) * 8];
@@ -96,6 +106,7 @@ __global__ __launch_bounds__(64 * SPLIT_NW, 2) void k_factor_split(double* __res
                                                                    const int iter_tag, const hpx_gen_batch GB, const int nbl,
                                                                    const int parts, const int force_heavy) {
   extern __shared__ double lds_panel[];        // [nrt][512]: the current column's tiles (odd-column swizzle)
+  __shared__ int wcount;                       // worker_barrier's counter
   const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
   const int b = (idx / parts) * 8 + xcd, w = idx % parts;
   if (b >= nbl) return;
@@ -129,6 +140,7 @@ __global__ __launch_bounds__(64 * SPLIT_NW, 2) void k_factor_split(double* __res
   lds_f64* const Vs = (lds_f64*)(hpx_stage1 + FV_OFF);
   // Which protocol: every part enters its XCD and counts itself in (`arrive`); when all have (no data is exchanged
   // yet, so no fence), a system whose parts share one XCD uses the light hand-off from the first column on.
+  if (tid == 0) wcount = 0;
   if (tid == 0) {
     const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 15u;        // HW_REG_XCC_ID, bits 3:0
     // (one word: XCD bits above the count -- the same thread's OR and ADD on one location stay in order)
@@ -175,6 +187,9 @@ __global__ __launch_bounds__(64 * SPLIT_NW, 2) void k_factor_split(double* __res
       bad |= elim16w(X, t, t + 1 == X.nct, er, ei, [&] {
         handoff_release(heavy);
         if (lane == 0) __hip_atomic_store(&flagA[t], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#ifdef HPX_SPLIT_TRACE
+        if (b == 0 && tid == 0) hpx_split_trace[(w * (SPLIT_MAX_CT + 1) + t) * 8 + 4] = wall_clock64();   // (slot 4 of step t-1: published)
+#endif
       });
       if (t & 1) {
         // odd tile of a pair: W10 = -inv(L11) L10 inv(L00); L10 = X(t, t-1) was stored by this workgroup in B(t-1),
@@ -245,9 +260,7 @@ __global__ __launch_bounds__(64 * SPLIT_NW, 2) void k_factor_split(double* __res
         const int r = w + s * parts;
         if (r > j + 1 && r < X.nct) tile_update(e1[s], e2[s], Pn + r * 512, Pn + r * 512, rd_re, rd_im);
       }
-      lds_barrier();                           // (3) the column is staged
-      HPX_STAMP(4, 0);
-      lds_barrier();                           // (4) the column and Vs are free again
+      lds_barrier();                           // (3) the workers are through with the column and Vs
     }
   } else {
     // =================== the workers: tiles (r, c) below the diagonal and of the right-hand-side rows ==========
@@ -323,14 +336,14 @@ __global__ __launch_bounds__(64 * SPLIT_NW, 2) void k_factor_split(double* __res
         wait_vm<0>();
       }
       HPX_STAMP(6, 64);
-      lds_barrier();                           // (3) the column is staged
+      worker_barrier(&wcount, (SPLIT_NW - 1) * (j + 1), lane);       // the column is staged (workers only)
 #pragma unroll
       for (int s = 0; s < SPLIT_NSW; ++s) {
         if (tc[s] > j) tile_update(a1[s], a2[s], Pn + tc[s] * 512, Pn + tr[s] * 512, rd_re, rd_im);
         __builtin_amdgcn_sched_barrier(0);     // one tile's operands at a time: the accumulators need the registers
       }
       HPX_STAMP(7, 64);
-      lds_barrier();                           // (4) the column and Vs are free again
+      lds_barrier();                           // (3) the column and Vs are free again
     }
   }
 #undef HPX_LANE_INDICES

@@ -299,7 +299,8 @@ __device__ HPX_INL bool elim16(const WideCtx& X, const int tcol /* global tile c
 // accumulator layout of a D^T tile, so the wave that owns the diagonal tile eliminates it where it lies.  No
 // workgroup barrier inside (elim16 has eighteen, and spends most of its time in them): per step the pivot column
 // and row k of the inverse go through LDS -- a wave's LDS operations execute in order, the reads behind the writes
-// see them -- and everything else stays in the lane.  Same operations in the same order per element as elim16.
+// see them -- and everything else stays in the lane.  Same operations in the same order per element as elim16
+// (the pivots' reciprocals included: see the loop).
 // out: as elim16; the CALLER puts a workgroup barrier between this and the first use of Vs by another wave.
 // `flag` (split form; else null): raised -- behind `publish()` -- as soon as the inverse tile is in Vt, the one thing
 // another workgroup waits for; the factor's own tile and the W blocks follow.
@@ -320,51 +321,107 @@ __device__ HPX_INL bool elim16w(const WideCtx& X, const int tcol, const bool las
     yr[v] = (li == g + 4 * v) ? 1.0 : 0.0;
     yi[v] = 0.0;
   }
+  // Software-pipelined: the recurrence of the factorisation is  column k+1 after step k -> LDS -> everyone's operands
+  // of step k+1, so per step ONLY  l = c / d_kk,  the 16 updates of D  and the LDS round trip are on the critical
+  // path.  Off it, in the shadow of that round trip: (a) the next pivot's reciprocal -- every lane forms
+  // d_{k+1,k+1} - l_{k+1,k} conj(D_{k+1,k}) itself, with the very operations its owner applies (same bits), from one
+  // broadcast read of the column and of the diagonal entry before the step; (b) the inverse's updates, one step behind
+  // (row k of Y is published after the step k-1 update, read back by all lanes and used one step later).
+  lds_f64* const rawn = raw;       // [4 lane groups][16]: real parts of the columns 4 (k+1 >> 2) + g BEFORE step k
+#define HPX_E16_FENCE()                                   \
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  \
+  __builtin_amdgcn_wave_barrier()
   __builtin_amdgcn_s_setprio(2);
+  col[g * 16 + li] = (cplx){li > 0 ? dr[0] : 0.0, li > 0 ? di[0] : 0.0};
+  rawn[g * 16 + li] = dr[0];
+  HPX_E16_FENCE();
+  double dkk = rawn[0];                                 // D[0][0]
+  cplx c = col[li], cq[4], cn = col[1];
+  double dn = rawn[16 + 1];                             // D[1][1] before step 0
+#pragma unroll
+  for (int v = 0; v < 4; ++v) cq[v] = col[g + 4 * v];
+  dgs[0] = dkk;
+  double rinv;
+  {
+    const double r0 = __builtin_amdgcn_rcp(dkk);
+    rinv = fma(r0, fma(-dkk, r0, 1.0), r0);
+  }
+  double plr = 0.0, plm = 0.0;                          // the multipliers of the step before (for the lagging Y update)
+  cplx sy[4];
+#pragma unroll
+  for (int v = 0; v < 4; ++v) sy[v] = (cplx){0.0, 0.0};
 #pragma unroll
   for (int k = 0; k < 16; ++k) {
-    const int kv = k >> 2, kg = k & 3;
-    const bool below = li > k;
-    col[g * 16 + li] = (cplx){below ? dr[kv] : 0.0, below ? di[kv] : 0.0};     // (group kg's copy is the column)
-    raw[g * 16 + li] = dr[kv];
-    if (li == k) {
-#pragma unroll
-      for (int v = 0; v < 4; ++v) yrw[g * 4 + v] = (cplx){yr[v], yi[v]};
-    }
-    // the lanes exchange data here: without the fence the compiler may (and did) move a lane's reads in front of
-    // the OTHER lanes' writes -- per thread there is no dependence
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    const double dkk = raw[kg * 16 + k];
-    const cplx c = col[kg * 16 + li];
-    cplx cq[4], sy[4];
-#pragma unroll
-    for (int v = 0; v < 4; ++v) {
-      cq[v] = col[kg * 16 + g + 4 * v];
-      sy[v] = yrw[g * 4 + v];
-    }
-    dgs[k] = dkk;
-    const double r0 = __builtin_amdgcn_rcp(dkk);
-    const double rinv = fma(r0, fma(-dkk, r0, 1.0), r0);
+    // ---- A (critical): multipliers, D update, the next column out, the next operands requested
     const double lr = c.x * rinv, lm = c.y * rinv;
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
-      yr[v] = fma(-lr, sy[v].x, yr[v]);
-      yr[v] = fma(lm, sy[v].y, yr[v]);
-      yi[v] = fma(-lr, sy[v].y, yi[v]);
-      yi[v] = fma(-lm, sy[v].x, yi[v]);
       dr[v] = fma(-lr, cq[v].x, dr[v]);
       dr[v] = fma(-lm, cq[v].y, dr[v]);
       di[v] = fma(-lm, cq[v].x, di[v]);
       di[v] = fma(lr, cq[v].y, di[v]);
       // (computed HERE: left alone, the compiler sinks the update chains of the elements that are only stored at the
       // end into that final block and keeps every step's operands alive for it -- in scratch)
-      asm volatile("" : "+v"(dr[v]), "+v"(di[v]), "+v"(yr[v]), "+v"(yi[v]));
+      asm volatile("" : "+v"(dr[v]), "+v"(di[v]));
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");     // (the reads above are done before the next step's writes)
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_sched_barrier(0);       // a step's operands die with it (the caller's accumulators need the rest)
+    const cplx cn_k = cn;
+    const double dn_k = dn, rinv_k = rinv;
+    if (k < 15) {
+      const int k1 = k + 1, kv1 = k1 >> 2, kg1 = k1 & 3;
+      const bool below = li > k1;
+      col[g * 16 + li] = (cplx){below ? dr[kv1] : 0.0, below ? di[kv1] : 0.0};
+      if (k1 < 15) rawn[g * 16 + li] = dr[(k1 + 1) >> 2];
+      HPX_E16_FENCE();
+      __builtin_amdgcn_sched_barrier(0);
+      c = col[kg1 * 16 + li];
+#pragma unroll
+      for (int v = 0; v < 4; ++v) cq[v] = col[kg1 * 16 + g + 4 * v];
+      if (k1 < 15) {
+        cn = col[kg1 * 16 + k1 + 1];
+        dn = rawn[((k1 + 1) & 3) * 16 + k1 + 1];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      // ---- in the shadow of that round trip: the next pivot (the owner's own operations on D[k+1][k+1]) ...
+      const double lrn = cn_k.x * rinv_k, lmn = cn_k.y * rinv_k;
+      double dkn = fma(-lrn, cn_k.x, dn_k);
+      dkn = fma(-lmn, cn_k.y, dkn);
+      dgs[k1] = dkn;
+      const double r0 = __builtin_amdgcn_rcp(dkn);
+      rinv = fma(r0, fma(-dkn, r0, 1.0), r0);
+    }
+    // ---- ... the inverse's update of the step before ...
+    if (k > 0) {
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        yr[v] = fma(-plr, sy[v].x, yr[v]);
+        yr[v] = fma(plm, sy[v].y, yr[v]);
+        yi[v] = fma(-plr, sy[v].y, yi[v]);
+        yi[v] = fma(-plm, sy[v].x, yi[v]);
+        asm volatile("" : "+v"(yr[v]), "+v"(yi[v]));
+      }
+    }
+    // ---- ... and row k of the inverse out (final since that update) and back in
+    if (li == k) {
+#pragma unroll
+      for (int v = 0; v < 4; ++v) yrw[g * 4 + v] = (cplx){yr[v], yi[v]};
+    }
+    HPX_E16_FENCE();
+#pragma unroll
+    for (int v = 0; v < 4; ++v) sy[v] = yrw[g * 4 + v];
+    plr = lr;
+    plm = lm;
+    HPX_E16_FENCE();
+    __builtin_amdgcn_sched_barrier(0);
   }
+#pragma unroll
+  for (int v = 0; v < 4; ++v) {                          // the last step's update of the inverse
+    yr[v] = fma(-plr, sy[v].x, yr[v]);
+    yr[v] = fma(plm, sy[v].y, yr[v]);
+    yi[v] = fma(-plr, sy[v].y, yi[v]);
+    yi[v] = fma(-plm, sy[v].x, yi[v]);
+  }
+  HPX_E16_FENCE();
+#undef HPX_E16_FENCE
   __builtin_amdgcn_s_setprio(0);
   bool bad = false;
   const double pib = dgs[li];

@@ -33,5 +33,5 @@ for j in range(-1, nct):
     for w in range(parts):
         row = tr[w, j + 1]
         us = [(v - t0) / 100 if v > 0 else float("nan") for v in row[:7]]
-        print("col %2d part %d  top %7.2f | inv %6.2f  stored %6.2f  ahead %6.2f  complete %6.2f  staged %6.2f  updated %6.2f" %
-              (j, w, us[0], *[u - us[0] for u in us[1:]]))
+        print("col %2d part %d  top %7.2f | inv %6.2f  stored %6.2f  ahead %6.2f  published %6.2f  Bdone %6.2f  staged %6.2f  updated %6.2f" %
+              (j, w, us[0], *[u - us[0] for u in us[1:]], (row[7] - t0) / 100 - us[0] if row[7] > 0 else float("nan")))
