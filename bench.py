@@ -419,12 +419,17 @@ def bench_aux(args):
         # leading eigenvectors of np.cov(bl_data.T) per baseline (scripts/calc-vis-cov-matrices.py:235-249)
         from hydra_pspec_amd import fgmodes
         nb, T, N, nm = args.nbl or 1024, 32, 512, 12
+        if args.order:
+            N, T = args.order, args.order + 8
         rng = np.random.default_rng(2)
         nu = np.linspace(-1, 1, N)
         basis = np.stack([np.cos(np.pi * k * nu / 2 + 0.3 * k) * np.exp(0.2j * k * nu) for k in range(16)], axis=1)
-        amps = (rng.standard_normal((nb, T, 16)) + 1j * rng.standard_normal((nb, T, 16))) * (2.0 ** -np.arange(16))
-        vis = amps @ basis.T + 0.01 * (rng.standard_normal((nb, T, N)) + 1j * rng.standard_normal((nb, T, N)))
+        nsrc = min(nb, 64)       # distinct cubes (the order-512 case would otherwise spend minutes in the host RNG)
+        amps = (rng.standard_normal((nsrc, T, 16)) + 1j * rng.standard_normal((nsrc, T, 16))) * (2.0 ** -np.arange(16))
+        vis = amps @ basis.T + 0.01 * (rng.standard_normal((nsrc, T, N)) + 1j * rng.standard_normal((nsrc, T, N)))
         d_vis = hpx.to_dev(torch, vis, torch.complex128, dev)
+        if nsrc < nb:
+            d_vis = d_vis.repeat((nb + nsrc - 1) // nsrc, 1, 1)[:nb].contiguous()
         out = {}
 
         def run():
@@ -436,12 +441,41 @@ def bench_aux(args):
         worst = 0.0
         hm, he = out["m"][:4].cpu().numpy(), out["e"][:4].cpu().numpy()
         for b in range(4):
-            lam, U = np.linalg.eigh(np.cov(vis[b].T))
+            lam, U = np.linalg.eigh(np.cov(vis[b % nsrc].T))
             lam, U = lam[::-1][:nm], U[:, ::-1][:, :nm]
             worst = max(worst, float(np.max(np.abs(he[b] / lam - 1))),
                         float(np.max(1 - np.abs(np.sum(U.conj() * hm[b], axis=0)))))
         cpu_s = (time.perf_counter() - t0) / 4
         by = nb * (16.0 * T * N + 16.0 * N * nm + 8.0 * nm)
+        if args.order:
+            # flop model of the blocked one-sided Jacobi (csrc/hpx_eigh.hip): per visit of a pair of 8-column blocks the
+            # 16 x 16 Gram matrix and the update W Q, 8 * 16 * 16 * n flops each; (n/16)(n/8 - 1) visits per sweep;
+            # + the covariance (8 T n^2) and its Cholesky factor (4/3 n^3)
+            n_ = ((N + 15) // 16) * 16
+            sweeps = int(os.environ.get("HPX_BENCH_EIGH_SWEEPS", "10"))
+            fl = sweeps * (n_ // 16) * (n_ // 8 - 1) * 2 * 8 * 256 * n_ + 8.0 * T * N * N + 4.0 / 3.0 * n_ ** 3
+            ach = nb * fl / (ms * 1e-3) / 1e12
+            res = {"metric": f"foreground-mode sets (baselines) per second: leading eigenvectors of np.cov(vis.T), "
+                             f"Ntimes {T}, Nfreq {N}, {nm} modes (the Nfreq x Nfreq covariance is diagonalised)",
+                   "value": nb / wall, "unit": "baselines/s", "n_gpus": 1, "steps": K, "warmup": W,
+                   "ms_per_step": wall * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                   "dtype": "f64", "data": "synthetic",
+                   "config": {"workload": f"fgmodes --order {N}: {nb} baselines x (Ntimes {T}, Nfreq {N}), {nm} modes; "
+                                          "hpx_fgmodes_eig: centring, covariance, Cholesky factor, blocked one-sided "
+                                          "Jacobi (hpx_eigh.hip), mode selection; includes its workspace allocation"},
+                   "roofline": {"kernel": "k_hj_step (16 x 16 block rotations of the one-sided Jacobi on the FP64 MFMA)",
+                                "bound": "mfma", "achieved": ach, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                "frac": ach / FP64_MFMA_PEAK_TFLOPS, "traffic": None, "avg_launch_ms": ms,
+                                "flops_per_unit": fl, "units_per_launch": nb,
+                                "note": f"flop model with {sweeps} sweeps (HPX_EIGH_TRACE=1 prints the count); the "
+                                        "method is bound by HBM: every step streams the factor once in and once out "
+                                        f"({sweeps} x {n_ // 8 - 1} steps x {2 * 16 * n_ * n_ / 1e6:.1f} MB per baseline)"},
+                   "cpu_baseline": {"value": 1.0 / cpu_s, "unit": "baselines/s", "cores": os.cpu_count(), "kind": "port",
+                                    "sample": "np.cov + np.linalg.eigh (the reference script's own calls, default BLAS "
+                                              "threads) on 4 baselines, incl. the comparison"},
+                   "max_rel_dev_vs_cpu": worst}
+            print(json.dumps(res))
+            return
         res = {"metric": "foreground-mode sets (baselines) per second: leading eigenvectors of np.cov(vis.T), "
                          "Ntimes 32, Nfreq 512, 12 modes", "value": nb / wall, "unit": "baselines/s", "n_gpus": 1,
                "steps": K, "warmup": W, "ms_per_step": wall * 1e3, "higher_is_better": True, "scaling": "weak",
@@ -520,6 +554,9 @@ def main():
                          "path).  pertime-dense: one such matrix per (baseline, time) with time-dependent flags "
                          "(needs --nbl small: nbl x Ntimes full matrices)")
     ap.add_argument("--flag-frac", type=float, default=None, help="override the config's flag fraction")
+    ap.add_argument("--order", type=int, default=0,
+                    help="--config fgmodes: diagonalise the Nfreq x Nfreq covariance itself (Ntimes = order + 8 > "
+                         "Nfreq = order, scripts/calc-vis-cov-matrices.py:239-247) instead of the Ntimes x Ntimes Gram matrix")
     ap.add_argument("--dry-run", action="store_true",
                     help="rank plumbing only (gloo, no GPU): print the blocks of baselines the ranks would own")
     args = ap.parse_args()

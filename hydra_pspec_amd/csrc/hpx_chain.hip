@@ -2142,7 +2142,10 @@ static int post_solve(hpx_plan* p, int it_abs, const IterOut& O, hipStream_t st)
   R.flags_t = p->per_time ? p->flags_t : nullptr;
   R.ninv_t = p->per_time ? p->ninv_t : nullptr;
   // time columns per block of the fused kernel: 64 KiB of LDS for the signal, as k_fft
-  int npart = 1, TC = 4096 / NP;
+#ifndef HPX_FR_ELEMS
+#define HPX_FR_ELEMS 4096      // complex elements of the signal block a workgroup of k_fft_resid holds in LDS
+#endif
+  int npart = 1, TC = HPX_FR_ELEMS / NP;
   if (TC > 16) TC = 16;
   const bool pow2 = N == NP && (N & (N - 1)) == 0 && N >= 32 && N <= 4096;
   const bool generic_post = p->dense_noise || p->per_time;      // modes only the two-kernel form implements

@@ -320,6 +320,10 @@ int hpx_launch_factor(int nbl, int npad, int ld, double* L, double* Wre, double*
 // the wide (128-column super-block, LDS-staged) form, hpx_factor_wide.hip
 int hpx_launch_factor_wide(int nbl, int npad, int ld, double* L, double* Wre, double* Wim, double* Vt,
                            int32_t* info, int iter_tag, const hpx_gen_batch* gen, hipStream_t st);
+// Hermitian positive semi-definite eigendecomposition, orders 128 .. (hpx_eigh.hip): planar in, eigenvalues on the
+// diagonal of gr, unit eigenvectors as the columns of (vr, vi); n a multiple of 16
+int hpx_eigh_psd_planar(int nb, int n, double* gr, const double* gi, double* vr, double* vi, int* sweeps_out,
+                        hipStream_t st);
 // the split form (hpx_factor_split.hip): several workgroups per system, for batches too small to fill the chip
 int hpx_factor_split_parts(int nbl, int npad, int ld);     // workgroups per system, 0 = not applicable
 int hpx_launch_factor_split(int nbl, int parts, int npad, int ld, double* L, double* Wre, double* Wim, double* Vt,

@@ -5,13 +5,16 @@
 // The covariance C = A A^H, A = Xc^T / sqrt(T-1) (Xc = data minus its time mean), has rank at
 // most T-1, so for T <= N its eigenvectors come from the T x T Gram matrix A^H A:
 // (lambda, v) -> u = A v / sqrt(lambda).  Either way a Hermitian n x n problem with
-// n = min(T, N) <= 1024 is diagonalised per baseline by a cyclic two-sided Jacobi method with the
-// round-robin parallel ordering: n/2 disjoint rotations per step, applied as a column phase and
-// a row phase by the whole workgroup.  One workgroup per baseline; the matrices live in global
-// memory (L2-resident up to n ~ 256, 1 MB per baseline; beyond that a step streams 32 n^2 bytes
-// through the cache hierarchy and a baseline takes O(n^3) rotations on one CU -- seconds at n = 1024,
-// measured in DESIGN.md; the usual case is the Gram path with n = Ntimes).
+// n = min(T, N) <= 1024 is diagonalised per baseline: below order 128 (the usual case: the Gram path with
+// n = Ntimes) by the cyclic two-sided Jacobi method of this file with the round-robin parallel ordering -- n/2
+// disjoint rotations per step, applied as a column phase and a row phase by the whole workgroup, one workgroup
+// per baseline, the matrices in LDS up to n = 64; from order 128 on by the blocked one-sided Jacobi of
+// hpx_eigh.hip (16 x 16 rotations on the MFMA, a workgroup per pair of column blocks: round 4).
 #include "hpx_internal.h"
+
+#ifndef HPX_EIGH_BLOCKED_MIN
+#define HPX_EIGH_BLOCKED_MIN 128
+#endif
 
 namespace {
 
@@ -344,7 +347,10 @@ extern "C" int hpx_fgmodes_eig(int nb, int T, int N, int nmodes, const double* v
   const int nreal = gram ? T : N;
   HPX_REQUIRE(nreal <= 1024, "hpx_fgmodes_eig: min(Ntimes, Nfreqs) must be <= 1024");
   HPX_REQUIRE(nmodes > 0 && nmodes <= nreal && nmodes <= 256, "hpx_fgmodes_eig: bad number of modes");
-  const int n = nreal + (nreal & 1);           // even order for the round-robin pairing
+  // from order 128 on: the blocked one-sided Jacobi of hpx_eigh.hip (order padded to a multiple of 16); below, the
+  // cyclic two-sided Jacobi of this file (even order for its round-robin pairing)
+  const bool blocked = nreal >= HPX_EIGH_BLOCKED_MIN;
+  const int n = blocked ? ((nreal + 15) & ~15) : nreal + (nreal & 1);
   hipStream_t st = (hipStream_t)stream;
   hpx_devbuf xbuf, gbuf;
   HPX_TRY(xbuf.alloc((size_t)2 * nb * T * N));
@@ -357,7 +363,9 @@ extern "C" int hpx_fgmodes_eig(int nb, int T, int N, int nmodes, const double* v
   hipLaunchKernelGGL(k_gram, dim3((nreal + 31) / 32, (nreal + 31) / 32, nb), dim3(256), 0, st, xr, xi, gr, gi, T, N,
                      nreal, n, gram);
   HPX_HIP(hipGetLastError());
-  {
+  if (blocked) {
+    HPX_TRY(hpx_eigh_psd_planar(nb, n, gr, gi, vr, vi, nullptr, st));
+  } else {
     const int in_lds = n <= 64;             // 4 n^2 doubles: 32 KB at n = 32, 128 KB at n = 64
     const size_t lds = ((size_t)(n / 2) * 4 + (in_lds ? (size_t)4 * n * (n + 1) : 0)) * sizeof(double);
     static hpx_lds_limit limit;

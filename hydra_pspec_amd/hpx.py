@@ -62,6 +62,7 @@ SIGNATURES = {
     "hpx_lincomb": (_i, [_i64, C.c_double, _vp, C.c_double, _vp, _vp, _vp]),
     "hpx_fgmodes_eig": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "hpx_oqe_qauto": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _i64, _vp]),
+    "hpx_zheev_psd_batched": (_i, [_i, _i, _vp, _vp, _vp, _vp, _vp]),
     "hpx_sqrtm_hpd_batched": (_i, [_i, _i, _vp, _vp, _vp, C.c_double, _i, _vp, _vp]),
     "hpx_mfma_probe": (_i, [_vp, _vp, _vp]),
     "hpx_mfma_f64_peak": (_i, [_i, _vp]),

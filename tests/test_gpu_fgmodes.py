@@ -68,3 +68,69 @@ def test_modes_drive_the_sampler():
     out = pspec.gibbs_sample_with_fg_batched(d["vis"], d["flags"], F, d["ninv_diag"], d["ps_prior"],
                                              ps_initial=d["ps0"], Niter=3, seed=2)
     assert np.isfinite(out["signal_ps"]).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n0,kind", [(512, "cov"), (1024, "cov"), (330, "gram"), (144, "hpd")])
+def test_zheev_psd_batched_vs_numpy(n0, kind):
+    """hpx_zheev_psd_batched (blocked one-sided Jacobi on the Cholesky factor, csrc/hpx_eigh.hip) against
+    numpy.linalg.eigh at the orders the covariance path meets (512 and 1024): eigenvalues to 1e-9 of the
+    largest, residual and orthogonality of the full eigenvector set, overlap of the 12 leading eigenvectors -- for a
+    foreground-dominated covariance (T > n samples), the exactly singular Gram matrix of a centred cube and a generic
+    positive definite matrix."""
+    import ctypes
+    import torch
+    from hydra_pspec_amd import hpx
+    rng = np.random.default_rng(n0)
+    nb = 2
+    if kind == "cov":
+        T = n0 + 24
+        modes = rng.standard_normal((n0, 12)) + 1j * rng.standard_normal((n0, 12))
+        amp = (rng.standard_normal((nb, T, 12)) + 1j * rng.standard_normal((nb, T, 12))) * np.logspace(3, 0.5, 12)
+        x = amp @ modes.T + (rng.standard_normal((nb, T, n0)) + 1j * rng.standard_normal((nb, T, n0)))
+        A = np.stack([np.cov(x[b].T) for b in range(nb)])
+    elif kind == "gram":
+        x = rng.standard_normal((nb, n0, n0 + 50)) + 1j * rng.standard_normal((nb, n0, n0 + 50))
+        x = x - x.mean(axis=1, keepdims=True)
+        A = np.stack([x[b].conj() @ x[b].T / (n0 - 1) for b in range(nb)])
+    else:
+        q = rng.standard_normal((nb, n0, n0)) + 1j * rng.standard_normal((nb, n0, n0))
+        A = q @ np.conj(np.swapaxes(q, 1, 2)) / n0 + np.eye(n0)
+    A = 0.5 * (A + np.conj(np.swapaxes(A, 1, 2)))
+    n = (n0 + 15) // 16 * 16
+    dA = torch.from_numpy(np.ascontiguousarray(A)).cuda()
+    w = torch.empty((nb, n), dtype=torch.float64, device="cuda")
+    v = torch.empty((nb, n0, n), dtype=torch.complex128, device="cuda")
+    sw = ctypes.c_int(0)
+    hpx.check(hpx.lib().hpx_zheev_psd_batched(nb, n0, hpx.ptr(dA), hpx.ptr(w), hpx.ptr(v), ctypes.byref(sw), None))
+    w, v = w.cpu().numpy(), v.cpu().numpy()
+    lam, U = np.linalg.eigh(A)
+    assert 0 < sw.value < 30
+    for b in range(nb):
+        order = np.argsort(-w[b])[:n0]
+        wb, vb = w[b][order], v[b][:, order]
+        lr, Ur = lam[b][::-1], U[b][:, ::-1]
+        assert np.max(np.abs(wb - lr)) < 1e-9 * lr[0]
+        assert np.linalg.norm(A[b] @ vb - vb * wb[None, :]) < 1e-9 * np.linalg.norm(A[b])
+        keep = wb > 1e-9 * lr[0]                       # (a null vector competes with the zero padding's)
+        assert np.abs(vb[:, keep].conj().T @ vb[:, keep] - np.eye(int(keep.sum()))).max() < 1e-12
+        if kind != "hpd":                             # well separated leading eigenvalues
+            assert np.max(1 - np.abs(np.sum(np.conj(Ur[:, :12]) * vb[:, :12], axis=0))) < 1e-9
+
+
+@pytest.mark.gpu
+def test_cov_eig_modes_more_times_than_channels():
+    """Ntimes > Nfreqs: the reference diagonalises the Nfreqs x Nfreqs covariance itself
+    (scripts/calc-vis-cov-matrices.py:239-247); here at Nfreqs = 256 through the blocked solver."""
+    from hydra_pspec_amd import fgmodes
+    rng = np.random.default_rng(8)
+    nbl, T, N, nm = 3, 300, 256, 10
+    modes = rng.standard_normal((N, nm)) + 1j * rng.standard_normal((N, nm))
+    amp = (rng.standard_normal((nbl, T, nm)) + 1j * rng.standard_normal((nbl, T, nm))) * np.logspace(2.5, 0.5, nm)
+    vis = amp @ modes.T + 0.1 * (rng.standard_normal((nbl, T, N)) + 1j * rng.standard_normal((nbl, T, N)))
+    got, evals = fgmodes.cov_eig_modes(vis, nm, return_evals=True)
+    for b in range(nbl):
+        lam, U = np.linalg.eigh(np.cov(vis[b].T))
+        lam, U = lam[::-1][:nm], U[:, ::-1][:, :nm]
+        assert np.max(np.abs(evals[b] / lam - 1)) < 1e-9
+        assert np.max(1 - np.abs(np.sum(U.conj() * got[b], axis=0))) < 1e-9
