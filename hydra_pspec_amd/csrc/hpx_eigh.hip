@@ -66,29 +66,35 @@ __global__ __launch_bounds__(256) void k_hj_prep(const double* __restrict__ gr, 
   }
 }
 
-// W = L (lower triangle of the interleaved factor, zero above) in block layout [n / 8][n rows][8]
-__global__ void k_hj_pack(const double* __restrict__ l, double* __restrict__ wre, double* __restrict__ wim, const int n) {
+// W = L (lower triangle of the interleaved factor, zero above) in block layout [n / NB][n rows][NB]
+__global__ void k_hj_pack(const double* __restrict__ l, double* __restrict__ wre, double* __restrict__ wim, const int n,
+                          const int NB) {
   const int b = blockIdx.y;
   const double* lb = l + (long)b * n * n * 2;
   double* wr = wre + (long)b * n * n;
   double* wi = wim + (long)b * n * n;
   for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < (long)n * n; e += (long)gridDim.x * blockDim.x) {
     const int row = (int)(e / n), col = (int)(e % n);
-    const long o = ((long)(col >> 3) * n + row) * 8 + (col & 7);
+    const long o = ((long)(col / NB) * n + row) * NB + (col % NB);
     const bool low = col <= row;
     wr[o] = low ? lb[e * 2] : 0.0;
     wi[o] = low ? lb[e * 2 + 1] : 0.0;
   }
 }
 
-// one step of the round-robin schedule: workgroup (pair, baseline)
+// one step of the round-robin schedule: workgroup (pair, baseline).  NB = columns per block (8 or 16): a pair is
+// M = 2 NB columns, its Gram matrix M x M.  With NB = 16 a sweep has half as many steps -- every step streams the
+// whole factor through HBM once in and once out, which is what bounds the method -- for the same MFMA work.
+template <int NB>
 __global__ __launch_bounds__(256, 2) void k_hj_step(double* __restrict__ wre, double* __restrict__ wim, const int n,
                                                     const int p, const int s, unsigned long long* __restrict__ meas,
                                                     const int inner_sweeps) {
-  __shared__ double part[4][2][256];
-  __shared__ double Ga[2][2][256], Qa[2][2][256];
-  __shared__ double rot[8][4];
-  __shared__ int partner[16], isq[16], pidx[16];
+  constexpr int M = 2 * NB, MM = M * M, MT = M / 16;      // MT x MT tiles of 16 x 16
+  constexpr int EPT = MM / 256;                           // entries per thread of the small problem
+  __shared__ double Ga[2][2][MM], Qa[2][2][MM];
+  __shared__ double partbuf[(MT == 1) ? 2048 : 1];        // NB = 8: the four waves' partial Gram matrices
+  __shared__ double rot[M / 2][4];
+  __shared__ int partner[M], isq[M], pidx[M];
   __shared__ double red[4];
   __shared__ int skip;
   const int b = blockIdx.y, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, g = lane >> 4;
@@ -96,16 +102,17 @@ __global__ __launch_bounds__(256, 2) void k_hj_step(double* __restrict__ wre, do
   rr_pair16(p, s, blockIdx.x, bi, bj);
   double* wr = wre + (long)b * n * n;
   double* wi = wim + (long)b * n * n;
-  const long offA = (long)bi * n * 8, offB = (long)bj * n * 8;
-  const int ntile = n >> 4;                         // 16-row tiles, dealt to the waves round-robin
-  // ---- 1. Gram matrix of the pair's 16 columns: G[i][j] = sum_k conj(W[k][i]) W[k][j]
-  {
-    const long cb = ((li < 8) ? offA : offB) + (li & 7);
+  const long offA = (long)bi * n * NB, offB = (long)bj * n * NB;
+  const int ntile = n >> 4;                         // 16-row tiles
+  // column c (0 .. M-1) of the pair, row r: offset of the element
+#define HPX_HJ_OFF(c_, r_) ((((c_) < NB) ? offA : offB) + (long)(r_) * NB + ((c_) & (NB - 1)))
+  // ---- 1. Gram matrix of the pair's M columns: G[i][j] = sum_k conj(W[k][i]) W[k][j]
+  if (MT == 1) {          // one tile: the four waves split the rows, partial sums through LDS
     d4 grr = {0., 0., 0., 0.}, gii = grr, gri = grr, gir = grr;
     for (int t = wave; t < ntile; t += 4) {
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
-        const long o = cb + (long)(16 * t + 4 * ks + g) * 8;
+        const long o = HPX_HJ_OFF(li, 16 * t + 4 * ks + g);
         const double xr = wr[o], xi = wi[o];
         grr = mfma64(xr, xr, grr);
         gii = mfma64(xi, xi, gii);
@@ -113,29 +120,57 @@ __global__ __launch_bounds__(256, 2) void k_hj_step(double* __restrict__ wre, do
         gir = mfma64(xi, xr, gir);
       }
     }
+    double* part = partbuf;                         // [wave][re | im][256]
 #pragma unroll
     for (int v = 0; v < 4; ++v) {                   // accumulator: row g + 4 v, column li
-      part[wave][0][HPX_ACC_ROW(g, v) * 16 + li] = grr[v] + gii[v];
-      part[wave][1][HPX_ACC_ROW(g, v) * 16 + li] = gri[v] - gir[v];
+      part[(wave * 2 + 0) * 256 + HPX_ACC_ROW(g, v) * 16 + li] = grr[v] + gii[v];
+      part[(wave * 2 + 1) * 256 + HPX_ACC_ROW(g, v) * 16 + li] = gri[v] - gir[v];
+    }
+    __syncthreads();
+    const double sre = part[0 * 256 + tid] + part[2 * 256 + tid] + part[4 * 256 + tid] + part[6 * 256 + tid];
+    const double sim = part[1 * 256 + tid] + part[3 * 256 + tid] + part[5 * 256 + tid] + part[7 * 256 + tid];
+    __syncthreads();
+    Ga[0][0][tid] = sre;
+    Ga[0][1][tid] = ((tid >> 4) == (tid & 15)) ? 0.0 : sim;
+  } else {                // 2 x 2 tiles: wave w forms tile (w >> 1, w & 1) over all the rows, nothing to reduce
+    const int ti = wave >> 1, tj = wave & 1;
+    d4 grr = {0., 0., 0., 0.}, gii = grr, gri = grr, gir = grr;
+    for (int t = 0; t < ntile; ++t) {
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const int row = 16 * t + 4 * ks + g;
+        const long oa = HPX_HJ_OFF(16 * ti + li, row), ob = HPX_HJ_OFF(16 * tj + li, row);
+        const double ar = wr[oa], ai = wi[oa], br = wr[ob], bm = wi[ob];
+        grr = mfma64(ar, br, grr);
+        gii = mfma64(ai, bm, gii);
+        gri = mfma64(ar, bm, gri);
+        gir = mfma64(ai, br, gir);
+      }
+    }
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const int rr_ = 16 * ti + HPX_ACC_ROW(g, v), cc_ = 16 * tj + li;
+      Ga[0][0][rr_ * M + cc_] = grr[v] + gii[v];
+      Ga[0][1][rr_ * M + cc_] = (rr_ == cc_) ? 0.0 : gri[v] - gir[v];
     }
   }
   __syncthreads();
-  const int r = tid >> 4, c = tid & 15;
-  {
-    const double sre = part[0][0][tid] + part[1][0][tid] + part[2][0][tid] + part[3][0][tid];
-    const double sim = part[0][1][tid] + part[1][1][tid] + part[2][1][tid] + part[3][1][tid];
-    Ga[0][0][tid] = sre;
-    Ga[0][1][tid] = (r == c) ? 0.0 : sim;
-    Qa[0][0][tid] = (r == c) ? 1.0 : 0.0;
-    Qa[0][1][tid] = 0.0;
+#pragma unroll
+  for (int q = 0; q < EPT; ++q) {
+    const int e = tid + 256 * q;
+    Qa[0][0][e] = ((e / M) == (e % M)) ? 1.0 : 0.0;
+    Qa[0][1][e] = 0.0;
   }
-  __syncthreads();
-  {   // how far from orthogonal the 16 columns were: max |G_rc|^2 / (G_rr G_cc)
+  {   // how far from orthogonal the M columns were: max |G_rc|^2 / (G_rr G_cc)
     double m = 0.0;
-    if (r < c) {
-      const double off = Ga[0][0][tid] * Ga[0][0][tid] + Ga[0][1][tid] * Ga[0][1][tid];
-      const double dd = Ga[0][0][r * 17] * Ga[0][0][c * 17];
-      m = (dd > 0.0) ? off / dd : (off > 0.0 ? 1.0 : 0.0);
+#pragma unroll
+    for (int q = 0; q < EPT; ++q) {
+      const int e = tid + 256 * q, r = e / M, c = e % M;
+      if (r < c) {
+        const double off = Ga[0][0][e] * Ga[0][0][e] + Ga[0][1][e] * Ga[0][1][e];
+        const double dd = Ga[0][0][r * (M + 1)] * Ga[0][0][c * (M + 1)];
+        m = fmax(m, (dd > 0.0) ? off / dd : (off > 0.0 ? 1.0 : 0.0));
+      }
     }
     for (int o = 32; o > 0; o >>= 1) m = fmax(m, __shfl_xor(m, o, 64));
     if (lane == 0) red[wave] = m;
@@ -148,15 +183,15 @@ __global__ __launch_bounds__(256, 2) void k_hj_step(double* __restrict__ wre, do
     __syncthreads();
     if (skip) return;
   }
-  // ---- 2. two-sided Jacobi on G (one entry per thread), Q accumulates the rotations
+  // ---- 2. two-sided Jacobi on G (EPT entries per thread), Q accumulates the rotations
   int cur = 0;
   for (int sw = 0; sw < inner_sweeps; ++sw)
-    for (int st = 0; st < 15; ++st) {
-      if (tid < 8) {
+    for (int st = 0; st < M - 1; ++st) {
+      if (tid < M / 2) {
         int pp, qq;
-        rr_pair16(16, st, tid, pp, qq);
-        const double a = Ga[cur][0][pp * 17], bq = Ga[cur][0][qq * 17];
-        const double cr = Ga[cur][0][pp * 16 + qq], ci = Ga[cur][1][pp * 16 + qq];
+        rr_pair16(M, st, tid, pp, qq);
+        const double a = Ga[cur][0][pp * (M + 1)], bq = Ga[cur][0][qq * (M + 1)];
+        const double cr = Ga[cur][0][pp * M + qq], ci = Ga[cur][1][pp * M + qq];
         const double ac2 = cr * cr + ci * ci;
         double cs = 1.0, sn = 0.0, cp = 1.0, sp = 0.0;
         if (ac2 > 1e-34 * fabs(a * bq) && ac2 > 0.0) {
@@ -174,81 +209,96 @@ __global__ __launch_bounds__(256, 2) void k_hj_step(double* __restrict__ wre, do
         pidx[pp] = tid; pidx[qq] = tid;
       }
       __syncthreads();
-      // x_a' = own_a x_a + part_a x_partner(a):  a = p: (cs, -sn e^{-i phi});  a = q: (cs, sn e^{i phi})
-      const int rp = partner[r], cq = partner[c];
-      const double* rc_ = rot[pidx[c]];
-      const double own_c = rc_[0];
-      const double pcr = isq[c] ? rc_[1] * rc_[2] : -rc_[1] * rc_[2];
-      const double pci = rc_[1] * rc_[3];
-      const double* rr_ = rot[pidx[r]];
-      const double own_r = rr_[0];
-      const double prr = isq[r] ? rr_[1] * rr_[2] : -rr_[1] * rr_[2];
-      const double pri = rr_[1] * rr_[3];
       const double* gre = Ga[cur][0];
       const double* gim = Ga[cur][1];
-      // T = G J (columns), at rows r and partner(r)
-      const double t1r = gre[r * 16 + c] * own_c + gre[r * 16 + cq] * pcr - gim[r * 16 + cq] * pci;
-      const double t1i = gim[r * 16 + c] * own_c + gre[r * 16 + cq] * pci + gim[r * 16 + cq] * pcr;
-      const double t2r = gre[rp * 16 + c] * own_c + gre[rp * 16 + cq] * pcr - gim[rp * 16 + cq] * pci;
-      const double t2i = gim[rp * 16 + c] * own_c + gre[rp * 16 + cq] * pci + gim[rp * 16 + cq] * pcr;
-      // G' = J^H T (rows): conj(part_r) = (prr, -pri)
-      const double nr = own_r * t1r + prr * t2r + pri * t2i;
-      const double ni = own_r * t1i + prr * t2i - pri * t2r;
       const double* qre = Qa[cur][0];
       const double* qim = Qa[cur][1];
-      const double qr_ = qre[r * 16 + c] * own_c + qre[r * 16 + cq] * pcr - qim[r * 16 + cq] * pci;
-      const double qi_ = qim[r * 16 + c] * own_c + qre[r * 16 + cq] * pci + qim[r * 16 + cq] * pcr;
-      Ga[cur ^ 1][0][tid] = nr;
-      Ga[cur ^ 1][1][tid] = (r == c) ? 0.0 : ni;
-      Qa[cur ^ 1][0][tid] = qr_;
-      Qa[cur ^ 1][1][tid] = qi_;
+#pragma unroll
+      for (int q = 0; q < EPT; ++q) {
+        const int e = tid + 256 * q, r = e / M, c = e % M;
+        // x_a' = own_a x_a + part_a x_partner(a):  a = p: (cs, -sn e^{-i phi});  a = q: (cs, sn e^{i phi})
+        const int rp = partner[r], cq = partner[c];
+        const double* rc_ = rot[pidx[c]];
+        const double own_c = rc_[0];
+        const double pcr = isq[c] ? rc_[1] * rc_[2] : -rc_[1] * rc_[2];
+        const double pci = rc_[1] * rc_[3];
+        const double* rr_ = rot[pidx[r]];
+        const double own_r = rr_[0];
+        const double prr = isq[r] ? rr_[1] * rr_[2] : -rr_[1] * rr_[2];
+        const double pri = rr_[1] * rr_[3];
+        // T = G J (columns), at rows r and partner(r)
+        const double t1r = gre[r * M + c] * own_c + gre[r * M + cq] * pcr - gim[r * M + cq] * pci;
+        const double t1i = gim[r * M + c] * own_c + gre[r * M + cq] * pci + gim[r * M + cq] * pcr;
+        const double t2r = gre[rp * M + c] * own_c + gre[rp * M + cq] * pcr - gim[rp * M + cq] * pci;
+        const double t2i = gim[rp * M + c] * own_c + gre[rp * M + cq] * pci + gim[rp * M + cq] * pcr;
+        // G' = J^H T (rows): conj(part_r) = (prr, -pri)
+        const double nr = own_r * t1r + prr * t2r + pri * t2i;
+        const double ni = own_r * t1i + prr * t2i - pri * t2r;
+        const double qr_ = qre[r * M + c] * own_c + qre[r * M + cq] * pcr - qim[r * M + cq] * pci;
+        const double qi_ = qim[r * M + c] * own_c + qre[r * M + cq] * pci + qim[r * M + cq] * pcr;
+        Ga[cur ^ 1][0][e] = nr;
+        Ga[cur ^ 1][1][e] = (r == c) ? 0.0 : ni;
+        Qa[cur ^ 1][0][e] = qr_;
+        Qa[cur ^ 1][1][e] = qi_;
+      }
       __syncthreads();
       cur ^= 1;
     }
-  // ---- 3. W <- W Q on the pair's columns, 16 rows at a time
+  // ---- 3. W <- W Q on the pair's columns, 16 rows at a time: out[r][j] = sum_i W[r][i] Q[i][j]
   {
-    double qr[4], qi[4];
+    double qr[MT][4 * MT], qi[MT][4 * MT];
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {                // B[k = 4 ks + g][n = li] = Q[k][li]
-      qr[ks] = Qa[cur][0][(4 * ks + g) * 16 + li];
-      qi[ks] = Qa[cur][1][(4 * ks + g) * 16 + li];
-    }
-    const long sb = ((li < 8) ? offA : offB) + (li & 7);
+    for (int jt = 0; jt < MT; ++jt)
+#pragma unroll
+      for (int ks = 0; ks < 4 * MT; ++ks) {         // B[k = 4 ks + g][n = li] = Q[k][16 jt + li]
+        qr[jt][ks] = Qa[cur][0][(4 * ks + g) * M + 16 * jt + li];
+        qi[jt][ks] = Qa[cur][1][(4 * ks + g) * M + 16 * jt + li];
+      }
     for (int t = wave; t < ntile; t += 4) {
       const int rt = 16 * t;
-      d4 dre = {0., 0., 0., 0.}, dim = dre;
+      d4 dre[MT], dim[MT];
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {              // A[m = li][k = 4 ks + g] = W[rt + li][column 4 ks + g of the pair]
-        const int i = 4 * ks + g;
-        const long o = ((i < 8) ? offA : offB) + (long)(rt + li) * 8 + (i & 7);
+      for (int jt = 0; jt < MT; ++jt) { dre[jt] = (d4){0., 0., 0., 0.}; dim[jt] = dre[jt]; }
+#pragma unroll
+      for (int ks = 0; ks < 4 * MT; ++ks) {         // A[m = li][k = 4 ks + g] = W[rt + li][column 4 ks + g of the pair]
+        const long o = HPX_HJ_OFF(4 * ks + g, rt + li);
         const double xr = wr[o], xi = wi[o];
-        dre = mfma64(xr, qr[ks], dre);
-        dre = mfma64(-xi, qi[ks], dre);
-        dim = mfma64(xr, qi[ks], dim);
-        dim = mfma64(xi, qr[ks], dim);
+#pragma unroll
+        for (int jt = 0; jt < MT; ++jt) {
+          dre[jt] = mfma64(xr, qr[jt][ks], dre[jt]);
+          dre[jt] = mfma64(-xi, qi[jt][ks], dre[jt]);
+          dim[jt] = mfma64(xr, qi[jt][ks], dim[jt]);
+          dim[jt] = mfma64(xi, qr[jt][ks], dim[jt]);
+        }
       }
 #pragma unroll
-      for (int v = 0; v < 4; ++v) {                 // accumulator: row rt + g + 4 v, column li of the pair
-        const long o = sb + (long)(rt + HPX_ACC_ROW(g, v)) * 8;
-        wr[o] = dre[v];
-        wi[o] = dim[v];
-      }
+      for (int jt = 0; jt < MT; ++jt)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {               // accumulator: row rt + g + 4 v, column 16 jt + li of the pair
+          const long o = HPX_HJ_OFF(16 * jt + li, rt + HPX_ACC_ROW(g, v));
+          wr[o] = dre[jt][v];
+          wi[o] = dim[jt][v];
+        }
     }
   }
+#undef HPX_HJ_OFF
 }
 
 // lambda_j = |w_j|^2 - ridge on the diagonal of gr, V = the normalised columns ([row][column], pitch n)
 __global__ __launch_bounds__(256) void k_hj_finish(const double* __restrict__ wre, const double* __restrict__ wim,
                                                    const double* __restrict__ ridge, double* __restrict__ gr,
-                                                   double* __restrict__ vr, double* __restrict__ vi, const int n) {
+                                                   double* __restrict__ vr, double* __restrict__ vi, const int n,
+                                                   const int NB) {
   __shared__ double acc[32][8];
   __shared__ double inv[8];
+  // workgroup = 8 consecutive columns (inside one block of NB = 8 or 16)
   const int b = blockIdx.y, blk = blockIdx.x, tid = threadIdx.x, cc = tid & 7, rr = tid >> 3;
-  const double* wr = wre + (long)b * n * n + (long)blk * n * 8;
-  const double* wi = wim + (long)b * n * n + (long)blk * n * 8;
+  const int col0 = blk * 8;
+  const double* wr = wre + (long)b * n * n + (long)(col0 / NB) * n * NB + (col0 % NB);
+  const double* wi = wim + (long)b * n * n + (long)(col0 / NB) * n * NB + (col0 % NB);
   double sum = 0.0;
   for (int k = rr; k < n; k += 32) {
-    const double xr = wr[(long)k * 8 + cc], xi = wi[(long)k * 8 + cc];
+    const double xr = wr[(long)k * NB + cc], xi = wi[(long)k * NB + cc];
     sum += xr * xr + xi * xi;
   }
   acc[rr][cc] = sum;
@@ -263,8 +313,8 @@ __global__ __launch_bounds__(256) void k_hj_finish(const double* __restrict__ wr
   __syncthreads();
   for (int k = rr; k < n; k += 32) {
     const long o = (long)b * n * n + (long)k * n + blk * 8 + cc;
-    vr[o] = wr[(long)k * 8 + cc] * inv[cc];
-    vi[o] = wi[(long)k * 8 + cc] * inv[cc];
+    vr[o] = wr[(long)k * NB + cc] * inv[cc];
+    vi[o] = wi[(long)k * NB + cc] * inv[cc];
   }
 }
 
@@ -297,6 +347,9 @@ __global__ void k_hj_out(const double* __restrict__ gr, const double* __restrict
 
 }  // namespace
 
+// the order a matrix of order n0 is padded to (zero rows / columns): a multiple of 16, of 32 from 256 on
+int hpx_eigh_padded_order(int n0) { return n0 >= 241 ? ((n0 + 31) & ~31) : ((n0 + 15) & ~15); }
+
 // Eigendecomposition of nb Hermitian positive semi-definite matrices given planar (gr, gi: [nb][n][n], n a multiple
 // of 16): on return the diagonal of gr holds the eigenvalues (unsorted) and vr, vi the unit eigenvectors as columns.
 // gi and the off-diagonal of gr are left as they were.  sweeps_out (host, optional): outer sweeps taken.
@@ -326,9 +379,11 @@ int hpx_eigh_psd_planar(int nb, int n, double* gr, const double* gi, double* vr,
         return HPX_EINVAL;
       }
   }
-  hipLaunchKernelGGL(k_hj_pack, dim3(64, nb), dim3(256), 0, st, lbuf.p, wre, wim, n);
+  // 16-column blocks when the order allows an even number of them (n a multiple of 32: hpx_eigh_padded_order)
+  const int NB = (n >= 256 && (n & 31) == 0) ? 16 : 8;
+  hipLaunchKernelGGL(k_hj_pack, dim3(64, nb), dim3(256), 0, st, lbuf.p, wre, wim, n, NB);
   HPX_HIP(hipGetLastError());
-  const int p = n >> 3;
+  const int p = n / NB;
   static const bool trace = getenv("HPX_EIGH_TRACE") != nullptr;
   // sweeps of the 16 x 16 problem per visit: one (measured at order 512, 256 matrices: 0.39 s with one, 0.51 s
   // with two, 0.56 s with three -- the outer sweep count, 10 - 11, does not change)
@@ -338,7 +393,8 @@ int hpx_eigh_psd_planar(int nb, int n, double* gr, const double* gi, double* vr,
   for (; sweeps < 30; ++sweeps) {
     HPX_HIP(hipMemsetAsync(meas, 0, (size_t)nb * sizeof(double), st));
     for (int s = 0; s < p - 1; ++s)
-      hipLaunchKernelGGL(k_hj_step, dim3(p / 2, nb), dim3(256), 0, st, wre, wim, n, p, s, meas, inner);
+      if (NB == 16) hipLaunchKernelGGL(k_hj_step<16>, dim3(p / 2, nb), dim3(256), 0, st, wre, wim, n, p, s, meas, inner);
+      else hipLaunchKernelGGL(k_hj_step<8>, dim3(p / 2, nb), dim3(256), 0, st, wre, wim, n, p, s, meas, inner);
     HPX_HIP(hipGetLastError());
     HPX_HIP(hipMemcpyAsync(hm.data(), meas, (size_t)nb * sizeof(double), hipMemcpyDeviceToHost, st));
     HPX_HIP(hipStreamSynchronize(st));
@@ -349,7 +405,7 @@ int hpx_eigh_psd_planar(int nb, int n, double* gr, const double* gi, double* vr,
     // 3e-8 -> 3e-16 -> 2e-30): below 1e-13 the sweep just done leaves the columns orthogonal to rounding
     if (worst < 1e-13) { ++sweeps; break; }
   }
-  hipLaunchKernelGGL(k_hj_finish, dim3(p, nb), dim3(256), 0, st, wre, wim, ridge, gr, vr, vi, n);
+  hipLaunchKernelGGL(k_hj_finish, dim3(n / 8, nb), dim3(256), 0, st, wre, wim, ridge, gr, vr, vi, n, NB);
   HPX_HIP(hipGetLastError());
   HPX_HIP(hipStreamSynchronize(st));
   if (sweeps_out) *sweeps_out = sweeps;
@@ -357,13 +413,13 @@ int hpx_eigh_psd_planar(int nb, int n, double* gr, const double* gi, double* vr,
 }
 
 // C-ABI: a (nb,n0,n0) c128 Hermitian positive semi-definite -> w (nb,n) f64 and v (nb,n0,n) c128 with
-// n = ceil16(n0): all n eigenpairs of the matrix padded with zeros, in the solver's order (the caller sorts; the
+// n = hpx_eigh_padded_order(n0) (hpx_zheev_psd_order): all n eigenpairs of the matrix padded with zeros, in the solver's order (the caller sorts; the
 // n - n0 pairs of the padding have eigenvalue 0 and zero vectors in the first n0 coordinates).
 extern "C" int hpx_zheev_psd_batched(int nb, int n0, const double* a, double* w, double* v, int* sweeps_out,
                                      void* stream) {
   HPX_REQUIRE(nb > 0 && n0 > 0 && n0 <= 2048 && a && w && v, "hpx_zheev_psd_batched: bad argument");
   hipStream_t st = (hipStream_t)stream;
-  const int n = (n0 + 15) & ~15;
+  const int n = hpx_eigh_padded_order(n0);
   hpx_devbuf g;
   HPX_TRY(g.alloc((size_t)4 * nb * n * n));
   double *gr = g.p, *gi = gr + (size_t)nb * n * n, *vr = gi + (size_t)nb * n * n, *vi = vr + (size_t)nb * n * n;
@@ -375,3 +431,5 @@ extern "C" int hpx_zheev_psd_batched(int nb, int n0, const double* a, double* w,
   HPX_HIP(hipStreamSynchronize(st));
   return HPX_OK;
 }
+
+extern "C" int hpx_zheev_psd_order(int n0) { return hpx_eigh_padded_order(n0); }

@@ -322,6 +322,7 @@ int hpx_launch_factor_wide(int nbl, int npad, int ld, double* L, double* Wre, do
                            int32_t* info, int iter_tag, const hpx_gen_batch* gen, hipStream_t st);
 // Hermitian positive semi-definite eigendecomposition, orders 128 .. (hpx_eigh.hip): planar in, eigenvalues on the
 // diagonal of gr, unit eigenvectors as the columns of (vr, vi); n a multiple of 16
+int hpx_eigh_padded_order(int n0);
 int hpx_eigh_psd_planar(int nb, int n, double* gr, const double* gi, double* vr, double* vi, int* sweeps_out,
                         hipStream_t st);
 // the split form (hpx_factor_split.hip): several workgroups per system, for batches too small to fill the chip

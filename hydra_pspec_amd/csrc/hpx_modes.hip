@@ -350,7 +350,7 @@ extern "C" int hpx_fgmodes_eig(int nb, int T, int N, int nmodes, const double* v
   // from order 128 on: the blocked one-sided Jacobi of hpx_eigh.hip (order padded to a multiple of 16); below, the
   // cyclic two-sided Jacobi of this file (even order for its round-robin pairing)
   const bool blocked = nreal >= HPX_EIGH_BLOCKED_MIN;
-  const int n = blocked ? ((nreal + 15) & ~15) : nreal + (nreal & 1);
+  const int n = blocked ? hpx_eigh_padded_order(nreal) : nreal + (nreal & 1);
   hipStream_t st = (hipStream_t)stream;
   hpx_devbuf xbuf, gbuf;
   HPX_TRY(xbuf.alloc((size_t)2 * nb * T * N));

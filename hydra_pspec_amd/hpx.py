@@ -63,6 +63,7 @@ SIGNATURES = {
     "hpx_fgmodes_eig": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "hpx_oqe_qauto": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _i64, _vp]),
     "hpx_zheev_psd_batched": (_i, [_i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "hpx_zheev_psd_order": (_i, [_i]),
     "hpx_sqrtm_hpd_batched": (_i, [_i, _i, _vp, _vp, _vp, C.c_double, _i, _vp, _vp]),
     "hpx_mfma_probe": (_i, [_vp, _vp, _vp]),
     "hpx_mfma_f64_peak": (_i, [_i, _vp]),

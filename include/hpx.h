@@ -336,10 +336,12 @@ int hpx_oqe_qauto(int nb, int nvis, int s, const double* R, const double* V, dou
 /* Eigendecomposition of nb Hermitian positive semi-definite matrices, orders up to 2048 (csrc/hpx_eigh.hip: blocked
  * one-sided Jacobi on the Cholesky factor, 16 x 16 rotations on the FP64 MFMA) -- the solver behind hpx_fgmodes_eig
  * from order 128 on (the covariance the reference diagonalises with numpy.linalg.eigh,
- * scripts/calc-vis-cov-matrices.py:239-247).  a (nb,n0,n0) c128; with n = ceil16(n0): w (nb,n) f64 eigenvalues and
- * v (nb,n0,n) c128 unit eigenvectors as columns, unsorted; the n - n0 pairs of the zero padding have eigenvalue 0.
+ * scripts/calc-vis-cov-matrices.py:239-247).  a (nb,n0,n0) c128; with n = hpx_zheev_psd_order(n0)
+ * (n0 rounded up to a multiple of 16, of 32 from 241 on): w (nb,n) f64 eigenvalues and v (nb,n0,n) c128 unit
+ * eigenvectors as columns, unsorted; the n - n0 pairs of the zero padding have eigenvalue 0.
  * sweeps_out (host int, optional). */
 int hpx_zheev_psd_batched(int nb, int n0, const double* a, double* w, double* v, int* sweeps_out, void* stream);
+int hpx_zheev_psd_order(int n0);
 
 /* Principal square root and inverse square root of nb Hermitian positive-definite matrices on the device
  * (coupled Newton-Schulz iteration on the batched FP64-MFMA product; csrc/hpx_sqrtm.hip).  Set-up of the

@@ -97,7 +97,7 @@ def test_zheev_psd_batched_vs_numpy(n0, kind):
         q = rng.standard_normal((nb, n0, n0)) + 1j * rng.standard_normal((nb, n0, n0))
         A = q @ np.conj(np.swapaxes(q, 1, 2)) / n0 + np.eye(n0)
     A = 0.5 * (A + np.conj(np.swapaxes(A, 1, 2)))
-    n = (n0 + 15) // 16 * 16
+    n = hpx.lib().hpx_zheev_psd_order(n0)
     dA = torch.from_numpy(np.ascontiguousarray(A)).cuda()
     w = torch.empty((nb, n), dtype=torch.float64, device="cuda")
     v = torch.empty((nb, n0, n), dtype=torch.complex128, device="cuda")

@@ -10,7 +10,7 @@ from hydra_pspec_amd import hpx
 
 def run(A):
     nb, n0, _ = A.shape
-    n = (n0 + 15) // 16 * 16
+    n = hpx.lib().hpx_zheev_psd_order(n0)
     dA = torch.from_numpy(np.ascontiguousarray(A)).cuda()
     w = torch.empty((nb, n), dtype=torch.float64, device="cuda")
     v = torch.empty((nb, n0, n), dtype=torch.complex128, device="cuda")
