@@ -145,8 +145,8 @@ def cpu_baseline_multiproc(N, T, M, flag_frac, niter=8, max_procs=None):
                        f"slowest {max(secs):.1f} s, wall incl. start-up {wall:.1f} s")
 
 
-DENSE_STEP_SOURCES = ("hpx_factor.hip", "hpx_factor_wide.hip", "hpx_backsolve.hip", "hpx_chain.hip", "hpx_transform.hip",
-                      "hpx_internal.h", "hpx_fft.h", "Makefile")
+DENSE_STEP_SOURCES = ("hpx_factor.hip", "hpx_factor_wide.hip", "hpx_factor_split.hip", "hpx_factor_tiles.h",
+                      "hpx_backsolve.hip", "hpx_chain.hip", "hpx_transform.hip", "hpx_internal.h", "hpx_fft.h", "Makefile")
 
 
 def kernel_source_hash():

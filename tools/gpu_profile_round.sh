@@ -3,11 +3,14 @@
 #   bench lines for C3 (with CPU baseline), C5, C2, N4, dpss, oqe and a 2-rank rehearsal; rocprofv3 kernel
 #   stats of the C3 / C5-auto / dpss / oqe benches; PMC passes (FETCH_SIZE, WRITE_SIZE, MFMA busy, L2 hits)
 #   of the C3 bench, one counter set per pass; the FETCH_SIZE calibration probe.
-# usage: tools/gpu_profile_round.sh <tag>      e.g. r02
+# usage: tools/gpu_profile_round.sh <tag> [A|B|AB]     e.g. r04 A (bench lines, rehearsals), then r04 B (kernel
+# traces, PMC passes, the C3 line): two calls fit gpurun's 20-minute limit
 TAG=${1:-r04}
 export TMPDIR=/tmp
 R=$PWD; O=$R/gpurun_out/prof; mkdir -p $O
 line() { grep -o '{"metric.*' $1 > $2; }
+PART=${2:-AB}
+if [[ $PART == *A* ]]; then
 # (the C3 line itself is taken LAST, after the PMC passes have re-stamped profiles/pmc_traffic.json for these sources)
 timeout -k 10 300 python3 bench.py --steps 5 --warmup 1 --config C5 --no-cpu-baseline > $O/bench_c5.log 2>&1 && line $O/bench_c5.log $O/${TAG}_bench_c5.json; echo "C5 done"
 timeout -k 10 300 python3 bench.py --steps 20 --warmup 2 --config C2 --no-cpu-baseline > $O/bench_c2.log 2>&1 && line $O/bench_c2.log $O/${TAG}_bench_c2.json; echo "C2 done"
@@ -15,10 +18,17 @@ timeout -k 10 300 python3 bench.py --steps 10 --warmup 2 --config N4 --no-cpu-ba
 timeout -k 10 300 python3 bench.py --config dpss --steps 20 --warmup 2 > $O/bench_dpss.log 2>&1 && line $O/bench_dpss.log $O/${TAG}_bench_dpss.json; echo "dpss done"
 timeout -k 10 300 python3 bench.py --config oqe --steps 5 --warmup 1 > $O/bench_oqe.log 2>&1 && line $O/bench_oqe.log $O/${TAG}_bench_oqe.json; echo "oqe done"
 timeout -k 10 300 python3 bench.py --config fgmodes --steps 10 --warmup 2 > $O/bench_fgmodes.log 2>&1 && line $O/bench_fgmodes.log $O/${TAG}_bench_fgmodes.json; echo "fgmodes done"
+timeout -k 10 300 python3 bench.py --config fgmodes --order 512 --steps 2 --warmup 1 > $O/bench_fgmodes512.log 2>&1 && line $O/bench_fgmodes512.log $O/${TAG}_bench_fgmodes_order512.json; echo "fgmodes order 512 done"
+timeout -k 10 400 python3 bench.py --config C3 --noise dense --flag-frac 0.15 --steps 5 --warmup 1 > $O/bench_dense_flagged.log 2>&1 && line $O/bench_dense_flagged.log $O/${TAG}_bench_c3_dense_noise_flagged.json; echo "dense+flags done"
+timeout -k 10 400 python3 bench.py --config C3 --noise dense --flag-frac 0.0 --steps 5 --warmup 1 > $O/bench_dense.log 2>&1 && line $O/bench_dense.log $O/${TAG}_bench_c3_dense_noise.json; echo "dense done"
+timeout -k 10 400 python3 bench.py --config C3 --noise pertime-dense --flag-frac 0.10 --steps 5 --warmup 1 > $O/bench_ptd.log 2>&1 && line $O/bench_ptd.log $O/${TAG}_bench_pertime_dense_noise.json; echo "per-time dense done"
+python3 bench.py --gpus 8 --dry-run > $O/${TAG}_dry_run_8.json 2> $O/dry_run_8.log; echo "dry run rc=$?"
 HPX_BENCH_DEVICE=0 HPX_BENCH_BACKEND=gloo timeout -k 10 400 python3 bench.py --gpus 2 --steps 10 --warmup 2 --no-cpu-baseline --no-full-length > $O/bench_2rank.log 2>&1 && line $O/bench_2rank.log $O/${TAG}_bench_2ranks_one_gpu.json; echo "2-rank rehearsal done"
 # the launcher with as many ranks as one box lets share its GPU (the pool's process guard allows six; the 8-rank
 # case is the driver's to run on a whole node): 6 ranks x 128 baselines
 HPX_BENCH_DEVICE=0 HPX_BENCH_BACKEND=gloo timeout -k 10 400 python3 bench.py --gpus 6 --nbl 128 --steps 10 --warmup 2 --no-cpu-baseline --no-full-length > $O/bench_6rank.log 2>&1 && line $O/bench_6rank.log $O/${TAG}_bench_6ranks_one_gpu.json; echo "6-rank rehearsal done"
+fi
+if [[ $PART != *B* ]]; then exit 0; fi
 kt() {   # kernel-trace stats: kt <name> <bench args...>
   local name=$1; shift
   cd /tmp
@@ -31,6 +41,9 @@ kt() {   # kernel-trace stats: kt <name> <bench args...>
 kt c3 --steps 10 --warmup 2 --no-cpu-baseline --no-full-length
 kt c5_auto --config C5 --solver auto --steps 10 --warmup 2 --no-cpu-baseline --no-full-length
 kt fgmodes --config fgmodes --steps 5 --warmup 1
+kt fgmodes_order512 --config fgmodes --order 512 --steps 1 --warmup 1
+kt c2 --config C2 --steps 20 --warmup 2 --no-cpu-baseline --no-full-length
+kt dense_flagged --config C3 --noise dense --flag-frac 0.15 --steps 5 --warmup 1
 kt dpss --config dpss --steps 10 --warmup 2
 kt oqe --config oqe --steps 3 --warmup 1
 i=0
@@ -64,7 +77,7 @@ for i, f in enumerate(sorted(glob.glob(O + "/pmc*/*/*counter_collection.csv")), 
         lines.append("pass%d %-34s n=%2d dur_ms=%7.3f %s" % (i, k[:34], n, sum(dur[k]) / len(dur[k]) / 1e6,
                                                            " ".join("%s=%.4g" % kv for kv in cs.items())))
         kk = k.split("<")[0]
-        kk = {"k_factor_wide": "k_factor", "k_backsolve_reg": "k_backsolve"}.get(kk, kk)     # (one name per stage)
+        kk = {"k_factor_wide": "k_factor", "k_factor_split": "k_factor", "k_backsolve_reg": "k_backsolve"}.get(kk, kk)     # (one name per stage)
         tot.setdefault(kk, {}).update(cs)
 lines += ["", "FETCH_SIZE calibration (tools/fetch_calib.hip: 1 GiB = 1048576 KB streamed once per shape):"]
 for f in glob.glob(O + "/calib/*/*counter_collection.csv"):
@@ -112,7 +125,7 @@ line $O/bench_c3.log $O/${TAG}_bench_c3.json; echo "C3 done"
 head -12 $O/${TAG}_kernel_stats_c3.csv | cut -c1-160
 python3 -c "
 import json
-for c in ('c3','c5','c2','n4','dpss','oqe','fgmodes','2ranks_one_gpu','6ranks_one_gpu'):
+for c in ('c3','c5','c2','n4','dpss','oqe','fgmodes','fgmodes_order512','c3_dense_noise_flagged','c3_dense_noise','pertime_dense_noise','2ranks_one_gpu','6ranks_one_gpu'):
     try:
         d=json.load(open('$O/${TAG}_bench_%s.json'%c)); r=d['roofline']
         print(c, 'value %.4g %s ms/step %.3f roofline %s %.4g frac %.3f n_gpus %d' % (d['value'], d['unit'], d['ms_per_step'], r['unit'], r['achieved'], r['frac'], d['n_gpus']), {k: round(v,3) for k,v in d.get('stage_ms_per_step',{}).items()}, 'cpu', d.get('cpu_baseline',{}).get('value'), 'dev', d.get('pk_max_rel_dev_vs_cpu', d.get('max_rel_dev_vs_cpu')))
