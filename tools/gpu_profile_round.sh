@@ -22,7 +22,7 @@ timeout -k 10 300 python3 bench.py --config fgmodes --order 512 --steps 2 --warm
 timeout -k 10 400 python3 bench.py --config C3 --noise dense --flag-frac 0.15 --steps 5 --warmup 1 > $O/bench_dense_flagged.log 2>&1 && line $O/bench_dense_flagged.log $O/${TAG}_bench_c3_dense_noise_flagged.json; echo "dense+flags done"
 timeout -k 10 400 python3 bench.py --config C3 --noise dense --flag-frac 0.0 --steps 5 --warmup 1 > $O/bench_dense.log 2>&1 && line $O/bench_dense.log $O/${TAG}_bench_c3_dense_noise.json; echo "dense done"
 timeout -k 10 400 python3 bench.py --config C3 --noise pertime-dense --flag-frac 0.10 --steps 5 --warmup 1 > $O/bench_ptd.log 2>&1 && line $O/bench_ptd.log $O/${TAG}_bench_pertime_dense_noise.json; echo "per-time dense done"
-python3 bench.py --gpus 8 --dry-run > $O/${TAG}_dry_run_8.json 2> $O/dry_run_8.log; echo "dry run rc=$?"
+python3 bench.py --gpus 8 --dry-run 2> $O/dry_run_8.log | grep "^{" > $O/${TAG}_dry_run_8.json; echo "dry run rc=$?"
 HPX_BENCH_DEVICE=0 HPX_BENCH_BACKEND=gloo timeout -k 10 400 python3 bench.py --gpus 2 --steps 10 --warmup 2 --no-cpu-baseline --no-full-length > $O/bench_2rank.log 2>&1 && line $O/bench_2rank.log $O/${TAG}_bench_2ranks_one_gpu.json; echo "2-rank rehearsal done"
 # the launcher with as many ranks as one box lets share its GPU (the pool's process guard allows six; the 8-rank
 # case is the driver's to run on a whole node): 6 ranks x 128 baselines
