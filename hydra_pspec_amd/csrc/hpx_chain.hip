@@ -2472,7 +2472,7 @@ __global__ __launch_bounds__(256) void k_assemble_general(
         const int t = r - npad;
         vr = rr[(long)c * B.ncol + t];
         vi = ri[(long)c * B.ncol + t];
-        if (B.has_omega) { vr += B.p2re[(long)c * TP + t]; vi += B.p2im[(long)c * TP + t]; }
+        if (B.has_omega) { vr += G.p2re[(long)c * TP + t]; vi += G.p2im[(long)c * TP + t]; }      // (the unit's own block)
         vi = -vi;
       }
     } else {
@@ -2502,10 +2502,67 @@ extern "C" int hpx_gibbs_step_general(hpx_plan* p, const double* shp, int iter0,
                                       double* lnpost_out, double* cr_out, double* fg_out,
                                       double* chisq_out, double* ps_last, void* stream) {
   HPX_REQUIRE(p && p->have_static && shp && ps_out && lnpost_out, "hpx_gibbs_step_general: bad argument");
-  HPX_REQUIRE(!p->per_time, "hpx_gibbs_step_general: not available with time-dependent flags / noise");
+  HPX_REQUIRE(!p->per_time || (p->child && !p->child->dense_noise),
+              "hpx_gibbs_step_general: with time-dependent flags / noise only for diagonal inverse noise covariances");
   HPX_REQUIRE(p->uni && iter0 >= 0 && iter0 < p->niter_tab, "hpx_gibbs_step_general: random tables too short");
   hipStream_t st = (hipStream_t)stream;
   const int nbl = p->nbl, N = p->N, M = p->M, T = p->T, NP = p->NP, TP = p->TP;
+  if (p->per_time) {
+    // One system per (baseline, time) as in run_iteration's per-time branch, each assembled from the explicit
+    // K' = [[I + Sh' C_t Sh', Sh' G_t], [., H_t]] of its own circulant C_t (flags and noise of that time):
+    // Sh' is the baseline's, copied to its Ntimes units for the batched products.
+    hpx_plan* c = p->child;
+    const int units = c->nbl;
+    const size_t um = (size_t)units * NP * NP, ur = (size_t)units * NP * c->ncolR;
+    const long mstr = (long)NP * NP;
+    if (!p->SHre) { HPX_TRY(dev_alloc(p, &p->SHre, (size_t)nbl * NP * NP)); HPX_TRY(dev_alloc(p, &p->SHim, (size_t)nbl * NP * NP)); }
+    if (!c->SHre) {
+      HPX_TRY(dev_alloc(c, &c->SHre, um)); HPX_TRY(dev_alloc(c, &c->SHim, um));
+      HPX_TRY(dev_alloc(c, &c->CMre, um)); HPX_TRY(dev_alloc(c, &c->CMim, um));
+      HPX_TRY(dev_alloc(c, &c->Y1re, um)); HPX_TRY(dev_alloc(c, &c->Y1im, um));
+      HPX_TRY(dev_alloc(c, &c->XTre, um)); HPX_TRY(dev_alloc(c, &c->XTim, um));
+      HPX_TRY(dev_alloc(c, &c->RSre, ur)); HPX_TRY(dev_alloc(c, &c->RSim, ur));
+    }
+    hipLaunchKernelGGL(k_mat_planar, dim3(64, nbl), dim3(256), 0, st, shp, p->SHre, p->SHim, N, NP);
+    hipLaunchKernelGGL(k_pt_expand_fg, dim3(64, units), dim3(256), 0, st, p->SHre, c->SHre, T, mstr);
+    hipLaunchKernelGGL(k_pt_expand_fg, dim3(64, units), dim3(256), 0, st, p->SHim, c->SHim, T, mstr);
+    hipLaunchKernelGGL(k_circ_matrix, dim3(64, units), dim3(256), 0, st, c->Cre, c->Cim, c->CMre, c->CMim, N, NP);
+    HPX_HIP(hipGetLastError());
+    HPX_TRY(hpx_launch_dft(units, NP, NP, c->CMre, c->CMim, 1, c->SHre, c->SHim, mstr, NP, nullptr, 0, c->Y1re, c->Y1im,
+                           mstr, NP, 1.0, st, 0, mstr));
+    HPX_TRY(hpx_launch_dft(units, NP, NP, c->SHre, c->SHim, 1, c->Y1re, c->Y1im, mstr, NP, nullptr, 0, c->XTre, c->XTim,
+                           mstr, NP, 1.0, st, 0, mstr));
+    HPX_TRY(hpx_launch_dft(units, NP, c->ncolR, c->SHre, c->SHim, 1, c->Rre, c->Rim, (long)NP * c->ncolR, c->ncolR,
+                           nullptr, 0, c->RSre, c->RSim, (long)NP * c->ncolR, c->ncolR, 1.0, st, 0, mstr));
+    HPX_HIP(hipMemsetAsync(p->info, 0, (size_t)nbl * sizeof(int32_t), st));
+    HPX_HIP(hipMemsetAsync(c->info, 0, (size_t)units * sizeof(int32_t), st));
+    p->ev_used = 0;
+    HPX_TRY(mark(p, st));
+    hipLaunchKernelGGL(k_assemble_general, dim3(c->npad / 16, units), dim3(256), 0, st, gen_of_child(p), c->XTre,
+                       c->XTim, c->RSre, c->RSim, c->L, c->npad, c->ld);
+    HPX_HIP(hipGetLastError());
+    HPX_TRY(mark(p, st));
+    HPX_TRY(hpx_launch_factor(units, c->npad, c->ld, c->L, c->Wre, c->Wim, c->Vt, c->info, iter0 + 1, nullptr, st));
+    HPX_TRY(mark(p, st));
+    HPX_TRY(hpx_launch_backsolve(units, c->npad, c->TP, c->ld, c->L, c->Wre, c->Wim, c->Xre, c->Xim, st));
+    // s' = Sh' y' per unit, then the units' solutions to their time column of this plan's X
+    HPX_TRY(hpx_launch_dft(units, NP, c->TP, c->SHre, c->SHim, 1, c->Xre, c->Xim, (long)c->npad * c->TP, c->TP, nullptr,
+                           0, c->Gre, c->Gim, (long)NP * c->TP, c->TP, 1.0, st, 0, mstr));
+    hipLaunchKernelGGL(k_take_sprime, dim3(32, units), dim3(256), 0, st, c->Gre, c->Gim, c->Xre, c->Xim, N, NP, c->TP,
+                       c->npad);
+    hipLaunchKernelGGL(k_pt_gather, dim3(32, nbl), dim3(256), 0, st, c->Xre, c->Xim, p->Xre, p->Xim, T, p->npad, TP,
+                       c->TP);
+    HPX_HIP(hipGetLastError());
+    HPX_TRY(mark(p, st));
+    IterOut O;
+    O.ps_forced = nullptr; O.forced_bstride = 0;
+    O.ps_out = ps_out; O.ps_bstride = N;
+    O.lnpost_out = lnpost_out; O.lnpost_pitch = 1;
+    O.cr_bstride = (long)T * N * 2; O.fg_bstride = (long)T * M * 2; O.chisq_bstride = (long)T * N;
+    O.cr_out = cr_out; O.fg_out = fg_out; O.chisq_out = chisq_out;
+    HPX_TRY(post_solve(p, iter0, O, st));
+    return finish_run(p, 1, ps_last, st);
+  }
   const size_t msz = (size_t)nbl * NP * NP, rsz = (size_t)nbl * NP * p->ncolR;
   if (!p->SHre) {
     HPX_TRY(dev_alloc(p, &p->SHre, msz)); HPX_TRY(dev_alloc(p, &p->SHim, msz));

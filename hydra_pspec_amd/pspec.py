@@ -476,8 +476,9 @@ class GibbsBatch:
         torch = self.torch
         nbl, T, N, M = self.nbl, self.T, self.N, self.M
         assert self.iter_done == 0, "a general starting covariance only makes sense for iteration 0"
-        if self.per_time:
-            raise NotImplementedError("time-dependent flags need an initial covariance of the form F^H diag(ps) F")
+        if self.per_time and self.dense_noise:
+            raise NotImplementedError("a full noise matrix per time needs an initial covariance of the form "
+                                      "F^H diag(ps) F")
         with torch.cuda.device(self.device):
             f64, c128, dev = torch.float64, torch.complex128, self.device
             d_shp = hpx.to_dev(torch, shp0, c128, dev)

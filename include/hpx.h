@@ -179,7 +179,9 @@ int hpx_gibbs_run(hpx_plan* p, const double* ps0, int iter0, int niter,
 /* Iteration 0 for an initial covariance that is NOT of the form
  * F^H diag(.) F (pspec.py:599 accepts any matrix): the caller supplies
  * Sh' = U^H sqrtm(S_initial) U, (nbl,N,N) c128.  Runs exactly one iteration
- * (table row iter0) with outputs as hpx_gibbs_run(niter=1). */
+ * (table row iter0) with outputs as hpx_gibbs_run(niter=1).  Also for plans with time-dependent flags /
+ * diagonal noise (one explicit system per baseline and time; pspec.py:442 accepts any matrix there too); not for
+ * a full noise matrix per time. */
 int hpx_gibbs_step_general(hpx_plan* p, const double* shp, int iter0,
                            double* ps_out, double* lnpost_out, double* cr_out,
                            double* fg_out, double* chisq_out, double* ps_last,

@@ -58,6 +58,30 @@ def test_pertime_chain_vs_oracle():
         assert relerr(out["chisq"][b], ref[4]) < 1e-6 and np.allclose(out["ln_post"][b], ref[5], rtol=1e-7)
 
 
+def test_pertime_chain_from_a_general_initial_covariance():
+    """Time-dependent flags with an S_initial that is NOT of the form F^H diag(ps) F (the reference accepts any matrix,
+    pspec.py:442, 599): the first iteration goes through the explicit system per (baseline, time)
+    (hpx_gibbs_step_general), the rest as usual; against the per-time exact-solve oracle."""
+    from hydra_pspec_amd import pspec
+    from oracle import pspec_ref
+    nbl, T, N, M, niter = 2, 6, 32, 4, 3
+    d, flt, nt = _pertime_inputs(nbl, T, N, M, seed=5)
+    rng = np.random.default_rng(12)
+    q = rng.standard_normal((N, N)) + 1j * rng.standard_normal((N, N))
+    S0 = d["S_initial"] + 0.05 * np.trace(d["S_initial"]).real / N * (q @ q.conj().T) / N     # Hermitian PD, not Fourier-diagonal
+    _, resid = pspec.pspec_from_covariance(S0)
+    assert resid > 1e-3
+    for b in range(nbl):
+        Ninv_t = np.stack([np.diag(nt[b, t]) for t in range(T)])
+        res = pspec.gibbs_sample_with_fg(d["vis"][b], flt[b], S0, d["fgmodes"], Ninv_t, d["ps_prior"], Niter=niter,
+                                         seed=21, verbose=False)
+        ref = pspec_ref.gibbs_sample_with_fg_pertime(d["vis"][b], flt[b], S0, d["fgmodes"], nt[b], d["ps_prior"],
+                                                     Niter=niter, seed=21)
+        assert np.max(np.abs(res[2] / ref[2] - 1)) < RTOL, b
+        assert relerr(res[0], ref[0]) < RTOL and relerr(res[3], ref[3]) < RTOL
+        assert np.allclose(res[5], ref[5], rtol=1e-7)
+
+
 def test_pertime_through_the_reference_call_surface():
     """gibbs_sample_with_fg with flags (Ntimes, Nfreqs) and Ninv (Ntimes, Nfreqs, Nfreqs) -- the shapes the
     reference's docstrings promise (pspec.py:337-340, :398-401)."""

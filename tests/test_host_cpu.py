@@ -186,6 +186,39 @@ def test_inversion_sample_invgamma_non_integer_alpha():
         pspec.inversion_sample_invgamma(-0.5, 1.0, 0.1, 1.0)
 
 
+def test_hermitian_completion_and_masked_square_root_formula():
+    """Host algebra behind the correlated-noise entry points (no GPU): (a) `_hermitian_completion` returns a Hermitian
+    positive-definite H whose unflagged columns are the reference's column-masked Ni = Ninv diag(w) (pspec.py:361);
+    (b) the block formula the device square root uses, sqrtm(Ni) = P [[A^1/2, 0], [B A^-1/2, 0]] P^T with
+    A = Ninv[u, u], B = Ninv[f, u], is scipy's principal root of that non-Hermitian matrix (pspec.py:362)."""
+    import scipy.linalg
+    from hydra_pspec_amd import pspec
+    rng = np.random.default_rng(4)
+    N = 24
+    q = rng.standard_normal((N, N)) + 1j * rng.standard_normal((N, N))
+    Ninv = q @ q.conj().T / N + np.eye(N)
+    w = rng.uniform(size=N) > 0.3
+    w[:2] = [True, False]
+    Ni = Ninv * w[None, :]
+    H = pspec._hermitian_completion(Ni, w)
+    assert np.abs(H - H.conj().T).max() < 1e-14
+    assert np.linalg.eigvalsh(H).min() > 0
+    assert np.abs(H * w[None, :] - Ni).max() < 1e-14
+    assert np.abs(pspec._hermitian_completion(Ninv, np.ones(N, bool)) - Ninv).max() < 1e-14
+    with pytest.raises(NotImplementedError):
+        pspec._hermitian_completion(Ni + 1e-3 * np.triu(np.ones((N, N)), 1) * w[None, :] * w[:, None], w)
+    # (b)
+    u, f = np.where(w)[0], np.where(~w)[0]
+    lam, V = np.linalg.eigh(Ninv[np.ix_(u, u)])
+    root = (V * np.sqrt(lam)) @ V.conj().T
+    iroot = (V / np.sqrt(lam)) @ V.conj().T
+    R = np.zeros((N, N), dtype=complex)
+    R[np.ix_(u, u)] = root
+    R[np.ix_(f, u)] = Ninv[np.ix_(f, u)] @ iroot
+    assert np.abs(R @ R - Ni).max() < 1e-12
+    assert np.abs(R - scipy.linalg.sqrtm(Ni)).max() < 1e-10
+
+
 def test_dense_noise_detection_rules():
     """Which `Ninv` inputs select the dense-noise path (host logic only; no GPU touched)."""
     from hydra_pspec_amd import pspec
