@@ -2084,6 +2084,116 @@ __global__ __launch_bounds__(256) void k_wb_solve(double* __restrict__ W_all, co
   }
 }
 // X[:, t] += sum_kf X[:, T + kf] c[kf][t]  for the solution rows (npad) and the signal realisation S (N rows)
+// The same solve with the whole system in LDS (f (f + T) complex entries: 134 KB at 77 flagged channels and 32
+// times; the launch takes this form when it fits, k_wb_solve otherwise): LU with partial pivoting, right-looking, the
+// right-hand sides swept along; the back substitution row-parallel (one barrier per unknown) instead of one thread
+// per right-hand side -- with per-time units (T = 1) that was a single lane.  Same pivoting rule and operations as
+// k_wb_solve.
+__global__ __launch_bounds__(256) void k_wb_solve_lds(double* __restrict__ W_all, const int32_t* __restrict__ fcount,
+                                                      const int fmax, const int T, int32_t* __restrict__ info,
+                                                      const int iter_tag) {
+  extern __shared__ double wl[];             // re [f][ldl] | im [f][ldl], ldl = f + T (+1 when even: bank spread)
+  __shared__ double redv[4];
+  __shared__ int redi[4], piv_s;
+  const int b = blockIdx.x, f = fcount[b], ldw = fmax + T, tid = threadIdx.x;
+  if (f == 0) return;
+  double* W = W_all + (long)b * fmax * ldw * 2;
+  const int nc = f + T, ldl = nc | 1;
+  double* wr = wl;
+  double* wi = wl + (size_t)f * ldl;
+  // compact copy: columns 0 .. f-1 the matrix, f .. f+T-1 the right-hand sides (global columns fmax ..)
+  for (int e = tid; e < f * nc; e += 256) {
+    const int r = e / nc, c = e % nc;
+    const int cg = (c < f) ? c : fmax + (c - f);
+    wr[r * ldl + c] = W[((long)r * ldw + cg) * 2];
+    wi[r * ldl + c] = W[((long)r * ldw + cg) * 2 + 1];
+  }
+  __syncthreads();
+  for (int k = 0; k < f; ++k) {
+    double best = -1.0;
+    int at = k;
+    for (int r = k + tid; r < f; r += 256) {
+      const double a2 = wr[r * ldl + k] * wr[r * ldl + k] + wi[r * ldl + k] * wi[r * ldl + k];
+      if (a2 > best) { best = a2; at = r; }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+      const double ob = __shfl_xor(best, o, 64);
+      const int oa = __shfl_xor(at, o, 64);
+      if (ob > best || (ob == best && oa < at)) { best = ob; at = oa; }
+    }
+    if ((tid & 63) == 0) { redv[tid >> 6] = best; redi[tid >> 6] = at; }
+    __syncthreads();
+    if (tid == 0) {
+      int w = 0;
+      for (int q = 1; q < 4; ++q)
+        if (redv[q] > redv[w] || (redv[q] == redv[w] && redi[q] < redi[w])) w = q;
+      piv_s = redi[w];
+      if (!(redv[w] > 1e-24)) atomicCAS(&info[b], 0, iter_tag);       // (see k_wb_solve)
+    }
+    __syncthreads();
+    const int pv = piv_s;
+    if (pv != k)
+      for (int c = k + tid; c < nc; c += 256) {
+        const double t0 = wr[k * ldl + c], t1 = wi[k * ldl + c];
+        wr[k * ldl + c] = wr[pv * ldl + c]; wi[k * ldl + c] = wi[pv * ldl + c];
+        wr[pv * ldl + c] = t0; wi[pv * ldl + c] = t1;
+      }
+    __syncthreads();
+    const double pr = wr[k * ldl + k], pi = wi[k * ldl + k];
+    const double den = 1.0 / (pr * pr + pi * pi);
+    // rows below: the multiplier l_r = W[r][k] / W[k][k] is formed by every thread of the row for itself (the
+    // column k entry is left alone until the step's barrier)
+    const int ncu = nc - k - 1, nr = f - k - 1;
+    for (int e = tid; e < nr * ncu; e += 256) {
+      const int r = k + 1 + e / ncu, c = k + 1 + e % ncu;
+      const double ar = wr[r * ldl + k], ai = wi[r * ldl + k];
+      const double lre = (ar * pr + ai * pi) * den, lim = (ai * pr - ar * pi) * den;
+      const double ur = wr[k * ldl + c], ui = wi[k * ldl + c];
+      wr[r * ldl + c] -= lre * ur - lim * ui;
+      wi[r * ldl + c] -= lre * ui + lim * ur;
+    }
+    __syncthreads();
+  }
+  // back substitution: unknown k of every right-hand side, then its column out of the rows above
+  for (int k = f - 1; k >= 0; --k) {
+    const double pr = wr[k * ldl + k], pi = wi[k * ldl + k];
+    const double den = 1.0 / (pr * pr + pi * pi);
+    for (int t = tid; t < T; t += 256) {
+      const double sr = wr[k * ldl + f + t], si = wi[k * ldl + f + t];
+      wr[k * ldl + f + t] = (sr * pr + si * pi) * den;
+      wi[k * ldl + f + t] = (si * pr - sr * pi) * den;
+    }
+    __syncthreads();
+    for (int e = tid; e < k * T; e += 256) {
+      const int r = e / T, t = e % T;
+      const double ur = wr[r * ldl + k], ui = wi[r * ldl + k];
+      const double cr = wr[k * ldl + f + t], ci = wi[k * ldl + f + t];
+      wr[r * ldl + f + t] -= ur * cr - ui * ci;
+      wi[r * ldl + f + t] -= ur * ci + ui * cr;
+    }
+    __syncthreads();
+  }
+  for (int e = tid; e < f * T; e += 256) {
+    const int r = e / T, t = e % T;
+    W[((long)r * ldw + fmax + t) * 2] = wr[r * ldl + f + t];
+    W[((long)r * ldw + fmax + t) * 2 + 1] = wi[r * ldl + f + t];
+  }
+}
+// k_wb_solve in the form that fits: the system in LDS up to 150 KB
+static int launch_wb_solve(int nbl, double* W, const int32_t* fcount, int fmax, int T, int32_t* info, int iter_tag,
+                           hipStream_t st) {
+  const size_t lds = (size_t)2 * fmax * ((fmax + T) | 1) * sizeof(double);
+  if (lds <= (size_t)150 * 1024) {
+    static hpx_lds_limit limit;
+    HPX_TRY(limit.ensure(reinterpret_cast<const void*>(&k_wb_solve_lds), lds));
+    hipLaunchKernelGGL(k_wb_solve_lds, dim3(nbl), dim3(256), lds, st, W, fcount, fmax, T, info, iter_tag);
+  } else {
+    hipLaunchKernelGGL(k_wb_solve, dim3(nbl), dim3(256), 0, st, W, fcount, fmax, T, info, iter_tag);
+  }
+  HPX_HIP(hipGetLastError());
+  return HPX_OK;
+}
+
 __global__ __launch_bounds__(256) void k_wb_correct(double* __restrict__ Sre, double* __restrict__ Sim,
                                                     double* __restrict__ Xre, double* __restrict__ Xim,
                                                     const double* __restrict__ W_all,
@@ -2180,7 +2290,7 @@ static int post_solve(hpx_plan* p, int it_abs, const IterOut& O, hipStream_t st)
       const int fm = p->wb_fmax;
       hipLaunchKernelGGL(k_wb_system, dim3(nbl), dim3(256), 0, st, p->Sre, p->Sim, p->Xre, p->Xim, p->Fre, p->Fim,
                          p->fg_shared, p->wb_flist, p->wb_fcount, p->wb_W, fm, N, M, T, NP, TP, p->npad);
-      hipLaunchKernelGGL(k_wb_solve, dim3(nbl), dim3(256), 0, st, p->wb_W, p->wb_fcount, fm, T, p->info, it_abs + 1);
+      HPX_TRY(launch_wb_solve(nbl, p->wb_W, p->wb_fcount, fm, T, p->info, it_abs + 1, st));
       hipLaunchKernelGGL(k_wb_correct, dim3(8, nbl), dim3(256), 0, st, p->Sre, p->Sim, p->Xre, p->Xim, p->wb_W,
                          p->wb_fcount, fm, T, NP, TP, p->npad);
       HPX_HIP(hipGetLastError());
@@ -2348,8 +2458,7 @@ static int run_iteration(hpx_plan* p, const RunArgs& A, int it) {
           hipLaunchKernelGGL(k_wb_system, dim3(c->nbl), dim3(256), 0, st, c->Sre, c->Sim, c->Xre, c->Xim, c->Fre,
                              c->Fim, c->fg_shared, c->wb_flist, c->wb_fcount, c->wb_W, fm, N, M, 1, c->NP, c->TP,
                              c->npad);
-          hipLaunchKernelGGL(k_wb_solve, dim3(c->nbl), dim3(256), 0, st, c->wb_W, c->wb_fcount, fm, 1, c->info,
-                             iter0 + it + 1);
+          HPX_TRY(launch_wb_solve(c->nbl, c->wb_W, c->wb_fcount, fm, 1, c->info, iter0 + it + 1, st));
           hipLaunchKernelGGL(k_wb_correct, dim3(8, c->nbl), dim3(256), 0, st, c->Sre, c->Sim, c->Xre, c->Xim, c->wb_W,
                              c->wb_fcount, fm, 1, c->NP, c->TP, c->npad);
           HPX_HIP(hipGetLastError());
