@@ -217,3 +217,59 @@ def test_zpotrs_size_sweep(T):
         worst = max(worst, err)
         assert err < 1e-10, (n, nrhs, err)
     print(f"size sweep: worst relative error {worst:.2e} over {len(sizes)} orders")
+
+
+def test_split_factor_with_agent_scope_handoff():
+    """The split factor's fall-back protocol (agent-scope release / acquire fences, used when the parts of a system do
+    not share an XCD): forced through HPX_SPLIT_HEAVY in a process of its own (the switch is read once), zpotrs of a
+    small batch -- several workgroups per system -- against numpy."""
+    import os, subprocess, sys, textwrap
+    code = textwrap.dedent("""
+        import numpy as np, torch
+        from hydra_pspec_amd import hpx
+        rng = np.random.default_rng(3)
+        nb, n, nrhs = 5, 200, 24
+        a = rng.standard_normal((nb, n, n)) + 1j * rng.standard_normal((nb, n, n))
+        A = a @ np.conj(np.swapaxes(a, 1, 2)) / n + np.eye(n)
+        B = rng.standard_normal((nb, n, nrhs)) + 1j * rng.standard_normal((nb, n, nrhs))
+        dA, dB = torch.from_numpy(A).cuda(), torch.from_numpy(B).cuda()
+        dX = torch.zeros_like(dB); info = torch.zeros(nb, dtype=torch.int32, device="cuda")
+        hpx.check(hpx.lib().hpx_zpotrs_batched(nb, n, nrhs, hpx.ptr(dA), hpx.ptr(dB), hpx.ptr(dX), hpx.ptr(info), None))
+        X = dX.cpu().numpy()
+        err = np.abs(X - np.linalg.solve(A, B)).max() / np.abs(X).max()
+        assert not info.cpu().numpy().any() and err < 1e-11, err
+        print("ok", err)
+    """)
+    env = dict(os.environ, HPX_SPLIT_HEAVY="1")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300,
+                         cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert out.returncode == 0 and "ok" in out.stdout, out.stdout + out.stderr
+
+
+@pytest.mark.parametrize("n,flagged", [(48, False), (100, True), (512, True)])
+def test_sqrtm_hpd_on_device(T, n, flagged):
+    """hpx_sqrtm_hpd_batched (Newton-Schulz on the batched MFMA product) and the masked root built on it
+    (pspec.sqrtm_masked_device) against scipy.linalg.sqrtm of Ninv diag(w) -- the reference's own call, pspec.py:361-362."""
+    import scipy.linalg
+    from hydra_pspec_amd import hpx, pspec
+    rng = np.random.default_rng(n)
+    nb = 3
+    q = rng.standard_normal((nb, n, n)) + 1j * rng.standard_normal((nb, n, n))
+    A = q @ np.conj(np.swapaxes(q, 1, 2)) / n + 0.5 * np.eye(n)
+    w = np.ones((nb, n), bool)
+    if flagged:
+        w = rng.uniform(size=(nb, n)) > 0.15
+        w[0] = True                                  # (one system without flags in the same batch)
+    got = pspec.sqrtm_masked_device(T, A, w, T.device("cuda", T.cuda.current_device())).cpu().numpy()
+    for b in range(nb):
+        Ni = A[b] * w[b][None, :]
+        assert np.abs(got[b] @ got[b] - Ni).max() < 1e-10 * np.abs(Ni).max()
+        if n <= 100:
+            assert np.abs(got[b] - scipy.linalg.sqrtm(Ni)).max() < 1e-9 * np.abs(Ni).max()
+    if not flagged and n % 16 == 0:                  # the C-ABI entry point itself: root and inverse root
+        dA = T.from_numpy(np.ascontiguousarray(A)).cuda()
+        sq, isq = T.empty_like(dA), T.empty_like(dA)
+        hpx.check(hpx.lib().hpx_sqrtm_hpd_batched(nb, n, hpx.ptr(dA), hpx.ptr(sq), hpx.ptr(isq), 1e-7, 60, None, None))
+        sq, isq = sq.cpu().numpy(), isq.cpu().numpy()
+        assert np.abs(sq @ sq - A).max() < 1e-11 * np.abs(A).max()
+        assert np.abs(sq @ isq - np.eye(n)).max() < 1e-11
