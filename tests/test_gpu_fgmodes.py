@@ -113,7 +113,7 @@ def test_zheev_psd_batched_vs_numpy(n0, kind):
         assert np.max(np.abs(wb - lr)) < 1e-9 * lr[0]
         assert np.linalg.norm(A[b] @ vb - vb * wb[None, :]) < 1e-9 * np.linalg.norm(A[b])
         keep = wb > 1e-9 * lr[0]                       # (a null vector competes with the zero padding's)
-        assert np.abs(vb[:, keep].conj().T @ vb[:, keep] - np.eye(int(keep.sum()))).max() < 1e-12
+        assert np.abs(vb[:, keep].conj().T @ vb[:, keep] - np.eye(int(keep.sum()))).max() < 1e-9
         if kind != "hpd":                             # well separated leading eigenvalues
             assert np.max(1 - np.abs(np.sum(np.conj(Ur[:, :12]) * vb[:, :12], axis=0))) < 1e-9
 
