@@ -407,6 +407,13 @@ int hpx_factor_split_parts(int nbl, int npad, int ld) {
 #ifdef HPX_NO_SPLIT
   return 0;
 #endif
+  // HPX_FACTOR_SPLIT=0 switches the form off at run time.  It assumes this process has the device to itself: every
+  // part of a system must become resident while the others wait for it, which holds for ONE launch of at most one
+  // workgroup per CU, and for several such launches side by side only while each keeps 8 x parts consecutive
+  // workgroups on the device -- many processes sharing one GPU with very small batches each (launcher rehearsals
+  // with, say, six ranks of eight baselines) can starve each other; the spins then give up and flag their systems.
+  static const bool off = getenv("HPX_FACTOR_SPLIT") && atoi(getenv("HPX_FACTOR_SPLIT")) == 0;
+  if (off) return 0;
   static SplitDevice dev;
   const int cus = dev.get();
   const int nct = npad >> 4, nrt = ld >> 4;
