@@ -354,8 +354,11 @@ __device__ HPX_INL bool elim16w(const WideCtx& X, const int tcol, const bool las
   for (int k = 0; k < 16; ++k) {
     // ---- A (critical): multipliers, D update, the next column out, the next operands requested
     const double lr = c.x * rinv, lm = c.y * rinv;
+    // (register v holds the columns g + 4 v: those with 4 v + 3 <= k are finished -- their operand cq is the masked
+    // zero -- and are skipped at compile time; likewise below, row k of the inverse is zero right of column k)
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
+      if (4 * v + 3 <= k) continue;
       dr[v] = fma(-lr, cq[v].x, dr[v]);
       dr[v] = fma(-lm, cq[v].y, dr[v]);
       di[v] = fma(-lm, cq[v].x, di[v]);
@@ -375,7 +378,8 @@ __device__ HPX_INL bool elim16w(const WideCtx& X, const int tcol, const bool las
       __builtin_amdgcn_sched_barrier(0);
       c = col[kg1 * 16 + li];
 #pragma unroll
-      for (int v = 0; v < 4; ++v) cq[v] = col[kg1 * 16 + g + 4 * v];
+      for (int v = 0; v < 4; ++v)
+        if (4 * v + 3 > k1) cq[v] = col[kg1 * 16 + g + 4 * v];
       if (k1 < 15) {
         cn = col[kg1 * 16 + k1 + 1];
         dn = rawn[((k1 + 1) & 3) * 16 + k1 + 1];
@@ -389,10 +393,14 @@ __device__ HPX_INL bool elim16w(const WideCtx& X, const int tcol, const bool las
       const double r0 = __builtin_amdgcn_rcp(dkn);
       rinv = fma(r0, fma(-dkn, r0, 1.0), r0);
     }
+#ifndef HPX_E16_PROBE
+#define HPX_E16_PROBE 0        // timing-only knobs of tools/experiments/elim/elim16w_probe.hip: 1 no inverse, 2 no outputs
+#endif
     // ---- ... the inverse's update of the step before ...
-    if (k > 0) {
+    if (k > 0 && !(HPX_E16_PROBE & 1)) {
 #pragma unroll
       for (int v = 0; v < 4; ++v) {
+        if (4 * v > k - 1) continue;                   // row k - 1 of the inverse is zero right of column k - 1
         yr[v] = fma(-plr, sy[v].x, yr[v]);
         yr[v] = fma(plm, sy[v].y, yr[v]);
         yi[v] = fma(-plr, sy[v].y, yi[v]);
@@ -401,21 +409,22 @@ __device__ HPX_INL bool elim16w(const WideCtx& X, const int tcol, const bool las
       }
     }
     // ---- ... and row k of the inverse out (final since that update) and back in
-    if (li == k) {
+    if (li == k && !(HPX_E16_PROBE & 1)) {
 #pragma unroll
       for (int v = 0; v < 4; ++v) yrw[g * 4 + v] = (cplx){yr[v], yi[v]};
     }
     HPX_E16_FENCE();
 #pragma unroll
-    for (int v = 0; v < 4; ++v) sy[v] = yrw[g * 4 + v];
+    for (int v = 0; v < 4; ++v)
+      if (4 * v <= k) sy[v] = yrw[g * 4 + v];
     plr = lr;
     plm = lm;
     HPX_E16_FENCE();
     __builtin_amdgcn_sched_barrier(0);
   }
 #pragma unroll
-  for (int v = 0; v < 4; ++v) {                          // the last step's update of the inverse
-    yr[v] = fma(-plr, sy[v].x, yr[v]);
+  for (int v = 0; v < 4; ++v) {                          // the last step's update of the inverse (all zero multipliers:
+    yr[v] = fma(-plr, sy[v].x, yr[v]);                   // no row lies below row 15 -- kept for the form)
     yr[v] = fma(plm, sy[v].y, yr[v]);
     yi[v] = fma(-plr, sy[v].y, yi[v]);
     yi[v] = fma(-plm, sy[v].x, yi[v]);
@@ -424,6 +433,7 @@ __device__ HPX_INL bool elim16w(const WideCtx& X, const int tcol, const bool las
 #undef HPX_E16_FENCE
   __builtin_amdgcn_s_setprio(0);
   bool bad = false;
+  if (HPX_E16_PROBE & 2) return dr[0] + yr[1] < -1e300;
   const double pib = dgs[li];
   const double sv = rsqrt_nr(pib);
   double wr[4], wi[4], sq[4];
