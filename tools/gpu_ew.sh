@@ -1,4 +1,5 @@
 #!/bin/bash
-# timing-only ablation of the wide factor's tail steps (no wait / no staging): what perfect prefetch could buy
+# wide factor with the one-wave elimination (HPX_ELIM_WAVE) against the shipped build
 mkdir -p gpurun_out
-bash tools/experiments/ab/run_time_variants.sh "prod tailnw prod tailnw" "C3" || exit 1
+bash tools/experiments/ab/run_time_variants.sh "prod elimwave prod elimwave" "C3" || exit 1
+bash tools/experiments/ab/run_time_variants.sh "prod elimwave" "C5" || exit 1
