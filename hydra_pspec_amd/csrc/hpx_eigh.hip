@@ -93,8 +93,8 @@ __global__ __launch_bounds__(256, 2) void k_hj_step(double* __restrict__ wre, do
   constexpr int EPT = MM / 256;                           // entries per thread of the small problem
   __shared__ double Ga[2][2][MM], Qa[2][2][MM];
   __shared__ double partbuf[(MT == 1) ? 2048 : 1];        // NB = 8: the four waves' partial Gram matrices
-  __shared__ double cown[M], cpre[M], cpim[M];            // per column of the small problem: its rotation's coefficients
-  __shared__ int cpar[M];                                 // ... and its partner
+  __shared__ double rot[M / 2][4];
+  __shared__ int partner[M], isq[M], pidx[M];
   __shared__ double red[4];
   __shared__ int skip;
   const int b = blockIdx.y, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, g = lane >> 4;
@@ -221,23 +221,29 @@ __global__ __launch_bounds__(256, 2) void k_hj_step(double* __restrict__ wre, do
           cp = cr / ac;
           sp = ci / ac;
         }
-        // x_a' = own x_a + part x_partner(a):  a = p: (cs, -sn e^{-i phi});  a = q: (cs, sn e^{i phi})
-        cown[pp] = cs; cpre[pp] = -sn * cp; cpim[pp] = sn * sp; cpar[pp] = qq;
-        cown[qq] = cs; cpre[qq] = sn * cp;  cpim[qq] = sn * sp; cpar[qq] = pp;
+        rot[tid][0] = cs; rot[tid][1] = sn; rot[tid][2] = cp; rot[tid][3] = sp;
+        partner[pp] = qq; partner[qq] = pp;
+        isq[pp] = 0; isq[qq] = 1;
+        pidx[pp] = tid; pidx[qq] = tid;
       }
       __syncthreads();
       const double* gre = Ga[cur][0];
       const double* gim = Ga[cur][1];
       const double* qre = Qa[cur][0];
       const double* qim = Qa[cur][1];
-      // (the column of a thread's entries is the same for all of them: tid % M -- its coefficients once per step)
-      const int c = tid % M, cq = cpar[c];
-      const double own_c = cown[c], pcr = cpre[c], pci = cpim[c];
 #pragma unroll
       for (int q = 0; q < EPT; ++q) {
-        const int e = tid + 256 * q, r = e / M;
-        const int rp = cpar[r];
-        const double own_r = cown[r], prr = cpre[r], pri = cpim[r];
+        const int e = tid + 256 * q, r = e / M, c = e % M;
+        // x_a' = own_a x_a + part_a x_partner(a):  a = p: (cs, -sn e^{-i phi});  a = q: (cs, sn e^{i phi})
+        const int rp = partner[r], cq = partner[c];
+        const double* rc_ = rot[pidx[c]];
+        const double own_c = rc_[0];
+        const double pcr = isq[c] ? rc_[1] * rc_[2] : -rc_[1] * rc_[2];
+        const double pci = rc_[1] * rc_[3];
+        const double* rr_ = rot[pidx[r]];
+        const double own_r = rr_[0];
+        const double prr = isq[r] ? rr_[1] * rr_[2] : -rr_[1] * rr_[2];
+        const double pri = rr_[1] * rr_[3];
         // T = G J (columns), at rows r and partner(r)
         const double t1r = gre[r * M + c] * own_c + gre[r * M + cq] * pcr - gim[r * M + cq] * pci;
         const double t1i = gim[r * M + c] * own_c + gre[r * M + cq] * pci + gim[r * M + cq] * pcr;
