@@ -1530,29 +1530,38 @@ __global__ void k_pt_diag(const double* __restrict__ m, double* __restrict__ dg,
 }
 // lnpart[b][0] = sum_t r_t^H Ninv_{b,t} r_t with the masked residual r [b][NP][TP] and the units' planar Ninv
 // [b*T + t][NP][NP] (Hermitian, row-major): one workgroup per baseline, times in order (deterministic)
+// sum_t (w r_t)^H Ninv_t (w r_t) with each time's own matrix: one workgroup per (time, baseline) -- it had been one
+// per baseline, every thread walking its own matrix row (a stride of NP doubles between neighbouring threads) -- leaves
+// the time's term in part[b][t]; the matrices are Hermitian, so row x is read as the conjugate of column x, which
+// neighbouring threads read from neighbouring addresses.  k_quadform_pt_sum adds the terms in time order.
 __global__ __launch_bounds__(256) void k_quadform_pt(const double* __restrict__ rre, const double* __restrict__ rim,
                                                      const double* __restrict__ nre, const double* __restrict__ nim,
-                                                     double* __restrict__ lnpart, const int N, const int T,
+                                                     double* __restrict__ part, const int N, const int T,
                                                      const int NP, const int TP) {
   __shared__ double red[4];
-  const int b = blockIdx.x;
+  const int t = blockIdx.x, b = blockIdx.y;
+  const double* mr = nre + ((long)b * T + t) * NP * NP;
+  const double* mi = nim + ((long)b * T + t) * NP * NP;
   double acc = 0.0;
-  for (int t = 0; t < T; ++t) {
-    const double* mr = nre + ((long)b * T + t) * NP * NP;
-    const double* mi = nim + ((long)b * T + t) * NP * NP;
-    for (int x = threadIdx.x; x < N; x += 256) {
-      double vr = 0.0, vi = 0.0;                         // v = (Ninv r)[x]
-      for (int k = 0; k < N; ++k) {
-        const double ar = mr[(long)x * NP + k], ai = mi[(long)x * NP + k];
-        const double br = rre[((long)b * NP + k) * TP + t], bi = rim[((long)b * NP + k) * TP + t];
-        vr += ar * br - ai * bi;
-        vi += ar * bi + ai * br;
-      }
-      acc += rre[((long)b * NP + x) * TP + t] * vr + rim[((long)b * NP + x) * TP + t] * vi;
+  for (int x = threadIdx.x; x < N; x += 256) {
+    double vr = 0.0, vi = 0.0;                         // v = (Ninv r)[x] = sum_k conj(Ninv[k][x]) r[k]
+    for (int k = 0; k < N; ++k) {
+      const double ar = mr[(long)k * NP + x], ai = -mi[(long)k * NP + x];
+      const double br = rre[((long)b * NP + k) * TP + t], bi = rim[((long)b * NP + k) * TP + t];
+      vr += ar * br - ai * bi;
+      vi += ar * bi + ai * br;
     }
+    acc += rre[((long)b * NP + x) * TP + t] * vr + rim[((long)b * NP + x) * TP + t] * vi;
   }
   const double tot = block_sum(acc, red);
-  if (threadIdx.x == 0) lnpart[(long)b * HPX_NPART] = tot;
+  if (threadIdx.x == 0) part[(long)b * T + t] = tot;
+}
+__global__ void k_quadform_pt_sum(const double* __restrict__ part, double* __restrict__ lnpart, const int T, const int nbl) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= nbl) return;
+  double tot = 0.0;
+  for (int t = 0; t < T; ++t) tot += part[(long)b * T + t];
+  lnpart[(long)b * HPX_NPART] = tot;
 }
 // flags_any[b][x] = AND_t flags_t[b][t][x];  ninv_any[b][x] = ninv_t[b][0][x]
 __global__ void k_pt_reduce(const uint8_t* __restrict__ ft, const double* __restrict__ nt,
@@ -2199,23 +2208,44 @@ __global__ __launch_bounds__(256) void k_wb_correct(double* __restrict__ Sre, do
                                                     const double* __restrict__ W_all,
                                                     const int32_t* __restrict__ fcount, const int fmax, const int T,
                                                     const int NP, const int TP, const int npad) {
+  // out[r][t] += sum_k Y_P[r][k] c[k][t] over the rows of X and of S: a (rows x f) by (f x T) product per baseline, on
+  // the matrix pipe (it had been a scalar loop per entry: 4.3 ms per iteration at the C3 shape with 77 flagged
+  // channels).  One wave per 16-row tile; k beyond the baseline's own f contributes zeros on both sides (those
+  // columns of X / S are never written).
   const int b = blockIdx.y, f = fcount[b], ldw = fmax + T;
   if (f == 0) return;
   const double* W = W_all + (long)b * fmax * ldw * 2;
-  const int nrow = npad + NP;                              // rows of X, then rows of S
-  for (int e = blockIdx.x * 256 + threadIdx.x; e < nrow * T; e += gridDim.x * 256) {
-    const int r = e / T, t = e % T;
-    double* pr = (r < npad) ? Xre + ((long)b * npad + r) * TP : Sre + ((long)b * NP + (r - npad)) * TP;
-    double* pi = (r < npad) ? Xim + ((long)b * npad + r) * TP : Sim + ((long)b * NP + (r - npad)) * TP;
-    double ar = pr[t], ai = pi[t];
-    for (int kf = 0; kf < f; ++kf) {
-      const double cr = W[((long)kf * ldw + fmax + t) * 2], ci = W[((long)kf * ldw + fmax + t) * 2 + 1];
-      const double yr = pr[T + kf], yi = pi[T + kf];
-      ar += yr * cr - yi * ci;
-      ai += yr * ci + yi * cr;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, g = lane >> 4;
+  const int ntile = (npad + NP) >> 4, nks = (f + 3) >> 2, ntt = (T + 15) >> 4;
+  for (int rt = blockIdx.x * 4 + wave; rt < ntile; rt += gridDim.x * 4) {
+    const int r0 = rt << 4;
+    double* pr = (r0 < npad) ? Xre + ((long)b * npad + r0) * TP : Sre + ((long)b * NP + (r0 - npad)) * TP;
+    double* pi = (r0 < npad) ? Xim + ((long)b * npad + r0) * TP : Sim + ((long)b * NP + (r0 - npad)) * TP;
+    for (int tt = 0; tt < ntt; ++tt) {
+      const int t = (tt << 4) + li;
+      const bool tok = t < T;
+      d4 ar = {0., 0., 0., 0.}, ai = ar;
+      for (int ks = 0; ks < nks; ++ks) {
+        const int k = 4 * ks + g;
+        const bool kok = k < f;
+        // A[m = li][k] = Y_P[r0 + li][k];  B[k][n = li] = c[k][t]
+        const double yr = kok ? pr[(long)li * TP + T + k] : 0.0, yi = kok ? pi[(long)li * TP + T + k] : 0.0;
+        const long wo = ((long)min(k, f - 1) * ldw + fmax + min(t, T - 1)) * 2;
+        const double cr = (kok && tok) ? W[wo] : 0.0, ci = (kok && tok) ? W[wo + 1] : 0.0;
+        ar = mfma64(yr, cr, ar);
+        ar = mfma64(-yi, ci, ar);
+        ai = mfma64(yr, ci, ai);
+        ai = mfma64(yi, cr, ai);
+      }
+      if (tok) {
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {               // accumulator: row g + 4 v, column li
+          const long o = (long)HPX_ACC_ROW(g, v) * TP + t;
+          pr[o] += ar[v];
+          pi[o] += ai[v];
+        }
+      }
     }
-    pr[t] = ar;
-    pi[t] = ai;
   }
 }
 
@@ -2236,6 +2266,7 @@ struct IterOut {
 #endif
 static int post_solve(hpx_plan* p, int it_abs, const IterOut& O, hipStream_t st) {
   const int nbl = p->nbl, N = p->N, M = p->M, T = p->T, NP = p->NP, TP = p->TP;
+  const int TPd = (T + 15) & ~15;          // the data's time columns, padded (TP may hold more right-hand sides)
   const double isn = 1.0 / sqrt((double)N);
   ResArgs R;
   R.Xre = p->Xre; R.Xim = p->Xim; R.Sre = p->Sre; R.Sim = p->Sim; R.Dre = p->Dre; R.Dim = p->Dim;
@@ -2306,19 +2337,21 @@ static int post_solve(hpx_plan* p, int it_abs, const IterOut& O, hipStream_t st)
     if (p->dense_noise) {
       // first ln-posterior term with the full matrix over the unflagged channels: sum_t (w r_t)^H Ninv (w r_t)
       // (pspec.py:472-477); k_resid left the masked residual behind, v = Ninv (w r) goes to the Z scratch
-      HPX_TRY(hpx_launch_dft(nbl, NP, TP, p->NIre, p->NIim, 1, R.Rdre, R.Rdim, (long)NP * TP, TP, nullptr, 0,
+      // (the data columns only: with flags TP also counts the Woodbury columns, 112 against 32 at the C3 shape)
+      HPX_TRY(hpx_launch_dft(nbl, NP, TPd, p->NIre, p->NIim, 1, R.Rdre, R.Rdim, (long)NP * TP, TP, nullptr, 0,
                              p->Zre, p->Zim, (long)NP * p->ncolR, p->ncolR, 1.0, st, 0, (long)NP * NP));
       hipLaunchKernelGGL(k_quadform, dim3(nbl), dim3(256), 0, st, R.Rdre, R.Rdim, (long)NP * TP, TP, p->Zre, p->Zim,
                          (long)NP * p->ncolR, p->ncolR, p->lnpart, N, T);
       HPX_HIP(hipGetLastError());
     } else if (p->per_time == 2) {      // ... with each time's own matrix (the child's units)
-      hipLaunchKernelGGL(k_quadform_pt, dim3(nbl), dim3(256), 0, st, R.Rdre, R.Rdim, p->child->NIre, p->child->NIim,
-                         p->lnpart, N, T, NP, TP);
+      hipLaunchKernelGGL(k_quadform_pt, dim3(T, nbl), dim3(256), 0, st, R.Rdre, R.Rdim, p->child->NIre, p->child->NIim,
+                         p->Zre, N, T, NP, TP);                      // (the Z scratch holds the per-time terms)
+      hipLaunchKernelGGL(k_quadform_pt_sum, dim3((nbl + 255) / 256), dim3(256), 0, st, p->Zre, p->lnpart, T, nbl);
       HPX_HIP(hipGetLastError());
     }
   }
   if (p->any_flags) {   // |F (w s)|^2 for the masked S^-1 quadratic form (pspec.py:479-483)
-    HPX_TRY(hpx_launch_dft(nbl, NP, TP, p->Fopre, p->Fopim, 0, p->Gre, p->Gim, (long)NP * TP, TP,
+    HPX_TRY(hpx_launch_dft(nbl, NP, TPd, p->Fopre, p->Fopim, 0, p->Gre, p->Gim, (long)NP * TP, TP,
                            nullptr, 0, p->Zre, p->Zim, (long)NP * p->ncolR, p->ncolR, 1.0, st,
                            N == NP));
     hipLaunchKernelGGL(k_betam, dim3(16, nbl), dim3(256), 0, st, p->Zre, p->Zim, p->betam, N, T, NP,

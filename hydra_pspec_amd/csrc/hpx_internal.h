@@ -190,8 +190,10 @@ __device__ __forceinline__ void hpx_gen_entry(const hpx_gen& G, const int r, con
     if (r < N) {
       const double ic = G.ia[c];
       if (G.cdre) {
-        vr = G.cdre[(long)r * G.NP + c] + (r == c ? ic * ic : 0.0);
-        vi = (r == c) ? 0.0 : G.cdim[(long)r * G.NP + c];
+        // C is Hermitian: entry (r, c) is read as the conjugate of (c, r) -- the callers walk down a column (r fastest),
+        // which in the row-major matrix is a stride of NP doubles for (r, c) and contiguous for (c, r)
+        vr = G.cdre[(long)c * G.NP + r] + (r == c ? ic * ic : 0.0);
+        vi = (r == c) ? 0.0 : -G.cdim[(long)c * G.NP + r];
       } else {
         vr = G.cre[r - c] + (r == c ? ic * ic : 0.0);
         vi = (r == c) ? 0.0 : G.cim[r - c];
