@@ -471,11 +471,14 @@ struct ResArgs {
 __global__ __launch_bounds__(256) void k_resid(const ResArgs A) {
   extern __shared__ double rl[];      // f_re[M][TP], f_im[M][TP], part[N][TP/16]
   __shared__ double red[4];
-  const int b = blockIdx.x, tid = threadIdx.x;
+  // blockIdx.x: one of A.npart slices of the channels (a workgroup per baseline walked N TP / 256 dependent rounds of
+  // loads: 1.1 ms at C5; the slices leave their chi^2 term in their own lnpart slot, k_draw adds the slots)
+  const int b = blockIdx.y, jp = blockIdx.x, tid = threadIdx.x;
   const int N = A.N, M = A.M, T = A.T, TP = A.TP, TG = TP >> 4;
+  const int xper = N / A.npart, x0 = jp * xper;
   double* lfr = rl;
   double* lfi = rl + (long)M * TP;
-  double* part = rl + 2L * M * TP;
+  double* part = rl + 2L * M * TP;                     // [xper][TG]
   const double* xre = A.Xre + (long)b * A.npad * TP;
   const double* xim = A.Xim + (long)b * A.npad * TP;
   const double* sre = A.Sre + (long)b * A.NP * TP;
@@ -492,11 +495,11 @@ __global__ __launch_bounds__(256) void k_resid(const ResArgs A) {
   }
   __syncthreads();
   double acc = 0.0;
-  const int tot = N * TP;                            // multiple of 16; threads of a 16-lane group
-  for (int e0 = 0; e0 < tot; e0 += 256) {            // share x, so the shuffles stay in range
+  const int tot = (x0 + xper) * TP;                  // multiple of 16; threads of a 16-lane group
+  for (int e0 = x0 * TP; e0 < tot; e0 += 256) {      // share x, so the shuffles stay in range
     const int e = e0 + tid;
     const bool in = e < tot;
-    const int x = in ? e / TP : 0, t = in ? e % TP : 0;
+    const int x = in ? e / TP : x0, t = in ? e % TP : 0;
     const long o = (long)x * TP + t;
     // beta partial: |z_xt|^2 summed over 16 consecutive times
     double v = 0.0;
@@ -508,7 +511,7 @@ __global__ __launch_bounds__(256) void k_resid(const ResArgs A) {
     v += __shfl_xor(v, 4, 16);
     v += __shfl_xor(v, 2, 16);
     v += __shfl_xor(v, 1, 16);
-    if (in && (t & 15) == 0) part[x * TG + (t >> 4)] = v;
+    if (in && (t & 15) == 0) part[(x - x0) * TG + (t >> 4)] = v;
     if (!in) continue;
     if (t >= T) {
       if (A.any_flags) { A.Gre[(long)b * A.NP * TP + o] = 0.0; A.Gim[(long)b * A.NP * TP + o] = 0.0; }
@@ -543,7 +546,7 @@ __global__ __launch_bounds__(256) void k_resid(const ResArgs A) {
     }
     if (A.chisq_out) A.chisq_out[(long)b * A.chisq_bstride + (long)t * N + x] = c2;
   }
-  if (A.fg_out) {
+  if (A.fg_out && jp == 0) {
     for (int e = tid; e < T * M; e += 256) {
       const int t = e / M, m = e % M;
       double* q = A.fg_out + (long)b * A.fg_bstride + (long)e * 2;
@@ -552,12 +555,16 @@ __global__ __launch_bounds__(256) void k_resid(const ResArgs A) {
     }
   }
   const double total = block_sum(acc, red);          // (barrier inside: part[] is complete)
-  if (tid == 0) A.lnpart[(long)b * HPX_NPART] = total;
-  // sum_t |z_kt|^2; k_draw turns it into beta_k = N sum_t |z_kt|^2  ( |F s|^2 with s = U z )
-  for (int k = tid; k < N; k += 256) {
+  // (dense noise: the quadratic form with the full matrix replaces this term afterwards, in slot 0 -- the other
+  // slices' slots must then hold nothing)
+  if (tid == 0) A.lnpart[(long)b * HPX_NPART + jp] = (A.Rdre && jp > 0) ? 0.0 : total;
+  // sum_t |z_kt|^2; k_draw turns it into beta_k = N sum_t |z_kt|^2  ( |F s|^2 with s = U z ): slot 0 for this
+  // slice's channels, nothing in the other slots
+  for (int k = x0 + tid; k < x0 + xper; k += 256) {
     double sum = 0.0;
-    for (int j = 0; j < TG; ++j) sum += part[k * TG + j];
+    for (int j = 0; j < TG; ++j) sum += part[(k - x0) * TG + j];
     A.bpart[(long)b * HPX_NPART * N + k] = sum;
+    for (int j = 1; j < A.npart; ++j) A.bpart[((long)b * HPX_NPART + j) * N + k] = 0.0;
   }
 }
 
@@ -1321,8 +1328,10 @@ static int set_static_impl(hpx_plan* p, const double* vis, const uint8_t* flags,
       HPX_REQUIRE(T + fmax <= TP, "hpx_plan_set_static_dense_flagged: the plan has too few right-hand-side columns "
                                   "(hpx_plan_create_ex with extra_rhs >= the largest number of flagged channels)");
       HPX_REQUIRE(fmax <= 512, "hpx_plan_set_static_dense_flagged: at most 512 flagged channels per baseline");
-      {   // the residual kernel keeps (2 M + N / 16) x TP doubles in LDS (k_resid): say so HERE, not at the first run
-        const size_t lds = (size_t)(2 * M * TP + N * (TP / 16)) * sizeof(double);
+      {   // the residual kernel keeps (2 M + N / (16 slices)) x TP doubles in LDS (k_resid): say so HERE, not at the first run
+        int P = 4;                       // (the slices of k_resid's launch, post_solve)
+        while (P > 1 && (N % P != 0 || N / P < 64)) P >>= 1;
+        const size_t lds = (size_t)(2 * M * TP + (N / P) * (TP / 16)) * sizeof(double);
         if (lds > (size_t)160 * 1024) {
           hpx_set_error("hpx_plan_set_static_dense_flagged: %d right-hand-side columns (%d times + %d flagged channels, "
                         "padded) need %zu bytes of LDS in the residual kernel, the CU has 160 KiB: at Nfreqs = %d and "
@@ -2328,10 +2337,15 @@ static int post_solve(hpx_plan* p, int it_abs, const IterOut& O, hipStream_t st)
     }
     HPX_TRY(mark(p, st));
     {
-      const size_t lds = (size_t)(2 * M * TP + N * (TP / 16)) * sizeof(double);
+      // slices of the channels: as many as keep 64 channels per workgroup, at most four
+      int P = 4;
+      while (P > 1 && (N % P != 0 || N / P < 64)) P >>= 1;
+      npart = P;
+      R.npart = P;
+      const size_t lds = (size_t)(2 * M * TP + (N / P) * (TP / 16)) * sizeof(double);
       static hpx_lds_limit limit;
       if (lds > 48 * 1024) HPX_TRY(limit.ensure(reinterpret_cast<const void*>(&k_resid), lds));
-      hipLaunchKernelGGL(k_resid, dim3(nbl), dim3(256), lds, st, R);
+      hipLaunchKernelGGL(k_resid, dim3(P, nbl), dim3(256), lds, st, R);
     }
     HPX_HIP(hipGetLastError());
     if (p->dense_noise) {
