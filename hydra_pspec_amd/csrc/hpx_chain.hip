@@ -1211,6 +1211,7 @@ static int plan_create_impl(hpx_plan** out, int nbl, int T, int N, int M, int ex
   p->nblk = (p->npad + HPX_NB - 1) / HPX_NB;
   p->lgam_T = lgamma((double)T);
   p->ev_used = 0;
+  p->allow_split = 1;
   const size_t nb = nbl, lsz = (size_t)p->npad * p->ld, xsz = (size_t)p->npad * p->TP,
                ssz = (size_t)p->NP * p->TP, rsz = (size_t)p->NP * p->ncolR;
   int rc = HPX_OK;
@@ -1946,6 +1947,25 @@ extern "C" int hpx_plan_set_solver(hpx_plan* p, int mode) {
   return HPX_OK;
 }
 
+// Options: of one plan (p != NULL) or of the library (p == NULL); see include/hpx.h
+extern "C" int hpx_set_option(hpx_plan* p, int key, int value) {
+  if (p) {
+    if (key == HPX_OPT_FACTOR_SPLIT) {
+      p->allow_split = value != 0;
+      if (p->child) p->child->allow_split = p->allow_split;
+      return HPX_OK;
+    }
+    hpx_set_error("hpx_set_option: key %d is not a plan option", key);
+    return HPX_EINVAL;
+  }
+  int rc = HPX_EINVAL;
+  if (key == HPX_OPT_FACTOR_SPLIT || key == HPX_OPT_SPLIT_HEAVY || key == HPX_OPT_SPLIT_SPIN_LIMIT)
+    rc = hpx_split_set_option(key, value);
+  else if (key == HPX_OPT_EIGH_INNER_SWEEPS || key == HPX_OPT_EIGH_TRACE) rc = hpx_eigh_set_option(key, value);
+  if (rc != HPX_OK) hpx_set_error("hpx_set_option: unknown key %d or bad value %d", key, value);
+  return rc;
+}
+
 extern "C" int hpx_plan_set_profiling(hpx_plan* p, int on) {
   HPX_REQUIRE(p, "null plan");
   p->profiling = on ? 1 : 0;
@@ -2410,6 +2430,14 @@ static int finish_run(hpx_plan* p, int niter, double* ps_last, hipStream_t st) {
   }
   std::vector<int32_t> info(nbl);   // report the first non-positive pivot, if any
   HPX_HIP(hipMemcpy(info.data(), p->info, (size_t)nbl * sizeof(int32_t), hipMemcpyDeviceToHost));
+  // a hand-off time-out of the split factor first: the factor of such a system is incomplete, whatever else is flagged
+  for (int b = 0; b < nbl; ++b)
+    if (info[b] & HPX_INFO_TIMEOUT) {
+      hpx_set_error("split factor: hand-off between the workgroups of baseline %d timed out at iteration %d (another "
+                    "process on this GPU? switch the form off: HPX_OPT_FACTOR_SPLIT = 0)", b,
+                    (info[b] & ~HPX_INFO_TIMEOUT) - 1);
+      return HPX_ETIMEOUT;
+    }
   for (int b = 0; b < nbl; ++b)
     if (info[b] != 0) {
       hpx_set_error("non-positive pivot: baseline %d, iteration %d", b, info[b] - 1);
@@ -2418,6 +2446,12 @@ static int finish_run(hpx_plan* p, int niter, double* ps_last, hipStream_t st) {
   if (p->child) {
     std::vector<int32_t> ci(p->child->nbl);
     HPX_HIP(hipMemcpy(ci.data(), p->child->info, ci.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+    for (size_t u = 0; u < ci.size(); ++u)
+      if (ci[u] & HPX_INFO_TIMEOUT) {
+        hpx_set_error("split factor: hand-off between the workgroups of baseline %d, time %d timed out at iteration %d",
+                      (int)(u / p->T), (int)(u % p->T), (ci[u] & ~HPX_INFO_TIMEOUT) - 1);
+        return HPX_ETIMEOUT;
+      }
     for (size_t u = 0; u < ci.size(); ++u)
       if (ci[u] != 0) {
         hpx_set_error("non-positive pivot: baseline %d, time %d, iteration %d", (int)(u / p->T), (int)(u % p->T),
@@ -2494,7 +2528,7 @@ static int run_iteration(hpx_plan* p, const RunArgs& A, int it) {
         HPX_HIP(hipGetLastError());
         HPX_TRY(mark(p, st));
         HPX_TRY(hpx_launch_factor(c->nbl, c->npad, c->ld, c->L, c->Wre, c->Wim, c->Vt, c->info, iter0 + it + 1,
-                                  c->dense_noise ? nullptr : &gc, st));
+                                  c->dense_noise ? nullptr : &gc, st, p->allow_split));
         HPX_TRY(mark(p, st));
         HPX_TRY(hpx_launch_backsolve(c->nbl, c->npad, c->TP, c->ld, c->L, c->Wre, c->Wim, c->Xre, c->Xim, st));
         if (c->dense_noise == 2) {      // flagged units: the Woodbury correction per unit (as post_solve, T = 1)
@@ -2519,12 +2553,12 @@ static int run_iteration(hpx_plan* p, const RunArgs& A, int it) {
         HPX_TRY(launch_assemble(p, st, 0));
         HPX_TRY(mark(p, st));
         HPX_TRY(hpx_launch_factor(nbl, p->npad, p->ld, p->L, p->Wre, p->Wim, p->Vt, p->info, iter0 + it + 1,
-                                  nullptr, st));
+                                  nullptr, st, p->allow_split));
       } else {
         HPX_TRY(launch_assemble_edge(p, st));
         HPX_TRY(mark(p, st));
         HPX_TRY(hpx_launch_factor(nbl, p->npad, p->ld, p->L, p->Wre, p->Wim, p->Vt, p->info, iter0 + it + 1,
-                                  &gen, st));
+                                  &gen, st, p->allow_split));
       }
       if (!p->per_time) {
         HPX_TRY(mark(p, st));
@@ -2698,7 +2732,8 @@ extern "C" int hpx_gibbs_step_general(hpx_plan* p, const double* shp, int iter0,
                        c->XTim, c->RSre, c->RSim, c->L, c->npad, c->ld);
     HPX_HIP(hipGetLastError());
     HPX_TRY(mark(p, st));
-    HPX_TRY(hpx_launch_factor(units, c->npad, c->ld, c->L, c->Wre, c->Wim, c->Vt, c->info, iter0 + 1, nullptr, st));
+    HPX_TRY(hpx_launch_factor(units, c->npad, c->ld, c->L, c->Wre, c->Wim, c->Vt, c->info, iter0 + 1, nullptr, st,
+                              p->allow_split));
     HPX_TRY(mark(p, st));
     HPX_TRY(hpx_launch_backsolve(units, c->npad, c->TP, c->ld, c->L, c->Wre, c->Wim, c->Xre, c->Xim, st));
     // s' = Sh' y' per unit, then the units' solutions to their time column of this plan's X
@@ -2753,7 +2788,8 @@ extern "C" int hpx_gibbs_step_general(hpx_plan* p, const double* shp, int iter0,
                      p->XTre, p->XTim, p->RSre, p->RSim, p->L, p->npad, p->ld);
   HPX_HIP(hipGetLastError());
   HPX_TRY(mark(p, st));
-  HPX_TRY(hpx_launch_factor(nbl, p->npad, p->ld, p->L, p->Wre, p->Wim, p->Vt, p->info, iter0 + 1, nullptr, st));
+  HPX_TRY(hpx_launch_factor(nbl, p->npad, p->ld, p->L, p->Wre, p->Wim, p->Vt, p->info, iter0 + 1, nullptr, st,
+                            p->allow_split));
   HPX_TRY(mark(p, st));
   HPX_TRY(hpx_launch_backsolve(nbl, p->npad, TP, p->ld, p->L, p->Wre, p->Wim, p->Xre, p->Xim, st));
   HPX_TRY(mark(p, st));

@@ -21,6 +21,10 @@
 #include "hpx_internal.h"
 #include "../../include/hpx.h"
 
+#ifndef HPX_EIGH_MAX_SWEEPS
+#define HPX_EIGH_MAX_SWEEPS 30
+#endif
+
 namespace {
 
 __device__ __forceinline__ void rr_pair16(const int n, const int s, const int i, int& p, int& q) {
@@ -390,6 +394,17 @@ int hpx_eigh_padded_order(int n0) { return n0 >= 241 ? ((n0 + 31) & ~31) : ((n0 
 // Eigendecomposition of nb Hermitian positive semi-definite matrices given planar (gr, gi: [nb][n][n], n a multiple
 // of 16): on return the diagonal of gr holds the eigenvalues (unsorted) and vr, vi the unit eigenvectors as columns.
 // gi and the off-diagonal of gr are left as they were.  sweeps_out (host, optional): outer sweeps taken.
+// HPX_OPT_EIGH_INNER_SWEEPS: sweeps of the small two-sided problem per visit (1; measured at order 512, 256 matrices:
+// 0.39 s with one, 0.51 s with two, 0.56 s with three -- the outer sweep count does not change); HPX_OPT_EIGH_TRACE:
+// the convergence measure of every sweep on stderr
+static int g_eigh_inner = 1, g_eigh_trace = 0;
+int hpx_eigh_set_option(int key, int value) {
+  if (key == HPX_OPT_EIGH_INNER_SWEEPS && value >= 1 && value <= 8) g_eigh_inner = value;
+  else if (key == HPX_OPT_EIGH_TRACE) g_eigh_trace = value != 0;
+  else return HPX_EINVAL;
+  return HPX_OK;
+}
+
 int hpx_eigh_psd_planar(int nb, int n, double* gr, const double* gi, double* vr, double* vi, int* sweeps_out,
                         hipStream_t st) {
   HPX_REQUIRE(nb > 0 && n >= 16 && (n & 15) == 0, "hpx_eigh_psd_planar: the order must be a multiple of 16");
@@ -421,13 +436,15 @@ int hpx_eigh_psd_planar(int nb, int n, double* gr, const double* gi, double* vr,
   hipLaunchKernelGGL(k_hj_pack, dim3(64, nb), dim3(256), 0, st, lbuf.p, wre, wim, n, NB);
   HPX_HIP(hipGetLastError());
   const int p = n / NB;
-  static const bool trace = getenv("HPX_EIGH_TRACE") != nullptr;
+  const bool trace = g_eigh_trace != 0;
   // sweeps of the 16 x 16 problem per visit: one (measured at order 512, 256 matrices: 0.39 s with one, 0.51 s
   // with two, 0.56 s with three -- the outer sweep count, 10 - 11, does not change)
-  static const int inner = getenv("HPX_EIGH_INNER") ? atoi(getenv("HPX_EIGH_INNER")) : 1;
+  const int inner = g_eigh_inner;
   std::vector<double> hm(nb);
   int sweeps = 0;
-  for (; sweeps < 30; ++sweeps) {
+  bool converged = false;
+  double worst = 0.0;
+  for (; sweeps < HPX_EIGH_MAX_SWEEPS; ++sweeps) {
     HPX_HIP(hipMemsetAsync(meas, 0, (size_t)nb * sizeof(double), st));
     for (int s = 0; s < p - 1; ++s)
       if (NB == 16) hipLaunchKernelGGL(k_hj_step<16>, dim3(p / 2, nb), dim3(256), 0, st, wre, wim, n, p, s, meas, inner);
@@ -435,12 +452,19 @@ int hpx_eigh_psd_planar(int nb, int n, double* gr, const double* gi, double* vr,
     HPX_HIP(hipGetLastError());
     HPX_HIP(hipMemcpyAsync(hm.data(), meas, (size_t)nb * sizeof(double), hipMemcpyDeviceToHost, st));
     HPX_HIP(hipStreamSynchronize(st));
-    double worst = 0.0;
+    worst = 0.0;
     for (int b = 0; b < nb; ++b) worst = hm[b] > worst ? hm[b] : worst;
     if (trace) fprintf(stderr, "hpx_eigh: sweep %d  max |G_ij|^2 / (G_ii G_jj) before its rotations = %.3e\n", sweeps, worst);
     // the measure was taken BEFORE this sweep's rotations, and the convergence is quadratic by then (measured:
     // 3e-7 -> 8e-13 -> 1e-25): below 1e-10 the sweep just done leaves the columns orthogonal to rounding
-    if (worst < 1e-10) { ++sweeps; break; }
+    if (worst < 1e-10) { ++sweeps; converged = true; break; }
+  }
+  if (!converged) {
+    // (the eigenpairs of the sweep limit are not handed out as if they were converged)
+    if (sweeps_out) *sweeps_out = -1;
+    hpx_set_error("hpx_eigh_psd_planar: no convergence in %d sweeps (order %d; max |G_ij|^2 / (G_ii G_jj) = %.3e before "
+                  "the last one, needs < 1e-10)", HPX_EIGH_MAX_SWEEPS, n, worst);
+    return HPX_EINVAL;
   }
   hipLaunchKernelGGL(k_hj_finish, dim3(n / 8, nb), dim3(256), 0, st, wre, wim, ridge, gr, vr, vi, n, NB);
   HPX_HIP(hipGetLastError());

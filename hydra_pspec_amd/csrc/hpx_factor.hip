@@ -980,8 +980,9 @@ static int launch_factor_t(int nbl, size_t lds, int npad, int ld, double* L, dou
 int hpx_launch_factor(int nbl, int npad, int ld, double* L, double* Wre, double* Wim, double* Vt,
                       int32_t* info, int iter_tag, const hpx_gen_batch* gen, hipStream_t st, int allow_split) {
   if (Vt && allow_split) {      // a batch too small for one workgroup per CU: several workgroups per system (hpx_factor_split.hip)
-    const int parts = hpx_factor_split_parts(nbl, npad, ld);
-    if (parts) return hpx_launch_factor_split(nbl, parts, npad, ld, L, Wre, Wim, Vt, info, iter_tag, gen, st);
+    int took = 0;
+    HPX_TRY(hpx_launch_factor_split(nbl, npad, ld, L, Wre, Wim, Vt, info, iter_tag, gen, st, &took));
+    if (took) return HPX_OK;    // (else: not applicable, or no room beside the split launches in flight on other streams)
   }
   if (Vt && npad >= HPX_WIDE_MIN)
     return hpx_launch_factor_wide(nbl, npad, ld, L, Wre, Wim, Vt, info, iter_tag, gen, st);

@@ -23,11 +23,18 @@
 //
 // Hand-off: release / acquire at agent scope on counters in the system's Vt block (HPX_VT_SYNC), no grid
 // sync; the parts of a system are placed on one XCD (block index mod 8) so the data they exchange stays in one
-// L2.  The LAST part to finish zeroes the system's counters again.  The launch never exceeds one workgroup per CU
-// of the device, so every part is resident (or becomes so without any other part's help) and every spin ends;
-// a spin that does not (it never should) gives up after SPIN_LIMIT polls and flags the system in `info`.
+// L2.  The LAST part to finish zeroes the system's counters again.
+// Residency: a part spins on the other parts of its system, so every part of every split launch in flight on the
+// device must be resident together (one workgroup of this kernel fills a CU's register file).  The launcher keeps
+// the books per device (SplitGuard below): the workgroups of the split launches still in flight on OTHER streams plus
+// those of the new launch must not exceed the CUs, else the new launch takes fewer parts or the one-workgroup kernel
+// (hpx_launch_factor).  What the books cannot see -- another PROCESS running split launches on the same GPU -- is
+// covered by the time-out: a spin gives up after `spin_limit` polls and flags the system in `info` with
+// HPX_INFO_TIMEOUT, which finish_run reports as HPX_ETIMEOUT (not as a non-positive pivot); callers that share a
+// GPU between processes switch the form off (HPX_OPT_FACTOR_SPLIT).
 #define HPX_TILES_STAGE0_D 512            // (only the tile hand-over area of the first staging buffer is used here)
 #include "hpx_factor_tiles.h"
+#include <mutex>
 
 namespace {
 
@@ -35,7 +42,7 @@ constexpr int SPLIT_NW = 8;             // waves per workgroup: the eliminator a
 constexpr int SPLIT_NSD = 5;            // diagonal tiles the eliminator can hold
 constexpr int SPLIT_NSW = 9;            // tiles a worker wave can hold
 constexpr int SPLIT_MAX_CT = 40;        // tile columns the counter block holds
-constexpr unsigned SPIN_LIMIT = 1u << 22;
+constexpr unsigned SPIN_LIMIT_DEFAULT = 1u << 22;
 static_assert(2 * SPLIT_MAX_CT + 2 <= 2 * HPX_VT_SYNC, "counters must fit the Vt block's sync area");
 
 // ---- hand-off between workgroups.  `heavy`: release / acquire fences at agent scope -- on this part a write-back
@@ -53,12 +60,12 @@ __device__ HPX_INL void handoff_acquire(const bool heavy) {
   else asm volatile("buffer_inv sc0" ::: "memory");
 }
 // wave-uniform wait for *flag >= target: relaxed polls (they go to L2 and invalidate nothing), the acquire follows
-__device__ HPX_INL bool spin_until(int* flag, const int target, const bool heavy) {
+__device__ HPX_INL bool spin_until(int* flag, const int target, const bool heavy, const unsigned spin_limit) {
   unsigned n = 0;
   bool ok = true;
   while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
     __builtin_amdgcn_s_sleep(1);
-    if (++n > SPIN_LIMIT) { ok = false; break; }
+    if (++n > spin_limit) { ok = false; break; }
   }
   handoff_acquire(heavy);
   return ok;
@@ -104,7 +111,8 @@ __global__ __launch_bounds__(64 * SPLIT_NW, 2) void k_factor_split(double* __res
                                                                    double* __restrict__ Wim_all, double* __restrict__ Vt_all,
                                                                    int32_t* __restrict__ info, const int npad, const int ld,
                                                                    const int iter_tag, const hpx_gen_batch GB, const int nbl,
-                                                                   const int parts, const int force_heavy) {
+                                                                   const int parts, const int force_heavy,
+                                                                   const unsigned spin_limit, int* __restrict__ xcd_miss) {
   extern __shared__ double lds_panel[];        // [nrt][512]: the current column's tiles (odd-column swizzle)
   __shared__ int wcount;                       // worker_barrier's counter
   const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
@@ -165,10 +173,14 @@ __global__ __launch_bounds__(64 * SPLIT_NW, 2) void k_factor_split(double* __res
     unsigned n = 0, word;
     while (((word = (unsigned)__hip_atomic_load(arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) & 255u) < (unsigned)parts) {
       __builtin_amdgcn_s_sleep(1);
-      if (++n > SPIN_LIMIT) { timed_out = true; break; }
+      if (++n > spin_limit) { timed_out = true; break; }
     }
     const unsigned m = word >> 8;
-    heavy = force_heavy || (m & (m - 1)) != 0 || timed_out;
+    const bool spread = (m & (m - 1)) != 0;
+    heavy = force_heavy || spread || timed_out;
+    // the parts do NOT share an XCD: this launch goes on with the agent-scope fences (correct, slow), and the host
+    // is told -- the launcher stops choosing the split form on this device (a word in pinned host memory)
+    if (spread && xcd_miss && tid == 0) __hip_atomic_store(xcd_miss, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   };
   if (X.wave == 0) {
     // =================== the eliminator: the workgroup's diagonal tiles (r = w + s parts) =====================
@@ -233,7 +245,7 @@ __global__ __launch_bounds__(64 * SPLIT_NW, 2) void k_factor_split(double* __res
       HPX_STAMP(0, 0);
       if (j >= 0) {
         if (w != j % parts) {                  // the inverse of the diagonal tile -> Vs
-          if (!spin_until(&flagA[j], 1, heavy)) timed_out = true;
+          if (!spin_until(&flagA[j], 1, heavy, spin_limit)) timed_out = true;
           glds_tile(X.Vt + (long)j * 512, 8 * src_lane, lds_addr(hpx_stage1 + FV_OFF));
           wait_vm<0>();
         }
@@ -324,7 +336,7 @@ __global__ __launch_bounds__(64 * SPLIT_NW, 2) void k_factor_split(double* __res
       }
       if (j + 1 == X.nct) break;               // last column: nothing to its right
       // ---- D: the other parts' tiles of the column -> LDS, then the trailing updates
-      if (!spin_until(&cntB[j], parts, heavy)) timed_out = true;
+      if (!spin_until(&cntB[j], parts, heavy, spin_limit)) timed_out = true;
       HPX_STAMP(5, 64);
       {
         int n = 0;
@@ -354,22 +366,12 @@ __global__ __launch_bounds__(64 * SPLIT_NW, 2) void k_factor_split(double* __res
       for (int i = 0; i < 2 * SPLIT_MAX_CT + 2; ++i) flagA[i] = 0;
     }
   }
-  if ((bad || timed_out) && info) atomicCAS(&info[b], 0, iter_tag);
+  // a time-out outranks a pivot report: what the other parts computed from tiles that never arrived is meaningless
+  if (timed_out && info) {
+    atomicOr(&info[b], HPX_INFO_TIMEOUT);
+    atomicCAS(&info[b], HPX_INFO_TIMEOUT, HPX_INFO_TIMEOUT | iter_tag);      // (the iteration, unless an earlier report holds one)
+  } else if (bad && info) atomicCAS(&info[b], 0, iter_tag);
 }
-
-struct SplitDevice {
-  int cus[32] = {};
-  int get() {
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 32) return 0;
-    if (!cus[dev]) {
-      int n = 0;
-      if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
-      cus[dev] = n;
-    }
-    return cus[dev];
-  }
-};
 
 // do the tiles of a system fit the waves' registers with `parts` workgroups per system?
 bool split_fits(const int parts, const int nct, const int nrt) {
@@ -384,45 +386,100 @@ bool split_fits(const int parts, const int nct, const int nrt) {
   return true;
 }
 
+// ---- the books of the split launches in flight, per device (see "Residency" at the top) -----------------------
+// One stream is the common case and costs nothing: launches of one stream run one after the other, so only the
+// newest counts and no event is needed.  From the moment a second stream takes the form, every split launch is
+// followed by an event on its stream, and a launch counts as in flight until its event has completed.
+struct SplitGuard {
+  std::mutex mu;
+  int cus = 0;
+  int* xcd_miss = nullptr;          // pinned host word the kernel sets when the parts of a system sat on different XCDs
+  bool multi = false;               // more than one stream has used the form
+  hipStream_t solo = nullptr;       // (!multi) the one stream so far, and the workgroups of its newest launch
+  bool have_solo = false;
+  int solo_wgs = 0;
+  struct Flight { hipStream_t st; hipEvent_t ev; int wgs; bool live; };
+  std::vector<Flight> flights;      // (multi) one slot per stream seen
+  int init(int dev) {
+    if (cus) return HPX_OK;
+    int n = 0;
+    HPX_HIP(hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev));
+    HPX_HIP(hipHostMalloc((void**)&xcd_miss, sizeof(int), hipHostMallocMapped));
+    *xcd_miss = 0;
+    cus = n;
+    return HPX_OK;
+  }
+  Flight* slot(hipStream_t st) {
+    for (auto& f : flights) if (f.st == st) return &f;
+    Flight f = {st, nullptr, 0, false};
+    if (hipEventCreateWithFlags(&f.ev, hipEventDisableTiming) != hipSuccess) return nullptr;
+    flights.push_back(f);
+    return &flights.back();
+  }
+  // workgroups of split launches that may still be running on streams other than `st`
+  int busy_elsewhere(hipStream_t st) {
+    int n = 0;
+    for (auto& f : flights) {
+      if (!f.live || f.st == st) continue;
+      if (hipEventQuery(f.ev) == hipErrorNotReady) n += f.wgs;
+      else f.live = false;
+    }
+    return n;
+  }
+};
+SplitGuard g_guard[32];
+int g_split_enabled = 1;                       // HPX_OPT_FACTOR_SPLIT at library level
+int g_force_heavy = 0;                         // HPX_OPT_SPLIT_HEAVY (testing)
+unsigned g_spin_limit = SPIN_LIMIT_DEFAULT;    // HPX_OPT_SPLIT_SPIN_LIMIT (testing)
+
+// Workgroups per system for a batch of nbl systems with `free_cus` CUs to run on, or 0 when the split form does not
+// apply: the batch must leave at least half of those CUs without a system, a wave's tiles must fit its registers and
+// the column its LDS.
+int split_parts_for(int nbl, int npad, int ld, int free_cus) {
+  const int nct = npad >> 4, nrt = ld >> 4;
+  if (free_cus <= 0 || nbl <= 0 || nct < 2 || nct > SPLIT_MAX_CT) return 0;
+  if ((size_t)nrt * 4096 + (BUF_D + HPX_TILES_STAGE0_D) * sizeof(double) > (size_t)156 * 1024) return 0;
+  const int live = 8 * ((nbl + 7) / 8);        // block indices are dealt in eights (one system's parts on one XCD)
+  for (int parts = 8; parts >= 2; parts >>= 1)
+    if (live * parts <= free_cus && split_fits(parts, nct, nrt)) return parts;
+  return 0;
+}
+
 template <bool GEN>
 int launch_split_t(int nbl, int parts, int npad, int ld, double* L, double* Wre, double* Wim, double* Vt, int32_t* info,
-                   int iter_tag, const hpx_gen_batch& gen, hipStream_t st) {
+                   int iter_tag, const hpx_gen_batch& gen, int* xcd_miss, hipStream_t st) {
   static hpx_lds_limit limit;
-  static const int force_heavy = getenv("HPX_SPLIT_HEAVY") ? 1 : 0;      // (testing: agent-scope fences throughout)
   const size_t lds = (size_t)(ld >> 4) * 512 * sizeof(double);
   HPX_TRY(limit.ensure(reinterpret_cast<const void*>(&k_factor_split<GEN>), lds));
   const int grid = 8 * ((nbl + 7) / 8) * parts;
   hipLaunchKernelGGL((k_factor_split<GEN>), dim3(grid), dim3(64 * SPLIT_NW), lds, st, L, Wre, Wim, Vt, info, npad, ld, iter_tag,
-                     gen, nbl, parts, force_heavy);
+                     gen, nbl, parts, g_force_heavy, g_spin_limit, xcd_miss);
   HPX_HIP(hipGetLastError());
   return HPX_OK;
 }
 
 }  // namespace
 
-// Workgroups per system for a batch of nbl systems, or 0 when the split form does not apply: the batch must leave
-// at least half of the CUs without a system, every part must be resident at one workgroup per CU, a wave's tiles must
-// fit its registers and the column its LDS.
+int hpx_split_set_option(int key, int value) {
+  if (key == HPX_OPT_FACTOR_SPLIT) g_split_enabled = value != 0;
+  else if (key == HPX_OPT_SPLIT_HEAVY) g_force_heavy = value != 0;
+  else if (key == HPX_OPT_SPLIT_SPIN_LIMIT) g_spin_limit = value > 0 ? (unsigned)value : SPIN_LIMIT_DEFAULT;
+  else return HPX_EINVAL;
+  return HPX_OK;
+}
+
+// what hpx_launch_factor asks: may this batch take the split form now?  (no books touched: a dry query for tests)
 int hpx_factor_split_parts(int nbl, int npad, int ld) {
 #ifdef HPX_NO_SPLIT
   return 0;
 #endif
-  // HPX_FACTOR_SPLIT=0 switches the form off at run time.  It assumes this process has the device to itself: every
-  // part of a system must become resident while the others wait for it, which holds for ONE launch of at most one
-  // workgroup per CU, and for several such launches side by side only while each keeps 8 x parts consecutive
-  // workgroups on the device -- many processes sharing one GPU with very small batches each (launcher rehearsals
-  // with, say, six ranks of eight baselines) can starve each other; the spins then give up and flag their systems.
-  static const bool off = getenv("HPX_FACTOR_SPLIT") && atoi(getenv("HPX_FACTOR_SPLIT")) == 0;
-  if (off) return 0;
-  static SplitDevice dev;
-  const int cus = dev.get();
-  const int nct = npad >> 4, nrt = ld >> 4;
-  if (cus <= 0 || nbl <= 0 || nct < 2 || nct > SPLIT_MAX_CT) return 0;
-  if ((size_t)nrt * 4096 + (BUF_D + HPX_TILES_STAGE0_D) * sizeof(double) > (size_t)156 * 1024) return 0;
-  const int live = 8 * ((nbl + 7) / 8);        // block indices are dealt in eights (one system's parts on one XCD)
-  for (int parts = 8; parts >= 2; parts >>= 1)
-    if (live * parts <= cus) return split_fits(parts, nct, nrt) ? parts : 0;
-  return 0;
+  if (!g_split_enabled) return 0;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 32) return 0;
+  SplitGuard& G = g_guard[dev];
+  std::lock_guard<std::mutex> lk(G.mu);
+  if (G.init(dev) != HPX_OK || *(volatile int*)G.xcd_miss) return 0;
+  return split_parts_for(nbl, npad, ld, G.cus);
 }
 
 #ifdef HPX_SPLIT_TRACE
@@ -432,11 +489,53 @@ extern "C" int hpx_debug_split_trace(long long* out) {
 }
 #endif
 
-int hpx_launch_factor_split(int nbl, int parts, int npad, int ld, double* L, double* Wre, double* Wim, double* Vt,
-                            int32_t* info, int iter_tag, const hpx_gen_batch* gen, hipStream_t st) {
+// The split launch, or *took = 0 when the form does not apply to this batch or the device has no room for its
+// parts beside the split launches in flight on other streams (the caller then takes a one-workgroup kernel).
+int hpx_launch_factor_split(int nbl, int npad, int ld, double* L, double* Wre, double* Wim, double* Vt,
+                            int32_t* info, int iter_tag, const hpx_gen_batch* gen, hipStream_t st, int* took) {
+  *took = 0;
+#ifdef HPX_NO_SPLIT
+  return HPX_OK;
+#endif
+  if (!g_split_enabled) return HPX_OK;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 32) return HPX_OK;
+  SplitGuard& G = g_guard[dev];
+  std::lock_guard<std::mutex> lk(G.mu);           // held over the launch: the books and the queue stay in step
+  HPX_TRY(G.init(dev));
+  if (*(volatile int*)G.xcd_miss) return HPX_OK;  // the parts of a system did not share an XCD on this device: not this form
+  if (!G.multi && G.have_solo && G.solo != st) {
+    // a second stream: from here on launches are followed by events.  The first stream's newest launch has none
+    // yet -- one is put behind everything that stream has queued so far.
+    G.multi = true;
+    SplitGuard::Flight* f = G.slot(G.solo);
+    if (f && hipEventRecord(f->ev, G.solo) == hipSuccess) { f->live = true; f->wgs = G.solo_wgs; }
+  }
+  const int busy = G.multi ? G.busy_elsewhere(st) : 0;
+  const int parts = split_parts_for(nbl, npad, ld, G.cus - busy);
+  if (!parts) return HPX_OK;
+  int rc;
   if (!gen) {
     hpx_gen_batch none = {};
-    return launch_split_t<false>(nbl, parts, npad, ld, L, Wre, Wim, Vt, info, iter_tag, none, st);
+    rc = launch_split_t<false>(nbl, parts, npad, ld, L, Wre, Wim, Vt, info, iter_tag, none, G.xcd_miss, st);
+  } else {
+    rc = launch_split_t<true>(nbl, parts, npad, ld, L, Wre, Wim, Vt, info, iter_tag, *gen, G.xcd_miss, st);
   }
-  return launch_split_t<true>(nbl, parts, npad, ld, L, Wre, Wim, Vt, info, iter_tag, *gen, st);
+  if (rc != HPX_OK) return rc;
+  *took = parts;
+  if (!G.multi) {
+    G.solo = st;
+    G.have_solo = true;
+    G.solo_wgs = 8 * ((nbl + 7) / 8) * parts;
+  } else {
+    SplitGuard::Flight* f = G.slot(st);
+    if (!f || hipEventRecord(f->ev, st) != hipSuccess) {
+      // no event: this launch cannot be tracked -- wait for it (never seen; keeps the books truthful)
+      HPX_HIP(hipStreamSynchronize(st));
+    } else {
+      f->live = true;
+      f->wgs = 8 * ((nbl + 7) / 8) * parts;
+    }
+  }
+  return HPX_OK;
 }

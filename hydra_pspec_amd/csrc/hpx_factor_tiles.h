@@ -28,7 +28,8 @@ template <int PAR> __device__ HPX_INL double* stage_buf() { return PAR ? hpx_sta
 // elimination; the K-split partial sums of narrow_column in slots 1..4); in buffer 1 one inverse tile and the
 // elimination's matrices
 constexpr int FV_OFF = 0, FD_OFF = 512, F_END = FD_OFF + 2 * 2 * 16 * 17 + 16;
-static_assert(F_END <= BUF_D, "F scratch must fit a staging buffer");
+constexpr int FV1_OFF = 2048;      // a second inverse tile (look-ahead of the wide form's F)
+static_assert(F_END <= FV1_OFF && FV1_OFF + 512 <= BUF_D, "F scratch must fit a staging buffer");
 
 // ---- vector-memory traffic of the staged loops: ALL of it through inline asm, waits included ----------------
 // The compiler's own s_waitcnt insertion cannot be used here: once an LDS-DMA and an ordinary global load are
@@ -111,6 +112,12 @@ __device__ HPX_INL int opaque(int v) {
   asm volatile("" : "+v"(v));
   return v;
 }
+// the same for a wave-uniform value (stays in a scalar register): what is derived from the result inside a branch
+// is computed inside that branch, not hoisted in front of it
+__device__ HPX_INL int opaque_s(int v) {
+  asm volatile("" : "+s"(v));
+  return v;
+}
 
 // 1 / a and the circulant's first column with their address space in the type (LDS copies when GLDS): through
 // the generic pointers of hpx_gen they become FLAT loads, which count on vmcnt as well and make the compiler
@@ -127,7 +134,26 @@ struct WideCtx {
   double* Wgim;
   long ptile;          // doubles per 16-row panel
   int npad, nct, nrt, wave, lane, tid;
+#ifdef HPX_WIDE_TRACE
+  mutable unsigned long long* tp;     // this wave's next trace record (a debugging build)
+#endif
 };
+// Step trace of the wide form (-DHPX_WIDE_TRACE, tools/experiments/trace/wide_trace.py): one 8-byte record per stamp
+// and wave, [id << 32 | low word of s_memtime], written with SCALAR stores -- they count on lgkmcnt, so the
+// hand-counted vmcnt waits of the staged loops see nothing of them.
+#ifdef HPX_WIDE_TRACE
+#define HPX_WTRACE_REC 1024
+__device__ HPX_INL void wtrace(const WideCtx& X, const unsigned id) {
+  unsigned long long t;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+  const unsigned long long rec = (t & 0xffffffffull) | ((unsigned long long)id << 32);
+  asm volatile("s_store_dwordx2 %0, %1, 0x0" :: "s"(rec), "s"(X.tp) : "memory");
+  X.tp += 1;
+}
+#define HPX_TR(X_, ph_, sb_, a_, b_) wtrace(X_, ((unsigned)(ph_) << 24) | ((unsigned)(sb_) << 16) | ((unsigned)(a_) << 8) | (unsigned)(b_))
+#else
+#define HPX_TR(X_, ph_, sb_, a_, b_)
+#endif
 
 // entry (r, c), r >= c, of the augmented matrix before the factorisation: closed form, edge tiles or
 // the factor buffer (hpx_internal.h)
@@ -197,12 +223,51 @@ __device__ HPX_INL void tile_init(const hpx_gen& G, const GenVec<GLDS>& V, const
           vi[v] = d > 0 ? cm : 0.0;
         }
       }
+    } else if (G.ere != nullptr) {
+      // an edge tile (foreground rows, padding, right-hand sides): hpx_edge_init's arithmetic, operation for
+      // operation, but with the tile's four column loads issued together through global-address-space pointers and
+      // the row test taken once per tile (r0 and npad are multiples of 16: a tile lies on one side).  Element by
+      // element through the generic pointers of hpx_gen every value was a FLAT load behind a per-lane branch and a
+      // full wait -- some 130 dependent memory round trips per strip of right-hand-side rows (80 - 100 us per
+      // super-block at C3: tools/experiments/trace/wide_trace.py).
+      const glb_f64* e = (const glb_f64*)G.ere + HPX_EIDX(r0, c0 + g, G.rmin) + li;
+      double er[4], ei[4];
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        er[v] = e[(4 * v) * 32];
+        ei[v] = e[(4 * v) * 32 + 16];
+      }
+      if (r0 >= npad) {
+        if (G.has_omega) {
+          const int t0 = r0 - npad;
+          const glb_f64* pr = (const glb_f64*)G.p2tre + ((((long)(t0 >> 4) * G.NP + c0 + g) << 4) + li);
+          const glb_f64* pi = (const glb_f64*)G.p2tim + ((((long)(t0 >> 4) * G.NP + c0 + g) << 4) + li);
+          double qr[4], qi[4], ic[4];
+#pragma unroll
+          for (int v = 0; v < 4; ++v) {
+            qr[v] = pr[(4 * v) * 16];
+            qi[v] = pi[(4 * v) * 16];
+            ic[v] = V.ia[c0 + g + 4 * v];
+          }
+#pragma unroll
+          for (int v = 0; v < 4; ++v) {
+            er[v] = fma(ic[v], qr[v], er[v]);
+            ei[v] = fma(ic[v], qi[v], ei[v]);
+          }
+        }
+#pragma unroll
+        for (int v = 0; v < 4; ++v) ei[v] = -ei[v];
+      }
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        vr[v] = er[v];
+        vi[v] = ei[v];
+      }
     } else {
-      const bool use_e = G.ere != nullptr;
 #pragma unroll
       for (int v = 0; v < 4; ++v) {
         double a, b;
-        hpx_edge_init<GEN>(G, Lb, Lb + 16, r0 + li, c0 + HPX_ACC_ROW(g, v), npad, use_e, a, b);
+        hpx_edge_init<GEN>(G, Lb, Lb + 16, r0 + li, c0 + HPX_ACC_ROW(g, v), npad, false, a, b);
         vr[v] = a;
         vi[v] = b;
       }
@@ -304,10 +369,11 @@ __device__ HPX_INL bool elim16(const WideCtx& X, const int tcol /* global tile c
 // out: as elim16; the CALLER puts a workgroup barrier between this and the first use of Vs by another wave.
 // `flag` (split form; else null): raised -- behind `publish()` -- as soon as the inverse tile is in Vt, the one thing
 // another workgroup waits for; the factor's own tile and the W blocks follow.
+// `Vs`: where the LDS copy of the inverse goes (the wide form's look-ahead keeps two: the next column's inverse is
+// written while the other waves still read the current one).
 template <class Publish>
 __device__ HPX_INL bool elim16w(const WideCtx& X, const int tcol, const bool last_tile, const d4 re, const d4 im,
-                             Publish publish) {
-  lds_f64* const Vs = (lds_f64*)(hpx_stage1 + FV_OFF);
+                             Publish publish, lds_f64* const Vs) {
   lds_cplx* const col = (lds_cplx*)(hpx_stage1 + FD_OFF);      // [4 lane groups][16 rows]: column k below the pivot
   lds_cplx* const yrw = col + 64;                               // [4 lane groups][4]: row k of the inverse
   lds_f64* const raw = (lds_f64*)(yrw + 16);                    // [4 lane groups][16]: the column's real parts, unmasked
@@ -480,6 +546,11 @@ __device__ HPX_INL bool elim16w(const WideCtx& X, const int tcol, const bool las
     }
   }
   return bad;
+}
+template <class Publish>
+__device__ HPX_INL bool elim16w(const WideCtx& X, const int tcol, const bool last_tile, const d4 re, const d4 im,
+                             Publish publish) {
+  return elim16w(X, tcol, last_tile, re, im, publish, (lds_f64*)(hpx_stage1 + FV_OFF));
 }
 __device__ HPX_INL bool elim16w(const WideCtx& X, const int tcol, const bool last_tile, const d4 re, const d4 im) {
   return elim16w(X, tcol, last_tile, re, im, [] {});

@@ -38,6 +38,10 @@
 
 namespace {
 
+#ifdef HPX_WIDE_TRACE
+__device__ unsigned long long hpx_wtrace[1024 * 4 * HPX_WTRACE_REC];
+#endif
+
 // ---- staging ---------------------------------------------------------------------------------------
 // Every wave stages two tile slots (2 wave, 2 wave + 1) of every chunk, PP pieces each: a constant
 // number (2 PP = 8) of LDS-DMA operations per wave and stage, so that the counted vmcnt waits hold for every wave.
@@ -52,8 +56,9 @@ __device__ HPX_INL void stage_k(const WideCtx& X, const int ct0, const int chunk
     glds_tile(X.Lb + (long)(ct0 + ci) * X.ptile + (long)chunk * TILE_D, 8 * src_lane, bb + ci * TILE_D * 8);
   }
 }
-// tail step cj: slot cj <- inv(L_cjcj) (Vt), slots ci > cj <- L[ci][cj]; the slots above re-stage the inverse
-// (never read)
+// tail step cj: slot cj <- inv(L_cjcj) (Vt), slots ci > cj <- L[ci][cj]; the slots above are not read and not staged
+// (a wave then issues fewer than 8 operations for this stage: the counted waits of the tail steps only name what
+// follows the stage -- the wave's 8 stores -- so they hold whatever the count)
 template <int PAR>
 __device__ HPX_INL void stage_t(const WideCtx& X, const int ct0, const int cj, const unsigned src_lane) {
   const unsigned bb = lds_addr(stage_buf<PAR>());
@@ -61,6 +66,7 @@ __device__ HPX_INL void stage_t(const WideCtx& X, const int ct0, const int cj, c
 #pragma unroll
   for (int u = 0; u < 2; ++u) {
     const int ci = 2 * X.wave + u;
+    if (ci < cj) continue;
     const double* src = vsrc;
     if (ci > cj) src = X.Lb + (long)(ct0 + ci) * X.ptile + (long)((ct0 + cj) * 16) * 32;
     glds_tile(src, 8 * src_lane, bb + ci * TILE_D * 8);
@@ -115,6 +121,7 @@ __device__ HPX_INL void diag_update(const WideCtx& X, const hpx_gen& G, const Ge
     wait_compiler_loads();
   }
   const int nk = c0 / KC;                  // (a multiple of 8)
+  HPX_TR(X, 1, ct0 >> 3, 0, 0);
   if (nk > 0) {
     stage_k<0>(X, ct0, 0, src_lane);
     // one chunk: wait for it (nothing but LDS-DMA is in flight), barrier, issue the next one into the other
@@ -157,6 +164,7 @@ __device__ HPX_INL void diag_update(const WideCtx& X, const hpx_gen& G, const Ge
 #undef HPX_S_STEP
     wait_vm<0>();                       // the re-staged chunk: nothing may land after F starts using the area
   }
+  HPX_TR(X, 1, ct0 >> 3, 0, 1);
 #pragma unroll
   for (int s = 0; s < 9; ++s) {
     const d4 re_ = -(a1[s] + a2[s]);
@@ -185,6 +193,7 @@ __device__ HPX_INL bool diag_factor(const WideCtx& X, const int ct0, d4 (&a1)[9]
     const int rd_re = g * 32 + li + 16 * (g & 1), rd_im = g * 32 + li + 16 * (1 - (g & 1));
     // (1) the diagonal tile goes to the elimination: all 256 threads (elim16) -- the one-wave form that eliminates the
     // tile where it lies (elim16w, HPX_ELIM_WAVE) measured no faster here: 4.13 against 4.08 ms per launch at C3
+    HPX_TR(X, 2, ct0 >> 3, i, 0);
     lds_barrier();                                        // Vs and the elimination's scratch are free
 #ifdef HPX_ELIM_WAVE
     {
@@ -209,6 +218,7 @@ __device__ HPX_INL bool diag_factor(const WideCtx& X, const int ct0, d4 (&a1)[9]
     lds_barrier();
     bad |= elim16(X, ct0 + i, false);
 #endif
+    HPX_TR(X, 2, ct0 >> 3, i, 1);
     // (2b) odd tile of a pair: W10 = -inv(L11) (L10 inv(L00))
     if ((i & 1) && X.wave == ((i >> 1) & 3)) {
       d4 zr = {0., 0., 0., 0.}, zi = {0., 0., 0., 0.};
@@ -254,7 +264,9 @@ __device__ HPX_INL bool diag_factor(const WideCtx& X, const int ct0, d4 (&a1)[9]
         }
       }
 #endif
+    HPX_TR(X, 2, ct0 >> 3, i, 2);
     lds_barrier();
+    HPX_TR(X, 2, ct0 >> 3, i, 3);
     // (3b) even tile of a pair: T = L10 inv(L00), kept in registers until the pair's second inverse exists
     if (!(i & 1) && X.wave == ((i >> 1) & 3)) {
       t_re = (d4){0., 0., 0., 0.};
@@ -289,8 +301,137 @@ __device__ HPX_INL bool diag_factor(const WideCtx& X, const int ct0, d4 (&a1)[9]
         }
       }
 #endif
+    HPX_TR(X, 2, ct0 >> 3, i, 4);
   }
   __syncthreads();        // F's stores (L_JJ, Vt) are complete before the passes stage them
+  HPX_TR(X, 2, ct0 >> 3, 8, 0);
+  return bad;
+}
+
+// ---- F with look-ahead (the default; -DHPX_F_NO_LOOKAHEAD restores diag_factor above for A/B) ---------------------
+// The chain of F is  eliminate tile i -> tiles below it -> update of diagonal tile i+1 -> eliminate tile i+1 -> ...
+// With the elimination on all 256 threads (elim16: 16 steps with a workgroup barrier each) every wave sits in that
+// chain for all of it; measured per tile column at C3 (tools/experiments/trace/wide_trace.py): elimination 5 - 6 us,
+// tiles below 1 - 2, trailing updates 6 -> 0.3.  Here, once column i's tiles are in LDS, the wave that OWNS diagonal
+// tile i+1 applies column i to that tile alone and eliminates it on its own (elim16w: the tile where it lies, no
+// barrier) while the other three waves run column i's trailing updates; the owner's own trailing tiles follow its
+// elimination.  Two workgroup barriers per tile column instead of twenty-one; the inverse tile has two LDS homes
+// (the next one is written while the current one is still read).  Everything is indexed at compile time (W, i).
+template <int W>
+__device__ HPX_INL bool diag_factor_la(const WideCtx& X, const int ct0, d4 (&a1)[9], d4 (&a2)[9]) {
+  typedef DiagDeal<W> TD;
+  lds_f64* const Xs = (lds_f64*)hpx_stage0;
+  bool bad = false;
+  d4 t_re = {0., 0., 0., 0.}, t_im = {0., 0., 0., 0.};     // L10 inv(L00) of the current pair of tiles (one wave)
+  lds_barrier();                                          // the staging area is free
+  // diagonal tile i belongs to wave min(i, 7 - i): slot 8 (tile (W, W)) or slot 7 - W (tile (7 - W, 7 - W))
+  if (W == 0) bad |= elim16w(X, ct0, false, a1[8], a2[8], [] {}, (lds_f64*)(hpx_stage1 + FV_OFF));
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int lane = opaque(X.lane), li = lane & 15, g = lane >> 4;
+    const int rd_re = g * 32 + li + 16 * (g & 1), rd_im = g * 32 + li + 16 * (1 - (g & 1));
+    const lds_f64* const Vs = (const lds_f64*)(hpx_stage1 + ((i & 1) ? FV1_OFF : FV_OFF));     // inv(L_ii)
+    lds_f64* const Vn = (lds_f64*)(hpx_stage1 + ((i & 1) ? FV_OFF : FV1_OFF));                 // inv(L_i+1,i+1) goes here
+    HPX_TR(X, 2, ct0 >> 3, i, 0);
+    lds_barrier();                      // inv(L_ii) is in LDS; column i - 1 and the other inverse are free
+    HPX_TR(X, 2, ct0 >> 3, i, 1);
+    // (2b) odd tile of a pair: W10 = -inv(L11) (L10 inv(L00))
+    if ((i & 1) && W == ((i >> 1) & 3)) {
+      d4 zr = {0., 0., 0., 0.}, zi = {0., 0., 0., 0.};
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const double ar = Vs[v * 128 + rd_re], ai = Vs[v * 128 + rd_im];     // inv(L11)[i' = li][r = 4 v + g]
+        zr = mfma64(-ar, t_re[v], zr);
+        zr = mfma64(ai, t_im[v], zr);
+        zi = mfma64(-ar, t_im[v], zi);
+        zi = mfma64(-ai, t_re[v], zi);
+      }
+      double* wgr = X.Wgre + (long)((ct0 + i) >> 1) * 1024;
+      double* wgi = X.Wgim + (long)((ct0 + i) >> 1) * 1024;
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        wgr[(16 + HPX_ACC_ROW(g, v)) * 32 + li] = zr[v];
+        wgi[(16 + HPX_ACC_ROW(g, v)) * 32 + li] = zi[v];
+      }
+    }
+    // (3) tiles below: X^T[c'][r'] = sum_c conj(inv(L)[c'][c]) D^T[c][r'], stored and handed to the others
+#pragma unroll
+    for (int s = 0; s < 9; ++s)
+      if (TD::col(s) == i && TD::row(s) > i) {
+        d4 xr = {0., 0., 0., 0.}, xi = {0., 0., 0., 0.};
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          const double pr = Vs[v * 128 + rd_re], pi = Vs[v * 128 + rd_im];
+          xr = mfma64(pr, a1[s][v], xr);
+          xr = mfma64(pi, a2[s][v], xr);
+          xi = mfma64(pr, a2[s][v], xi);
+          xi = mfma64(-pi, a1[s][v], xi);
+        }
+        double* o_ = X.Lb + HPX_LIDX((ct0 + TD::row(s)) * 16 + li, (ct0 + i) * 16 + g, X.npad);
+        lds_f64* xs = Xs + TD::row(s) * 512;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          o_[(4 * v) * 32] = xr[v];
+          o_[(4 * v) * 32 + 16] = xi[v];
+          const int k = g + 4 * v;                         // column of the tile; row li
+          xs[k * 32 + li + 16 * (k & 1)] = xr[v];
+          xs[k * 32 + li + 16 * (1 - (k & 1))] = xi[v];
+        }
+      }
+    HPX_TR(X, 2, ct0 >> 3, i, 2);
+    lds_barrier();                      // column i is in LDS
+    HPX_TR(X, 2, ct0 >> 3, i, 3);
+    // (L) look-ahead: the owner of diagonal tile i + 1 brings it up to date and eliminates it
+    if (i < 7 && W == ((i + 1 <= 3) ? i + 1 : 6 - i)) {
+      const int sd = (i + 1 <= 3) ? 8 : 7 - W;
+      const lds_f64* pd = Xs + (i + 1) * 512;
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const double pr = pd[v * 128 + rd_re], pi = pd[v * 128 + rd_im];
+        a1[sd] = mfma64(-pr, pr, a1[sd]);
+        a1[sd] = mfma64(-pi, pi, a1[sd]);
+        a2[sd] = mfma64(-pr, pi, a2[sd]);
+        a2[sd] = mfma64(pi, pr, a2[sd]);
+      }
+      bad |= elim16w(X, ct0 + i + 1, false, a1[sd], a2[sd], [] {}, Vn);
+      HPX_TR(X, 2, ct0 >> 3, i, 5);
+    }
+    // (3b) even tile of a pair: T = L10 inv(L00), kept in registers until the pair's second inverse exists
+    if (!(i & 1) && W == ((i >> 1) & 3)) {
+      t_re = (d4){0., 0., 0., 0.};
+      t_im = t_re;
+      const lds_f64* l10 = Xs + (i + 1) * 512;
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const double ar = l10[v * 128 + rd_re], ai = l10[v * 128 + rd_im];      // L10[r = li][k = 4 v + g]
+        const int k = 4 * v + g;                                                   // inv(L00)[k][c' = li]
+        const double br = Vs[li * 32 + k + 16 * (li & 1)], bm = Vs[li * 32 + k + 16 * (1 - (li & 1))];
+        t_re = mfma64(ar, br, t_re);
+        t_re = mfma64(-ai, bm, t_re);
+        t_im = mfma64(ar, bm, t_im);
+        t_im = mfma64(ai, br, t_im);
+      }
+    }
+    // (4) trailing tiles: D^T[c'][r'] -= sum_k conj(X(c,i)[c'][k]) X(r,i)[r'][k]  (diagonal tile i + 1: done above)
+#pragma unroll
+    for (int s = 0; s < 9; ++s)
+      if (TD::col(s) > i && !(TD::col(s) == i + 1 && TD::row(s) == i + 1)) {
+        const lds_f64* pa = Xs + TD::col(s) * 512;
+        const lds_f64* pb = Xs + TD::row(s) * 512;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          const double pr = pa[v * 128 + rd_re], pi = pa[v * 128 + rd_im];
+          const double br = pb[v * 128 + rd_re], bm = pb[v * 128 + rd_im];
+          a1[s] = mfma64(-pr, br, a1[s]);
+          a1[s] = mfma64(-pi, bm, a1[s]);
+          a2[s] = mfma64(-pr, bm, a2[s]);
+          a2[s] = mfma64(pi, br, a2[s]);
+        }
+      }
+    HPX_TR(X, 2, ct0 >> 3, i, 4);
+  }
+  __syncthreads();        // F's stores (L_JJ, Vt) are complete before the passes stage them
+  HPX_TR(X, 2, ct0 >> 3, 8, 0);
   return bad;
 }
 
@@ -341,10 +482,14 @@ __device__ HPX_INL void strip_passes(const WideCtx& X, const hpx_gen& G, const G
           a3[ci] = vi;
         }
       } else {
+        // (the last strips of a super-block: edge tiles.  Their addresses hang on opaque copies of the indices:
+        // computed at the top of every group's body instead -- where the compiler moved them -- they cost every
+        // group some 500 instructions and 50 spills)
+        const int rt16 = opaque_s(rt * 16), c0o = opaque_s(c0), lio = opaque(li), go = opaque(g);
 #pragma unroll
         for (int ci = 0; ci < 8; ++ci) {
           d4 vr, vi;
-          tile_init<GEN, GLDS>(G, V, X.Lb, rt * 16, c0 + 16 * ci, X.npad, li, g, vr, vi);
+          tile_init<GEN, GLDS>(G, V, X.Lb, rt16, c0o + 16 * ci, X.npad, lio, go, vr, vi);
           a1[ci] = -0.5 * vr;
           a2[ci] = -0.5 * vr;
           a3[ci] = vi;
@@ -355,10 +500,13 @@ __device__ HPX_INL void strip_passes(const WideCtx& X, const hpx_gen& G, const G
     const double* brow = X.Lb + (long)(active ? rt : first) * X.ptile;      // (uniform) + lane offset `blane`
     // step `st_` of this group (buffer PAR_): wait for its chunk, barrier, issue the next one
 #define HPX_STEP_HEAD(PAR_, st_)                                                                     \
+    HPX_TR(X, 3, ct0 >> 3, (rt0 - first) >> 2, st_);                                                 \
     if (first_step || !active) wait_vm<0>();            /* the chunk of this step has landed ... */  \
     else wait_vm<8>();              /* ... behind this wave's 8 row-operand loads or 8 stores */     \
     first_step = false;                                                                              \
+    HPX_TR(X, 4, ct0 >> 3, (rt0 - first) >> 2, st_);                                                 \
     wg_barrier();                                                                                    \
+    HPX_TR(X, 5, ct0 >> 3, (rt0 - first) >> 2, st_);                                                 \
     {                                                                                                \
       int sn_ = (st_) + 1;                                                                           \
       if (sn_ >= total) sn_ = last_group ? total - 1 : 0;        /* a harmless re-stage / the next group's first */ \
@@ -480,8 +628,10 @@ __device__ HPX_INL void strip_passes(const WideCtx& X, const hpx_gen& G, const G
 #undef HPX_ROW_LOAD
   }
   // the pass's stores and the re-staged chunk are done, every wave has finished reading the buffers
+  HPX_TR(X, 6, ct0 >> 3, 0, 0);
   wait_vm<0>();
   wg_barrier();
+  HPX_TR(X, 6, ct0 >> 3, 0, 1);
 }
 
 // ---- a single 16-wide tile column t (those after the last full super-block): register-only ----------
@@ -662,6 +812,16 @@ __global__ __launch_bounds__(256, 2) void k_factor_wide(double* __restrict__ L_a
   const int nblk = (npad + HPX_NB - 1) / HPX_NB;
   X.Wgre = Wre_all + (long)b * nblk * 1024;
   X.Wgim = Wim_all + (long)b * nblk * 1024;
+#ifdef HPX_WIDE_TRACE
+  X.tp = hpx_wtrace + ((long)b * 4 + X.wave) * HPX_WTRACE_REC;
+  {
+    unsigned long long rt_;
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt_) :: "memory");
+    wtrace(X, (unsigned)rt_);                                                   // record 0: memtime | realtime (low words)
+    wtrace(X, __builtin_amdgcn_s_getreg((31 << 11) | 4));                      // record 1: HW_REG_HW_ID
+    wtrace(X, __builtin_amdgcn_s_getreg((3 << 11) | 20));                      // record 2: HW_REG_XCC_ID
+  }
+#endif
   GenVec<GLDS> V = {};
   if constexpr (GEN && GLDS) {
     double* ga = lds_dyn;
@@ -693,7 +853,12 @@ __global__ __launch_bounds__(256, 2) void k_factor_wide(double* __restrict__ L_a
 #else
     for (int s = 0; s < 9; ++s) { a1[s] = (d4){1.0 * tid, 0., 0., 0.}; a2[s] = a1[s]; }
 #endif
-#ifndef HPX_DBG_NO_F
+#if !defined(HPX_DBG_NO_F) && !defined(HPX_F_NO_LOOKAHEAD)
+    if (X.wave == 0) bad |= diag_factor_la<0>(X, ct0, a1, a2);
+    else if (X.wave == 1) bad |= diag_factor_la<1>(X, ct0, a1, a2);
+    else if (X.wave == 2) bad |= diag_factor_la<2>(X, ct0, a1, a2);
+    else bad |= diag_factor_la<3>(X, ct0, a1, a2);
+#elif !defined(HPX_DBG_NO_F)
     bad |= diag_factor(X, ct0, a1, a2);
 #else
     for (int s = 0; s < 9; ++s) X.Lb[s * 64 + tid] = a1[s][0] + a2[s][1];
@@ -702,10 +867,20 @@ __global__ __launch_bounds__(256, 2) void k_factor_wide(double* __restrict__ L_a
     strip_passes<GEN, GLDS>(X, G, V, ct0);
 #endif
   }
+  HPX_TR(X, 7, 0, 0, 0);
 #ifndef HPX_DBG_NO_N
   for (; ct0 < X.nct; ++ct0) bad |= narrow_column<GEN, GLDS>(X, G, V, ct0);
 #endif
   if (bad && info) atomicCAS(&info[b], 0, iter_tag);
+#ifdef HPX_WIDE_TRACE
+  {
+    unsigned long long rt_;
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt_) :: "memory");
+    wtrace(X, (unsigned)rt_);
+    wtrace(X, 0xffffffffu);
+    asm volatile("s_dcache_wb\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+  }
+#endif
 }
 
 template <bool GEN, bool GLDS>
@@ -720,6 +895,13 @@ int launch_wide_t(int nbl, size_t lds, int npad, int ld, double* L, double* Wre,
 }
 
 }  // namespace
+
+#ifdef HPX_WIDE_TRACE
+extern "C" int hpx_debug_wide_trace(unsigned long long* host, int nblocks) {
+  HPX_HIP(hipMemcpyFromSymbol(host, HIP_SYMBOL(hpx_wtrace), sizeof(unsigned long long) * (size_t)nblocks * 4 * HPX_WTRACE_REC));
+  return HPX_OK;
+}
+#endif
 
 int hpx_launch_factor_wide(int nbl, int npad, int ld, double* L, double* Wre, double* Wim, double* Vt,
                            int32_t* info, int iter_tag, const hpx_gen_batch* gen, hipStream_t st) {

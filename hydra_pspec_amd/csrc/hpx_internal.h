@@ -83,6 +83,7 @@ struct hpx_plan {
   double *E;               // [nbl][(ld - rmin)/16 tiles][rmin columns][re16|im16]; RHS rows hold Q (not conjugated)
   double *P2Tre, *P2Tim;   // [TP/16 tiles][NP columns][16 rows]: P2 by row tile (shared by the baselines)
   int solver;   // HPX_SOLVER_DENSE / HPX_SOLVER_FLAT / HPX_SOLVER_LOWRANK (hpx_plan_set_solver)
+  int allow_split;  // HPX_OPT_FACTOR_SPLIT of this plan: small batches may take the split factor (default 1)
   // HPX_SOLVER_LOWRANK: flagged channels per baseline, the small Schur system and its solution
   int lr_fmax, lr_npad;
   int32_t *lr_flist, *lr_fcount;
@@ -328,9 +329,16 @@ int hpx_eigh_padded_order(int n0);
 int hpx_eigh_psd_planar(int nb, int n, double* gr, const double* gi, double* vr, double* vi, int* sweeps_out,
                         hipStream_t st);
 // the split form (hpx_factor_split.hip): several workgroups per system, for batches too small to fill the chip
-int hpx_factor_split_parts(int nbl, int npad, int ld);     // workgroups per system, 0 = not applicable
-int hpx_launch_factor_split(int nbl, int parts, int npad, int ld, double* L, double* Wre, double* Wim, double* Vt,
-                            int32_t* info, int iter_tag, const hpx_gen_batch* gen, hipStream_t st);
+int hpx_factor_split_parts(int nbl, int npad, int ld);     // workgroups per system on an idle device, 0 = not applicable
+// *took = workgroups per system, or 0 when the form was not taken (not applicable; switched off; no room on the device
+// beside the split launches in flight on other streams): the caller then launches a one-workgroup kernel
+int hpx_launch_factor_split(int nbl, int npad, int ld, double* L, double* Wre, double* Wim, double* Vt,
+                            int32_t* info, int iter_tag, const hpx_gen_batch* gen, hipStream_t st, int* took);
+int hpx_split_set_option(int key, int value);
+int hpx_eigh_set_option(int key, int value);
+// `info` words: the iteration tag (k > 0: first seen at iteration k - 1) with HPX_INFO_TIMEOUT on top when the split
+// factor's hand-off between workgroups timed out (the factor is then incomplete -- not a statement about the matrix)
+#define HPX_INFO_TIMEOUT 0x40000000
 // structured solve for flat noise with flags (hpx_lowrank.hip): writes X = [z; f]
 int hpx_launch_solve_lowrank(hpx_plan* p, int iter_tag, hipStream_t st);
 size_t hpx_lowrank_lds_bytes(const hpx_plan* p);

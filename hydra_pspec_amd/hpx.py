@@ -14,7 +14,9 @@ _LIB = None
 # HPX_LIB_PATH: another build of the same library (A/B measurements of kernel variants, tools/build_variant.sh)
 _LIB_PATH = Path(os.environ.get("HPX_LIB_PATH") or Path(__file__).resolve().parent / "libhpx.so")
 
-HPX_OK, HPX_EINVAL, HPX_EHIP, HPX_ENOTPD = 0, -1, -2, -3
+HPX_OK, HPX_EINVAL, HPX_EHIP, HPX_ENOTPD, HPX_ETIMEOUT = 0, -1, -2, -3, -4
+OPT_FACTOR_SPLIT, OPT_SPLIT_HEAVY, OPT_SPLIT_SPIN_LIMIT, OPT_EIGH_INNER_SWEEPS, OPT_EIGH_TRACE = 1, 2, 3, 4, 5
+INFO_TIMEOUT = 0x40000000
 NSTAGE = 6
 SOLVER_DENSE, SOLVER_FLAT, SOLVER_LOWRANK, SOLVER_LOWRANK_DIRECT = 0, 1, 2, 3
 STAGES = ("assemble", "factor", "backsolve", "transform", "residual", "draw")
@@ -40,6 +42,7 @@ SIGNATURES = {
     "hpx_gibbs_run": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
     "hpx_gibbs_step_general": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "hpx_plan_info": (_i, [_vp, _vp]),
+    "hpx_set_option": (_i, [_vp, _i, _i]),
     "hpx_plan_set_profiling": (_i, [_vp, _i]),
     "hpx_plan_set_solver": (_i, [_vp, _i]),
     "hpx_plan_stage_ms": (_i, [_vp, _vp]),
@@ -95,6 +98,11 @@ def last_error():
     return lib().hpx_last_error().decode(errors="replace")
 
 
+class HpxTimeout(RuntimeError):
+    """HPX_ETIMEOUT: a hand-off between the workgroups of a split factorisation timed out -- the GPU is shared with
+    another process running the same form (set OPT_FACTOR_SPLIT to 0), not a property of the data."""
+
+
 def check(rc, what=""):
     if rc == HPX_OK:
         return
@@ -103,7 +111,14 @@ def check(rc, what=""):
         raise ValueError(msg)
     if rc == HPX_ENOTPD:
         raise FloatingPointError(msg)
+    if rc == HPX_ETIMEOUT:
+        raise HpxTimeout(msg)
     raise RuntimeError(msg)
+
+
+def set_option(key, value, plan=None):
+    """hpx_set_option: library-wide (plan=None) or for one plan (OPT_* keys)."""
+    check(lib().hpx_set_option(plan.handle if plan is not None else None, int(key), int(value)), "hpx_set_option")
 
 
 def require_gpu():

@@ -243,8 +243,13 @@ class GibbsBatch:
     """
 
     def __init__(self, vis, flags, fgmodes, ninv_diag, ps_prior, Niter, seed=None,
-                 map_estimate=False, device=None, tables=None, omega=None, solver="auto", ninv_dense=None):
-        """``ninv_dense``: Hermitian non-diagonal inverse noise covariance(s) (N,N) or (Nbl,N,N) -- or, time
+                 map_estimate=False, device=None, tables=None, omega=None, solver="auto", ninv_dense=None,
+                 allow_split=True):
+        """``allow_split=False``: never the split factorisation (several co-operating workgroups per system, taken for
+        batches of fewer baselines than half the CUs): what a caller sets that shares the GPU with other processes, or
+        that wants a baseline's chain to be bit for bit the same in a batch of any size (``hpx.OPT_FACTOR_SPLIT``).
+
+        ``ninv_dense``: Hermitian non-diagonal inverse noise covariance(s) (N,N) or (Nbl,N,N) -- or, time
         dependent, (Nbl,Ntimes,N,N) -- instead of
         ``ninv_diag`` (:func:`make_batch` routes them here): dense solver only.  With flagged channels the
         reference's column-masked ``Ni`` is not Hermitian (pspec.py:361): the solution then comes from the
@@ -333,6 +338,8 @@ class GibbsBatch:
             d_fop = hpx.to_dev(torch, utils.fourier_operator(N), c128, self.device)
             self.plan = hpx.Plan(nbl, T, N, M, extra_rhs=extra_rhs)
             L = hpx.lib()
+            if not allow_split:
+                hpx.set_option(hpx.OPT_FACTOR_SPLIT, 0, plan=self.plan)
             if self.per_time and self.dense_noise:
                 hpx.check(L.hpx_plan_set_static_pertime_dense(
                     self.plan.handle, hpx.ptr(d_vis), hpx.ptr(d_flags), hpx.ptr(d_nd), hpx.ptr(d_nh),
@@ -519,7 +526,7 @@ class GibbsBatch:
 
 
 def make_batch(vis, flags, fgmodes, Ninv, ps_prior, Niter, seed=None, map_estimate=False, device=None,
-               solver="auto", tables=None):
+               solver="auto", tables=None, allow_split=True):
     """A :class:`GibbsBatch` from the inverse noise covariance in any form the path accepts:
     diagonals ``(Nfreqs,)`` / ``(Nbl,Nfreqs)`` or matrices ``(Nfreqs,Nfreqs)`` / ``(Nbl,Nfreqs,Nfreqs)``
     (reference run-hydra-pspec.py:427-438 passes ``inv(noise_cov)``)."""
@@ -538,15 +545,15 @@ def make_batch(vis, flags, fgmodes, Ninv, ps_prior, Niter, seed=None, map_estima
         nd = np.ascontiguousarray(np.broadcast_to(nd, (nbl, T, N, N)))
     if nd is not None:
         return GibbsBatch(vis, flags, fgmodes, None, ps_prior, Niter, seed=seed, map_estimate=map_estimate,
-                          device=device, solver=solver, ninv_dense=nd, tables=tables)
+                          device=device, solver=solver, ninv_dense=nd, tables=tables, allow_split=allow_split)
     return GibbsBatch(vis, flags, fgmodes, _ninv_diag(Ninv, nbl, T, N), ps_prior, Niter, seed=seed,
-                      map_estimate=map_estimate, device=device, solver=solver, tables=tables)
+                      map_estimate=map_estimate, device=device, solver=solver, tables=tables, allow_split=allow_split)
 
 
 def gibbs_sample_with_fg_batched(vis, flags, fgmodes, Ninv, ps_prior, S_initial=None,
                                  ps_initial=None, Niter=100, seed=None, map_estimate=False,
                                  keep=("ps", "ln_post"), thin=1, ps_forced=None, device=None,
-                                 as_numpy=True, iter0=0, solver="auto"):
+                                 as_numpy=True, iter0=0, solver="auto", allow_split=True):
     """Run the Gibbs chain of ``gibbs_sample_with_fg`` for ``Nbl`` baselines at once.
 
     Parameters mirror the reference (pspec.py:493-571) with a leading baseline
@@ -571,7 +578,8 @@ def gibbs_sample_with_fg_batched(vis, flags, fgmodes, Ninv, ps_prior, S_initial=
     ``solver``: ``"auto"`` (default) solves baselines whose unflagged channels share one ``Ninv``
     value through the diagonal + border structure of the system (hpx_flat.hip without flags,
     hpx_lowrank.hip with flags) and everything else with the batched dense Cholesky; ``"dense"``
-    forces the latter.  All are exact solves.
+    forces the latter.  All are exact solves.  ``allow_split=False``: see :class:`GibbsBatch` (several
+    processes on one GPU; bit-identical chains at every batch size).
 
     ``iter0 > 0`` continues interrupted chains: ``ps_initial`` must then be the bandpowers of
     iteration ``iter0 - 1`` and only iterations ``iter0 .. Niter-1`` are run and returned (the
@@ -587,7 +595,7 @@ def gibbs_sample_with_fg_batched(vis, flags, fgmodes, Ninv, ps_prior, S_initial=
         if np.any(resid > FOURIER_FORM_TOL):     # general covariance: first iteration via Sh'
             shp0 = np.ascontiguousarray(np.broadcast_to(sqrt_cov_delay_basis(S0), (nbl, N, N)))
     gb = make_batch(vis, flags, fgmodes, Ninv, ps_prior, Niter, seed=seed, map_estimate=map_estimate,
-                    device=device, solver=solver)
+                    device=device, solver=solver, allow_split=allow_split)
     try:
         if shp0 is not None:
             assert iter0 == 0, "a general S_initial cannot be combined with iter0 > 0"

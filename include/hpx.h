@@ -13,7 +13,9 @@
  *  - `stream` is a hipStream_t passed as void* (NULL = default stream).
  *  - Return value: 0 = ok, HPX_EINVAL bad argument, HPX_EHIP HIP runtime
  *    error, HPX_ENOTPD non-positive pivot in some baseline's factorisation
- *    (reported after the run; see hpx_plan_info).  Nothing throws.
+ *    (reported after the run; see hpx_plan_info), HPX_ETIMEOUT a hand-off
+ *    between the workgroups of a split factorisation timed out (a statement
+ *    about the device being shared, not about the matrix).  Nothing throws.
  *    hpx_last_error() returns a thread-local message for the last failure.
  *  - No global state besides the plan.  One host thread per plan.
  */
@@ -28,6 +30,7 @@ extern "C" {
 #define HPX_EINVAL (-1)
 #define HPX_EHIP   (-2)
 #define HPX_ENOTPD (-3)
+#define HPX_ETIMEOUT (-4)   /* the split factor's hand-off between workgroups timed out (see HPX_OPT_FACTOR_SPLIT) */
 
 #define HPX_VERSION 100
 
@@ -188,8 +191,31 @@ int hpx_gibbs_step_general(hpx_plan* p, const double* shp, int iter0,
                            void* stream);
 
 /* per-baseline factorisation status of the last run: (nbl,) int32 host array,
- * 0 = ok, k>0 = non-positive pivot first seen at iteration k-1+iter0. */
+ * 0 = ok, k>0 = non-positive pivot first seen at iteration k-1+iter0; with bit 30
+ * (0x40000000) set: the split factor's hand-off timed out at iteration
+ * (k & ~0x40000000)-1+iter0 (hpx_gibbs_run then returns HPX_ETIMEOUT).  The `info`
+ * arrays of hpx_zpotrf_batched / hpx_zpotrs_batched use the same encoding with k = 1. */
 int hpx_plan_info(hpx_plan* p, int32_t* info_host);
+
+/* Options of one plan (p != NULL) or of the library (p == NULL: process-wide, set before the first use
+ * of what they steer).  Returns HPX_EINVAL for an unknown key.
+ *   HPX_OPT_FACTOR_SPLIT (plan or library; default 1): batches of fewer systems than half the CUs may take the
+ *     SPLIT factorisation (several co-operating workgroups per system).  Its workgroups wait for each other, so
+ *     all of them must be resident together: the library keeps count of its own split launches per device and
+ *     stream, but cannot see another PROCESS on the same GPU -- a caller that shares a GPU between processes
+ *     (several ranks per device) sets 0.  Also: the split form orders its additions differently, so a baseline's
+ *     chain inside a small batch and inside a large one agree to rounding, not bit for bit; 0 gives one order of
+ *     operations at every batch size (what a driver that re-shards between runs wants).
+ *   HPX_OPT_SPLIT_HEAVY (library, testing; default 0): agent-scope fences in every hand-off of the split form
+ *     (the protocol it falls back to when the parts of a system do not share an XCD).
+ *   HPX_OPT_SPLIT_SPIN_LIMIT (library, testing; default 1<<22): polls before a hand-off gives up.
+ *   HPX_OPT_EIGH_INNER_SWEEPS (library; default 1), HPX_OPT_EIGH_TRACE (library; default 0): hpx_zheev_psd_batched. */
+#define HPX_OPT_FACTOR_SPLIT 1
+#define HPX_OPT_SPLIT_HEAVY 2
+#define HPX_OPT_SPLIT_SPIN_LIMIT 3
+#define HPX_OPT_EIGH_INNER_SWEEPS 4
+#define HPX_OPT_EIGH_TRACE 5
+int hpx_set_option(hpx_plan* p, int key, int value);
 
 /* Solver of the per-iteration linear system.  HPX_SOLVER_DENSE (default): batched Cholesky of
  * the (N+M) system (k_factor / k_backsolve), any diagonal Ninv and flags.  HPX_SOLVER_FLAT: for
@@ -324,7 +350,8 @@ int hpx_lincomb(int64_t n, double a, const double* x, double b, const double* y,
  * frequency-frequency covariance over time np.cov(vis_b.T) -- what
  * scripts/calc-vis-cov-matrices.py:235-249 writes and run-hydra-pspec.py:453 truncates to
  * Nfgmodes columns.  vis (nb,T,N) c128; modes (nb,N,nmodes) c128; evals (nb,nmodes) f64.
- * Needs min(T,N) <= 256 (T <= N goes through the T x T Gram matrix). */
+ * min(T,N) <= 1024 (T <= N goes through the T x T Gram matrix; orders from 128 on through
+ * hpx_zheev_psd_batched's solver). */
 int hpx_fgmodes_eig(int nb, int T, int N, int nmodes, const double* vis, double* modes,
                     double* evals, void* stream);
 
@@ -341,7 +368,8 @@ int hpx_oqe_qauto(int nb, int nvis, int s, const double* R, const double* V, dou
  * scripts/calc-vis-cov-matrices.py:239-247).  a (nb,n0,n0) c128; with n = hpx_zheev_psd_order(n0)
  * (n0 rounded up to a multiple of 16, of 32 from 241 on): w (nb,n) f64 eigenvalues and v (nb,n0,n) c128 unit
  * eigenvectors as columns, unsorted; the n - n0 pairs of the zero padding have eigenvalue 0.
- * sweeps_out (host int, optional). */
+ * sweeps_out (host int, optional).  HPX_EINVAL (and *sweeps_out = -1) if the sweeps do not converge within
+ * the limit (30): no unconverged pair is handed out. */
 int hpx_zheev_psd_batched(int nb, int n0, const double* a, double* w, double* v, int* sweeps_out, void* stream);
 int hpx_zheev_psd_order(int n0);
 

@@ -219,33 +219,6 @@ def test_zpotrs_size_sweep(T):
     print(f"size sweep: worst relative error {worst:.2e} over {len(sizes)} orders")
 
 
-def test_split_factor_with_agent_scope_handoff():
-    """The split factor's fall-back protocol (agent-scope release / acquire fences, used when the parts of a system do
-    not share an XCD): forced through HPX_SPLIT_HEAVY in a process of its own (the switch is read once), zpotrs of a
-    small batch -- several workgroups per system -- against numpy."""
-    import os, subprocess, sys, textwrap
-    code = textwrap.dedent("""
-        import numpy as np, torch
-        from hydra_pspec_amd import hpx
-        rng = np.random.default_rng(3)
-        nb, n, nrhs = 5, 200, 24
-        a = rng.standard_normal((nb, n, n)) + 1j * rng.standard_normal((nb, n, n))
-        A = a @ np.conj(np.swapaxes(a, 1, 2)) / n + np.eye(n)
-        B = rng.standard_normal((nb, n, nrhs)) + 1j * rng.standard_normal((nb, n, nrhs))
-        dA, dB = torch.from_numpy(A).cuda(), torch.from_numpy(B).cuda()
-        dX = torch.zeros_like(dB); info = torch.zeros(nb, dtype=torch.int32, device="cuda")
-        hpx.check(hpx.lib().hpx_zpotrs_batched(nb, n, nrhs, hpx.ptr(dA), hpx.ptr(dB), hpx.ptr(dX), hpx.ptr(info), None))
-        X = dX.cpu().numpy()
-        err = np.abs(X - np.linalg.solve(A, B)).max() / np.abs(X).max()
-        assert not info.cpu().numpy().any() and err < 1e-11, err
-        print("ok", err)
-    """)
-    env = dict(os.environ, HPX_SPLIT_HEAVY="1")
-    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300,
-                         cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    assert out.returncode == 0 and "ok" in out.stdout, out.stdout + out.stderr
-
-
 @pytest.mark.parametrize("n,flagged", [(48, False), (100, True), (512, True)])
 def test_sqrtm_hpd_on_device(T, n, flagged):
     """hpx_sqrtm_hpd_batched (Newton-Schulz on the batched MFMA product) and the masked root built on it
