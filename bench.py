@@ -193,8 +193,13 @@ def roofline_for(solver, stage, nbl, N, M, T, fmax, K, traffic, peak_meas):
         ms = stage["factor"] / K
         fl = flops_factor(N, M, T)
         ach = nbl * fl / (ms * 1e-3) / 1e12
-        return {"kernel": "k_factor_wide / k_factor (batched complex Cholesky + forward solve, FP64 MFMA; the wide form from "
-                          "order 400 on)", "bound": "mfma",
+        import ctypes
+        from hydra_pspec_amd import hpx
+        parts = ctypes.c_int(0)
+        form = hpx.lib().hpx_factor_form(nbl, N + M, T, ctypes.byref(parts))
+        name = {0: "k_factor (32-wide block columns)", 1: "k_factor_wide (128-column super-blocks, LDS-staged panels)",
+                2: f"k_factor_split ({parts.value} co-operating workgroups per system, tiles in registers)"}[form]
+        return {"kernel": name + ": batched complex Cholesky + forward solve, FP64 MFMA", "bound": "mfma",
                 "achieved": ach, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": ach / FP64_MFMA_PEAK_TFLOPS, "traffic": traffic,
                 "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; see profiles/pmc_traffic.json "
@@ -631,8 +636,12 @@ def main():
         ninv_in = None
     torch.cuda.synchronize()
     t_setup = time.perf_counter()
+    # ranks that share a GPU (a launcher rehearsal) must not take the split factorisation: its co-operating
+    # workgroups need the device to themselves (hpx.h, HPX_OPT_FACTOR_SPLIT)
+    shared_gpu = world > 1 and "HPX_BENCH_DEVICE" in os.environ
     gb = pspec.GibbsBatch(d["vis"], flags_in, d["fgmodes"], ninv_in, d["ps_prior"],
-                          W + K, seed=d["seed"], solver=args.solver, ninv_dense=ninv_dense)
+                          W + K, seed=d["seed"], solver=args.solver, ninv_dense=ninv_dense,
+                          allow_split=not shared_gpu)
     torch.cuda.synchronize()
     t_setup = time.perf_counter() - t_setup
     ps0 = np.broadcast_to(d["ps0"], (nbl, N)).copy()

@@ -238,7 +238,11 @@ __device__ HPX_INL void bs_reg_pass(const double* __restrict__ Lre, const double
 #undef HPX_BS_LOADW
 }
 
-template <int NS>
+// TSPLIT: one workgroup per (baseline, t-tile) -- for batches that would leave most CUs without a baseline (config 2:
+// 64 baselines on 256 CUs).  The right-hand-side columns are independent, so the t-tiles of a baseline run side by
+// side; each workgroup then reads the baseline's factor for itself (the second read comes from L2 / the Infinity
+// Cache: the whole batch's factors are a few tens of MB) and its chain of dependent steps is half as heavy.
+template <int NS, bool TSPLIT>
 __global__ __launch_bounds__(512, 2) void k_backsolve_reg(const double* __restrict__ L_all,
                                                           const double* __restrict__ Wre_all,
                                                           const double* __restrict__ Wim_all,
@@ -254,6 +258,10 @@ __global__ __launch_bounds__(512, 2) void k_backsolve_reg(const double* __restri
   double* Xre = Xre_all + (long)b * npad * TP;
   double* Xim = Xim_all + (long)b * npad * TP;
   const int TT = TP >> 4;
+  if (TSPLIT) {
+    bs_reg_pass<NS, 1>(Lre, Wgre, Wgim, Xre, Xim, xs, npad, TP, (int)blockIdx.y << 4, wave, lane);
+    return;
+  }
   constexpr int NTMAX = (NS >= 5) ? 1 : 2;      // accumulators + L operands within the register file
   for (int tp = 0; tp < TT; tp += NTMAX) {
     if (NTMAX == 2 && tp + 1 < TT) bs_reg_pass<NS, 2>(Lre, Wgre, Wgim, Xre, Xim, xs, npad, TP, tp << 4, wave, lane);
@@ -262,10 +270,26 @@ __global__ __launch_bounds__(512, 2) void k_backsolve_reg(const double* __restri
   }
 }
 
+int device_cus() {
+  static int cus[32] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 32) return 0;
+  if (!cus[dev]) {
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+    cus[dev] = n;
+  }
+  return cus[dev];
+}
+
 template <int NS>
 int launch_reg(int nbl, int npad, int TP, int ld, const double* L, const double* Wre, const double* Wim, double* Xre,
                double* Xim, hipStream_t st) {
-  hipLaunchKernelGGL((k_backsolve_reg<NS>), dim3(nbl), dim3(512), 0, st, L, Wre, Wim, Xre, Xim, npad, TP, ld);
+  const int TT = TP >> 4;
+  if (TT >= 2 && 2 * nbl <= device_cus())
+    hipLaunchKernelGGL((k_backsolve_reg<NS, true>), dim3(nbl, TT), dim3(512), 0, st, L, Wre, Wim, Xre, Xim, npad, TP, ld);
+  else
+    hipLaunchKernelGGL((k_backsolve_reg<NS, false>), dim3(nbl), dim3(512), 0, st, L, Wre, Wim, Xre, Xim, npad, TP, ld);
   HPX_HIP(hipGetLastError());
   return HPX_OK;
 }

@@ -1082,44 +1082,48 @@ struct DrawArgs {
   long ps_bstride, forced_bstride;   // strides between baselines in ps_out / ps_forced
   int N, T, ngrid, prior_shared, any_flags;
   double lgam_T;
+  double* lnblk;                     // [nbl][ceil(N / 64)]: the second ln-posterior term by blocks of 64 channels
+  unsigned* dcount;                  // [nbl]: slices of the baseline that have finished (wraps to 0)
+  double* lnpost_out;                // the caller's ln-posterior history, offset to this iteration
+  long lnpost_pitch;
 };
 
+// Grid (slices, baselines): a baseline's channels are dealt to `gridDim.x` workgroups in blocks of 64 -- one per
+// baseline for large batches, up to eight for batches that would leave most CUs idle (config 2).  The ln-posterior's
+// sum over the channels is formed per block of 64 (a fixed shuffle tree) and added in block order by the slice
+// that finishes last, so the result does not depend on the number of slices.
 __global__ __launch_bounds__(256) void k_draw(const DrawArgs A) {
   extern __shared__ double dyn[];     // N ints: the channels with a prior
-  __shared__ double red[4];
   __shared__ int pcount;
   __shared__ double rk_s[HPX_RK_MAX];
-  const int b = blockIdx.x, tid = threadIdx.x, N = A.N;
+  const int b = blockIdx.y, tid = threadIdx.x, N = A.N;
+  const int nblk = (N + 63) >> 6;
+  const int cb0 = (int)(((long)nblk * blockIdx.x) / gridDim.x), cb1 = (int)(((long)nblk * (blockIdx.x + 1)) / gridDim.x);
+  const int k0 = cb0 * 64, k1 = min(N, cb1 * 64);
   for (int k = tid; k < HPX_RK_MAX; k += 256) rk_s[k] = 1.0 / (double)(k > 0 ? k : 1);
   const double* rk = (A.T <= HPX_RK_MAX) ? rk_s : nullptr;
-  // beta_k = N sum_t |z_kt|^2 and the chi^2 total from the partial sums of the residual kernel
-  // (one slot per block of a baseline there), added in slot order
+  // beta_k = N sum_t |z_kt|^2 from the partial sums of the residual kernel (one slot per block of a baseline
+  // there), added in slot order
   double* beta = A.beta + (long)b * N;
-  for (int k = tid; k < N; k += 256) {
+  for (int k = k0 + tid; k < k1; k += 256) {
     double sum = 0.0;
     for (int j = 0; j < A.npart; ++j) sum += A.bpart[((long)b * HPX_NPART + j) * N + k];
     beta[k] = (double)N * sum;
   }
-  if (tid == 0) {
-    double tot = 0.0;
-    for (int j = 0; j < A.npart; ++j) tot += A.lnpart[(long)b * HPX_NPART + j];
-    A.lnp1[b] = -tot;
-  }
+  if (tid == 0) pcount = 0;
   __syncthreads();
   const double* bm = A.any_flags ? A.betam + (long)b * N : beta;
   const int32_t* pmap = A.pmap + (A.prior_shared ? 0 : (long)b * N);
   double* ps_out = A.ps_out + (long)b * A.ps_bstride;
   // channels without a prior: x = beta * invgamma.ppf(U, a=T-1)   (pspec.py:125)
-  for (int k = tid; k < N; k += 256)
-    if (pmap[k] < 0) ps_out[k] = A.igy[k] * beta[k];
   // channels with a prior: truncated draw with shape alpha+1 = T   (pspec.py:121-123).
   // They are collected first (a scan of pmap by one thread per channel would be N dependent
   // global loads); each draw depends only on its own channel, so their order is immaterial.
   int* plist = reinterpret_cast<int*>(dyn);
-  if (tid == 0) pcount = 0;
-  __syncthreads();
-  for (int k = tid; k < N; k += 256)
-    if (pmap[k] >= 0) plist[atomicAdd(&pcount, 1)] = k;
+  for (int k = k0 + tid; k < k1; k += 256) {
+    if (pmap[k] < 0) ps_out[k] = A.igy[k] * beta[k];
+    else plist[atomicAdd(&pcount, 1)] = k;
+  }
   __syncthreads();
   const int np = pcount;
   for (int i = tid >> 4; i < np; i += 16) {            // one prior channel per group of 16 lanes
@@ -1129,16 +1133,43 @@ __global__ __launch_bounds__(256) void k_draw(const DrawArgs A) {
     if ((tid & 15) == 0) ps_out[k] = v;
   }
   __syncthreads();
-  double acc = 0.0;
-  for (int k = tid; k < N; k += 256) {
-    const double pn = ps_out[k];
-    acc += bm[k] / pn;
-    const double nx = A.ps_forced ? A.ps_forced[(long)b * A.forced_bstride + k] : pn;
-    A.ps_cur[(long)b * N + k] = nx;
-    A.ia[(long)b * N + k] = inv_a(nx, (double)N);
+  // second ln-posterior term, the next 1 / a: one wave per block of 64 channels
+  __shared__ double part[64];
+  for (int cb = cb0 + (tid >> 6); cb < cb1; cb += 4) {
+    const int k = cb * 64 + (tid & 63);
+    double v = 0.0;
+    if (k < N) {
+      const double pn = ps_out[k];
+      v = bm[k] / pn;
+      const double nx = A.ps_forced ? A.ps_forced[(long)b * A.forced_bstride + k] : pn;
+      A.ps_cur[(long)b * N + k] = nx;
+      A.ia[(long)b * N + k] = inv_a(nx, (double)N);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+    if ((tid & 63) == 0) part[(cb - cb0) & 63] = v;          // (a slice holds at most 64 blocks: N <= 4096 per slice)
   }
-  const double tot = block_sum(acc, red);
-  if (tid == 0) A.lnp1[b] = A.lnp1[b] - tot;          // -> ln posterior, scattered by the host code
+  __syncthreads();
+  if (tid != 0) return;
+  double tot = 0.0;                  // chi^2 total of the residual kernel's partial sums, in slot order
+  for (int j = 0; j < A.npart; ++j) tot += A.lnpart[(long)b * HPX_NPART + j];
+  double s = 0.0;
+  if (gridDim.x == 1) {              // one slice: nothing to hand over
+    for (int cb = 0; cb < nblk; ++cb) s += part[cb];
+  } else {
+    // several slices: this slice's block sums go to memory behind an agent-scope release; the slice that counts
+    // itself in last acquires and adds all blocks in block order
+    double* gl = A.lnblk + (long)b * nblk;
+    for (int cb = cb0; cb < cb1; ++cb) __hip_atomic_store(&gl[cb], part[cb - cb0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    const unsigned old = atomicInc(&A.dcount[b], gridDim.x - 1);     // (wraps: zero again after the last slice)
+    if (old != gridDim.x - 1) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    for (int cb = 0; cb < nblk; ++cb) s += __hip_atomic_load(&gl[cb], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  const double lnp = -tot - s;       // -> ln posterior
+  A.lnp1[b] = lnp;
+  if (A.lnpost_out) A.lnpost_out[(long)b * A.lnpost_pitch] = lnp;
 }
 
 __global__ void k_inv_test(const int alpha, const double lgam, const double* __restrict__ beta,
@@ -1223,6 +1254,7 @@ static int plan_create_impl(hpx_plan** out, int nbl, int T, int N, int M, int ex
   A_(Xre, nb * xsz); A_(Xim, nb * xsz);
   A_(info, nb);
   A_(ia, nb * N); A_(ps_cur, nb * N); A_(beta, nb * N); A_(betam, nb * N); A_(lnp1, nb);
+  A_(lnblk, nb * ((N + 63) / 64)); A_(dcount, nb);
   A_(bpart, nb * HPX_NPART * N); A_(lnpart, nb * HPX_NPART);
   A_(Rre, nb * rsz); A_(Rim, nb * rsz); A_(Zre, nb * rsz); A_(Zim, nb * rsz);
   A_(Cre, nb * N); A_(Cim, nb * N);
@@ -1248,6 +1280,7 @@ static int plan_create_impl(hpx_plan** out, int nbl, int T, int N, int M, int ex
   if (e == hipSuccess) e = hipMemset(p->P2re, 0, ssz * sizeof(double));
   if (e == hipSuccess) e = hipMemset(p->P2im, 0, ssz * sizeof(double));
   if (e == hipSuccess) e = hipMemset(p->info, 0, nb * sizeof(int32_t));
+  if (e == hipSuccess) e = hipMemset(p->dcount, 0, nb * sizeof(unsigned));
   if (e == hipSuccess) e = hipDeviceSynchronize();   // null-stream memsets vs. the caller's (non-blocking) streams
   if (e != hipSuccess) {
     hpx_set_error("hpx_plan_create: memset failed: %s", hipGetErrorString(e));
@@ -2403,10 +2436,22 @@ static int post_solve(hpx_plan* p, int it_abs, const IterOut& O, hipStream_t st)
   D.ps_out = O.ps_out; D.ps_bstride = O.ps_bstride;
   D.N = N; D.T = T; D.ngrid = p->ngrid; D.prior_shared = p->prior_shared;
   D.any_flags = p->any_flags; D.lgam_T = p->lgam_T;
-  hipLaunchKernelGGL(k_draw, dim3(nbl), dim3(256), (size_t)N * sizeof(int) + 8, st, D);
+  D.lnblk = p->lnblk; D.dcount = p->dcount;
+  D.lnpost_out = O.lnpost_out; D.lnpost_pitch = O.lnpost_pitch;      // (written by the kernel: no copy afterwards)
+  // slices per baseline: as many as leave no CU without work, in blocks of 64 channels
+  int nslice = 1;
+  {
+    int dev = 0, cus = 0;
+    static int cu_of[32] = {};
+    if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 32) {
+      if (!cu_of[dev]) (void)hipDeviceGetAttribute(&cu_of[dev], hipDeviceAttributeMultiprocessorCount, dev);
+      cus = cu_of[dev];
+    }
+    while (nslice < 8 && 2 * nslice * nbl <= cus && 2 * nslice <= (N + 63) / 64) nslice *= 2;
+    while (((N + 63) / 64 + nslice - 1) / nslice > 64) nslice *= 2;      // (a slice keeps at most 64 block sums)
+  }
+  hipLaunchKernelGGL(k_draw, dim3(nslice, nbl), dim3(256), (size_t)N * sizeof(int) + 8, st, D);
   HPX_HIP(hipGetLastError());
-  HPX_HIP(hipMemcpy2DAsync(O.lnpost_out, (size_t)O.lnpost_pitch * sizeof(double), p->lnp1,
-                           sizeof(double), sizeof(double), nbl, hipMemcpyDeviceToDevice, st));
   HPX_TRY(mark(p, st));
   return HPX_OK;
 }
@@ -2496,6 +2541,24 @@ static int run_begin(hpx_plan* p, const RunArgs& A) {
   return HPX_OK;
 }
 
+// Per-time units with a full noise matrix AND flagged channels: the Woodbury correction per unit (as post_solve's,
+// with one data column), on the unit solutions X = [Y_r | Y_P] of the unflagged-noise systems
+static int child_woodbury(hpx_plan* c, int iter_tag, hipStream_t st) {
+  const int N = c->N, M = c->M;
+  HPX_TRY(hpx_launch_dft(c->nbl, c->NP, c->TP, c->Fopre, c->Fopim, 1, c->Xre, c->Xim, (long)c->npad * c->TP,
+                         c->TP, nullptr, 0, c->Sre, c->Sim, (long)c->NP * c->TP, c->TP,
+                         1.0 / sqrt((double)N), st, N == c->NP));
+  const int fm = c->wb_fmax;
+  hipLaunchKernelGGL(k_wb_system, dim3(c->nbl), dim3(256), 0, st, c->Sre, c->Sim, c->Xre, c->Xim, c->Fre,
+                     c->Fim, c->fg_shared, c->wb_flist, c->wb_fcount, c->wb_W, fm, N, M, 1, c->NP, c->TP,
+                     c->npad);
+  HPX_TRY(launch_wb_solve(c->nbl, c->wb_W, c->wb_fcount, fm, 1, c->info, iter_tag, st));
+  hipLaunchKernelGGL(k_wb_correct, dim3(8, c->nbl), dim3(256), 0, st, c->Sre, c->Sim, c->Xre, c->Xim, c->wb_W,
+                     c->wb_fcount, fm, 1, c->NP, c->TP, c->npad);
+  HPX_HIP(hipGetLastError());
+  return HPX_OK;
+}
+
 // iteration `it` (0-based within the run) of plan p: everything is enqueued on A.st, nothing waits
 static int run_iteration(hpx_plan* p, const RunArgs& A, int it) {
   hipStream_t st = A.st;
@@ -2531,19 +2594,7 @@ static int run_iteration(hpx_plan* p, const RunArgs& A, int it) {
                                   c->dense_noise ? nullptr : &gc, st, p->allow_split));
         HPX_TRY(mark(p, st));
         HPX_TRY(hpx_launch_backsolve(c->nbl, c->npad, c->TP, c->ld, c->L, c->Wre, c->Wim, c->Xre, c->Xim, st));
-        if (c->dense_noise == 2) {      // flagged units: the Woodbury correction per unit (as post_solve, T = 1)
-          HPX_TRY(hpx_launch_dft(c->nbl, c->NP, c->TP, c->Fopre, c->Fopim, 1, c->Xre, c->Xim, (long)c->npad * c->TP,
-                                 c->TP, nullptr, 0, c->Sre, c->Sim, (long)c->NP * c->TP, c->TP,
-                                 1.0 / sqrt((double)N), st, N == c->NP));
-          const int fm = c->wb_fmax;
-          hipLaunchKernelGGL(k_wb_system, dim3(c->nbl), dim3(256), 0, st, c->Sre, c->Sim, c->Xre, c->Xim, c->Fre,
-                             c->Fim, c->fg_shared, c->wb_flist, c->wb_fcount, c->wb_W, fm, N, M, 1, c->NP, c->TP,
-                             c->npad);
-          HPX_TRY(launch_wb_solve(c->nbl, c->wb_W, c->wb_fcount, fm, 1, c->info, iter0 + it + 1, st));
-          hipLaunchKernelGGL(k_wb_correct, dim3(8, c->nbl), dim3(256), 0, st, c->Sre, c->Sim, c->Xre, c->Xim, c->wb_W,
-                             c->wb_fcount, fm, 1, c->NP, c->TP, c->npad);
-          HPX_HIP(hipGetLastError());
-        }
+        if (c->dense_noise == 2) HPX_TRY(child_woodbury(c, iter0 + it + 1, st));
         hipLaunchKernelGGL(k_pt_gather, dim3(32, nbl), dim3(256), 0, st, c->Xre, c->Xim, p->Xre, p->Xim, T, p->npad,
                            TP, c->TP);
         HPX_HIP(hipGetLastError());
@@ -2692,8 +2743,7 @@ extern "C" int hpx_gibbs_step_general(hpx_plan* p, const double* shp, int iter0,
                                       double* lnpost_out, double* cr_out, double* fg_out,
                                       double* chisq_out, double* ps_last, void* stream) {
   HPX_REQUIRE(p && p->have_static && shp && ps_out && lnpost_out, "hpx_gibbs_step_general: bad argument");
-  HPX_REQUIRE(!p->per_time || (p->child && !p->child->dense_noise),
-              "hpx_gibbs_step_general: with time-dependent flags / noise only for diagonal inverse noise covariances");
+  HPX_REQUIRE(!p->per_time || p->child, "hpx_gibbs_step_general: per-time plan without its units");
   HPX_REQUIRE(p->uni && iter0 >= 0 && iter0 < p->niter_tab, "hpx_gibbs_step_general: random tables too short");
   hipStream_t st = (hipStream_t)stream;
   const int nbl = p->nbl, N = p->N, M = p->M, T = p->T, NP = p->NP, TP = p->TP;
@@ -2716,7 +2766,12 @@ extern "C" int hpx_gibbs_step_general(hpx_plan* p, const double* shp, int iter0,
     hipLaunchKernelGGL(k_mat_planar, dim3(64, nbl), dim3(256), 0, st, shp, p->SHre, p->SHim, N, NP);
     hipLaunchKernelGGL(k_pt_expand_fg, dim3(64, units), dim3(256), 0, st, p->SHre, c->SHre, T, mstr);
     hipLaunchKernelGGL(k_pt_expand_fg, dim3(64, units), dim3(256), 0, st, p->SHim, c->SHim, T, mstr);
-    hipLaunchKernelGGL(k_circ_matrix, dim3(64, units), dim3(256), 0, st, c->Cre, c->Cim, c->CMre, c->CMim, N, NP);
+    if (c->dense_noise) {       // a full noise matrix per unit: C_t = U^H Ninv_t U as laid out at set-up
+      HPX_HIP(hipMemcpyAsync(c->CMre, c->CDre, um * sizeof(double), hipMemcpyDeviceToDevice, st));
+      HPX_HIP(hipMemcpyAsync(c->CMim, c->CDim, um * sizeof(double), hipMemcpyDeviceToDevice, st));
+    } else {
+      hipLaunchKernelGGL(k_circ_matrix, dim3(64, units), dim3(256), 0, st, c->Cre, c->Cim, c->CMre, c->CMim, N, NP);
+    }
     HPX_HIP(hipGetLastError());
     HPX_TRY(hpx_launch_dft(units, NP, NP, c->CMre, c->CMim, 1, c->SHre, c->SHim, mstr, NP, nullptr, 0, c->Y1re, c->Y1im,
                            mstr, NP, 1.0, st, 0, mstr));
@@ -2741,6 +2796,8 @@ extern "C" int hpx_gibbs_step_general(hpx_plan* p, const double* shp, int iter0,
                            0, c->Gre, c->Gim, (long)NP * c->TP, c->TP, 1.0, st, 0, mstr));
     hipLaunchKernelGGL(k_take_sprime, dim3(32, units), dim3(256), 0, st, c->Gre, c->Gim, c->Xre, c->Xim, N, NP, c->TP,
                        c->npad);
+    HPX_HIP(hipGetLastError());
+    if (c->dense_noise == 2) HPX_TRY(child_woodbury(c, iter0 + 1, st));      // (every column went through Sh' alike)
     hipLaunchKernelGGL(k_pt_gather, dim3(32, nbl), dim3(256), 0, st, c->Xre, c->Xim, p->Xre, p->Xim, T, p->npad, TP,
                        c->TP);
     HPX_HIP(hipGetLastError());

@@ -998,6 +998,16 @@ int hpx_launch_factor(int nbl, int npad, int ld, double* L, double* Wre, double*
   return launch_factor_t<true, false>(nbl, base, npad, ld, L, Wre, Wim, info, iter_tag, *gen, st);
 }
 
+// Which form a batch of nb systems of order n with nrhs right-hand sides takes on the current device (an idle one):
+// 0 the 32-wide kernel, 1 the wide kernel, 2 the split kernel (*parts = workgroups per system)
+extern "C" int hpx_factor_form(int nb, int n, int nrhs, int* parts) {
+  const int npad = ceil16(n), ld = npad + (nrhs > 0 ? ceil16(nrhs) : 0);
+  const int pr = hpx_factor_split_parts(nb, npad, ld);
+  if (parts) *parts = pr;
+  if (pr) return 2;
+  return npad >= HPX_WIDE_MIN ? 1 : 0;
+}
+
 int hpx_launch_backsolve(int nbl, int npad, int TP, int ld, const double* L, const double* Wre,
                          const double* Wim, double* Xre, double* Xim, hipStream_t st) {
 #ifndef HPX_BACKSOLVE_OLD

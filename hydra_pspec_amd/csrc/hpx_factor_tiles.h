@@ -28,8 +28,7 @@ template <int PAR> __device__ HPX_INL double* stage_buf() { return PAR ? hpx_sta
 // elimination; the K-split partial sums of narrow_column in slots 1..4); in buffer 1 one inverse tile and the
 // elimination's matrices
 constexpr int FV_OFF = 0, FD_OFF = 512, F_END = FD_OFF + 2 * 2 * 16 * 17 + 16;
-constexpr int FV1_OFF = 2048;      // a second inverse tile (look-ahead of the wide form's F)
-static_assert(F_END <= FV1_OFF && FV1_OFF + 512 <= BUF_D, "F scratch must fit a staging buffer");
+static_assert(F_END <= BUF_D, "F scratch must fit a staging buffer");
 
 // ---- vector-memory traffic of the staged loops: ALL of it through inline asm, waits included ----------------
 // The compiler's own s_waitcnt insertion cannot be used here: once an LDS-DMA and an ordinary global load are

@@ -308,133 +308,6 @@ __device__ HPX_INL bool diag_factor(const WideCtx& X, const int ct0, d4 (&a1)[9]
   return bad;
 }
 
-// ---- F with look-ahead (the default; -DHPX_F_NO_LOOKAHEAD restores diag_factor above for A/B) ---------------------
-// The chain of F is  eliminate tile i -> tiles below it -> update of diagonal tile i+1 -> eliminate tile i+1 -> ...
-// With the elimination on all 256 threads (elim16: 16 steps with a workgroup barrier each) every wave sits in that
-// chain for all of it; measured per tile column at C3 (tools/experiments/trace/wide_trace.py): elimination 5 - 6 us,
-// tiles below 1 - 2, trailing updates 6 -> 0.3.  Here, once column i's tiles are in LDS, the wave that OWNS diagonal
-// tile i+1 applies column i to that tile alone and eliminates it on its own (elim16w: the tile where it lies, no
-// barrier) while the other three waves run column i's trailing updates; the owner's own trailing tiles follow its
-// elimination.  Two workgroup barriers per tile column instead of twenty-one; the inverse tile has two LDS homes
-// (the next one is written while the current one is still read).  Everything is indexed at compile time (W, i).
-template <int W>
-__device__ HPX_INL bool diag_factor_la(const WideCtx& X, const int ct0, d4 (&a1)[9], d4 (&a2)[9]) {
-  typedef DiagDeal<W> TD;
-  lds_f64* const Xs = (lds_f64*)hpx_stage0;
-  bool bad = false;
-  d4 t_re = {0., 0., 0., 0.}, t_im = {0., 0., 0., 0.};     // L10 inv(L00) of the current pair of tiles (one wave)
-  lds_barrier();                                          // the staging area is free
-  // diagonal tile i belongs to wave min(i, 7 - i): slot 8 (tile (W, W)) or slot 7 - W (tile (7 - W, 7 - W))
-  if (W == 0) bad |= elim16w(X, ct0, false, a1[8], a2[8], [] {}, (lds_f64*)(hpx_stage1 + FV_OFF));
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int lane = opaque(X.lane), li = lane & 15, g = lane >> 4;
-    const int rd_re = g * 32 + li + 16 * (g & 1), rd_im = g * 32 + li + 16 * (1 - (g & 1));
-    const lds_f64* const Vs = (const lds_f64*)(hpx_stage1 + ((i & 1) ? FV1_OFF : FV_OFF));     // inv(L_ii)
-    lds_f64* const Vn = (lds_f64*)(hpx_stage1 + ((i & 1) ? FV_OFF : FV1_OFF));                 // inv(L_i+1,i+1) goes here
-    HPX_TR(X, 2, ct0 >> 3, i, 0);
-    lds_barrier();                      // inv(L_ii) is in LDS; column i - 1 and the other inverse are free
-    HPX_TR(X, 2, ct0 >> 3, i, 1);
-    // (2b) odd tile of a pair: W10 = -inv(L11) (L10 inv(L00))
-    if ((i & 1) && W == ((i >> 1) & 3)) {
-      d4 zr = {0., 0., 0., 0.}, zi = {0., 0., 0., 0.};
-#pragma unroll
-      for (int v = 0; v < 4; ++v) {
-        const double ar = Vs[v * 128 + rd_re], ai = Vs[v * 128 + rd_im];     // inv(L11)[i' = li][r = 4 v + g]
-        zr = mfma64(-ar, t_re[v], zr);
-        zr = mfma64(ai, t_im[v], zr);
-        zi = mfma64(-ar, t_im[v], zi);
-        zi = mfma64(-ai, t_re[v], zi);
-      }
-      double* wgr = X.Wgre + (long)((ct0 + i) >> 1) * 1024;
-      double* wgi = X.Wgim + (long)((ct0 + i) >> 1) * 1024;
-#pragma unroll
-      for (int v = 0; v < 4; ++v) {
-        wgr[(16 + HPX_ACC_ROW(g, v)) * 32 + li] = zr[v];
-        wgi[(16 + HPX_ACC_ROW(g, v)) * 32 + li] = zi[v];
-      }
-    }
-    // (3) tiles below: X^T[c'][r'] = sum_c conj(inv(L)[c'][c]) D^T[c][r'], stored and handed to the others
-#pragma unroll
-    for (int s = 0; s < 9; ++s)
-      if (TD::col(s) == i && TD::row(s) > i) {
-        d4 xr = {0., 0., 0., 0.}, xi = {0., 0., 0., 0.};
-#pragma unroll
-        for (int v = 0; v < 4; ++v) {
-          const double pr = Vs[v * 128 + rd_re], pi = Vs[v * 128 + rd_im];
-          xr = mfma64(pr, a1[s][v], xr);
-          xr = mfma64(pi, a2[s][v], xr);
-          xi = mfma64(pr, a2[s][v], xi);
-          xi = mfma64(-pi, a1[s][v], xi);
-        }
-        double* o_ = X.Lb + HPX_LIDX((ct0 + TD::row(s)) * 16 + li, (ct0 + i) * 16 + g, X.npad);
-        lds_f64* xs = Xs + TD::row(s) * 512;
-#pragma unroll
-        for (int v = 0; v < 4; ++v) {
-          o_[(4 * v) * 32] = xr[v];
-          o_[(4 * v) * 32 + 16] = xi[v];
-          const int k = g + 4 * v;                         // column of the tile; row li
-          xs[k * 32 + li + 16 * (k & 1)] = xr[v];
-          xs[k * 32 + li + 16 * (1 - (k & 1))] = xi[v];
-        }
-      }
-    HPX_TR(X, 2, ct0 >> 3, i, 2);
-    lds_barrier();                      // column i is in LDS
-    HPX_TR(X, 2, ct0 >> 3, i, 3);
-    // (L) look-ahead: the owner of diagonal tile i + 1 brings it up to date and eliminates it
-    if (i < 7 && W == ((i + 1 <= 3) ? i + 1 : 6 - i)) {
-      const int sd = (i + 1 <= 3) ? 8 : 7 - W;
-      const lds_f64* pd = Xs + (i + 1) * 512;
-#pragma unroll
-      for (int v = 0; v < 4; ++v) {
-        const double pr = pd[v * 128 + rd_re], pi = pd[v * 128 + rd_im];
-        a1[sd] = mfma64(-pr, pr, a1[sd]);
-        a1[sd] = mfma64(-pi, pi, a1[sd]);
-        a2[sd] = mfma64(-pr, pi, a2[sd]);
-        a2[sd] = mfma64(pi, pr, a2[sd]);
-      }
-      bad |= elim16w(X, ct0 + i + 1, false, a1[sd], a2[sd], [] {}, Vn);
-      HPX_TR(X, 2, ct0 >> 3, i, 5);
-    }
-    // (3b) even tile of a pair: T = L10 inv(L00), kept in registers until the pair's second inverse exists
-    if (!(i & 1) && W == ((i >> 1) & 3)) {
-      t_re = (d4){0., 0., 0., 0.};
-      t_im = t_re;
-      const lds_f64* l10 = Xs + (i + 1) * 512;
-#pragma unroll
-      for (int v = 0; v < 4; ++v) {
-        const double ar = l10[v * 128 + rd_re], ai = l10[v * 128 + rd_im];      // L10[r = li][k = 4 v + g]
-        const int k = 4 * v + g;                                                   // inv(L00)[k][c' = li]
-        const double br = Vs[li * 32 + k + 16 * (li & 1)], bm = Vs[li * 32 + k + 16 * (1 - (li & 1))];
-        t_re = mfma64(ar, br, t_re);
-        t_re = mfma64(-ai, bm, t_re);
-        t_im = mfma64(ar, bm, t_im);
-        t_im = mfma64(ai, br, t_im);
-      }
-    }
-    // (4) trailing tiles: D^T[c'][r'] -= sum_k conj(X(c,i)[c'][k]) X(r,i)[r'][k]  (diagonal tile i + 1: done above)
-#pragma unroll
-    for (int s = 0; s < 9; ++s)
-      if (TD::col(s) > i && !(TD::col(s) == i + 1 && TD::row(s) == i + 1)) {
-        const lds_f64* pa = Xs + TD::col(s) * 512;
-        const lds_f64* pb = Xs + TD::row(s) * 512;
-#pragma unroll
-        for (int v = 0; v < 4; ++v) {
-          const double pr = pa[v * 128 + rd_re], pi = pa[v * 128 + rd_im];
-          const double br = pb[v * 128 + rd_re], bm = pb[v * 128 + rd_im];
-          a1[s] = mfma64(-pr, br, a1[s]);
-          a1[s] = mfma64(-pi, bm, a1[s]);
-          a2[s] = mfma64(-pr, bm, a2[s]);
-          a2[s] = mfma64(pi, br, a2[s]);
-        }
-      }
-    HPX_TR(X, 2, ct0 >> 3, i, 4);
-  }
-  __syncthreads();        // F's stores (L_JJ, Vt) are complete before the passes stage them
-  HPX_TR(X, 2, ct0 >> 3, 8, 0);
-  return bad;
-}
-
 // ---- P: the row strips below the full super-block at ct0, four at a time ----------------------------
 // The chunks of all groups form ONE stream through the two staging buffers: every step waits for its own
 // chunk, passes the barrier, issues the next chunk (the next group's first when this one is done) into the other
@@ -853,12 +726,7 @@ __global__ __launch_bounds__(256, 2) void k_factor_wide(double* __restrict__ L_a
 #else
     for (int s = 0; s < 9; ++s) { a1[s] = (d4){1.0 * tid, 0., 0., 0.}; a2[s] = a1[s]; }
 #endif
-#if !defined(HPX_DBG_NO_F) && !defined(HPX_F_NO_LOOKAHEAD)
-    if (X.wave == 0) bad |= diag_factor_la<0>(X, ct0, a1, a2);
-    else if (X.wave == 1) bad |= diag_factor_la<1>(X, ct0, a1, a2);
-    else if (X.wave == 2) bad |= diag_factor_la<2>(X, ct0, a1, a2);
-    else bad |= diag_factor_la<3>(X, ct0, a1, a2);
-#elif !defined(HPX_DBG_NO_F)
+#ifndef HPX_DBG_NO_F
     bad |= diag_factor(X, ct0, a1, a2);
 #else
     for (int s = 0; s < 9; ++s) X.Lb[s * 64 + tid] = a1[s][0] + a2[s][1];

@@ -90,6 +90,162 @@ __global__ void k_ns_out(const double* __restrict__ pr, const double* __restrict
   }
 }
 
+// ---- the masked root's bookkeeping (hpx_sqrtm_masked_batched) ----------------------------------------------------
+// per matrix: the permutation "unflagged channels first" (stable), the number of unflagged channels, the mean of the
+// unflagged diagonal (the value of the padding's diagonal: it keeps the padded block's condition number that of A)
+__global__ __launch_bounds__(256) void k_sm_order(const uint8_t* __restrict__ w, const double* __restrict__ a,
+                                                  const long a_bstride, int32_t* __restrict__ perm,
+                                                  int32_t* __restrict__ nu, double* __restrict__ dmean, const int n) {
+  const int b = blockIdx.x;
+  __shared__ int cnt;
+  __shared__ double dsum;
+  if (threadIdx.x == 0) {
+    const uint8_t* wb = w + (long)b * n;
+    const double* ab = a + (long)b * a_bstride;
+    int32_t* pb = perm + (long)b * n;
+    int k = 0;
+    double d = 0.0;
+    for (int i = 0; i < n; ++i)
+      if (wb[i]) { pb[k++] = i; d += ab[((long)i * n + i) * 2]; }
+    cnt = k;
+    dsum = d;
+    for (int i = 0; i < n; ++i)
+      if (!wb[i]) pb[k++] = i;
+    nu[b] = cnt;
+    dmean[b] = cnt > 0 ? dsum / cnt : 1.0;
+  }
+}
+// A[b] (npad x npad, interleaved) = Ninv[u, u] in the permuted order, the padding's diagonal = the mean of A's
+__global__ void k_sm_block(const double* __restrict__ a, const long a_bstride, const int32_t* __restrict__ perm,
+                           const int32_t* __restrict__ nu, const double* __restrict__ dmean, double* __restrict__ out,
+                           const int n, const int npad) {
+  const int b = blockIdx.y;
+  const double* ab = a + (long)b * a_bstride;
+  const int32_t* pb = perm + (long)b * n;
+  const int m = nu[b];
+  double* ob = out + (long)b * npad * npad * 2;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < (long)npad * npad; e += (long)gridDim.x * blockDim.x) {
+    const int i = (int)(e / npad), j = (int)(e % npad);
+    double re = 0.0, im = 0.0;
+    if (i < m && j < m) {
+      const long o = ((long)pb[i] * n + pb[j]) * 2;
+      re = ab[o];
+      im = ab[o + 1];
+    } else if (i == j) {
+      re = dmean[b];
+    }
+    ob[e * 2] = re;
+    ob[e * 2 + 1] = im;
+  }
+}
+// planar in[b][k][c] (npad x ncol) = B^T: B[c][k] = Ninv[perm c][perm k] for a flagged row c >= nu and an unflagged
+// column k < nu, zero elsewhere
+__global__ void k_sm_bt(const double* __restrict__ a, const long a_bstride, const int32_t* __restrict__ perm,
+                        const int32_t* __restrict__ nu, double* __restrict__ inr, double* __restrict__ ini, const int n,
+                        const int npad, const int ncol) {
+  const int b = blockIdx.y;
+  const double* ab = a + (long)b * a_bstride;
+  const int32_t* pb = perm + (long)b * n;
+  const int m = nu[b];
+  const long o = (long)b * npad * ncol;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < (long)npad * ncol; e += (long)gridDim.x * blockDim.x) {
+    const int k = (int)(e / ncol), c = (int)(e % ncol);
+    double re = 0.0, im = 0.0;
+    if (k < m && c >= m && c < n) {
+      const long q = ((long)pb[c] * n + pb[k]) * 2;
+      re = ab[q];
+      im = ab[q + 1];
+    }
+    inr[o + e] = re;
+    ini[o + e] = im;
+  }
+}
+// out[b][perm r][perm j] (n x n, interleaved): sqrt(s) Y[r][j] for r, j < nu; (B A^-1/2)[r][j] = lowT[j][r] / sqrt(s)
+// for r >= nu, j < nu; zero in the flagged columns
+__global__ void k_sm_scatter(const double* __restrict__ yr, const double* __restrict__ yi, const double* __restrict__ lr,
+                             const double* __restrict__ li, const double* __restrict__ s,
+                             const int32_t* __restrict__ perm, const int32_t* __restrict__ nu, double* __restrict__ out,
+                             const int n, const int npad, const int ncol) {
+  const int b = blockIdx.y;
+  const int32_t* pb = perm + (long)b * n;
+  const int m = nu[b];
+  const double f = sqrt(s[b]), fi = 1.0 / f;
+  const long oy = (long)b * npad * npad, ol = (long)b * npad * ncol;
+  double* ob = out + (long)b * n * n * 2;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < (long)n * n; e += (long)gridDim.x * blockDim.x) {
+    const int r = (int)(e / n), j = (int)(e % n);
+    double re = 0.0, im = 0.0;
+    if (j < m) {
+      if (r < m) {
+        re = f * yr[oy + (long)r * npad + j];
+        im = f * yi[oy + (long)r * npad + j];
+      } else {
+        re = fi * lr[ol + (long)j * ncol + r];
+        im = fi * li[ol + (long)j * ncol + r];
+      }
+    }
+    const long q = ((long)pb[r] * n + pb[j]) * 2;
+    ob[q] = re;
+    ob[q + 1] = im;
+  }
+}
+
+// The iteration on one chunk of nc systems (interleaved input `ab`): on return (yr, yi) = (A / s)^1/2 and (zr, zi) =
+// (A / s)^-1/2 in planar form (the buffers are swapped among the five pairs of `W`), s[b] the scales.
+struct NsWork {
+  double *yr, *yi, *zr, *zi, *tr, *ti, *y2r, *y2i, *z2r, *z2i, *s, *err;
+};
+int ns_iterate(const int nc, const int n, const double* ab, NsWork& K, const double tol, const int max_iter,
+               std::vector<double>& herr, int* iters, hipStream_t st) {
+  const long m = (long)n * n;
+  hipLaunchKernelGGL(k_ns_norm, dim3(nc), dim3(256), 0, st, ab, K.s, n);
+  hipLaunchKernelGGL(k_ns_init, dim3(64, nc), dim3(256), 0, st, ab, K.s, K.yr, K.yi, K.zr, K.zi, n);
+  HPX_HIP(hipGetLastError());
+  int it = 0, polish = 1;      // one more step after the stop test is met (it squares the residual once more)
+  bool done = false;
+  while (it < max_iter + 1) {
+    // T = Z Y  (the kernel forms W^H in with W = the stored matrix: the iterates are Hermitian to rounding)
+    HPX_TRY(hpx_launch_dft(nc, n, n, K.zr, K.zi, 1, K.yr, K.yi, m, n, nullptr, 0, K.tr, K.ti, m, n, 1.0, st, 0, m));
+    HPX_HIP(hipMemsetAsync(K.err, 0, (size_t)nc * sizeof(double), st));
+    hipLaunchKernelGGL(k_ns_resid, dim3(64, nc), dim3(256), 0, st, K.tr, K.ti, K.err, n);       // T <- R = (3 I - T) / 2
+    HPX_HIP(hipGetLastError());
+    // the stable coupling: Y' = Y R (R on the right), Z' = R Z
+    HPX_TRY(hpx_launch_dft(nc, n, n, K.yr, K.yi, 1, K.tr, K.ti, m, n, nullptr, 0, K.y2r, K.y2i, m, n, 1.0, st, 0, m));
+    HPX_TRY(hpx_launch_dft(nc, n, n, K.tr, K.ti, 1, K.zr, K.zi, m, n, nullptr, 0, K.z2r, K.z2i, m, n, 1.0, st, 0, m));
+    std::swap(K.yr, K.y2r); std::swap(K.yi, K.y2i); std::swap(K.zr, K.z2r); std::swap(K.zi, K.z2i);
+    ++it;
+    if (done) break;           // that was the polishing step
+    // the residual measured at the START of this step: the step just taken squares it
+    HPX_HIP(hipMemcpyAsync(herr.data(), K.err, (size_t)nc * sizeof(double), hipMemcpyDeviceToHost, st));
+    HPX_HIP(hipStreamSynchronize(st));
+    double worst = 0.0;
+    for (int b = 0; b < nc; ++b) worst = herr[b] > worst ? herr[b] : worst;
+    if (!(worst == worst)) {
+      hpx_set_error("hpx_sqrtm_hpd_batched: the iteration diverged (a matrix is not positive definite?)");
+      return HPX_EINVAL;
+    }
+    done = sqrt(worst) < tol * n;       // || I - Z Y ||_F below tol * n before the step: below (tol n)^2 after it
+    if (done && !polish) break;
+    if (!done && it >= max_iter) {
+      hpx_set_error("hpx_sqrtm_hpd_batched: no convergence in %d iterations", max_iter);
+      return HPX_EINVAL;
+    }
+  }
+  *iters = it;
+  return HPX_OK;
+}
+int ns_alloc(hpx_devbuf& work, hpx_devbuf& sc, const int chunk, const long m, NsWork& K) {
+  HPX_TRY(work.alloc((size_t)chunk * m * 10));      // 5 planar work matrices per system: 80 n^2 bytes each
+  HPX_TRY(sc.alloc((size_t)chunk * 2));
+  double* W = work.p;
+  K.yr = W; K.yi = W + chunk * m; K.zr = W + 2 * chunk * m; K.zi = W + 3 * chunk * m; K.tr = W + 4 * chunk * m;
+  K.ti = W + 5 * chunk * m; K.y2r = W + 6 * chunk * m; K.y2i = W + 7 * chunk * m; K.z2r = W + 8 * chunk * m;
+  K.z2i = W + 9 * chunk * m;
+  K.s = sc.p;
+  K.err = sc.p + chunk;
+  return HPX_OK;
+}
+
 }  // namespace
 
 extern "C" int hpx_sqrtm_hpd_batched(int nb, int n, const double* a, double* sq, double* isq, double tol,
@@ -99,54 +255,88 @@ extern "C" int hpx_sqrtm_hpd_batched(int nb, int n, const double* a, double* sq,
   HPX_REQUIRE(tol > 0 && max_iter > 0, "hpx_sqrtm_hpd_batched: need tol > 0 and max_iter > 0");
   hipStream_t st = (hipStream_t)stream;
   const long m = (long)n * n;
-  const int chunk = nb < 256 ? nb : 256;       // 5 planar work matrices per system: 80 n^2 bytes each
+  const int chunk = nb < 256 ? nb : 256;
   hpx_devbuf work, sc;
-  HPX_TRY(work.alloc((size_t)chunk * m * 10));
-  HPX_TRY(sc.alloc((size_t)chunk * 2));
-  double* W = work.p;
-  double *yr = W, *yi = W + chunk * m, *zr = W + 2 * chunk * m, *zi = W + 3 * chunk * m, *tr = W + 4 * chunk * m,
-         *ti = W + 5 * chunk * m, *y2r = W + 6 * chunk * m, *y2i = W + 7 * chunk * m, *z2r = W + 8 * chunk * m,
-         *z2i = W + 9 * chunk * m;
-  double* s = sc.p;
-  double* err = s + chunk;
+  NsWork K;
+  HPX_TRY(ns_alloc(work, sc, chunk, m, K));
   std::vector<double> herr(chunk);
   int worst_iters = 0;
   for (int b0 = 0; b0 < nb; b0 += chunk) {
     const int nc = (nb - b0 < chunk) ? nb - b0 : chunk;
-    const double* ab = a + (long)b0 * m * 2;
-    hipLaunchKernelGGL(k_ns_norm, dim3(nc), dim3(256), 0, st, ab, s, n);
-    hipLaunchKernelGGL(k_ns_init, dim3(64, nc), dim3(256), 0, st, ab, s, yr, yi, zr, zi, n);
-    HPX_HIP(hipGetLastError());
     int it = 0;
-    bool done = false;
-    while (!done && it < max_iter) {
-      // T = Z Y  (the kernel forms W^H in with W = the stored matrix: Z is Hermitian)
-      HPX_TRY(hpx_launch_dft(nc, n, n, zr, zi, 1, yr, yi, m, n, nullptr, 0, tr, ti, m, n, 1.0, st, 0, m));
-      HPX_HIP(hipMemsetAsync(err, 0, (size_t)nc * sizeof(double), st));
-      hipLaunchKernelGGL(k_ns_resid, dim3(64, nc), dim3(256), 0, st, tr, ti, err, n);       // T <- R = (3 I - T) / 2
-      HPX_HIP(hipGetLastError());
-      HPX_TRY(hpx_launch_dft(nc, n, n, tr, ti, 1, yr, yi, m, n, nullptr, 0, y2r, y2i, m, n, 1.0, st, 0, m));   // Y' = R Y
-      HPX_TRY(hpx_launch_dft(nc, n, n, tr, ti, 1, zr, zi, m, n, nullptr, 0, z2r, z2i, m, n, 1.0, st, 0, m));   // Z' = R Z
-      std::swap(yr, y2r); std::swap(yi, y2i); std::swap(zr, z2r); std::swap(zi, z2i);
-      ++it;
-      // the residual measured at the START of this step: the step just taken squares it
-      HPX_HIP(hipMemcpyAsync(herr.data(), err, (size_t)nc * sizeof(double), hipMemcpyDeviceToHost, st));
-      HPX_HIP(hipStreamSynchronize(st));
-      double worst = 0.0;
-      for (int b = 0; b < nc; ++b) worst = herr[b] > worst ? herr[b] : worst;
-      if (!(worst == worst)) {
-        hpx_set_error("hpx_sqrtm_hpd_batched: the iteration diverged (a matrix is not positive definite?)");
-        return HPX_EINVAL;
-      }
-      done = sqrt(worst) < tol * n;       // || I - Z Y ||_F below tol * n before the step: below (tol n)^2 after it
-    }
-    if (!done) {
-      hpx_set_error("hpx_sqrtm_hpd_batched: no convergence in %d iterations", max_iter);
-      return HPX_EINVAL;
-    }
+    HPX_TRY(ns_iterate(nc, n, a + (long)b0 * m * 2, K, tol, max_iter, herr, &it, st));
     worst_iters = it > worst_iters ? it : worst_iters;
-    if (sq) hipLaunchKernelGGL(k_ns_out, dim3(64, nc), dim3(256), 0, st, yr, yi, s, 0, sq + (long)b0 * m * 2, n);
-    if (isq) hipLaunchKernelGGL(k_ns_out, dim3(64, nc), dim3(256), 0, st, zr, zi, s, 1, isq + (long)b0 * m * 2, n);
+    if (sq) hipLaunchKernelGGL(k_ns_out, dim3(64, nc), dim3(256), 0, st, K.yr, K.yi, K.s, 0, sq + (long)b0 * m * 2, n);
+    if (isq) hipLaunchKernelGGL(k_ns_out, dim3(64, nc), dim3(256), 0, st, K.zr, K.zi, K.s, 1, isq + (long)b0 * m * 2, n);
+    HPX_HIP(hipGetLastError());
+    HPX_HIP(hipStreamSynchronize(st));
+  }
+  if (iters_out) *iters_out = worst_iters;
+  return HPX_OK;
+}
+
+// sqrtm(Ninv diag(w)) for nb Hermitian positive-definite Ninv (a: (nb | 1, n, n) c128; shared != 0: one matrix for
+// all) and channel masks w (nb, n) u8 (1 = use): with the unflagged channels u first,
+// Ninv diag(w) = P [[A, 0], [B, 0]] P^T  ->  P [[A^1/2, 0], [B A^-1/2, 0]] P^T.  Everything on the device, in chunks
+// of at most 256 systems: permutation, the A blocks (padded to a common multiple of 16 with mean(diag A) on the
+// diagonal), Newton-Schulz, the product B A^-1/2 on the batched FP64-MFMA GEMM, the scatter back to channel order.
+extern "C" int hpx_sqrtm_masked_batched(int nb, int n, const double* a, int shared, const uint8_t* w, double* out,
+                                        double tol, int max_iter, int* iters_out, void* stream) {
+  HPX_REQUIRE(nb > 0 && n > 0 && a && w && out, "hpx_sqrtm_masked_batched: bad argument");
+  HPX_REQUIRE(tol > 0 && max_iter > 0, "hpx_sqrtm_masked_batched: need tol > 0 and max_iter > 0");
+  hipStream_t st = (hipStream_t)stream;
+  const long a_bs = shared ? 0 : (long)n * n * 2;
+  const int chunk = nb < 256 ? nb : 256;
+  hpx_devbuf ibuf, dbuf;
+  HPX_TRY(ibuf.alloc(((size_t)chunk * (n + 1) + 1) / 2 + 1));        // int32 perm [chunk][n] + nu [chunk]
+  HPX_TRY(dbuf.alloc((size_t)chunk));
+  int32_t* perm = (int32_t*)ibuf.p;
+  int32_t* nu = perm + (size_t)chunk * n;
+  std::vector<int32_t> hnu(chunk);
+  int worst_iters = 0;
+  for (int b0 = 0; b0 < nb; b0 += chunk) {
+    const int nc = (nb - b0 < chunk) ? nb - b0 : chunk;
+    const double* ab = a + (long)b0 * a_bs;
+    hipLaunchKernelGGL(k_sm_order, dim3(nc), dim3(256), 0, st, w + (long)b0 * n, ab, a_bs, perm, nu, dbuf.p, n);
+    HPX_HIP(hipGetLastError());
+    HPX_HIP(hipMemcpyAsync(hnu.data(), nu, (size_t)nc * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    HPX_HIP(hipStreamSynchronize(st));
+    int mx = 0, mn = n;
+    for (int b = 0; b < nc; ++b) { mx = hnu[b] > mx ? hnu[b] : mx; mn = hnu[b] < mn ? hnu[b] : mn; }
+    double* ob = out + (long)b0 * n * n * 2;
+    if (mx == 0) {
+      HPX_HIP(hipMemsetAsync(ob, 0, (size_t)nc * n * n * 2 * sizeof(double), st));
+      continue;
+    }
+    const int npad = ceil16(mx), ncol = ceil16(n);
+    const long m = (long)npad * npad;
+    hpx_devbuf work, sc, abuf, lbuf;
+    NsWork K;
+    HPX_TRY(ns_alloc(work, sc, nc, m, K));
+    HPX_TRY(abuf.alloc((size_t)nc * m * 2));
+    hipLaunchKernelGGL(k_sm_block, dim3(64, nc), dim3(256), 0, st, ab, a_bs, perm, nu, dbuf.p, abuf.p, n, npad);
+    HPX_HIP(hipGetLastError());
+    std::vector<double> herr(nc);
+    int it = 0;
+    HPX_TRY(ns_iterate(nc, npad, abuf.p, K, tol, max_iter, herr, &it, st));
+    worst_iters = it > worst_iters ? it : worst_iters;
+    double *lr = nullptr, *li = nullptr;
+    if (mn < n) {
+      // rows of the flagged channels: (B A^-1/2)^T = (A^-1/2)^T B^T  (the kernel's W^T in form, conjW = 0)
+      HPX_TRY(lbuf.alloc((size_t)nc * npad * ncol * 4));
+      double *inr = lbuf.p, *ini = inr + (size_t)nc * npad * ncol;
+      lr = ini + (size_t)nc * npad * ncol;
+      li = lr + (size_t)nc * npad * ncol;
+      hipLaunchKernelGGL(k_sm_bt, dim3(64, nc), dim3(256), 0, st, ab, a_bs, perm, nu, inr, ini, n, npad, ncol);
+      HPX_HIP(hipGetLastError());
+      HPX_TRY(hpx_launch_dft(nc, npad, ncol, K.zr, K.zi, 0, inr, ini, (long)npad * ncol, ncol, nullptr, 0, lr, li,
+                             (long)npad * ncol, ncol, 1.0, st, 0, m));
+    } else {
+      HPX_TRY(lbuf.alloc(2));          // (never read: no flagged row)
+      lr = lbuf.p;
+      li = lbuf.p;
+    }
+    hipLaunchKernelGGL(k_sm_scatter, dim3(64, nc), dim3(256), 0, st, K.yr, K.yi, lr, li, K.s, perm, nu, ob, n, npad, ncol);
     HPX_HIP(hipGetLastError());
     HPX_HIP(hipStreamSynchronize(st));
   }

@@ -48,6 +48,7 @@ SIGNATURES = {
     "hpx_plan_stage_ms": (_i, [_vp, _vp]),
     "hpx_assemble_K": (_i, [_vp, _vp, _vp, _vp]),
     "hpx_plan_dims": (_i, [_vp, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),
+    "hpx_factor_form": (_i, [_i, _i, _i, C.POINTER(_i)]),
     "hpx_zpotrf_batched": (_i, [_i, _i, _vp, _vp, _vp, _vp]),
     "hpx_zpotrs_batched": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "hpx_dft_batched": (_i, [_i, _i, _i, _vp, _vp, _vp, _i, _vp]),
@@ -68,6 +69,7 @@ SIGNATURES = {
     "hpx_zheev_psd_batched": (_i, [_i, _i, _vp, _vp, _vp, _vp, _vp]),
     "hpx_zheev_psd_order": (_i, [_i]),
     "hpx_sqrtm_hpd_batched": (_i, [_i, _i, _vp, _vp, _vp, C.c_double, _i, _vp, _vp]),
+    "hpx_sqrtm_masked_batched": (_i, [_i, _i, _vp, _i, _vp, _vp, C.c_double, _i, _vp, _vp]),
     "hpx_mfma_probe": (_i, [_vp, _vp, _vp]),
     "hpx_mfma_f64_peak": (_i, [_i, _vp]),
 }

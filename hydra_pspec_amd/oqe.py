@@ -94,45 +94,30 @@ def M_Finv(Fm):
     return np.linalg.inv(Fm)
 
 
-def M_Fhalf(Fm, tol=1e-15, maxit=60):
-    """``inv(sqrtm(F))`` (oqe.py:69-70).  For a Hermitian positive-definite ``F`` the principal inverse
-    square root is the limit of the Denman-Beavers iteration ``Y <- (Y + Z^-1)/2, Z <- (Z + Y^-1)/2``
-    from ``Y = F, Z = I`` (``Z -> F^-1/2``); the inverses run on the GPU's batched Cholesky solver and
-    the averages in ``hpx_lincomb``.  Other matrices fall back to scipy's ``sqrtm``."""
+def M_Fhalf(Fm, tol=1e-9, maxit=80):
+    """``inv(sqrtm(F))`` (oqe.py:69-70).  For a Hermitian positive-definite ``F`` the principal inverse square root
+    comes from ONE library call: the coupled Newton-Schulz iteration of ``hpx_sqrtm_hpd_batched`` (batched FP64-MFMA
+    products, the stop test on the device side of the call) returns it directly.  ``F`` is padded to a multiple of 16
+    with its mean diagonal value.  Other matrices -- and any result that is not a solution to 1e-6 -- fall back to
+    scipy's ``sqrtm``."""
     if _is_hpd_candidate(Fm):
         torch, dev = _dev()
-        s = np.shape(Fm)[0]
-        L = hpx.lib()
-        st = hpx.stream_ptr(torch)
-        Y = _c128(torch, dev, np.asarray(Fm)[None])
-        scale = float(np.trace(np.asarray(Fm)).real) / s          # F / scale has unit-order eigenvalues
-        Y = (Y / scale).contiguous()
-        Z = torch.eye(s, dtype=torch.complex128, device=dev)[None].contiguous()
-        ok, converged, last = True, False, np.inf
-        for _ in range(maxit):
-            Yi, Zi = _device_inverse(torch, dev, Y), _device_inverse(torch, dev, Z)
-            if Yi is None or Zi is None:
-                ok = False
-                break
-            Yn, Zn = torch.empty_like(Y), torch.empty_like(Z)
-            n = 2 * s * s
-            hpx.check(L.hpx_lincomb(n, 0.5, hpx.ptr(Y), 0.5, hpx.ptr(Zi), hpx.ptr(Yn), st), "hpx_lincomb")
-            hpx.check(L.hpx_lincomb(n, 0.5, hpx.ptr(Z), 0.5, hpx.ptr(Yi), hpx.ptr(Zn), st), "hpx_lincomb")
-            delta = float((Zn - Z).abs().max() / Zn.abs().max())
-            Y, Z = Yn, Zn
-            if delta < tol:
-                converged = True
-                break
-            if not np.isfinite(delta) or (delta > 1e-3 and delta > 4.0 * last):
-                break                 # the iteration is not stable for very ill-conditioned F: it has started to diverge
-            last = delta
-        if ok:
-            out = (Z[0] / np.sqrt(scale)).cpu().numpy()
-            # accept only a solution: Z F Z = I to rounding x condition (one host product; the iteration's
-            # own stopping test cannot tell a stagnated run from a converged one)
-            Fh = np.asarray(Fm, dtype=complex)
+        Fh = np.asarray(Fm, dtype=complex)
+        s = Fh.shape[0]
+        npad = 16 * ((s + 15) // 16)
+        A = np.zeros((1, npad, npad), dtype=complex)
+        A[0, :s, :s] = Fh
+        if npad > s:
+            A[0, np.arange(s, npad), np.arange(s, npad)] = float(np.trace(Fh).real) / s
+        d_A = _c128(torch, dev, A)
+        d_Z = torch.empty_like(d_A)
+        rc = hpx.lib().hpx_sqrtm_hpd_batched(1, npad, hpx.ptr(d_A), None, hpx.ptr(d_Z), float(tol), int(maxit), None,
+                                             hpx.stream_ptr(torch))
+        if rc == hpx.HPX_OK:
+            out = d_Z[0, :s, :s].cpu().numpy()
+            # accept only a solution: Z F Z = I to rounding x condition (one host product)
             resid = np.abs(out @ Fh @ out - np.eye(s)).max()
-            if (converged or resid < 1e-9) and np.isfinite(resid) and resid < 1e-6:
+            if np.isfinite(resid) and resid < 1e-6:
                 return out.real.copy() if np.isrealobj(Fm) else out
     return np.linalg.inv(scipy.linalg.sqrtm(Fm))
 

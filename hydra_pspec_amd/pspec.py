@@ -24,7 +24,7 @@ import scipy.special
 
 from . import hpx, utils
 
-GCR_SEED0 = 912983          # reference pspec.py:153 (multiprocess_seed, never overridden)
+GCR_SEED0 = 912983          # reference pspec.py:153 (multiprocess_seed's default)
 NGRID = 1000                # reference pspec.py:11 (ngrid default)
 FOURIER_FORM_TOL = 1e-9     # relative off-diagonal power allowed in F S F^H
 
@@ -94,47 +94,44 @@ def sqrtm_hermitian(A):
 
 
 def sqrtm_masked_device(torch, nd, w, device, tol=1e-7, max_iter=60):
-    """``sqrtm(Ninv diag(w))`` for a stack of Hermitian positive-definite ``Ninv`` (K,N,N) and channel masks ``w``
-    (K,N) bool (True = use), on the device: what the reference gets from ``scipy.linalg.sqrtm(Ni)`` per baseline
-    (pspec.py:361-362).  With the unflagged channels ``u`` first, ``Ni = [[A, 0], [B, 0]]`` with ``A = Ninv[u, u]``
-    Hermitian positive definite, and the principal root is ``[[A^1/2, 0], [B A^-1/2, 0]]``: one call of
-    ``hpx_sqrtm_hpd_batched`` (Newton-Schulz on the batched FP64-MFMA product) on the ``A`` blocks -- each padded with
-    an identity block to a common multiple of 16 -- gives both factors.  Returns a (K,N,N) complex128 device tensor."""
+    """``sqrtm(Ninv diag(w))`` for a stack of Hermitian positive-definite ``Ninv`` (K,N,N) -- or one (N,N) matrix shared
+    by all -- and channel masks ``w`` (K,N) bool (True = use), on the device: what the reference gets from
+    ``scipy.linalg.sqrtm(Ni)`` per baseline (pspec.py:361-362).  With the unflagged channels ``u`` first,
+    ``Ni = [[A, 0], [B, 0]]`` with ``A = Ninv[u, u]`` Hermitian positive definite, and the principal root is
+    ``[[A^1/2, 0], [B A^-1/2, 0]]``.  One library call (``hpx_sqrtm_masked_batched``: permutation, Newton-Schulz on
+    the ``A`` blocks, ``B A^-1/2`` and the scatter back are kernels of this repository, 256 systems at a time); a
+    matrix the iteration does not converge for (ill-conditioned beyond ``max_iter`` steps, or only positive
+    SEMI-definite) falls back to the host's eigendecomposition for the whole call.
+    Returns a (K,N,N) complex128 device tensor."""
     c128 = torch.complex128
     nd = nd if hasattr(nd, "device") and not isinstance(nd, np.ndarray) else hpx.to_dev(torch, np.ascontiguousarray(nd), c128, device)
-    K, N = int(nd.shape[0]), int(nd.shape[-1])
-    w_t = torch.as_tensor(np.ascontiguousarray(w), device=device).reshape(K, N).bool()
-    nu = w_t.sum(dim=1)
-    npad = 16 * ((int(nu.max().item()) + 15) // 16)
-    if npad == 0:
-        return torch.zeros_like(nd)
-    # unflagged channels first (stable), one permutation per matrix
-    order = torch.argsort((~w_t).to(torch.int8), dim=1, stable=True)                 # (K,N)
-    P = nd.gather(1, order[:, :, None].expand(K, N, N)).gather(2, order[:, None, :].expand(K, N, N))
-    A = torch.zeros((K, npad, npad), dtype=c128, device=device)
-    m = min(npad, N)
-    A[:, :m, :m] = P[:, :m, :m]
-    inside = (torch.arange(npad, device=device)[None, :] < nu[:, None])              # (K,npad): a column of A's block
-    blockmask = inside[:, :, None] & inside[:, None, :]
-    A = torch.where(blockmask, A, torch.zeros((), dtype=c128, device=device))
-    A = A + torch.diag_embed((~inside).to(c128))                                       # identity on the padding
-    A = A.contiguous()
-    sq, isq = torch.empty_like(A), torch.empty_like(A)
-    hpx.check(hpx.lib().hpx_sqrtm_hpd_batched(K, npad, hpx.ptr(A), hpx.ptr(sq), hpx.ptr(isq), float(tol), int(max_iter),
-                                              None, hpx.stream_ptr(torch)), "hpx_sqrtm_hpd_batched")
-    R = torch.zeros((K, N, N), dtype=c128, device=device)
-    R[:, :m, :m] = torch.where(blockmask[:, :m, :m], sq[:, :m, :m], torch.zeros((), dtype=c128, device=device))
-    if bool((nu < N).any()):
-        # rows of the flagged channels: B A^-1/2 with B = (permuted Ninv)[f, u]
-        Bfull = torch.zeros((K, N, npad), dtype=c128, device=device)
-        Bfull[:, :, :m] = P[:, :, :m]
-        rows_f = (torch.arange(N, device=device)[None, :] >= nu[:, None])           # (K,N)
-        Bfull = torch.where(rows_f[:, :, None] & inside[:, None, :], Bfull, torch.zeros((), dtype=c128, device=device))
-        low = torch.matmul(Bfull, torch.where(blockmask, isq, torch.zeros((), dtype=c128, device=device)))   # (K,N,npad)
-        R[:, :, :m] = R[:, :, :m] + low[:, :, :m]
-    # back to channel order
-    inv = torch.argsort(order, dim=1)
-    return R.gather(1, inv[:, :, None].expand(K, N, N)).gather(2, inv[:, None, :].expand(K, N, N)).contiguous()
+    w_np = np.ascontiguousarray(np.asarray(w).astype(bool))
+    K, N = int(w_np.shape[0]), int(nd.shape[-1])
+    shared = nd.dim() == 2
+    assert shared or int(nd.shape[0]) == K
+    nd = nd.contiguous()
+    d_w = hpx.to_dev(torch, w_np.astype(np.uint8), torch.uint8, device)
+    out = torch.empty((K, N, N), dtype=c128, device=device)
+    rc = hpx.lib().hpx_sqrtm_masked_batched(K, N, hpx.ptr(nd), int(shared), hpx.ptr(d_w), hpx.ptr(out), float(tol),
+                                            int(max_iter), None, hpx.stream_ptr(torch))
+    if rc == hpx.HPX_EINVAL and "sqrtm" in hpx.last_error():
+        # not converged / not positive definite: the exact route on the host (eigh of the unflagged block)
+        full = nd.cpu().numpy()
+        host = np.zeros((K, N, N), dtype=complex)
+        for k in range(K):
+            A = full if shared else full[k]
+            u, f = np.where(w_np[k])[0], np.where(~w_np[k])[0]
+            if len(u) == 0:
+                continue
+            lam, V = np.linalg.eigh(0.5 * (A[np.ix_(u, u)] + A[np.ix_(u, u)].conj().T))
+            if lam.min() <= 0:
+                raise FloatingPointError("the inverse noise covariance is not positive definite on the unflagged channels")
+            host[k][np.ix_(u, u)] = (V * np.sqrt(lam)) @ V.conj().T
+            if len(f):
+                host[k][np.ix_(f, u)] = A[np.ix_(f, u)] @ ((V / np.sqrt(lam)) @ V.conj().T)
+        return hpx.to_dev(torch, host, c128, device)
+    hpx.check(rc, "hpx_sqrtm_masked_batched")
+    return out
 
 
 def _ninv_dense(Ninv, nbl, N):
@@ -306,8 +303,7 @@ class GibbsBatch:
                     # the reference masks the COLUMNS of Ninv (Ni = flags.T * Ninv * flags, pspec.py:361) and takes
                     # scipy's sqrtm of that general matrix (:362): the same principal root, on the device
                     w = fl_np.astype(bool)
-                    full = d_nd if nd.ndim == 3 else d_nd[None].expand(nbl, N, N)
-                    d_nh = sqrtm_masked_device(torch, full, w, self.device)
+                    d_nh = sqrtm_masked_device(torch, d_nd, w, self.device)
                     extra_rhs = int((~w).sum(axis=1).max())        # one more right-hand side per flagged channel
                 else:
                     d_nh = sqrtm_masked_device(torch, d_nd.reshape(-1, N, N), np.ones((d_nd.numel() // (N * N), N), bool),
@@ -483,9 +479,6 @@ class GibbsBatch:
         torch = self.torch
         nbl, T, N, M = self.nbl, self.T, self.N, self.M
         assert self.iter_done == 0, "a general starting covariance only makes sense for iteration 0"
-        if self.per_time and self.dense_noise:
-            raise NotImplementedError("a full noise matrix per time needs an initial covariance of the form "
-                                      "F^H diag(ps) F")
         with torch.cuda.device(self.device):
             f64, c128, dev = torch.float64, torch.complex128, self.device
             d_shp = hpx.to_dev(torch, shp0, c128, dev)
@@ -733,14 +726,14 @@ def _hermitian_completion(Ni, fl):
     return H
 
 
-def _gcr_solve(vis2d, w, matrices, fgmodes, map_estimate, idx):
+def _gcr_solve(vis2d, w, matrices, fgmodes, map_estimate, idx, seed0=GCR_SEED0):
     """Constrained realisations [s_t ; f_t] for the rows of ``vis2d`` on the GPU, with the
-    reference's per-time noise streams for time indices ``idx``."""
+    reference's per-time noise streams (seeded ``seed0 + t``) for time indices ``idx``."""
     vis2d = np.asarray(vis2d, dtype=complex)
     if vis2d.shape[0] == 1:      # a plan holds at least two times (the draw's shape is Ntimes - 1)
         idx = [0] if idx is None else idx
         return _gcr_solve(np.repeat(vis2d, 2, axis=0), w, matrices, fgmodes, map_estimate,
-                          [idx[0], idx[0]])[:1]
+                          [idx[0], idx[0]], seed0=seed0)[:1]
     T, N = vis2d.shape
     F = np.asarray(fgmodes, dtype=complex)
     M = F.shape[1]
@@ -754,10 +747,11 @@ def _gcr_solve(vis2d, w, matrices, fgmodes, map_estimate, idx):
         # a non-diagonal Ni: the chain's dense-noise path (GibbsBatch(ninv_dense=...): Hermitian noise factorisation
         # + one Woodbury column per flagged channel) on a Hermitian matrix whose unflagged columns are Ni's
         gb = GibbsBatch(vis2d[None], fl[None], F, None, np.zeros((2, N)), 1, map_estimate=map_estimate, tables=tables,
-                        omega=omega_table(T, N, idx=idx), ninv_dense=_hermitian_completion(Ni, fl)[None], solver="dense")
+                        omega=omega_table(T, N, idx=idx, seed0=seed0), ninv_dense=_hermitian_completion(Ni, fl)[None],
+                        solver="dense")
     else:
         gb = GibbsBatch(vis2d[None], fl[None], F, np.ascontiguousarray(ni)[None], np.zeros((2, N)), 1,
-                        map_estimate=map_estimate, tables=tables, omega=omega_table(T, N, idx=idx))
+                        map_estimate=map_estimate, tables=tables, omega=omega_table(T, N, idx=idx, seed0=seed0))
     try:
         if resid > FOURIER_FORM_TOL:
             out = gb.run(1, shp0=sqrt_cov_delay_basis(S)[None], keep=("signal_cr", "fg_amps"))
@@ -772,19 +766,22 @@ def gcr_fgmodes_1d(idx, vis, w, matrices, fgmodes, f0=None, map_estimate=False, 
                    multiprocess_seed=GCR_SEED0):
     """GCR step for one time sample (reference pspec.py:151-235): returns
     ``(xsoln (Nfreqs+Nmodes,), residual, info)``.  The noise realisation is the reference's
-    (stream seeded with ``multiprocess_seed + idx``); the system is solved directly on the GPU,
-    so ``f0`` is accepted and ignored and ``info`` is always 0.  ``residual`` (verbose only) is
+    (stream seeded with ``multiprocess_seed + idx``, any seed: pspec.py:196-197), and like the reference the call
+    leaves numpy's GLOBAL stream seeded with that value and advanced past the four draws; the system is solved
+    directly on the GPU, so ``f0`` is accepted and ignored and ``info`` is always 0.  ``residual`` (verbose only) is
     the mean absolute residual of the reference's own system ``A x = b``."""
     F = np.asarray(fgmodes)
     N = F.shape[0]
     d = np.asarray(vis).reshape(1, N)
-    if multiprocess_seed != GCR_SEED0:
-        raise NotImplementedError("the reference never overrides multiprocess_seed (pspec.py:289-298)")
-    x = _gcr_solve(d, w, matrices, fgmodes, map_estimate, [idx])[0]
+    seed0 = int(multiprocess_seed)
+    x = _gcr_solve(d, w, matrices, fgmodes, map_estimate, [idx], seed0=seed0)[0]
+    np.random.seed(seed0 + int(idx))           # the reference's side effect on the global stream (pspec.py:196-216)
+    if not map_estimate:
+        np.random.randn(4, N)
     residual = None
     if verbose:
         Sh, S, Ni, Nih, A = matrices[0][0], matrices[0][1], matrices[0][2], matrices[0][3], matrices[1][0]
-        o = np.zeros((4, N)) if map_estimate else omega_table(1, N, idx=[idx])[0]
+        o = np.zeros((4, N)) if map_estimate else omega_table(1, N, idx=[idx], seed0=seed0)[0]
         oma, omb = (o[0] + 1j * o[1]) / 2 ** 0.5, (o[2] + 1j * o[3]) / 2 ** 0.5
         wd = (np.asarray(w).reshape(-1) * d[0])
         b = np.concatenate([S @ (Ni @ wd) + Sh @ oma + S @ (Nih @ omb),

@@ -183,8 +183,8 @@ int hpx_gibbs_run(hpx_plan* p, const double* ps0, int iter0, int niter,
  * F^H diag(.) F (pspec.py:599 accepts any matrix): the caller supplies
  * Sh' = U^H sqrtm(S_initial) U, (nbl,N,N) c128.  Runs exactly one iteration
  * (table row iter0) with outputs as hpx_gibbs_run(niter=1).  Also for plans with time-dependent flags /
- * diagonal noise (one explicit system per baseline and time; pspec.py:442 accepts any matrix there too); not for
- * a full noise matrix per time. */
+ * noise, diagonal or a full matrix per time (one explicit system per baseline and time; pspec.py:442 accepts any
+ * matrix there too). */
 int hpx_gibbs_step_general(hpx_plan* p, const double* shp, int iter0,
                            double* ps_out, double* lnpost_out, double* cr_out,
                            double* fg_out, double* chisq_out, double* ps_last,
@@ -275,6 +275,12 @@ int hpx_zpotrf_batched(int nb, int n, const double* a, double* l_out, int32_t* i
 int hpx_zpotrs_batched(int nb, int n, int nrhs, const double* a, const double* b,
                        double* x_out, int32_t* info, void* stream);
 
+/* Which of the three forms of the batched factorisation a batch of nb systems of order n with nrhs right-hand
+ * sides takes on the current device when nothing else runs there (diagnostic; bench.py names the kernel it prices
+ * with it): 0 = the 32-wide kernel (k_factor), 1 = the wide kernel (k_factor_wide, 128-column super-blocks, from
+ * order 400 on), 2 = the split kernel (k_factor_split: *parts co-operating workgroups per system; small batches). */
+int hpx_factor_form(int nb, int n, int nrhs, int* parts);
+
 /* Batched centred DFT along the channel axis: out[b,t,:] = F in[b,t,:]
  * (inverse!=0: F^H in / N), (nb,T,N) c128.  fop as in hpx_plan_set_static.
  * Replaces sample_S's fftshift(fft(ifftshift())) (pspec.py:92-95) and
@@ -340,8 +346,8 @@ int hpx_oqe_mopt(int nb, int s, const double* F, double* M_out, void* stream);
 /* beta[b][k] = sum_t |sk[b][t][k]|^2: the statistic of the bandpower draw (sample_S, pspec.py:96-100);
  * sk (nb,T,N) c128 -> out (nb,N) f64. */
 int hpx_power_sum(int nb, int T, int N, const double* sk, double* out, void* stream);
-/* out = a x + b y over n doubles (the averaging step of the inverse-square-root iteration behind
- * oqe.M_Fhalf, whose inverses run on hpx_zpotrs_batched). */
+/* out = a x + b y over n doubles (a utility for callers that iterate on device matrices; oqe.M_Fhalf itself
+ * is one call of hpx_sqrtm_hpd_batched since round 5). */
 int hpx_lincomb(int64_t n, double a, const double* x, double b, const double* y, double* out,
                 void* stream);
 
@@ -378,10 +384,21 @@ int hpx_zheev_psd_order(int n0);
  * correlated-noise paths: replaces the per-baseline host calls scipy.linalg.sqrtm(Ni) / eigh of reference
  * pspec.py:361-362 (for flagged channels through Ni = P [[A, 0], [B, 0]] P^T -> P [[A^1/2, 0], [B A^-1/2, 0]] P^T).
  * a (nb,n,n) c128 row-major, n a multiple of 16 (pad with an identity block); sq, isq (nb,n,n) c128, either may be
- * NULL; stops when ||I - Z Y||_F < tol * n (tol ~ 1e-7: the step taken after that squares it), HPX_EINVAL if that
+ * NULL; stops when ||I - Z Y||_F < tol * n (tol ~ 1e-7: the step taken after that squares it, and one more
+ * polishing step follows), HPX_EINVAL if that
  * takes more than max_iter steps or a matrix is not positive definite; iters_out (host int, optional). */
 int hpx_sqrtm_hpd_batched(int nb, int n, const double* a, double* sq, double* isq, double tol,
                           int max_iter, int* iters_out, void* stream);
+/* The reference's sqrtm(Ni) of the column-masked Ni = Ninv diag(w) (pspec.py:361-362), for nb Hermitian
+ * positive-definite Ninv and channel masks, entirely on the device: with the unflagged channels u first
+ * Ni = P [[A, 0], [B, 0]] P^T has the principal root P [[A^1/2, 0], [B A^-1/2, 0]] P^T.
+ *   a (nb | 1, n, n) c128   Ninv (shared != 0: one matrix for all systems)
+ *   w (nb, n) u8            1 = use the channel, 0 = flagged
+ *   out (nb, n, n) c128     the root, in channel order
+ * Works in chunks of at most 256 systems (workspace 100 n^2 bytes per system of a chunk); tol / max_iter /
+ * iters_out as in hpx_sqrtm_hpd_batched. */
+int hpx_sqrtm_masked_batched(int nb, int n, const double* a, int shared, const uint8_t* w, double* out,
+                             double tol, int max_iter, int* iters_out, void* stream);
 
 /* Empirical lane map of v_mfma_f64_16x16x4_f64 (diagnostic used by the tests):
  * computes D = A(16x4) * B(4x16) and writes, for lane l and register v, the

@@ -112,14 +112,26 @@ def any_time_unflagged(w):
     return np.all(w, axis=0)
 
 
+def _parent_start_ticks():
+    """Start time of the parent process (clock ticks since boot, /proc/<ppid>/stat field 22): with its pid it names
+    ONE launch -- the ranks of a launch are children of one agent (torchrun) or one spawning process, a later launch
+    has another parent or another start time."""
+    try:
+        with open(f"/proc/{os.getppid()}/stat") as f:
+            return f.read().rsplit(")", 1)[1].split()[19]
+    except (OSError, IndexError):
+        return "0"
+
+
 def launch_token():
     """What the ranks of ONE launch have in common (and an earlier launch does not): names the files they
-    meet through.  torchrun exports TORCHELASTIC_RUN_ID / MASTER_PORT; plain `RANK=.. WORLD_SIZE=..` launches of
-    one parent share its pid."""
+    meet through.  torchrun exports TORCHELASTIC_RUN_ID / MASTER_PORT (both repeat from launch to launch: the parent's
+    pid and start time are appended); plain `RANK=.. WORLD_SIZE=..` launches of one parent share its pid."""
+    tail = f"pp{os.getppid()}-{_parent_start_ticks()}"
     for k in ("HYDRA_PSPEC_RUN_ID", "TORCHELASTIC_RUN_ID", "MASTER_PORT"):
         if os.environ.get(k):
-            return f"{k.lower()}-{os.environ[k]}"
-    return f"ppid-{os.getppid()}"
+            return f"{k.lower()}-{os.environ[k]}-{tail}"
+    return tail
 
 
 def write_json_atomic(path, obj):
@@ -318,15 +330,22 @@ def main(argv=None):
             write_json_atomic(marker, {"created": time.time(), "old_args": old_args, "nonce": nonce})
     else:
         met = wait_for_file(marker, t_launch - 300.0, what="rank 0 to prepare the output tree")
+        # A marker of an earlier launch with the same token (one shell starting the ranks by hand, twice) may still
+        # lie there for the instant before rank 0 removes it: read again a moment later and take what is there then
+        time.sleep(0.3)
+        met = wait_for_file(marker, t_launch - 300.0, what="rank 0 to prepare the output tree")
         old_args, nonce = met["old_args"], met.get("nonce")
 
     # ---- sampling -----------------------------------------------------------------------
     try:
         return sample_and_write(args, rank, world, local_rank, results, marker, nonce, old_args, locals())
-    except SystemExit as e:
+    except BaseException as e:      # SystemExit, and what the library raises (FloatingPointError, RuntimeError, ...)
         if rank > 0:        # rank 0 waits for this rank's timings file: tell it not to
-            write_json_atomic(results / f".timings-{rank}.json",
-                              {"created": time.time(), "nonce": nonce, "rank": rank, "failed": str(e)})
+            try:
+                write_json_atomic(results / f".timings-{rank}.json",
+                                  {"created": time.time(), "nonce": nonce, "rank": rank, "failed": repr(e)})
+            except OSError:
+                pass
         raise
 
 
@@ -393,8 +412,12 @@ def sample_and_write(args, rank, world, local_rank, results, marker, nonce, old_
     Ninv_arg = ninv if ninv_dense is None else ninv_dense
     gb = None
     if not args.dry_run:
+        # Several ranks: never the split factorisation.  Its order of operations depends on the size of the batch, so a
+        # baseline's chain would depend (in the last bits) on how many ranks the baselines were dealt to -- a --resume
+        # with another Nproc must continue the very same chain -- and ranks that share a GPU (rehearsals, more ranks
+        # than devices) could starve each other's co-operating workgroups (hpx.h, HPX_OPT_FACTOR_SPLIT).
         gb = pspec.make_batch(vis, flags_any if flags_pt is None else flags_pt, fg, Ninv_arg, ps_prior, Niter,
-                              seed=args.seed, map_estimate=args.map_estimate)
+                              seed=args.seed, map_estimate=args.map_estimate, allow_split=(world == 1))
     fop = utils.fourier_operator(N)
     write_times, ant_strs = [0.0] * nbl, [f"{ap[0]}_{ap[1]}" for ap in antpairs]
 

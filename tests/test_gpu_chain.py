@@ -270,6 +270,16 @@ def test_build_matrices_and_gcr_vs_reference(golden, tag):
     smp = pspec.gcr_fgmodes(vis * fl, fl, [ops, sys_], F, nproc=3)
     assert smp.shape == (vis.shape[0], 19)
     assert relerr(smp[0], xs[0]) < RTOL and relerr(smp[3], xs[1]) < RTOL
+    # any multiprocess_seed (reference pspec.py:153, :196-197): against the oracle's exact solve with the same seed; and
+    # like the reference the call leaves numpy's global stream seeded with seed + idx and advanced past the four draws
+    from oracle import pspec_ref
+    x, _, _ = pspec.gcr_fgmodes_1d(2, (vis * fl)[2], fl, mats, F, multiprocess_seed=4242)
+    after = np.random.random_sample(3)
+    xr, _, _ = pspec_ref.gcr_fgmodes_1d(2, (vis * fl)[2], fl, [ops, sys_], F, multiprocess_seed=4242, solver="direct")
+    assert np.array_equal(after, np.random.random_sample(3))
+    assert relerr(x, xr) < RTOL
+    x0, _, _ = pspec.gcr_fgmodes_1d(2, (vis * fl)[2], fl, mats, F)
+    assert relerr(x, x0) > 1e-5          # (another noise realisation)
 
 
 @pytest.mark.parametrize("flagged", [False, True])
