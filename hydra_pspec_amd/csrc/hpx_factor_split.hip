@@ -190,7 +190,7 @@ __global__ __launch_bounds__(64 * SPLIT_NW, 2) void k_factor_split(double* __res
       const int r = w + s * parts;
       e1[s] = (d4){0., 0., 0., 0.};
       e2[s] = e1[s];
-      if (r < X.nct) tile_init<GEN, false>(G, V, X.Lb, r * 16, r * 16, npad, li, g, e1[s], e2[s]);
+      if (r < X.nct) tile_init<GEN, false, true>(G, V, X.Lb, r * 16, r * 16, npad, li, g, e1[s], e2[s]);
     }
     agree();
     // E: diagonal tile t, fully updated -> L_tt, inv(L_tt) (Vt, Vs), W; then flag A[t]
@@ -290,7 +290,7 @@ __global__ __launch_bounds__(64 * SPLIT_NW, 2) void k_factor_split(double* __res
         if (r < X.nrt) {
           tr[s] = r;
           tc[s] = c;
-          tile_init<GEN, false>(G, V, X.Lb, r * 16, c * 16, npad, li, g, a1[s], a2[s]);
+          tile_init<GEN, false, true>(G, V, X.Lb, r * 16, c * 16, npad, li, g, a1[s], a2[s]);
           c += NWK;
           __builtin_amdgcn_sched_barrier(0);
         } else {

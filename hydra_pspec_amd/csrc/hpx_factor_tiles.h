@@ -199,7 +199,10 @@ __device__ HPX_INL void tile_init_closed(const GenVec<GLDS>& V, const int r0, co
 }
 // the 16 x 16 tile at (r0, c0), r0 >= c0, as acc^T: lane li <-> row r0 + li, register v <-> column c0 + g + 4 v.
 // rmin is a multiple of 32, so a tile lies on one side of it and the source is chosen per tile.
-template <bool GEN, bool GLDS>
+// TAILGEN (with GEN): the tiles of the last columns (c0 >= rmin: foreground x foreground block, identity padding, their
+// right-hand sides) are generated here too, entry by entry (hpx_gen_entry -- what k_assemble_tail lays out for the
+// other forms): the split form then needs no assembly launch in front of it.
+template <bool GEN, bool GLDS, bool TAILGEN = false>
 __device__ HPX_INL void tile_init(const hpx_gen& G, const GenVec<GLDS>& V, const double* __restrict__ Lb, const int r0,
                                   const int c0, const int npad, const int li, const int g, d4& vr, d4& vi) {
   if (GEN && c0 < G.rmin) {
@@ -270,6 +273,14 @@ __device__ HPX_INL void tile_init(const hpx_gen& G, const GenVec<GLDS>& V, const
         vr[v] = a;
         vi[v] = b;
       }
+    }
+  } else if (GEN && TAILGEN) {
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      double a, b;
+      hpx_gen_entry(G, r0 + li, c0 + HPX_ACC_ROW(g, v), npad, a, b);
+      vr[v] = a;
+      vi[v] = b;
     }
   } else {
 #pragma unroll

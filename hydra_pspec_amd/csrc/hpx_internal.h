@@ -106,8 +106,8 @@ struct hpx_plan {
   double *beta, *betam;    // [nbl][N]
   double *bpart, *lnpart;  // [nbl][HPX_NPART][N], [nbl][HPX_NPART]: partial sums of the residual kernel
   double *lnp1;            // [nbl]
-  double *lnblk;           // [nbl][ceil(N / 64)]: the draw kernel's ln-posterior sums by blocks of 64 channels
-  unsigned *dcount;        // [nbl]: slices of k_draw that have finished (wraps to zero)
+  double *lnhist;          // sliced k_draw (small batches): [niter_tab][nbl][ceil(N / 16) + 1] group sums per iteration
+  int draw_slices;         // workgroups per baseline of k_draw (hpx_plan_set_rng)
   // invariants
   double *Rre, *Rim;       // [nbl][NP][ncolR]
   double *Cre, *Cim;       // [nbl][N] generator of the circulant C = U^H Ni U

@@ -1,0 +1,931 @@
+// Everything after the solve: back transform, model, residual, chi^2, ln posterior, the inverse-gamma bandpower
+// draw (k_resid, k_fft_resid, k_dft_resid, k_betam, k_draw) and their launcher.
+#include "hpx_chain.h"
+#include "hpx_fft.h"
+
+namespace {
+
+// lnpart[b][0] = sum_{x,t} Re( conj(r[x][t]) v[x][t] )  (r^H Ninv r summed over the times; v = Ninv r)
+__global__ __launch_bounds__(256) void k_quadform(const double* __restrict__ rre, const double* __restrict__ rim,
+                                                  const long r_bs, const int ld_r, const double* __restrict__ vre,
+                                                  const double* __restrict__ vim, const long v_bs, const int ld_v,
+                                                  double* __restrict__ lnpart, const int N, const int T) {
+  __shared__ double red[4];
+  const int b = blockIdx.x;
+  double acc = 0.0;
+  for (int e = threadIdx.x; e < N * T; e += 256) {
+    const int x = e / T, t = e % T;
+    const long o1 = (long)b * r_bs + (long)x * ld_r + t, o2 = (long)b * v_bs + (long)x * ld_v + t;
+    acc += rre[o1] * vre[o2] + rim[o1] * vim[o2];
+  }
+  const double tot = block_sum(acc, red);
+  if (threadIdx.x == 0) lnpart[(long)b * HPX_NPART] = tot;
+}
+
+// ---- residual, chi^2, first part of ln posterior, beta --------------------------
+struct ResArgs {
+  const double *Xre, *Xim, *Sre, *Sim, *Dre, *Dim, *Fre, *Fim, *ninv;
+  const uint8_t* flags;
+  double *bpart, *lnpart, *Gre, *Gim;   // partial sums (HPX_NPART slots per baseline); G: masked
+                                        // signal (only if any_flags)
+  const double *twre, *twim;            // centred Fourier operator (twiddles of the fused kernel)
+  double isn;                           // 1 / sqrt(N)
+  int logN, tcs;                        // fused kernel: log2 N, log2 of the time columns per block
+  double *cr_out, *fg_out, *chisq_out;  // already offset to the slot; may be NULL
+  long cr_bstride, fg_bstride, chisq_bstride;
+  int N, M, T, NP, TP, npad, fg_shared, any_flags;
+  int nbl, npart;                       // fused kernel: batch size, column groups per baseline
+  const uint8_t* flags_t;               // k_resid, per-time mode: [nbl][T][N] flags and inverse noise
+  const double* ninv_t;                 // variances (NULL: the time-independent ones above)
+  double *Rdre, *Rdim;                  // k_resid: where the masked residual w (d - model) goes, or NULL (dense
+                                        // noise: the quadratic form r^H Ninv r over the unflagged channels is
+                                        // taken afterwards).  May be G itself when there are no flags.
+};
+
+__global__ __launch_bounds__(256) void k_resid(const ResArgs A) {
+  extern __shared__ double rl[];      // f_re[M][TP], f_im[M][TP], part[N][TP/16]
+  __shared__ double red[4];
+  // blockIdx.x: one of A.npart slices of the channels (a workgroup per baseline walked N TP / 256 dependent rounds of
+  // loads: 1.1 ms at C5; the slices leave their chi^2 term in their own lnpart slot, k_draw adds the slots)
+  const int b = blockIdx.y, jp = blockIdx.x, tid = threadIdx.x;
+  const int N = A.N, M = A.M, T = A.T, TP = A.TP, TG = TP >> 4;
+  const int xper = N / A.npart, x0 = jp * xper;
+  double* lfr = rl;
+  double* lfi = rl + (long)M * TP;
+  double* part = rl + 2L * M * TP;                     // [xper][TG]
+  const double* xre = A.Xre + (long)b * A.npad * TP;
+  const double* xim = A.Xim + (long)b * A.npad * TP;
+  const double* sre = A.Sre + (long)b * A.NP * TP;
+  const double* sim = A.Sim + (long)b * A.NP * TP;
+  const double* dre = A.Dre + (long)b * A.NP * TP;
+  const double* dim_ = A.Dim + (long)b * A.NP * TP;
+  const double* fre = A.Fre + (A.fg_shared ? 0 : (long)b * N * M);
+  const double* fim = A.Fim + (A.fg_shared ? 0 : (long)b * N * M);
+  const double* ninv = A.ninv + (long)b * N;
+  const uint8_t* fl = A.flags + (long)b * N;
+  for (int e = tid; e < M * TP; e += 256) {          // foreground amplitudes f[m][t]
+    lfr[e] = xre[(long)N * TP + e];
+    lfi[e] = xim[(long)N * TP + e];
+  }
+  __syncthreads();
+  double acc = 0.0;
+  const int tot = (x0 + xper) * TP;                  // multiple of 16; threads of a 16-lane group
+  for (int e0 = x0 * TP; e0 < tot; e0 += 256) {      // share x, so the shuffles stay in range
+    const int e = e0 + tid;
+    const bool in = e < tot;
+    const int x = in ? e / TP : x0, t = in ? e % TP : 0;
+    const long o = (long)x * TP + t;
+    // beta partial: |z_xt|^2 summed over 16 consecutive times
+    double v = 0.0;
+    if (in && t < T) {          // (columns >= T are padding, or the Woodbury columns of the dense-noise-with-flags mode)
+      const double yr = xre[o], yi = xim[o];
+      v = yr * yr + yi * yi;
+    }
+    v += __shfl_xor(v, 8, 16);
+    v += __shfl_xor(v, 4, 16);
+    v += __shfl_xor(v, 2, 16);
+    v += __shfl_xor(v, 1, 16);
+    if (in && (t & 15) == 0) part[(x - x0) * TG + (t >> 4)] = v;
+    if (!in) continue;
+    if (t >= T) {
+      if (A.any_flags) { A.Gre[(long)b * A.NP * TP + o] = 0.0; A.Gim[(long)b * A.NP * TP + o] = 0.0; }
+      if (A.Rdre) { A.Rdre[(long)b * A.NP * TP + o] = 0.0; A.Rdim[(long)b * A.NP * TP + o] = 0.0; }
+      continue;
+    }
+    const double sr = sre[o], si = sim[o];
+    double mr = sr, mi = si;
+    for (int m = 0; m < M; ++m) {
+      const double fr = fre[(long)x * M + m], fi = fim[(long)x * M + m];
+      const double gr = lfr[m * TP + t], gi = lfi[m * TP + t];
+      mr += gr * fr - gi * fi;
+      mi += gr * fi + gi * fr;
+    }
+    const double rr = dre[o] - mr, ri = dim_[o] - mi;
+    const long ot = ((long)b * T + t) * N + x;
+    const double w = (A.flags_t ? A.flags_t[ot] : fl[x]) ? 1.0 : 0.0;
+    const double c2 = (rr * rr + ri * ri) * (A.ninv_t ? A.ninv_t[ot] : ninv[x]);
+    acc += w * c2;
+    if (A.any_flags) {
+      A.Gre[(long)b * A.NP * TP + o] = w * sr;
+      A.Gim[(long)b * A.NP * TP + o] = w * si;
+    }
+    if (A.Rdre) {
+      A.Rdre[(long)b * A.NP * TP + o] = w * rr;
+      A.Rdim[(long)b * A.NP * TP + o] = w * ri;
+    }
+    if (A.cr_out) {
+      double* q = A.cr_out + (long)b * A.cr_bstride + ((long)t * N + x) * 2;
+      q[0] = sr;
+      q[1] = si;
+    }
+    if (A.chisq_out) A.chisq_out[(long)b * A.chisq_bstride + (long)t * N + x] = c2;
+  }
+  if (A.fg_out && jp == 0) {
+    for (int e = tid; e < T * M; e += 256) {
+      const int t = e / M, m = e % M;
+      double* q = A.fg_out + (long)b * A.fg_bstride + (long)e * 2;
+      q[0] = lfr[m * TP + t];
+      q[1] = lfi[m * TP + t];
+    }
+  }
+  const double total = block_sum(acc, red);          // (barrier inside: part[] is complete)
+  // (dense noise: the quadratic form with the full matrix replaces this term afterwards, in slot 0 -- the other
+  // slices' slots must then hold nothing)
+  if (tid == 0) A.lnpart[(long)b * HPX_NPART + jp] = (A.Rdre && jp > 0) ? 0.0 : total;
+  // sum_t |z_kt|^2; k_draw turns it into beta_k = N sum_t |z_kt|^2  ( |F s|^2 with s = U z ): slot 0 for this
+  // slice's channels, nothing in the other slots
+  for (int k = x0 + tid; k < x0 + xper; k += 256) {
+    double sum = 0.0;
+    for (int j = 0; j < TG; ++j) sum += part[(k - x0) * TG + j];
+    A.bpart[(long)b * HPX_NPART * N + k] = sum;
+    for (int j = 1; j < A.npart; ++j) A.bpart[((long)b * HPX_NPART + j) * N + k] = 0.0;
+  }
+}
+
+#ifndef HPX_FR_NT
+#define HPX_FR_NT 0          // bit 0: solution (z) loads non-temporal, bit 1: data loads
+#endif
+// Back transform s = U z and everything k_resid does, in one kernel (N a power of two): the
+// block that holds TC time columns of the signal in LDS after the FFT goes straight on to the
+// model, residual, chi^2 and the optional sample write-back for those columns, so s never goes
+// to HBM and back.  Blocks of one baseline leave their partial sums (|z|^2 per channel, the
+// chi^2 total) in slot blockIdx.x; k_draw adds the slots in a fixed order.
+__global__ __launch_bounds__(256) void k_fft_resid(const ResArgs A) {
+  extern __shared__ double fl[];
+  __shared__ double red[4];
+  const int N = A.N, M = A.M, T = A.T, TP = A.TP, tcs = A.tcs, TC = 1 << tcs, logN = A.logN;
+  // column groups of one baseline on one XCD (they share cache lines of X, D and the outputs);
+  // workgroup ids go round-robin over the 8 XCDs
+  const int b = ((int)(blockIdx.x >> 3) / A.npart) * 8 + (int)(blockIdx.x & 7);
+  if (b >= A.nbl) return;
+  const int cg = (int)(blockIdx.x >> 3) % A.npart;
+  const int c0 = cg * TC, tid = threadIdx.x, h = N >> 1;
+  double* fre = fl;
+  double* fim = fl + ((long)N << tcs);
+  double* tw = fim + ((long)N << tcs);              // N doubles
+  double* lfr = tw + N;                             // f[m][tc]: M * TC
+  double* lfi = lfr + (M << tcs);
+  const double* xre = A.Xre + (long)b * A.npad * TP;
+  const double* xim = A.Xim + (long)b * A.npad * TP;
+  for (int j = tid; j < h; j += 256) {
+    tw[j] = A.twre[(long)(h + 1) * N + h + j];
+    tw[h + j] = A.twim[(long)(h + 1) * N + h + j];
+  }
+  for (int e = tid; e < (M << tcs); e += 256) {
+    const int m = e >> tcs, tc = e & (TC - 1);
+    lfr[e] = xre[(long)(N + m) * TP + c0 + tc];
+    lfi[e] = xim[(long)(N + m) * TP + c0 + tc];
+  }
+  double* bp = A.bpart + ((long)b * HPX_NPART + cg) * N;
+  // loads in batches of 16 per thread, all in flight before the first use (one element at a time
+  // every iteration waits out a memory round trip); N * TC is a multiple of 256
+  {
+    constexpr int UB = 16;
+    const int total = N << tcs;
+    for (int e0 = tid; e0 < total; e0 += 256 * UB) {
+      double zr[UB], zi[UB];
+#pragma unroll
+      for (int u = 0; u < UB; ++u) {
+        const int e = min(e0 + 256 * u, total - 1), k = e >> tcs, tc = e & (TC - 1);
+#if HPX_FR_NT & 1
+        zr[u] = __builtin_nontemporal_load(&xre[(long)k * TP + c0 + tc]);
+        zi[u] = __builtin_nontemporal_load(&xim[(long)k * TP + c0 + tc]);
+#else
+        zr[u] = xre[(long)k * TP + c0 + tc];
+        zi[u] = xim[(long)k * TP + c0 + tc];
+#endif
+      }
+#pragma unroll
+      for (int u = 0; u < UB; ++u) {
+        const int e = e0 + 256 * u;
+        if (e < total) {                                  // uniform over the workgroup
+          const int k = e >> tcs, tc = e & (TC - 1);
+          const double sg = (k & 1) ? -1.0 : 1.0;
+          fre[e] = zr[u] * sg;
+          fim[e] = zi[u] * sg;
+          double v = zr[u] * zr[u] + zi[u] * zi[u];       // sum over this block's time columns
+          for (int o = TC >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+          if (tc == 0) bp[k] = v;
+        }
+      }
+    }
+  }
+  int s = 0;
+  for (; s + 3 <= logN; s += 3) {
+    __syncthreads();
+    fft_pass<3, 1>(fre, fim, tw, N, h, logN, s, tcs, tid);
+  }
+  if (logN - s == 2) {
+    __syncthreads();
+    fft_pass<2, 1>(fre, fim, tw, N, h, logN, s, tcs, tid);
+  } else if (logN - s == 1) {
+    __syncthreads();
+    fft_pass<1, 1>(fre, fim, tw, N, h, logN, s, tcs, tid);
+  }
+  __syncthreads();
+  const double* dre = A.Dre + (long)b * A.NP * TP;
+  const double* dim_ = A.Dim + (long)b * A.NP * TP;
+  const double* fmr = A.Fre + (A.fg_shared ? 0 : (long)b * N * M);
+  const double* fmi = A.Fim + (A.fg_shared ? 0 : (long)b * N * M);
+  const double* ninv = A.ninv + (long)b * N;
+  const uint8_t* fl8 = A.flags + (long)b * N;
+  double acc = 0.0;
+  if (M <= 16) {
+    // Model term F f on the matrix pipe: tiles of 16 channels x the block's time columns, K =
+    // the (padded) mode index.  The accumulator lane (li, g) then holds channels x0 + g + 4v,
+    // column tc = li: the residual is finished from there with a handful of vector ops per
+    // element instead of 8 per mode.
+    const int wave = tid >> 6, lane = tid & 63, li = lane & 15, g = lane >> 4;
+    double bfr[4], bfi[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {                  // B[m = 4 ks + g][tc = li] = f[m][tc]
+      const int m = 4 * ks + g;
+      const bool ok = (m < M) && (li < TC);
+      bfr[ks] = ok ? lfr[(m << tcs) + li] : 0.0;
+      bfi[ks] = ok ? lfi[(m << tcs) + li] : 0.0;
+    }
+    const int t = c0 + li;
+    // Tiles run over channels in NATURAL order, so that everything in global memory (data, mode
+    // rows, noise, outputs) is touched with unit stride; the bit reversal of the FFT output is
+    // undone by the LDS read of s instead.  The global operands of the next tile are requested
+    // before the current one is worked on (two workgroups per CU: nothing else hides them).
+    const int ntile = N >> 4;
+    const int tlast = wave + 4 * ((ntile - 1 - wave) >> 2);       // this wave's last tile
+    const bool tvalid = (li < TC) && (t < T);
+    double nfr[4], nfi[4], ndr[4], ndi[4], nnv[4], nw[4];
+#if HPX_FR_NT & 2
+#define HPX_FR_LDD(p_, o_) __builtin_nontemporal_load(&(p_)[o_])
+#else
+#define HPX_FR_LDD(p_, o_) (p_)[o_]
+#endif
+#define HPX_FR_LOAD(xt_)                                                              \
+  {                                                                                   \
+    const int x0_ = (xt_) << 4;                                                       \
+    _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {                                \
+      const int m = 4 * ks + g;                  /* unconditional (clamped) load, then the  */ \
+      const long fo_ = (long)(x0_ + li) * M + min(m, M - 1);      /* select: no branch      */ \
+      const double fr_ = fmr[fo_], fi_ = fmi[fo_];                                    \
+      nfr[ks] = (m < M) ? fr_ : 0.0;                                                  \
+      nfi[ks] = (m < M) ? fi_ : 0.0;                                                  \
+    }                                                                                 \
+    _Pragma("unroll") for (int v = 0; v < 4; ++v) {                                   \
+      const int x_ = x0_ + HPX_ACC_ROW(g, v);                                         \
+      const long o_ = (long)x_ * TP + (tvalid ? t : 0);                               \
+      ndr[v] = HPX_FR_LDD(dre, o_);                                                   \
+      ndi[v] = HPX_FR_LDD(dim_, o_);                                                  \
+      nnv[v] = ninv[x_];                                                              \
+      nw[v] = fl8[x_] ? 1.0 : 0.0;                                                    \
+    }                                                                                 \
+  }
+    if (wave < ntile) HPX_FR_LOAD(wave)
+    for (int xt = wave; xt < ntile; xt += 4) {
+      const int x0 = xt << 4;
+      double cfr[4], cfi[4], cdr[4], cdi[4], cnv[4], cw[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        cfr[q] = nfr[q]; cfi[q] = nfi[q]; cdr[q] = ndr[q]; cdi[q] = ndi[q]; cnv[q] = nnv[q]; cw[q] = nw[q];
+      }
+      HPX_FR_LOAD(min(xt + 4, tlast))                 // branch-free: re-read at the end
+      d4 mr = {0., 0., 0., 0.}, mi = {0., 0., 0., 0.};
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {                // A[channel x0 + li][m = 4 ks + g] = F[x][m]
+        if (4 * ks >= M) break;                       // k-steps made of padding only (M <= 12: one in four)
+        mr = mfma64(cfr[ks], bfr[ks], mr);
+        mr = mfma64(-cfi[ks], bfi[ks], mr);
+        mi = mfma64(cfr[ks], bfi[ks], mi);
+        mi = mfma64(cfi[ks], bfr[ks], mi);
+      }
+      if (li >= TC) continue;
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const int x = x0 + HPX_ACC_ROW(g, v);
+        const int pidx = (int)(__brev((unsigned)x) >> (32 - logN));
+        const long o = (long)x * TP + t;
+        if (t >= T) {
+          if (A.any_flags) { A.Gre[(long)b * A.NP * TP + o] = 0.0; A.Gim[(long)b * A.NP * TP + o] = 0.0; }
+          continue;
+        }
+        const double sc = (x & 1) ? -A.isn : A.isn;
+        const double sr = fre[(pidx << tcs) + li] * sc, si = fim[(pidx << tcs) + li] * sc;
+        const double rr = cdr[v] - (sr + mr[v]), ri = cdi[v] - (si + mi[v]);
+        const double w = cw[v];
+        const double c2 = (rr * rr + ri * ri) * cnv[v];
+        acc += w * c2;
+        if (A.any_flags) {
+          A.Gre[(long)b * A.NP * TP + o] = w * sr;
+          A.Gim[(long)b * A.NP * TP + o] = w * si;
+        }
+        if (A.cr_out) {
+          double* q = A.cr_out + (long)b * A.cr_bstride + ((long)t * N + x) * 2;
+          q[0] = sr;
+          q[1] = si;
+        }
+        if (A.chisq_out) A.chisq_out[(long)b * A.chisq_bstride + (long)t * N + x] = c2;
+      }
+    }
+#undef HPX_FR_LOAD
+  } else {
+    // 256 elements (256 / TC channels x TC times) per round; the foreground-mode rows F[x][:] of
+    // the round's channels are staged in LDS first (TC threads share a channel: from global
+    // memory each of them would fetch the same 2 M values again)
+    double* sfr = lfi + (M << tcs);                   // [256 / TC][M]
+    double* sfi = sfr + (256 >> tcs) * M;
+    const int xper = 256 >> tcs;
+    for (int e0 = 0; e0 < (N << tcs); e0 += 256) {
+      __syncthreads();
+      for (int q = tid; q < xper * M; q += 256) {
+        const int xi = q / M, m = q - xi * M;
+        const int xx = (int)(__brev((unsigned)((e0 >> tcs) + xi)) >> (32 - logN));
+        sfr[q] = fmr[(long)xx * M + m];
+        sfi[q] = fmi[(long)xx * M + m];
+      }
+      __syncthreads();
+      const int e = e0 + tid;
+      const int pidx = e >> tcs, tc = e & (TC - 1), t = c0 + tc;
+      const int x = (int)(__brev((unsigned)pidx) >> (32 - logN));
+      const long o = (long)x * TP + t;
+      if (t >= T) {
+        if (A.any_flags) { A.Gre[(long)b * A.NP * TP + o] = 0.0; A.Gim[(long)b * A.NP * TP + o] = 0.0; }
+        continue;
+      }
+      const double sc = (x & 1) ? -A.isn : A.isn;
+      const double sr = fre[e] * sc, si = fim[e] * sc;
+      double mr = sr, mi = si;
+      const double* myfr = sfr + (tid >> tcs) * M;
+      const double* myfi = sfi + (tid >> tcs) * M;
+      for (int m = 0; m < M; ++m) {
+        const double fr = myfr[m], fi = myfi[m];
+        const double gr = lfr[(m << tcs) + tc], gi = lfi[(m << tcs) + tc];
+        mr += gr * fr - gi * fi;
+        mi += gr * fi + gi * fr;
+      }
+      const double rr = dre[o] - mr, ri = dim_[o] - mi;
+      const double w = fl8[x] ? 1.0 : 0.0;
+      const double c2 = (rr * rr + ri * ri) * ninv[x];
+      acc += w * c2;
+      if (A.any_flags) {
+        A.Gre[(long)b * A.NP * TP + o] = w * sr;
+        A.Gim[(long)b * A.NP * TP + o] = w * si;
+      }
+      if (A.cr_out) {
+        double* q = A.cr_out + (long)b * A.cr_bstride + ((long)t * N + x) * 2;
+        q[0] = sr;
+        q[1] = si;
+      }
+      if (A.chisq_out) A.chisq_out[(long)b * A.chisq_bstride + (long)t * N + x] = c2;
+    }
+  }
+  if (A.fg_out) {
+    for (int e = tid; e < (M << tcs); e += 256) {
+      const int m = e >> tcs, t = c0 + (e & (TC - 1));
+      if (t >= T) continue;
+      double* q = A.fg_out + (long)b * A.fg_bstride + ((long)t * M + m) * 2;
+      q[0] = lfr[e];
+      q[1] = lfi[e];
+    }
+  }
+  const double total = block_sum(acc, red);
+  if (tid == 0) A.lnpart[(long)b * HPX_NPART + cg] = total;
+}
+
+// The same for channel counts without an in-LDS FFT (N not a power of two, e.g. the 120 channels of
+// the reference's test data) and small enough for the dense transform to be cheap (NP <= 256): s = U z
+// as a contraction with conj(Fop) on the MFMA, tile by tile (16 channels x 16 times), and each tile
+// goes straight on to the model term, residual, chi^2 and outputs from its accumulators -- s is not
+// written to and read back from HBM, and one launch replaces k_dft + k_resid.  Wave w of block j owns
+// the channel tile 4 j + w and sweeps the time tiles; it also forms sum_t |z|^2 of its own channels.
+__global__ __launch_bounds__(256) void k_dft_resid(const ResArgs A) {
+  __shared__ double red[4];
+  const int b = blockIdx.y, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, g = lane >> 4;
+  const int N = A.N, M = A.M, T = A.T, TP = A.TP, NP = A.NP, TT = TP >> 4;
+  const double* xre = A.Xre + (long)b * A.npad * TP;
+  const double* xim = A.Xim + (long)b * A.npad * TP;
+  const double* dre = A.Dre + (long)b * NP * TP;
+  const double* dim_ = A.Dim + (long)b * NP * TP;
+  const double* fmr = A.Fre + (A.fg_shared ? 0 : (long)b * N * M);
+  const double* fmi = A.Fim + (A.fg_shared ? 0 : (long)b * N * M);
+  const double* ninv = A.ninv + (long)b * N;
+  const uint8_t* fl8 = A.flags + (long)b * N;
+  const int xt = blockIdx.x * 4 + wave, x0 = xt << 4;
+  double acc = 0.0;
+  if (x0 < NP) {
+    // A operand of the model term, F[x0 + li][m = 4 ks + g]: the same for every time tile
+    double cfr[4], cfi[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const int m = 4 * ks + g;
+      const long fo = (long)min(x0 + li, N - 1) * (M > 0 ? M : 1) + min(m, (M > 0 ? M : 1) - 1);
+      const double fr = (M > 0) ? fmr[fo] : 0.0, fi = (M > 0) ? fmi[fo] : 0.0;
+      const bool ok = (m < M) && (x0 + li < N);
+      cfr[ks] = ok ? fr : 0.0;
+      cfi[ks] = ok ? fi : 0.0;
+    }
+    double cnv[4], cw[4], zz[4];
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const int x = min(x0 + HPX_ACC_ROW(g, v), N - 1);
+      cnv[v] = ninv[x];
+      cw[v] = fl8[x] ? 1.0 : 0.0;
+      zz[v] = 0.0;
+    }
+    const int nks = NP >> 2;                       // a multiple of 4
+    for (int tt = 0; tt < TT; ++tt) {
+      const int t = (tt << 4) + li;
+      // s^[x][t] = sum_k conj(Fop)[x][k] z[k][t]: A[x0 + li][k = 4 ks + g], B[k][t]; two operand sets
+      d4 sr = {0., 0., 0., 0.}, si = {0., 0., 0., 0.};
+      double w0r, w0i, w1r, w1i, b0r, b0i, b1r, b1i;
+#define HPX_DR_LOAD(wr_, wi_, br_, bi_, ks_)                          \
+  {                                                                   \
+    const int k_ = 4 * (ks_) + g;                                     \
+    wr_ = A.twre[(long)k_ * NP + x0 + li];                            \
+    wi_ = A.twim[(long)k_ * NP + x0 + li];                            \
+    br_ = xre[(long)k_ * TP + t];                                     \
+    bi_ = xim[(long)k_ * TP + t];                                     \
+  }
+#define HPX_DR_MMA(wr_, wi_, br_, bi_)    /* conj(W) z */             \
+  {                                                                   \
+    sr = mfma64(wr_, br_, sr);                                        \
+    sr = mfma64(wi_, bi_, sr);                                        \
+    si = mfma64(wr_, bi_, si);                                        \
+    si = mfma64(-wi_, br_, si);                                       \
+  }
+      HPX_DR_LOAD(w0r, w0i, b0r, b0i, 0)
+      for (int ks = 0; ks < nks; ks += 2) {
+        HPX_DR_LOAD(w1r, w1i, b1r, b1i, ks + 1)
+        __builtin_amdgcn_sched_barrier(0);
+        HPX_DR_MMA(w0r, w0i, b0r, b0i)
+        __builtin_amdgcn_sched_barrier(0);
+        HPX_DR_LOAD(w0r, w0i, b0r, b0i, min(ks + 2, nks - 1))
+        __builtin_amdgcn_sched_barrier(0);
+        HPX_DR_MMA(w1r, w1i, b1r, b1i)
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#undef HPX_DR_LOAD
+#undef HPX_DR_MMA
+      // model term F f: B[m = 4 ks + g][t] = f[m][t] (rows N + m of X)
+      d4 mr = {0., 0., 0., 0.}, mi = {0., 0., 0., 0.};
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        if (4 * ks >= M) break;
+        const int m = min(4 * ks + g, M - 1);
+        const double fr = xre[(long)(N + m) * TP + t], fi = xim[(long)(N + m) * TP + t];
+        const double br = (4 * ks + g < M) ? fr : 0.0, bi = (4 * ks + g < M) ? fi : 0.0;
+        mr = mfma64(cfr[ks], br, mr);
+        mr = mfma64(-cfi[ks], bi, mr);
+        mi = mfma64(cfr[ks], bi, mi);
+        mi = mfma64(cfi[ks], br, mi);
+      }
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const int x = x0 + HPX_ACC_ROW(g, v);
+        const long o = (long)min(x, NP - 1) * TP + t;
+        const double zr = xre[o], zi = xim[o];             // this channel's z (rows < N of X)
+        if (x < N) zz[v] += zr * zr + zi * zi;
+        if (x >= N) continue;
+        if (t >= T) {
+          if (A.any_flags) { A.Gre[(long)b * NP * TP + o] = 0.0; A.Gim[(long)b * NP * TP + o] = 0.0; }
+          continue;
+        }
+        const double s_r = sr[v] * A.isn, s_i = si[v] * A.isn;
+        const double rr = dre[o] - (s_r + mr[v]), ri = dim_[o] - (s_i + mi[v]);
+        const double w = cw[v];
+        const double c2 = (rr * rr + ri * ri) * cnv[v];
+        acc += w * c2;
+        if (A.any_flags) {
+          A.Gre[(long)b * NP * TP + o] = w * s_r;
+          A.Gim[(long)b * NP * TP + o] = w * s_i;
+        }
+        if (A.cr_out) {
+          double* q = A.cr_out + (long)b * A.cr_bstride + ((long)t * N + x) * 2;
+          q[0] = s_r;
+          q[1] = s_i;
+        }
+        if (A.chisq_out) A.chisq_out[(long)b * A.chisq_bstride + (long)t * N + x] = c2;
+      }
+    }
+    // sum_t |z_xt|^2 of the tile's channels: over the 16 lanes of a row group, then slot 0 of the
+    // partial-sum table (the other slots of these channels are zero: every channel has one owner)
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      double s = zz[v];
+      s += __shfl_xor(s, 8, 16);
+      s += __shfl_xor(s, 4, 16);
+      s += __shfl_xor(s, 2, 16);
+      s += __shfl_xor(s, 1, 16);
+      const int x = x0 + HPX_ACC_ROW(g, v);
+      if (li == 0 && x < N)
+        for (int j = 0; j < A.npart; ++j) A.bpart[((long)b * HPX_NPART + j) * N + x] = (j == 0) ? s : 0.0;
+    }
+  }
+  if (A.fg_out && blockIdx.x == 0) {
+    for (int e = tid; e < T * M; e += 256) {
+      const int t = e / M, m = e % M;
+      double* q = A.fg_out + (long)b * A.fg_bstride + (long)e * 2;
+      q[0] = xre[(long)(N + m) * TP + t];
+      q[1] = xim[(long)(N + m) * TP + t];
+    }
+  }
+  const double total = block_sum(acc, red);
+  if (tid == 0) A.lnpart[(long)b * HPX_NPART + blockIdx.x] = total;
+}
+
+// betam_k = sum_t |SK[k][t]|^2 (SK = F (w s), in the Z scratch with leading dim ncol).
+// Sixteen lanes share a row (consecutive t: one 128-byte segment per load) and reduce by shuffles;
+// a thread per row would touch 64 different cache lines with every load.
+__global__ __launch_bounds__(256) void k_betam(const double* __restrict__ Kre, const double* __restrict__ Kim,
+                                               double* __restrict__ betam, const int N, const int T,
+                                               const int NP, const int ncol) {
+  const int b = blockIdx.y, c = threadIdx.x & 15, r = threadIdx.x >> 4;
+  for (int k0 = blockIdx.x * 16; k0 < N; k0 += gridDim.x * 16) {
+    const int k = k0 + r;
+    double s = 0.0;
+    if (k < N) {
+      const long o = ((long)b * NP + k) * ncol;
+      for (int t = c; t < T; t += 16) s += Kre[o + t] * Kre[o + t] + Kim[o + t] * Kim[o + t];
+    }
+#pragma unroll
+    for (int m = 8; m >= 1; m >>= 1) s += __shfl_xor(s, m, 16);
+    if (c == 0 && k < N) betam[(long)b * N + k] = s;
+  }
+}
+
+// ---- bandpower draw ---------------------------------------------------------------
+// Regularised upper incomplete gamma Q(a, z) for integer a >= 1:
+// Q = exp(-z) sum_{k<a} z^k / k!  (= scipy.special.gammaincc(a, z) = invgamma.cdf
+// of pspec.py:51 at x = beta/z).  Forward sum for z < a, scaled Horner form
+// around the leading term for z >= a (no overflow, all terms positive).
+#define HPX_RK_MAX 512
+// rk[k] = 1 / k (LDS table, k < a <= HPX_RK_MAX, else NULL): the forward sum multiplies by it instead of dividing --
+// an fp64 division is ~10 dependent vector instructions, and the 1000-point CDF grids of the
+// prior channels made that loop the bulk of k_draw (one more rounding per term: ~a ulp in Q).
+__device__ double igamc_int(const int a, const double z, const double lgam_a, const double* rk) {
+  if (!(z > 0.0)) return 1.0;
+  if (z < (double)a) {
+    double t = 1.0, s = 1.0;
+    if (rk) {
+      // eight terms per trip: their table reads are issued together (one LDS round trip per term
+      // on the dependent chain otherwise, ~10x the latency of the multiply itself)
+      int k = 1;
+      for (; k + 8 <= a; k += 8) {
+        double r[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) r[u] = z * rk[k + u];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          t *= r[u];
+          s += t;
+        }
+      }
+      for (; k < a; ++k) {
+        t *= z * rk[k];
+        s += t;
+      }
+    } else {                                   // shape beyond the table (Ntimes > HPX_RK_MAX)
+      for (int k = 1; k < a; ++k) {
+        t *= z / (double)k;
+        s += t;
+      }
+    }
+    return exp(-z) * s;
+  }
+  const double rz = 1.0 / z;
+  double s = 1.0;
+#pragma unroll 8
+  for (int m = 1; m < a; ++m) s = 1.0 + s * ((double)m * rz);
+  return exp(-z + (double)(a - 1) * log(z) - lgam_a) * s;
+}
+
+// One inversion draw by a group of 16 lanes; pspec.py:50-62.  The reference tabulates the CDF on the
+// 1000-point grid, normalises it (cdf -= min; cdf /= max), de-duplicates and interpolates linearly
+// at u.  The table is monotone, so min and max are its end points and the bracket
+// [first occurrence of the previous distinct value, first value >= u] is found by two 16-ary searches
+// (three rounds of one evaluation per lane each) instead of evaluating all 1000 points: ~13
+// incomplete-gamma sums per lane and channel instead of 1000 per channel by the whole block, and
+// the prior channels of a baseline are sampled side by side (16 groups per workgroup).
+// All 16 lanes of the group return the sample.
+template <class Pred>
+__device__ __forceinline__ int first_true16(const int n, Pred pred) {
+  // smallest i in [0, n) with pred(i), n if none; pred is monotone (false ... false true ... true)
+  const int j = threadIdx.x & 15, gsh = (threadIdx.x & 63) & ~15;
+  int lo = 0, hi = n;                   // the answer is in [lo, hi]; hi < n is known to be true
+  while (hi > lo) {
+    const int step = (hi - lo + 15) >> 4;
+    const int idx = min(lo + (j + 1) * step - 1, hi - 1);
+    const bool p = pred(idx);
+    const int m = __popc((unsigned)((__ballot(!p) >> gsh) & 0xFFFFull));     // leading false probes
+    if (m == 16) break;                 // every probe up to hi - 1 is false: the answer is hi
+    const int nlo = lo + m * step;
+    hi = min(lo + (m + 1) * step - 1, hi - 1);
+    lo = nlo;
+  }
+  return hi;
+}
+
+__device__ double inversion_draw(const int alpha, const double lgam, const double beta, const double u,
+                                 const double* __restrict__ xg, const int ngrid, const double* rk) {
+  const double mn = igamc_int(alpha, beta / xg[0], lgam, rk);                    // cdf.min()
+  const double mx = igamc_int(alpha, beta / xg[ngrid - 1], lgam, rk) - mn;       // (cdf - min).max()
+  auto cval = [&](const int i) { return (igamc_int(alpha, beta / xg[i], lgam, rk) - mn) / mx; };
+  // searchsorted(unique, u, 'left') in original indexing = number of table values < u
+  int hi = first_true16(ngrid, [&](const int i) { return !(cval(i) < u); });
+  if (hi >= ngrid) {                    // u above the table: last two distinct values
+    const double top = cval(ngrid - 1);
+    hi = first_true16(ngrid, [&](const int i) { return !(cval(i) < top); });
+  }
+  int lo;
+  if (hi == 0) {                        // u at/below the first value: first two distinct values
+    const double bot = cval(0);
+    hi = first_true16(ngrid, [&](const int i) { return !(cval(i) <= bot); });
+    lo = 0;
+    if (hi >= ngrid) return xg[0];      // degenerate table (all equal): the reference would give NaN
+  } else {
+    const double below = cval(hi - 1);  // previous distinct value; its first occurrence:
+    lo = first_true16(ngrid, [&](const int i) { return !(cval(i) < below); });
+  }
+  const double clo = cval(lo), chi = cval(hi), xlo = xg[lo], xhi = xg[hi];
+  const double slope = (xhi - xlo) / (chi - clo);
+  return slope * (u - clo) + xlo;
+}
+
+// The ln posterior's sum over the channels from its sums over groups of 16 channels: four groups make a block of 64,
+// ((g0 + g1) + (g2 + g3)), the blocks are added in order -- one definition for the kernel that has a baseline to itself
+// and for the combination of a sliced run (hpx_chain.hip: k_lnpost_combine uses the same function).
+struct DrawArgs {
+  const double *bpart, *lnpart, *betam, *uni, *igy, *xgrid, *ps_forced;
+  double *beta, *lnp1;
+  int npart;
+  const int32_t* pmap;
+  double *ia, *ps_cur, *ps_out;
+  long ps_bstride, forced_bstride;   // strides between baselines in ps_out / ps_forced
+  int N, T, ngrid, prior_shared, any_flags;
+  double lgam_T;
+  double* lnhist;                    // several slices: this iteration's [nbl][ceil(N / 16) + 1] group sums (k_lnpost_combine)
+  double* lnpost_out;                // one slice: the caller's ln-posterior history, offset to this iteration
+  long lnpost_pitch;
+};
+
+// Grid (slices, baselines): a baseline's channels are dealt to `gridDim.x` workgroups in blocks of 64 -- one per
+// baseline for large batches, up to sixteen for batches that would leave most CUs idle (config 2).  The ln-posterior's
+// sum over the channels is formed per group of 16 (a fixed shuffle tree) and the groups are added in a fixed order
+// (lnpost_blocks): by
+// this kernel when a baseline has one slice, else by k_lnpost_combine at the end of the run from the block sums every
+// slice leaves in the plan's history (no hand-off between workgroups: an agent-scope release per workgroup is an L2
+// write-back, serialised between the CUs of an XCD -- 34 us for a 10 us kernel when it was tried).  Either way the
+// result does not depend on the number of slices.
+__global__ __launch_bounds__(256) void k_draw(const DrawArgs A) {
+  extern __shared__ double dyn[];     // N ints: the channels with a prior
+  __shared__ int pcount;
+  __shared__ double rk_s[HPX_RK_MAX];
+  __shared__ double part[256];        // the slice's sums over groups of 16 channels
+  const int b = blockIdx.y, tid = threadIdx.x, N = A.N;
+  const int nsub = (N + 15) >> 4;     // groups of 16 channels: what the slices are made of
+  const int sb0 = (int)(((long)nsub * blockIdx.x) / gridDim.x), sb1 = (int)(((long)nsub * (blockIdx.x + 1)) / gridDim.x);
+  const int k0 = sb0 * 16, k1 = min(N, sb1 * 16);
+  for (int k = tid; k < HPX_RK_MAX; k += 256) rk_s[k] = 1.0 / (double)(k > 0 ? k : 1);
+  const double* rk = (A.T <= HPX_RK_MAX) ? rk_s : nullptr;
+  // beta_k = N sum_t |z_kt|^2 from the partial sums of the residual kernel (one slot per block of a baseline
+  // there), added in slot order
+  double* beta = A.beta + (long)b * N;
+  for (int k = k0 + tid; k < k1; k += 256) {
+    double sum = 0.0;
+    for (int j = 0; j < A.npart; ++j) sum += A.bpart[((long)b * HPX_NPART + j) * N + k];
+    beta[k] = (double)N * sum;
+  }
+  if (tid == 0) pcount = 0;
+  __syncthreads();
+  const double* bm = A.any_flags ? A.betam + (long)b * N : beta;
+  const int32_t* pmap = A.pmap + (A.prior_shared ? 0 : (long)b * N);
+  double* ps_out = A.ps_out + (long)b * A.ps_bstride;
+  // channels without a prior: x = beta * invgamma.ppf(U, a=T-1)   (pspec.py:125)
+  // channels with a prior: truncated draw with shape alpha+1 = T   (pspec.py:121-123).
+  // They are collected first (a scan of pmap by one thread per channel would be N dependent
+  // global loads); each draw depends only on its own channel, so their order is immaterial.
+  int* plist = reinterpret_cast<int*>(dyn);
+  for (int k = k0 + tid; k < k1; k += 256) {
+    if (pmap[k] < 0) ps_out[k] = A.igy[k] * beta[k];
+    else plist[atomicAdd(&pcount, 1)] = k;
+  }
+  __syncthreads();
+  const int np = pcount;
+  for (int i = tid >> 4; i < np; i += 16) {            // one prior channel per group of 16 lanes
+    const int k = plist[i], row = pmap[k];
+    const double v = inversion_draw(A.T, A.lgam_T, beta[k], A.uni[k], A.xgrid + (long)row * A.ngrid,
+                                    A.ngrid, rk);
+    if ((tid & 15) == 0) ps_out[k] = v;
+  }
+  __syncthreads();
+  // second ln-posterior term, the next 1 / a: sixteen lanes per group of 16 channels, a fixed shuffle tree each
+  for (int sb = sb0 + (tid >> 4); sb < sb1; sb += 16) {
+    const int k = sb * 16 + (tid & 15);
+    double v = 0.0;
+    if (k < N) {
+      const double pn = ps_out[k];
+      v = bm[k] / pn;
+      const double nx = A.ps_forced ? A.ps_forced[(long)b * A.forced_bstride + k] : pn;
+      A.ps_cur[(long)b * N + k] = nx;
+      A.ia[(long)b * N + k] = inv_a(nx, (double)N);
+    }
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) v += __shfl_down(v, o, 16);
+    if ((tid & 15) == 0) part[(sb - sb0) & 255] = v;      // (a slice holds at most 256 groups: 4096 channels)
+  }
+  __syncthreads();
+  if (tid != 0) return;
+  double tot = 0.0;                  // chi^2 total of the residual kernel's partial sums, in slot order
+  for (int j = 0; j < A.npart; ++j) tot += A.lnpart[(long)b * HPX_NPART + j];
+  if (gridDim.x == 1) {
+    const double lnp = -tot - lnpost_blocks(part, nsub);     // -> ln posterior
+    A.lnp1[b] = lnp;
+    if (A.lnpost_out) A.lnpost_out[(long)b * A.lnpost_pitch] = lnp;
+  } else {
+    double* h = A.lnhist + (long)b * (nsub + 1);
+    for (int sb = sb0; sb < sb1; ++sb) h[sb] = part[sb - sb0];
+    if (blockIdx.x == 0) h[nsub] = tot;
+  }
+}
+
+__global__ void k_inv_test(const int alpha, const double lgam, const double* __restrict__ beta,
+                           const double* __restrict__ u, const double* __restrict__ xgrid,
+                           const int ngrid, double* __restrict__ out) {
+  __shared__ double rk_s[HPX_RK_MAX];
+  const int i = blockIdx.x;
+  for (int k = threadIdx.x; k < HPX_RK_MAX; k += 256) rk_s[k] = 1.0 / (double)(k > 0 ? k : 1);
+  __syncthreads();
+  if (threadIdx.x < 16) {
+    const double v = inversion_draw(alpha, lgam, beta[i], u[i], xgrid + (long)i * ngrid, ngrid,
+                                    alpha <= HPX_RK_MAX ? rk_s : nullptr);
+    if (threadIdx.x == 0) out[i] = v;
+  }
+}
+// lnpart[b][0] = sum_t r_t^H Ninv_{b,t} r_t with the masked residual r [b][NP][TP] and the units' planar Ninv
+// [b*T + t][NP][NP] (Hermitian, row-major): one workgroup per baseline, times in order (deterministic)
+// sum_t (w r_t)^H Ninv_t (w r_t) with each time's own matrix: one workgroup per (time, baseline) -- it had been one
+// per baseline, every thread walking its own matrix row (a stride of NP doubles between neighbouring threads) -- leaves
+// the time's term in part[b][t]; the matrices are Hermitian, so row x is read as the conjugate of column x, which
+// neighbouring threads read from neighbouring addresses.  k_quadform_pt_sum adds the terms in time order.
+__global__ __launch_bounds__(256) void k_quadform_pt(const double* __restrict__ rre, const double* __restrict__ rim,
+                                                     const double* __restrict__ nre, const double* __restrict__ nim,
+                                                     double* __restrict__ part, const int N, const int T,
+                                                     const int NP, const int TP) {
+  __shared__ double red[4];
+  const int t = blockIdx.x, b = blockIdx.y;
+  const double* mr = nre + ((long)b * T + t) * NP * NP;
+  const double* mi = nim + ((long)b * T + t) * NP * NP;
+  double acc = 0.0;
+  for (int x = threadIdx.x; x < N; x += 256) {
+    double vr = 0.0, vi = 0.0;                         // v = (Ninv r)[x] = sum_k conj(Ninv[k][x]) r[k]
+    for (int k = 0; k < N; ++k) {
+      const double ar = mr[(long)k * NP + x], ai = -mi[(long)k * NP + x];
+      const double br = rre[((long)b * NP + k) * TP + t], bi = rim[((long)b * NP + k) * TP + t];
+      vr += ar * br - ai * bi;
+      vi += ar * bi + ai * br;
+    }
+    acc += rre[((long)b * NP + x) * TP + t] * vr + rim[((long)b * NP + x) * TP + t] * vi;
+  }
+  const double tot = block_sum(acc, red);
+  if (threadIdx.x == 0) part[(long)b * T + t] = tot;
+}
+__global__ void k_quadform_pt_sum(const double* __restrict__ part, double* __restrict__ lnpart, const int T, const int nbl) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= nbl) return;
+  double tot = 0.0;
+  for (int t = 0; t < T; ++t) tot += part[(long)b * T + t];
+  lnpart[(long)b * HPX_NPART] = tot;
+}
+
+}  // namespace
+
+
+#ifndef HPX_DFT_RESID
+#define HPX_DFT_RESID 1       // small N without an FFT: dense transform + residual in one kernel
+#endif
+#ifndef HPX_FUSE_TC
+#define HPX_FUSE_TC 8      // fewest time columns per block for which the fused transform + residual kernel is used
+#endif
+int hpx_post_solve(hpx_plan* p, int it_abs, const IterOut& O, hipStream_t st) {
+  const int nbl = p->nbl, N = p->N, M = p->M, T = p->T, NP = p->NP, TP = p->TP;
+  const int TPd = (T + 15) & ~15;          // the data's time columns, padded (TP may hold more right-hand sides)
+  const double isn = 1.0 / sqrt((double)N);
+  ResArgs R;
+  R.Xre = p->Xre; R.Xim = p->Xim; R.Sre = p->Sre; R.Sim = p->Sim; R.Dre = p->Dre; R.Dim = p->Dim;
+  R.Fre = p->Fre; R.Fim = p->Fim; R.ninv = p->ninv; R.flags = p->flags;
+  R.bpart = p->bpart; R.lnpart = p->lnpart; R.Gre = p->Gre; R.Gim = p->Gim;
+  R.cr_bstride = O.cr_bstride; R.fg_bstride = O.fg_bstride; R.chisq_bstride = O.chisq_bstride;
+  R.cr_out = O.cr_out; R.fg_out = (M > 0) ? O.fg_out : nullptr; R.chisq_out = O.chisq_out;
+  R.N = N; R.M = M; R.T = T; R.NP = NP; R.TP = TP; R.npad = p->npad;
+  R.fg_shared = p->fg_shared; R.any_flags = p->any_flags;
+  R.twre = p->Fopre; R.twim = p->Fopim; R.isn = isn; R.logN = 0; R.tcs = 0; R.nbl = nbl; R.npart = 1;
+  // dense noise: the masked residual for the quadratic form; it can share G unless G holds w s (flags)
+  R.Rdre = p->dense_noise ? (p->dense_noise == 2 ? p->RDre : p->Gre) : (p->per_time == 2 ? p->RDre : nullptr);
+  R.Rdim = p->dense_noise ? (p->dense_noise == 2 ? p->RDim : p->Gim) : (p->per_time == 2 ? p->RDim : nullptr);
+  R.flags_t = p->per_time ? p->flags_t : nullptr;
+  R.ninv_t = p->per_time ? p->ninv_t : nullptr;
+  // time columns per block of the fused kernel: 64 KiB of LDS for the signal, as k_fft
+#ifndef HPX_FR_ELEMS
+#define HPX_FR_ELEMS 4096      // complex elements of the signal block a workgroup of k_fft_resid holds in LDS
+#endif
+  int npart = 1, TC = HPX_FR_ELEMS / NP;
+  if (TC > 16) TC = 16;
+  const bool pow2 = N == NP && (N & (N - 1)) == 0 && N >= 32 && N <= 4096;
+  const bool generic_post = p->dense_noise || p->per_time;      // modes only the two-kernel form implements
+  if (pow2 && hpx_dft_use_fft && TC >= HPX_FUSE_TC && TP / TC <= HPX_NPART && !generic_post) {   // fewer columns per block: two kernels win
+    while ((1 << R.logN) < N) ++R.logN;
+    while ((1 << R.tcs) < TC) ++R.tcs;
+    npart = TP / TC;
+    // s = U z, residual, chi^2, |z|^2 sums in one pass (k_fft_resid); the two event marks
+    // book it under "transform"
+    const size_t lds = ((size_t)N * TC * 2 + N + (size_t)2 * M * TC + (size_t)2 * M * (256 / TC)) * sizeof(double);
+    static hpx_lds_limit limit;
+    HPX_TRY(limit.ensure(reinterpret_cast<const void*>(&k_fft_resid), lds));
+    R.nbl = nbl; R.npart = npart;
+    hipLaunchKernelGGL(k_fft_resid, dim3(((nbl + 7) / 8) * 8 * npart), dim3(256), lds, st, R);
+    HPX_HIP(hipGetLastError());
+    HPX_TRY(hpx_mark(p, st));
+  } else if (HPX_DFT_RESID && NP <= 256 && M <= 16 && hpx_dft_use_fft && !generic_post) {
+    // small N without an in-LDS FFT: dense transform fused with the residual (k_dft_resid), booked
+    // under "transform"
+    npart = (NP / 16 + 3) / 4;
+    R.nbl = nbl; R.npart = npart;
+    hipLaunchKernelGGL(k_dft_resid, dim3(npart, nbl), dim3(256), 0, st, R);
+    HPX_HIP(hipGetLastError());
+    HPX_TRY(hpx_mark(p, st));
+  } else {
+    // s = U z = conj(F) X / sqrt(N)   (rows >= N of X meet the zero padding of the operator)
+    HPX_TRY(hpx_launch_dft(nbl, NP, TP, p->Fopre, p->Fopim, 1, p->Xre, p->Xim, (long)p->npad * TP,
+                           TP, nullptr, 0, p->Sre, p->Sim, (long)NP * TP, TP, isn, st, N == NP));
+    if (p->dense_noise == 2) {
+      // dense noise with flags: X = [Y_r | Y_P] so far (unflagged-noise system); the Woodbury correction
+      // x = Y_r + Y_P (I - Q^H Y_P)^-1 Q^H Y_r, where Q^H Y is the model U y + F f at the flagged channels
+      HPX_TRY(hpx_woodbury_correct(p, T, it_abs + 1, st));
+    }
+    HPX_TRY(hpx_mark(p, st));
+    {
+      // slices of the channels: as many as keep 64 channels per workgroup, at most four
+      int P = 4;
+      while (P > 1 && (N % P != 0 || N / P < 64)) P >>= 1;
+      npart = P;
+      R.npart = P;
+      const size_t lds = (size_t)(2 * M * TP + (N / P) * (TP / 16)) * sizeof(double);
+      static hpx_lds_limit limit;
+      if (lds > 48 * 1024) HPX_TRY(limit.ensure(reinterpret_cast<const void*>(&k_resid), lds));
+      hipLaunchKernelGGL(k_resid, dim3(P, nbl), dim3(256), lds, st, R);
+    }
+    HPX_HIP(hipGetLastError());
+    if (p->dense_noise) {
+      // first ln-posterior term with the full matrix over the unflagged channels: sum_t (w r_t)^H Ninv (w r_t)
+      // (pspec.py:472-477); k_resid left the masked residual behind, v = Ninv (w r) goes to the Z scratch
+      // (the data columns only: with flags TP also counts the Woodbury columns, 112 against 32 at the C3 shape)
+      HPX_TRY(hpx_launch_dft(nbl, NP, TPd, p->NIre, p->NIim, 1, R.Rdre, R.Rdim, (long)NP * TP, TP, nullptr, 0,
+                             p->Zre, p->Zim, (long)NP * p->ncolR, p->ncolR, 1.0, st, 0, (long)NP * NP));
+      hipLaunchKernelGGL(k_quadform, dim3(nbl), dim3(256), 0, st, R.Rdre, R.Rdim, (long)NP * TP, TP, p->Zre, p->Zim,
+                         (long)NP * p->ncolR, p->ncolR, p->lnpart, N, T);
+      HPX_HIP(hipGetLastError());
+    } else if (p->per_time == 2) {      // ... with each time's own matrix (the child's units)
+      hipLaunchKernelGGL(k_quadform_pt, dim3(T, nbl), dim3(256), 0, st, R.Rdre, R.Rdim, p->child->NIre, p->child->NIim,
+                         p->Zre, N, T, NP, TP);                      // (the Z scratch holds the per-time terms)
+      hipLaunchKernelGGL(k_quadform_pt_sum, dim3((nbl + 255) / 256), dim3(256), 0, st, p->Zre, p->lnpart, T, nbl);
+      HPX_HIP(hipGetLastError());
+    }
+  }
+  if (p->any_flags) {   // |F (w s)|^2 for the masked S^-1 quadratic form (pspec.py:479-483)
+    HPX_TRY(hpx_launch_dft(nbl, NP, TPd, p->Fopre, p->Fopim, 0, p->Gre, p->Gim, (long)NP * TP, TP,
+                           nullptr, 0, p->Zre, p->Zim, (long)NP * p->ncolR, p->ncolR, 1.0, st,
+                           N == NP));
+    hipLaunchKernelGGL(k_betam, dim3(16, nbl), dim3(256), 0, st, p->Zre, p->Zim, p->betam, N, T, NP,
+                       p->ncolR);
+    HPX_HIP(hipGetLastError());
+  }
+  HPX_TRY(hpx_mark(p, st));
+  DrawArgs D;
+  D.beta = p->beta; D.betam = p->betam; D.lnp1 = p->lnp1;
+  D.bpart = p->bpart; D.lnpart = p->lnpart; D.npart = npart;
+  D.uni = p->uni + (long)it_abs * N; D.igy = p->igy + (long)it_abs * N;
+  D.xgrid = p->xgrid; D.pmap = p->pmap;
+  D.ps_forced = O.ps_forced; D.forced_bstride = O.forced_bstride;
+  D.ia = p->ia; D.ps_cur = p->ps_cur;
+  D.ps_out = O.ps_out; D.ps_bstride = O.ps_bstride;
+  D.N = N; D.T = T; D.ngrid = p->ngrid; D.prior_shared = p->prior_shared;
+  D.any_flags = p->any_flags; D.lgam_T = p->lgam_T;
+  // slices per baseline (hpx_plan_set_rng): more than one only for batches that would leave most CUs idle
+  const int nslice = p->draw_slices > 0 ? p->draw_slices : 1;
+  D.lnhist = nslice > 1 ? p->lnhist + (long)it_abs * nbl * ((N + 15) / 16 + 1) : nullptr;
+  D.lnpost_out = nslice > 1 ? nullptr : O.lnpost_out;      // (several slices: k_lnpost_combine at the end of the run)
+  D.lnpost_pitch = O.lnpost_pitch;
+  hipLaunchKernelGGL(k_draw, dim3(nslice, nbl), dim3(256), (size_t)N * sizeof(int) + 8, st, D);
+  HPX_HIP(hipGetLastError());
+  HPX_TRY(hpx_mark(p, st));
+  return HPX_OK;
+}
+
+extern "C" int hpx_invgamma_inversion(int n, int alpha, const double* beta, const double* u,
+                                      const double* xgrid, int ngrid, double* out, void* stream) {
+  HPX_REQUIRE(n > 0 && alpha >= 1 && beta && u && xgrid && out && ngrid >= 2 && ngrid <= 8192,
+              "hpx_invgamma_inversion: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_inv_test, dim3(n), dim3(256), 0, st, alpha,
+                     lgamma((double)alpha), beta, u, xgrid, ngrid, out);
+  HPX_HIP(hipGetLastError());
+  HPX_HIP(hipStreamSynchronize(st));
+  return HPX_OK;
+}
+
