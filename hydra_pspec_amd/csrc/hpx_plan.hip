@@ -147,14 +147,14 @@ extern "C" int hpx_plan_set_rng(hpx_plan* p, const double* uniforms, const doubl
   HPX_HIP(hipMemcpyAsync(p->uni, uniforms, cnt * sizeof(double), hipMemcpyDeviceToDevice, st));
   HPX_HIP(hipMemcpyAsync(p->igy, igy, cnt * sizeof(double), hipMemcpyDeviceToDevice, st));
   HPX_HIP(hipStreamSynchronize(st));
-  // k_draw's slices per baseline: as many as keep the launch within two workgroups per CU, in groups of 16 channels
-  // (at least two groups, at most 256 per slice); with more than one the group sums of every iteration are kept until
+  // k_draw's slices per baseline: as many as keep the launch within four (256-thread) workgroups per CU, in groups of 16
+  // channels (at most 256 per slice); with more than one the group sums of every iteration are kept until
   // the end of a run
   {
     int dev = 0, cus = 0, nslice = 1;
     const int nsub = (p->N + 15) / 16;
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    while (nslice < 16 && 2 * nslice * p->nbl <= 2 * cus && 4 * nslice <= nsub) nslice *= 2;
+    while (nslice < 16 && 2 * nslice * p->nbl <= 4 * cus && 2 * nslice <= nsub) nslice *= 2;
     while ((nsub + nslice - 1) / nslice > 256) nslice *= 2;
     if (nslice > 1 && (niter != p->niter_tab || nslice != p->draw_slices || !p->lnhist))
       HPX_TRY(dev_alloc(p, &p->lnhist, (size_t)niter * p->nbl * (nsub + 1)));
