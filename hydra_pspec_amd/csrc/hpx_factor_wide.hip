@@ -716,14 +716,6 @@ __global__ __launch_bounds__(256, 2) void k_factor_wide(double* __restrict__ L_a
   }
   bool bad = false;
   int ct0 = 0;
-#ifdef HPX_WIDE_STAGGER_US
-  // (experiment: the second workgroup of a CU -- block index b and b + 256 share one at C3 -- starts late, so that its
-  // latency-bound F phases fall beside the other's matrix-bound P phases instead of beside its F phases)
-  if ((blockIdx.x >> 8) & 1) {
-    const unsigned long long t0_ = wall_clock64();
-    while (wall_clock64() - t0_ < (unsigned long long)(HPX_WIDE_STAGGER_US) * 100ull) __builtin_amdgcn_s_sleep(8);
-  }
-#endif
   for (; ct0 + 8 <= X.nct; ct0 += 8) {
     d4 a1[9], a2[9];
 #ifndef HPX_DBG_NO_S
