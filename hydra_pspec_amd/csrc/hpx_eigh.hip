@@ -27,6 +27,18 @@
 
 namespace {
 
+__device__ __forceinline__ double hj_rsqrt(const double d) {
+  double q = __builtin_amdgcn_rsq(d);
+  q = fma(q * 0.5, fma(-d * q, q, 1.0), q);
+  q = fma(q * 0.5, fma(-d * q, q, 1.0), q);
+  return q;
+}
+__device__ __forceinline__ double hj_rcp(const double d) {
+  double r = __builtin_amdgcn_rcp(d);
+  r = fma(r, fma(-d, r, 1.0), r);
+  r = fma(r, fma(-d, r, 1.0), r);
+  return r;
+}
 __device__ __forceinline__ void rr_pair16(const int n, const int s, const int i, int& p, int& q) {
   const int m = n - 1;
   int a, b;
@@ -96,9 +108,8 @@ __global__ __launch_bounds__(256, 2) void k_hj_step(double* __restrict__ wre, do
   constexpr int M = 2 * NB, MM = M * M, MT = M / 16;      // MT x MT tiles of 16 x 16
   constexpr int EPT = MM / 256;                           // entries per thread of the small problem
   __shared__ double Ga[2][2][MM], Qa[2][2][MM];
-  __shared__ double partbuf[(MT == 1) ? 2048 : 1];        // NB = 8: the four waves' partial Gram matrices
   __shared__ double rot[M / 2][4];
-  __shared__ int partner[M], isq[M], pidx[M];
+  __shared__ double partbuf[(MT == 1) ? 2048 : 1];        // NB = 8: the four waves' partial Gram matrices
   __shared__ double red[4];
   __shared__ int skip;
   const int b = blockIdx.y, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, g = lane >> 4;
@@ -203,69 +214,90 @@ __global__ __launch_bounds__(256, 2) void k_hj_step(double* __restrict__ wre, do
     __syncthreads();
     if (skip) return;
   }
-  // ---- 2. two-sided Jacobi on G (EPT entries per thread), Q accumulates the rotations
-  int cur = 0;
+  // ---- 2. two-sided Jacobi on G, Q accumulates the rotations.  A step rotates M / 2 disjoint pairs; entry (r, c) of
+  // G' = J^H G J needs G at {r, partner r} x {c, partner c} -- a 2 x 2 block that maps to itself.  One THREAD per
+  // block (pair of rows i, pair of columns j: (M/2)^2 = 256 blocks for M = 32): it reads its four entries of G and of
+  // Q once and the two rotations from the step's table.  (Round 4: one entry per thread -- eight reads of G, four of Q
+  // and four table look-ups per entry.)  The rotations themselves stay on 16 lanes of ONE wave: their square roots
+  // and divisions are fp64 vector work, which shares the pipe with the co-resident workgroup's MFMAs -- formed by
+  // every thread for itself (no table, one barrier less) the kernel took 2.2 - 2.7 s instead of 1.6.  Same operations
+  // per entry, in the same order, as before.
   // (rotating only the pairs (column of block I, column of block J), M / 2 steps instead of M - 1, does not
   // converge: the columns inside a block have to meet each other too)
-  for (int sw = 0; sw < inner_sweeps; ++sw)
-    for (int st = 0; st < M - 1; ++st) {
-      if (tid < M / 2) {
-        int pp, qq;
-        rr_pair16(M, st, tid, pp, qq);
-        const double a = Ga[cur][0][pp * (M + 1)], bq = Ga[cur][0][qq * (M + 1)];
-        const double cr = Ga[cur][0][pp * M + qq], ci = Ga[cur][1][pp * M + qq];
-        const double ac2 = cr * cr + ci * ci;
-        double cs = 1.0, sn = 0.0, cp = 1.0, sp = 0.0;
-        if (ac2 > 1e-34 * fabs(a * bq) && ac2 > 0.0) {
-          const double ac = sqrt(ac2);
-          const double tau = (bq - a) / (2.0 * ac);
-          const double t = ((tau >= 0.0) ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
-          cs = 1.0 / sqrt(1.0 + t * t);
-          sn = t * cs;
-          cp = cr / ac;
-          sp = ci / ac;
+  int cur = 0;
+  {
+    const int bi_ = tid / (M / 2), bj_ = tid % (M / 2);
+    const bool act = tid < (M / 2) * (M / 2);
+    for (int sw = 0; sw < inner_sweeps; ++sw)
+      for (int st = 0; st < M - 1; ++st) {
+        if (tid < M / 2) {
+          int pp, qq;
+          rr_pair16(M, st, tid, pp, qq);
+          const double a = Ga[cur][0][pp * (M + 1)], bq = Ga[cur][0][qq * (M + 1)];
+          const double cr = Ga[cur][0][pp * M + qq], ci = Ga[cur][1][pp * M + qq];
+          const double ac2 = cr * cr + ci * ci;
+          double cs = 1.0, sn = 0.0, cp = 1.0, sp = 0.0;
+          if (ac2 > 1e-34 * fabs(a * bq) && ac2 > 0.0) {
+            // reciprocal square roots / reciprocal by the hardware seed + two Newton steps (2e-16) instead of three
+            // IEEE square roots and four divisions: this chain, on one wave, is what a step waits for
+            const double iac = hj_rsqrt(ac2);                      // 1 / |c|
+            const double tau = (bq - a) * 0.5 * iac;
+            const double h2 = 1.0 + tau * tau;
+            const double t = ((tau >= 0.0) ? 1.0 : -1.0) * hj_rcp(fabs(tau) + h2 * hj_rsqrt(h2));
+            cs = hj_rsqrt(1.0 + t * t);
+            sn = t * cs;
+            cp = cr * iac;
+            sp = ci * iac;
+          }
+          rot[tid][0] = cs; rot[tid][1] = sn; rot[tid][2] = cp; rot[tid][3] = sp;
         }
-        rot[tid][0] = cs; rot[tid][1] = sn; rot[tid][2] = cp; rot[tid][3] = sp;
-        partner[pp] = qq; partner[qq] = pp;
-        isq[pp] = 0; isq[qq] = 1;
-        pidx[pp] = tid; pidx[qq] = tid;
-      }
-      __syncthreads();
-      const double* gre = Ga[cur][0];
-      const double* gim = Ga[cur][1];
-      const double* qre = Qa[cur][0];
-      const double* qim = Qa[cur][1];
+        __syncthreads();
+        if (act) {
+          const double* gre = Ga[cur][0];
+          const double* gim = Ga[cur][1];
+          const double* qre = Qa[cur][0];
+          const double* qim = Qa[cur][1];
+          int rw[2], cl[2];
+          rr_pair16(M, st, bi_, rw[0], rw[1]);
+          rr_pair16(M, st, bj_, cl[0], cl[1]);
+          const double csr = rot[bi_][0], snr = rot[bi_][1], cpr = rot[bi_][2], spr = rot[bi_][3];
+          const double csc = rot[bj_][0], snc = rot[bj_][1], cpc = rot[bj_][2], spc = rot[bj_][3];
+          // x_a' = own_a x_a + part_a x_partner(a):  a = p: (cs, -sn e^{-i phi});  a = q: (cs, sn e^{i phi})
+          double g_r[2][2], g_i[2][2], q_r[2][2], q_i[2][2];
 #pragma unroll
-      for (int q = 0; q < EPT; ++q) {
-        const int e = tid + 256 * q, r = e / M, c = e % M;
-        // x_a' = own_a x_a + part_a x_partner(a):  a = p: (cs, -sn e^{-i phi});  a = q: (cs, sn e^{i phi})
-        const int rp = partner[r], cq = partner[c];
-        const double* rc_ = rot[pidx[c]];
-        const double own_c = rc_[0];
-        const double pcr = isq[c] ? rc_[1] * rc_[2] : -rc_[1] * rc_[2];
-        const double pci = rc_[1] * rc_[3];
-        const double* rr_ = rot[pidx[r]];
-        const double own_r = rr_[0];
-        const double prr = isq[r] ? rr_[1] * rr_[2] : -rr_[1] * rr_[2];
-        const double pri = rr_[1] * rr_[3];
-        // T = G J (columns), at rows r and partner(r)
-        const double t1r = gre[r * M + c] * own_c + gre[r * M + cq] * pcr - gim[r * M + cq] * pci;
-        const double t1i = gim[r * M + c] * own_c + gre[r * M + cq] * pci + gim[r * M + cq] * pcr;
-        const double t2r = gre[rp * M + c] * own_c + gre[rp * M + cq] * pcr - gim[rp * M + cq] * pci;
-        const double t2i = gim[rp * M + c] * own_c + gre[rp * M + cq] * pci + gim[rp * M + cq] * pcr;
-        // G' = J^H T (rows): conj(part_r) = (prr, -pri)
-        const double nr = own_r * t1r + prr * t2r + pri * t2i;
-        const double ni = own_r * t1i + prr * t2i - pri * t2r;
-        const double qr_ = qre[r * M + c] * own_c + qre[r * M + cq] * pcr - qim[r * M + cq] * pci;
-        const double qi_ = qim[r * M + c] * own_c + qre[r * M + cq] * pci + qim[r * M + cq] * pcr;
-        Ga[cur ^ 1][0][e] = nr;
-        Ga[cur ^ 1][1][e] = (r == c) ? 0.0 : ni;
-        Qa[cur ^ 1][0][e] = qr_;
-        Qa[cur ^ 1][1][e] = qi_;
+          for (int x = 0; x < 2; ++x)
+#pragma unroll
+            for (int y = 0; y < 2; ++y) {
+              g_r[x][y] = gre[rw[x] * M + cl[y]]; g_i[x][y] = gim[rw[x] * M + cl[y]];
+              q_r[x][y] = qre[rw[x] * M + cl[y]]; q_i[x][y] = qim[rw[x] * M + cl[y]];
+            }
+#pragma unroll
+          for (int x = 0; x < 2; ++x)
+#pragma unroll
+            for (int y = 0; y < 2; ++y) {
+              const double own_c = csc, pcr = y ? snc * cpc : -snc * cpc, pci = snc * spc;
+              const double own_r = csr, prr = x ? snr * cpr : -snr * cpr, pri = snr * spr;
+              // T = G J (columns), at rows r and partner(r)
+              const double t1r = g_r[x][y] * own_c + g_r[x][1 - y] * pcr - g_i[x][1 - y] * pci;
+              const double t1i = g_i[x][y] * own_c + g_r[x][1 - y] * pci + g_i[x][1 - y] * pcr;
+              const double t2r = g_r[1 - x][y] * own_c + g_r[1 - x][1 - y] * pcr - g_i[1 - x][1 - y] * pci;
+              const double t2i = g_i[1 - x][y] * own_c + g_r[1 - x][1 - y] * pci + g_i[1 - x][1 - y] * pcr;
+              // G' = J^H T (rows): conj(part_r) = (prr, -pri)
+              const double nr = own_r * t1r + prr * t2r + pri * t2i;
+              const double ni = own_r * t1i + prr * t2i - pri * t2r;
+              const double qr_ = q_r[x][y] * own_c + q_r[x][1 - y] * pcr - q_i[x][1 - y] * pci;
+              const double qi_ = q_i[x][y] * own_c + q_r[x][1 - y] * pci + q_i[x][1 - y] * pcr;
+              const int e = rw[x] * M + cl[y];
+              Ga[cur ^ 1][0][e] = nr;
+              Ga[cur ^ 1][1][e] = (rw[x] == cl[y]) ? 0.0 : ni;
+              Qa[cur ^ 1][0][e] = qr_;
+              Qa[cur ^ 1][1][e] = qi_;
+            }
+        }
+        __syncthreads();
+        cur ^= 1;
       }
-      __syncthreads();
-      cur ^= 1;
-    }
+  }
   // ---- 3. W <- W Q on the pair's columns, 16 rows at a time: out[r][j] = sum_i W[r][i] Q[i][j]
   {
     double qr[MT][4 * MT], qi[MT][4 * MT];

@@ -17,7 +17,9 @@
  *    between the workgroups of a split factorisation timed out (a statement
  *    about the device being shared, not about the matrix).  Nothing throws.
  *    hpx_last_error() returns a thread-local message for the last failure.
- *  - No global state besides the plan.  One host thread per plan.
+ *  - State lives in the plan.  Process-wide: the library options of hpx_set_option(NULL, ..) and, per
+ *    device, the books of the split factorisations in flight (thread-safe).  One host thread per plan;
+ *    different plans may be driven from different threads / streams.
  */
 #ifndef HPX_H
 #define HPX_H
