@@ -20,6 +20,7 @@
 // write).  Complex products are four real MFMAs on (re, im) accumulators: the three-product form would need 24
 // instead of 16 registers per tile, and the tiles no longer fit.
 #include "hpx_internal.h"
+#include <type_traits>
 
 #define HPX_INL __forceinline__
 
@@ -260,6 +261,170 @@ __device__ HPX_INL void bs_reg_pass(const double* __restrict__ Lre, const double
 #undef HPX_BS_LOADW
 }
 
+// ---- one t-tile per workgroup with HAND-COUNTED operand waits (the small-batch form) --------------------------------
+// bs_reg_pass's operand loads sit under data-dependent conditions (tile below the current row?  this wave's turn to
+// finalise?), so the compiler cannot count what is in flight: after every such branch it waits with vmcnt(0) -- for the
+// operands it has just requested for later steps too.  Every step then costs a memory round trip, whatever the
+// prefetch distance (config 2: 3.4 us per step for 1 us of dependent work).  Here every wave issues the SAME loads
+// in every step (clamped addresses where a tile does not exist or is not needed: tiles above the diagonal are read
+// and dropped -- up to twice the factor's bytes, which is why only the small batches whose chain of steps is what
+// takes the time come here), through asm statements the compiler does not see, and the waits are counted by hand:
+// before step J uses operand set S, all but the (DEPTH - 1) NS * 4 youngest loads are complete.  The stores of a
+// finalised tile (compiler-issued, on the owner's path only) count on the same counter: they only make a wait
+// stricter.  The inverse diagonal tiles of all the wave's row tiles are fetched once, up front.
+typedef double bs_d2 __attribute__((ext_vector_type(2)));
+__device__ HPX_INL bs_d2 bs_ld16(const double* ubase, const unsigned lane_bytes) {
+  bs_d2 r;
+  asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(r) : "v"(lane_bytes), "s"(ubase) : "memory");
+  return r;
+}
+template <int N>
+__device__ HPX_INL void bs_wait_vm() {
+  asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N < 63 ? N : 63) : "memory");
+}
+template <int NS, int DEPTH>
+__device__ HPX_INL void bs_tile_pass_ul(const double* __restrict__ Lre, const double* __restrict__ Wgre,
+                                        const double* __restrict__ Wgim, double* __restrict__ Xre,
+                                        double* __restrict__ Xim, double* xs, const int npad, const int TP, const int t0,
+                                        const int wave, const int lane) {
+  static_assert(NS >= 1 && DEPTH >= 1 && (DEPTH - 1) * NS * 4 <= 60, "operand ring out of range");
+  const int nct = npad >> 4, Jlast = nct - 1;
+  const int li = lane & 15, g = lane >> 4;
+  const unsigned lz = 8u * (g * 32 + li);          // lane offsets (bytes): Z / X tiles, L operand, inverse tile
+  const unsigned ll = 8u * (li * 32 + 4 * g);
+  const unsigned lw = 8u * (g * 32 + li);
+  int tl[NS];                                      // the wave's row tiles (slot q), clamped for addressing
+#pragma unroll
+  for (int q = 0; q < NS; ++q) tl[q] = tile_of(q, wave);
+  // ---- everything the compiler loads: Z, the inverse tiles (complete before the first hand-placed load is issued)
+  d4 ar[NS], ai[NS];
+#pragma unroll
+  for (int q = 0; q < NS; ++q) {
+    const int Ic = min(tl[q], nct - 1);
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {                  // Z[c][t] = conj(Laug[npad + t][c]) as acc[m = c][n = t]
+      const double* zb = Lre + ((long)((npad + t0) >> 4) * npad + 16 * Ic + 4 * v) * 32;
+      const double a_ = *lane_ptr<double>(zb, lz), b_ = *lane_ptr<double>(zb + 16, lz);
+      ar[q][v] = (tl[q] < nct) ? a_ : 0.0;
+      ai[q][v] = (tl[q] < nct) ? -b_ : 0.0;
+    }
+  }
+  double wa_r[NS + 1][4], wa_i[NS + 1][4];          // inv(L_II) of slot q's tile; [NS]: of the last tile row
+#pragma unroll
+  for (int q = 0; q <= NS; ++q) {
+    const int Ic = (q < NS) ? min(tl[q < NS ? q : 0], nct - 1) : nct - 1;
+    const double* wr_ = Wgre + (long)(Ic >> 1) * 1024 + (16 * (Ic & 1)) * 33;
+    const double* wi_ = Wgim + (long)(Ic >> 1) * 1024 + (16 * (Ic & 1)) * 33;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      wa_r[q][s] = *lane_ptr<double>(wr_ + (4 * s) * 32, lw);
+      wa_i[q][s] = *lane_ptr<double>(wi_ + (4 * s) * 32, lw);
+    }
+  }
+  d4 zl_r = {0., 0., 0., 0.}, zl_i = zl_r;          // Z of the last tile row when it has no slot (alone in its block)
+  const bool last_alone = (Jlast >> 3) >= NS;
+  if (last_alone) {
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const double* zb = Lre + ((long)((npad + t0) >> 4) * npad + 16 * Jlast + 4 * v) * 32;
+      zl_r[v] = *lane_ptr<double>(zb, lz);
+      zl_i[v] = -*lane_ptr<double>(zb + 16, lz);
+    }
+  }
+  __builtin_amdgcn_s_waitcnt(0x0f70);               // vmcnt(0): the compiler's loads are in (and it knows)
+  // ---- the operand ring: set S holds rows 4 g .. 4 g + 3 (k index (g, s)) of column li of tiles (J, I_q)
+  bs_d2 la[DEPTH][NS][2], lb[DEPTH][NS][2];
+  auto issue = [&](auto sc, const int J) {
+    constexpr int S = decltype(sc)::value;
+    const int Jc = max(J, 0);
+#pragma unroll
+    for (int q = 0; q < NS; ++q) {
+      const double* lb_ = Lre + ((long)Jc * npad + 16 * min(tl[q], nct - 1)) * 32;
+      la[S][q][0] = bs_ld16(lb_, ll);
+      la[S][q][1] = bs_ld16(lb_ + 2, ll);
+      lb[S][q][0] = bs_ld16(lb_ + 16, ll);
+      lb[S][q][1] = bs_ld16(lb_ + 18, ll);
+    }
+  };
+  // X_J = inv(L_JJ)^H acc: stored, and published in LDS slot J & 1 as [re 16 x 16 | im 16 x 16], row-major
+  auto finalise = [&](const int J, const d4& accr, const d4& acci, const double (&wr)[4], const double (&wi)[4]) {
+    double* xb_ = xs + (J & 1) * 512;
+    d4 xr_ = {0., 0., 0., 0.}, xi_ = {0., 0., 0., 0.};
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      xr_ = mfma64(wr[s], accr[s], xr_);
+      xr_ = mfma64(wi[s], acci[s], xr_);
+      xi_ = mfma64(wr[s], acci[s], xi_);
+      xi_ = mfma64(-wi[s], accr[s], xi_);
+    }
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const int c_ = HPX_ACC_ROW(g, v);
+      xb_[c_ * 16 + li] = xr_[v];
+      xb_[256 + c_ * 16 + li] = xi_[v];
+      const long xo_ = (long)(16 * J + 4 * v) * TP + t0;
+      *lane_ptr_w(Xre + xo_, 8u * (g * TP + li)) = xr_[v];
+      *lane_ptr_w(Xim + xo_, 8u * (g * TP + li)) = xi_[v];
+    }
+  };
+  if (wave == owner_of(Jlast)) {
+    if (last_alone) finalise(Jlast, zl_r, zl_i, wa_r[NS], wa_i[NS]);
+    else {
+#pragma unroll
+      for (int q = 0; q < NS; ++q)
+        if (q == (Jlast >> 3)) finalise(Jlast, ar[q], ai[q], wa_r[q], wa_i[q]);
+    }
+  }
+  // the ring's first DEPTH rows (behind the owner's stores above: they only make the first waits stricter)
+  issue(std::integral_constant<int, 0>{}, Jlast);
+  if (DEPTH > 1) issue(std::integral_constant<int, (DEPTH > 1 ? 1 : 0)>{}, Jlast - 1);
+  if (DEPTH > 2) issue(std::integral_constant<int, (DEPTH > 2 ? 2 : 0)>{}, Jlast - 2);
+  if (DEPTH > 3) issue(std::integral_constant<int, (DEPTH > 3 ? 3 : 0)>{}, Jlast - 3);
+  // acc_I -= L[J, I]^H X_J with X_J from LDS slot `sl`:  conj(l) x = (lr xr + lm xi) + i (lr xi - lm xr)
+  auto step = [&](auto sc, const int J) {
+    constexpr int S = decltype(sc)::value;
+    lds_barrier();                                  // X_J is in its slot; the other slot is free again
+    bs_wait_vm<(DEPTH - 1) * NS * 4>();             // operand set S has landed (all but the later sets' loads)
+#pragma unroll
+    for (int q = 0; q < NS; ++q)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) asm volatile("" : "+v"(la[S][q][h]), "+v"(lb[S][q][h]));
+    const int sl = J & 1, qn = (J - 1) >> 3;
+    const bool next_mine = (wave == owner_of(J - 1));
+    const lds_f64* xb = (const lds_f64*)(xs + sl * 512);
+    auto update = [&](const int q) {
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const double lr_ = la[S][q][s >> 1][s & 1], lm_ = lb[S][q][s >> 1][s & 1];
+        const double xr_ = xb[(4 * g + s) * 16 + li], xi_ = xb[256 + (4 * g + s) * 16 + li];
+        ar[q] = mfma64(-lr_, xr_, ar[q]);
+        ar[q] = mfma64(-lm_, xi_, ar[q]);
+        ai[q] = mfma64(-lr_, xi_, ai[q]);
+        ai[q] = mfma64(lm_, xr_, ai[q]);
+      }
+    };
+    if (next_mine) {                                // the next tile to finalise first: it is what the next step waits for
+#pragma unroll
+      for (int q = 0; q < NS; ++q)
+        if (q == qn) {
+          update(q);
+          finalise(J - 1, ar[q], ai[q], wa_r[q], wa_i[q]);
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < NS; ++q)
+      if (!(next_mine && q == qn) && tl[q] < J) update(q);
+    issue(sc, J - DEPTH);                           // (every wave, every step: the counts above rest on it)
+  };
+  for (int J0 = Jlast; J0 >= 1; J0 -= DEPTH) {
+    step(std::integral_constant<int, 0>{}, J0);
+    if (DEPTH > 1 && J0 - 1 >= 1) step(std::integral_constant<int, (DEPTH > 1 ? 1 : 0)>{}, J0 - 1);
+    if (DEPTH > 2 && J0 - 2 >= 1) step(std::integral_constant<int, (DEPTH > 2 ? 2 : 0)>{}, J0 - 2);
+    if (DEPTH > 3 && J0 - 3 >= 1) step(std::integral_constant<int, (DEPTH > 3 ? 3 : 0)>{}, J0 - 3);
+  }
+  bs_wait_vm<0>();                                  // nothing lands in a register after its last use
+}
+
 // TSPLIT: one workgroup per (baseline, t-tile) -- for batches that would leave most CUs without a baseline (config 2:
 // 64 baselines on 256 CUs).  The right-hand-side columns are independent, so the t-tiles of a baseline run side by
 // side; each workgroup then reads the baseline's factor for itself (the second read comes from L2 / the Infinity
@@ -288,7 +453,8 @@ __global__ __launch_bounds__(512, 2) void k_backsolve_reg(const double* __restri
   const int TT = TP >> 4;
   constexpr int DEPTH = (NS <= 2) ? (TSPLIT ? 3 : 2) : ((TSPLIT && NS <= 4) ? HPX_BS_DEPTH4 : 1);   // operand sets the registers hold without spills
   if (TSPLIT) {
-    bs_reg_pass<NS, 1, DEPTH>(Lre, Wgre, Wgim, Xre, Xim, xs, npad, TP, tsel << 4, wave, lane);
+    if constexpr (NS >= 1 && NS <= 2) bs_tile_pass_ul<NS, 3>(Lre, Wgre, Wgim, Xre, Xim, xs, npad, TP, tsel << 4, wave, lane);
+    else bs_reg_pass<NS, 1, DEPTH>(Lre, Wgre, Wgim, Xre, Xim, xs, npad, TP, tsel << 4, wave, lane);
     return;
   }
   constexpr int NTMAX = (NS >= 5) ? 1 : 2;      // accumulators + L operands within the register file
