@@ -17,8 +17,11 @@
 // step J - 1 as soon as step J has used them (a whole step of latency cover).
 //
 // inv(L_JJ) is read from the diagonal 16 x 16 sub-blocks of W (the 32 x 32 inverse blocks both factor kernels
-// write).  Complex products are four real MFMAs on (re, im) accumulators: the three-product form would need 24
-// instead of 16 registers per tile, and the tiles no longer fit.
+// write).  Complex products: up to two row tiles per wave (17 tile rows, N = 256) from THREE real MFMAs on three
+// accumulators per tile (24 instead of 16 registers, 12 instead of 16 MFMAs per tile and step: 0.308 against 0.333 ms
+// for 1024 baselines at N = 256); with more row tiles per wave the third accumulator no longer fits 256 registers
+// (54 .. 62 spilled) and the four-product form on (re, im) accumulators stays.  The whole register file of a CU
+// (512 KB) cannot hold 33 row tiles x 2 t-tiles x 3 accumulators (396 KB) next to one set of L operands (132 KB).
 #include "hpx_internal.h"
 #include <type_traits>
 
@@ -63,7 +66,10 @@ __device__ HPX_INL int owner_of(const int I) { return ((I >> 3) & 1) ? 7 - (I & 
 // by DEPTH so that every set is a compile-time register range).  One step ahead leaves a step's worth of time --
 // under a microsecond at small orders -- to cover a memory round trip of two to three: the chain of dependent steps
 // then runs at the memory latency (config 2: 52 us for 16 steps).  Four steps ahead where the registers allow it.
-template <int NS, int NT, int DEPTH>
+// M3: complex products from THREE real ones (see bs_tile_pass_ul, whose results this form then reproduces bit for
+// bit -- a baseline gives the same chain alone and inside a large batch): ar = Re z - sum lr xr, ai = sum lm xi,
+// a3 = (Re z + Im z) - sum (lr - lm)(xr + xi); the accumulator is (ar - ai) + i (a3 - ar - ai).
+template <int NS, int NT, int DEPTH, bool M3>
 __device__ HPX_INL void bs_reg_pass(const double* __restrict__ Lre, const double* __restrict__ Wgre,
                                     const double* __restrict__ Wgim, double* __restrict__ Xre,
                                     double* __restrict__ Xim, double* xs, const int npad, const int TP, const int t0,
@@ -74,7 +80,7 @@ __device__ HPX_INL void bs_reg_pass(const double* __restrict__ Lre, const double
   const unsigned lz = 8u * (g * 32 + li);          // lane offsets (bytes): Z / X tiles, L operand, inverse tile
   const unsigned ll = 8u * (li * 32 + 4 * g);
   const unsigned lw = 8u * (g * 32 + li);
-  d4 ar[NS > 0 ? NS : 1][NT], ai[NS > 0 ? NS : 1][NT];
+  d4 ar[NS > 0 ? NS : 1][NT], ai[NS > 0 ? NS : 1][NT], a3[NS > 0 ? NS : 1][NT];
   // ---- Z[c][t] = conj(Laug[npad + t][c]) as acc[m = c][n = t]
 #pragma unroll
   for (int q = 0; q < NS; ++q) {
@@ -90,7 +96,8 @@ __device__ HPX_INL void bs_reg_pass(const double* __restrict__ Lre, const double
           zi = -*lane_ptr<double>(zb + 16, lz);
         }
         ar[q][tt][v] = zr;
-        ai[q][tt][v] = zi;
+        ai[q][tt][v] = M3 ? 0.0 : zi;
+        a3[q][tt][v] = zr + zi;
       }
   }
   // ---- L operand of a step: rows 4 g .. 4 g + 3 (k index (g, s)) of column li of tile (J, I)
@@ -115,13 +122,20 @@ __device__ HPX_INL void bs_reg_pass(const double* __restrict__ Lre, const double
     _Pragma("unroll") for (int s = 0; s < 4; ++s) {                                      \
       __builtin_amdgcn_sched_barrier(0);                                                 \
       const double nlr_ = -lr[S_][q_][s], nlm_ = -lm[S_][q_][s], plm_ = lm[S_][q_][s];   \
+      const double dl_ = lm[S_][q_][s] - lr[S_][q_][s];                                  \
       _Pragma("unroll") for (int tt = 0; tt < NT; ++tt) {                                \
         const double xr_ = xb_[tt * 512 + (4 * g + s) * 16 + li];                        \
         const double xi_ = xb_[tt * 512 + 256 + (4 * g + s) * 16 + li];                  \
-        ar[q_][tt] = mfma64(nlr_, xr_, ar[q_][tt]);                                      \
-        ar[q_][tt] = mfma64(nlm_, xi_, ar[q_][tt]);                                      \
-        ai[q_][tt] = mfma64(nlr_, xi_, ai[q_][tt]);                                      \
-        ai[q_][tt] = mfma64(plm_, xr_, ai[q_][tt]);                                      \
+        if (M3) {                                                                        \
+          ar[q_][tt] = mfma64(nlr_, xr_, ar[q_][tt]);                                    \
+          ai[q_][tt] = mfma64(plm_, xi_, ai[q_][tt]);                                    \
+          a3[q_][tt] = mfma64(dl_, xr_ + xi_, a3[q_][tt]);                               \
+        } else {                                                                         \
+          ar[q_][tt] = mfma64(nlr_, xr_, ar[q_][tt]);                                    \
+          ar[q_][tt] = mfma64(nlm_, xi_, ar[q_][tt]);                                    \
+          ai[q_][tt] = mfma64(nlr_, xi_, ai[q_][tt]);                                    \
+          ai[q_][tt] = mfma64(plm_, xr_, ai[q_][tt]);                                    \
+        }                                                                                \
       }                                                                                  \
     }                                                                                    \
   }
@@ -143,11 +157,25 @@ __device__ HPX_INL void bs_reg_pass(const double* __restrict__ Lre, const double
     double* xb_ = xs + ((J_) & 1) * (NT * 512);                                          \
     _Pragma("unroll") for (int tt = 0; tt < NT; ++tt) {                                  \
       d4 xr_ = {0., 0., 0., 0.}, xi_ = {0., 0., 0., 0.};                                 \
-      _Pragma("unroll") for (int s = 0; s < 4; ++s) {                                    \
-        xr_ = mfma64(w_r[s], HPX_BS_ACC_R(tt)[s], xr_);                                  \
-        xr_ = mfma64(w_i[s], HPX_BS_ACC_I(tt)[s], xr_);                                  \
-        xi_ = mfma64(w_r[s], HPX_BS_ACC_I(tt)[s], xi_);                                  \
-        xi_ = mfma64(-w_i[s], HPX_BS_ACC_R(tt)[s], xi_);                                 \
+      const d4 cr_ = HPX_BS_ACC_R(tt), ci_ = HPX_BS_ACC_I(tt);                           \
+      if (M3) {                                                                          \
+        const d4 cs_ = cr_ + ci_;                                                        \
+        d4 p3_ = {0., 0., 0., 0.};                                                       \
+        _Pragma("unroll") for (int s = 0; s < 4; ++s) {                                  \
+          xr_ = mfma64(w_r[s], cr_[s], xr_);                                             \
+          xi_ = mfma64(w_i[s], ci_[s], xi_);                                             \
+          p3_ = mfma64(w_r[s] - w_i[s], cs_[s], p3_);                                    \
+        }                                                                                \
+        const d4 p1_ = xr_;                                                              \
+        xr_ = p1_ + xi_;                                                                 \
+        xi_ = (p3_ - p1_) + xi_;                                                         \
+      } else {                                                                           \
+        _Pragma("unroll") for (int s = 0; s < 4; ++s) {                                  \
+          xr_ = mfma64(w_r[s], cr_[s], xr_);                                             \
+          xr_ = mfma64(w_i[s], ci_[s], xr_);                                             \
+          xi_ = mfma64(w_r[s], ci_[s], xi_);                                             \
+          xi_ = mfma64(-w_i[s], cr_[s], xi_);                                            \
+        }                                                                                \
       }                                                                                  \
       _Pragma("unroll") for (int v = 0; v < 4; ++v) {                                    \
         const int c_ = HPX_ACC_ROW(g, v);                                                \
@@ -188,8 +216,8 @@ __device__ HPX_INL void bs_reg_pass(const double* __restrict__ Lre, const double
 #pragma unroll
       for (int q = 0; q < NS; ++q)
         if (q == (Jlast >> 3)) {
-#define HPX_BS_ACC_R(tt_) ar[q][tt_]
-#define HPX_BS_ACC_I(tt_) ai[q][tt_]
+#define HPX_BS_ACC_R(tt_) (M3 ? ar[q][tt_] - ai[q][tt_] : ar[q][tt_])
+#define HPX_BS_ACC_I(tt_) (M3 ? (a3[q][tt_] - ar[q][tt_]) - ai[q][tt_] : ai[q][tt_])
           HPX_BS_FINAL_OF(Jlast)
 #undef HPX_BS_ACC_R
 #undef HPX_BS_ACC_I
@@ -223,19 +251,27 @@ __device__ HPX_INL void bs_reg_pass(const double* __restrict__ Lre, const double
       const lds_f64* xb = (const lds_f64*)(xs + sl * (NT * 512));                                      \
       _Pragma("unroll") for (int s = 0; s < 4; ++s) {                                                  \
         __builtin_amdgcn_sched_barrier(0);                                                             \
-        double xr[NT], xi[NT];                                                                         \
+        double xr[NT], xi[NT], xq[NT];                                                                 \
         _Pragma("unroll") for (int tt = 0; tt < NT; ++tt) {                                            \
           xr[tt] = xb[tt * 512 + (4 * g + s) * 16 + li];                                               \
           xi[tt] = xb[tt * 512 + 256 + (4 * g + s) * 16 + li];                                         \
+          xq[tt] = xr[tt] + xi[tt];                                                                    \
         }                                                                                              \
         _Pragma("unroll") for (int q = 0; q < NL; ++q)                                                 \
           if (!(next_mine && q == qn) && tile_of(q, wave) < J) {                                       \
             const double nlr = -lr[S_][q][s], nlm = -lm[S_][q][s], plm = lm[S_][q][s];                 \
+            const double dl = lm[S_][q][s] - lr[S_][q][s];                                             \
             _Pragma("unroll") for (int tt = 0; tt < NT; ++tt) {                                        \
-              ar[q][tt] = mfma64(nlr, xr[tt], ar[q][tt]);                                              \
-              ar[q][tt] = mfma64(nlm, xi[tt], ar[q][tt]);                                              \
-              ai[q][tt] = mfma64(nlr, xi[tt], ai[q][tt]);                                              \
-              ai[q][tt] = mfma64(plm, xr[tt], ai[q][tt]);                                              \
+              if (M3) {                                                                                \
+                ar[q][tt] = mfma64(nlr, xr[tt], ar[q][tt]);                                            \
+                ai[q][tt] = mfma64(plm, xi[tt], ai[q][tt]);                                            \
+                a3[q][tt] = mfma64(dl, xq[tt], a3[q][tt]);                                             \
+              } else {                                                                                 \
+                ar[q][tt] = mfma64(nlr, xr[tt], ar[q][tt]);                                            \
+                ar[q][tt] = mfma64(nlm, xi[tt], ar[q][tt]);                                            \
+                ai[q][tt] = mfma64(nlr, xi[tt], ai[q][tt]);                                            \
+                ai[q][tt] = mfma64(plm, xr[tt], ai[q][tt]);                                            \
+              }                                                                                        \
             }                                                                                          \
           }                                                                                            \
       }                                                                                                \
@@ -244,8 +280,8 @@ __device__ HPX_INL void bs_reg_pass(const double* __restrict__ Lre, const double
         if (!(next_mine && q == qn) && tile_of(q, wave) < J) HPX_BS_LOADL(S_, q, J - DEPTH)            \
     }                                                                                                  \
   }
-#define HPX_BS_ACC_R(tt_) ar[q][tt_]
-#define HPX_BS_ACC_I(tt_) ai[q][tt_]
+#define HPX_BS_ACC_R(tt_) (M3 ? ar[q][tt_] - ai[q][tt_] : ar[q][tt_])
+#define HPX_BS_ACC_I(tt_) (M3 ? (a3[q][tt_] - ar[q][tt_]) - ai[q][tt_] : ai[q][tt_])
   for (int J0 = Jlast; J0 >= 1; J0 -= DEPTH) {
     HPX_BS_STEP(0, J0)
     if (DEPTH > 1) HPX_BS_STEP(1 % DEPTH, J0 - 1)
@@ -272,6 +308,13 @@ __device__ HPX_INL void bs_reg_pass(const double* __restrict__ Lre, const double
 // before step J uses operand set S, all but the (DEPTH - 1) NS * 4 youngest loads are complete.  The stores of a
 // finalised tile (compiler-issued, on the owner's path only) count on the same counter: they only make a wait
 // stricter.  The inverse diagonal tiles of all the wave's row tiles are fetched once, up front.
+#ifndef HPX_BS_M3_MAXNS
+#define HPX_BS_M3_MAXNS 2          // slots per wave up to which the three-product form is used
+#endif
+#ifndef HPX_BS_DEPTH2W
+#define HPX_BS_DEPTH2W 1            // operand sets ahead, two slots x two t-tiles with three accumulators each (two spill)
+#endif
+#define HPX_BS_M3(NS_) ((NS_) <= HPX_BS_M3_MAXNS)
 typedef double bs_d2 __attribute__((ext_vector_type(2)));
 __device__ HPX_INL bs_d2 bs_ld16(const double* ubase, const unsigned lane_bytes) {
   bs_d2 r;
@@ -297,7 +340,10 @@ __device__ HPX_INL void bs_tile_pass_ul(const double* __restrict__ Lre, const do
 #pragma unroll
   for (int q = 0; q < NS; ++q) tl[q] = tile_of(q, wave);
   // ---- everything the compiler loads: Z, the inverse tiles (complete before the first hand-placed load is issued)
-  d4 ar[NS], ai[NS];
+  // Complex products with THREE real ones (as in the factor's trailing updates): for acc -= conj(l) x, per row tile
+  //   a1 = Re z - sum lr xr,   a2 = sum lm xi,   a3 = (Re z + Im z) - sum (lr - lm)(xr + xi)
+  // and acc = (a1 - a2) + i (a3 - a1 - a2), formed once, when the tile is finalised.
+  d4 a1[NS], a2[NS], a3[NS];
 #pragma unroll
   for (int q = 0; q < NS; ++q) {
     const int Ic = min(tl[q], nct - 1);
@@ -305,8 +351,9 @@ __device__ HPX_INL void bs_tile_pass_ul(const double* __restrict__ Lre, const do
     for (int v = 0; v < 4; ++v) {                  // Z[c][t] = conj(Laug[npad + t][c]) as acc[m = c][n = t]
       const double* zb = Lre + ((long)((npad + t0) >> 4) * npad + 16 * Ic + 4 * v) * 32;
       const double a_ = *lane_ptr<double>(zb, lz), b_ = *lane_ptr<double>(zb + 16, lz);
-      ar[q][v] = (tl[q] < nct) ? a_ : 0.0;
-      ai[q][v] = (tl[q] < nct) ? -b_ : 0.0;
+      a1[q][v] = (tl[q] < nct) ? a_ : 0.0;
+      a2[q][v] = 0.0;
+      a3[q][v] = (tl[q] < nct) ? a_ - b_ : 0.0;
     }
   }
   double wa_r[NS + 1][4], wa_i[NS + 1][4];          // inv(L_II) of slot q's tile; [NS]: of the last tile row
@@ -346,17 +393,20 @@ __device__ HPX_INL void bs_tile_pass_ul(const double* __restrict__ Lre, const do
       lb[S][q][1] = bs_ld16(lb_ + 18, ll);
     }
   };
-  // X_J = inv(L_JJ)^H acc: stored, and published in LDS slot J & 1 as [re 16 x 16 | im 16 x 16], row-major
+  // X_J = inv(L_JJ)^H acc: stored, and published in LDS slot J & 1 as [re 16 x 16 | im 16 x 16], row-major.
+  // conj(w) acc = (wr accr + wi acci) + i (wr acci - wi accr), again from three products:
+  //   p1 = wr accr,  p2 = wi acci,  p3 = (wr - wi)(accr + acci):  re = p1 + p2,  im = p3 - p1 + p2
   auto finalise = [&](const int J, const d4& accr, const d4& acci, const double (&wr)[4], const double (&wi)[4]) {
     double* xb_ = xs + (J & 1) * 512;
-    d4 xr_ = {0., 0., 0., 0.}, xi_ = {0., 0., 0., 0.};
+    const d4 accs = accr + acci;
+    d4 p1 = {0., 0., 0., 0.}, p2 = p1, p3 = p1;
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-      xr_ = mfma64(wr[s], accr[s], xr_);
-      xr_ = mfma64(wi[s], acci[s], xr_);
-      xi_ = mfma64(wr[s], acci[s], xi_);
-      xi_ = mfma64(-wi[s], accr[s], xi_);
+      p1 = mfma64(wr[s], accr[s], p1);
+      p2 = mfma64(wi[s], acci[s], p2);
+      p3 = mfma64(wr[s] - wi[s], accs[s], p3);
     }
+    const d4 xr_ = p1 + p2, xi_ = (p3 - p1) + p2;
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
       const int c_ = HPX_ACC_ROW(g, v);
@@ -367,12 +417,15 @@ __device__ HPX_INL void bs_tile_pass_ul(const double* __restrict__ Lre, const do
       *lane_ptr_w(Xim + xo_, 8u * (g * TP + li)) = xi_[v];
     }
   };
+  auto finalise3 = [&](const int J, const d4& b1, const d4& b2, const d4& b3, const double (&wr)[4], const double (&wi)[4]) {
+    finalise(J, b1 - b2, (b3 - b1) - b2, wr, wi);
+  };
   if (wave == owner_of(Jlast)) {
     if (last_alone) finalise(Jlast, zl_r, zl_i, wa_r[NS], wa_i[NS]);
     else {
 #pragma unroll
       for (int q = 0; q < NS; ++q)
-        if (q == (Jlast >> 3)) finalise(Jlast, ar[q], ai[q], wa_r[q], wa_i[q]);
+        if (q == (Jlast >> 3)) finalise3(Jlast, a1[q], a2[q], a3[q], wa_r[q], wa_i[q]);
     }
   }
   // the ring's first DEPTH rows (behind the owner's stores above: they only make the first waits stricter)
@@ -392,15 +445,20 @@ __device__ HPX_INL void bs_tile_pass_ul(const double* __restrict__ Lre, const do
     const int sl = J & 1, qn = (J - 1) >> 3;
     const bool next_mine = (wave == owner_of(J - 1));
     const lds_f64* xb = (const lds_f64*)(xs + sl * 512);
+    double xr_[4], xi_[4], xs_[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      xr_[s] = xb[(4 * g + s) * 16 + li];
+      xi_[s] = xb[256 + (4 * g + s) * 16 + li];
+      xs_[s] = xr_[s] + xi_[s];
+    }
     auto update = [&](const int q) {
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
         const double lr_ = la[S][q][s >> 1][s & 1], lm_ = lb[S][q][s >> 1][s & 1];
-        const double xr_ = xb[(4 * g + s) * 16 + li], xi_ = xb[256 + (4 * g + s) * 16 + li];
-        ar[q] = mfma64(-lr_, xr_, ar[q]);
-        ar[q] = mfma64(-lm_, xi_, ar[q]);
-        ai[q] = mfma64(-lr_, xi_, ai[q]);
-        ai[q] = mfma64(lm_, xr_, ai[q]);
+        a1[q] = mfma64(-lr_, xr_[s], a1[q]);
+        a2[q] = mfma64(lm_, xi_[s], a2[q]);
+        a3[q] = mfma64(lm_ - lr_, xs_[s], a3[q]);
       }
     };
     if (next_mine) {                                // the next tile to finalise first: it is what the next step waits for
@@ -408,7 +466,7 @@ __device__ HPX_INL void bs_tile_pass_ul(const double* __restrict__ Lre, const do
       for (int q = 0; q < NS; ++q)
         if (q == qn) {
           update(q);
-          finalise(J - 1, ar[q], ai[q], wa_r[q], wa_i[q]);
+          finalise3(J - 1, a1[q], a2[q], a3[q], wa_r[q], wa_i[q]);
         }
     }
 #pragma unroll
@@ -451,16 +509,17 @@ __global__ __launch_bounds__(512, 2) void k_backsolve_reg(const double* __restri
   double* Xre = Xre_all + (long)b * npad * TP;
   double* Xim = Xim_all + (long)b * npad * TP;
   const int TT = TP >> 4;
-  constexpr int DEPTH = (NS <= 2) ? (TSPLIT ? 3 : 2) : ((TSPLIT && NS <= 4) ? HPX_BS_DEPTH4 : 1);   // operand sets the registers hold without spills
+  constexpr int DEPTH = (NS <= 2) ? (TSPLIT ? 3 : (NS == 2 && HPX_BS_M3(NS) ? HPX_BS_DEPTH2W : 2))
+                                  : ((TSPLIT && NS <= 4) ? HPX_BS_DEPTH4 : 1);   // operand sets the registers hold without spills
   if (TSPLIT) {
     if constexpr (NS >= 1 && NS <= 2) bs_tile_pass_ul<NS, 3>(Lre, Wgre, Wgim, Xre, Xim, xs, npad, TP, tsel << 4, wave, lane);
-    else bs_reg_pass<NS, 1, DEPTH>(Lre, Wgre, Wgim, Xre, Xim, xs, npad, TP, tsel << 4, wave, lane);
+    else bs_reg_pass<NS, 1, DEPTH, HPX_BS_M3(NS)>(Lre, Wgre, Wgim, Xre, Xim, xs, npad, TP, tsel << 4, wave, lane);
     return;
   }
   constexpr int NTMAX = (NS >= 5) ? 1 : 2;      // accumulators + L operands within the register file
   for (int tp = 0; tp < TT; tp += NTMAX) {
-    if (NTMAX == 2 && tp + 1 < TT) bs_reg_pass<NS, 2, DEPTH>(Lre, Wgre, Wgim, Xre, Xim, xs, npad, TP, tp << 4, wave, lane);
-    else bs_reg_pass<NS, 1, DEPTH>(Lre, Wgre, Wgim, Xre, Xim, xs, npad, TP, tp << 4, wave, lane);
+    if (NTMAX == 2 && tp + 1 < TT) bs_reg_pass<NS, 2, DEPTH, HPX_BS_M3(NS)>(Lre, Wgre, Wgim, Xre, Xim, xs, npad, TP, tp << 4, wave, lane);
+    else bs_reg_pass<NS, 1, DEPTH, HPX_BS_M3(NS)>(Lre, Wgre, Wgim, Xre, Xim, xs, npad, TP, tp << 4, wave, lane);
     __syncthreads();                       // the slots are free for the next pass
   }
 }

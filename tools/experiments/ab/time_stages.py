@@ -11,7 +11,7 @@ import numpy as np
 ROOT = pathlib.Path(__file__).resolve().parents[3]
 sys.path.insert(0, str(ROOT))
 CFG = {"C2": (64, 32, 256, 12, 0.0), "C3": (1024, 32, 512, 12, 0.0), "C5": (1024, 32, 1024, 12, 0.15),
-       "C3H": (512, 32, 512, 12, 0.0), "C3Q": (256, 32, 512, 12, 0.0)}
+       "C2L": (1024, 32, 256, 12, 0.0), "C3H": (512, 32, 512, 12, 0.0), "C3Q": (256, 32, 512, 12, 0.0)}
 
 
 def main():
