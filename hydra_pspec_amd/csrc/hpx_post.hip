@@ -1,6 +1,7 @@
 // Everything after the solve: back transform, model, residual, chi^2, ln posterior, the inverse-gamma bandpower
 // draw (k_resid, k_fft_resid, k_dft_resid, k_betam, k_draw) and their launcher.
 #include "hpx_chain.h"
+#include <type_traits>
 #include "hpx_fft.h"
 
 namespace {
@@ -558,7 +559,7 @@ __global__ __launch_bounds__(256) void k_betam(const double* __restrict__ Kre, c
 // rk[k] = 1 / k (LDS table, k < a <= HPX_RK_MAX, else NULL): the forward sum multiplies by it instead of dividing --
 // an fp64 division is ~10 dependent vector instructions, and the 1000-point CDF grids of the
 // prior channels made that loop the bulk of k_draw (one more rounding per term: ~a ulp in Q).
-__device__ double igamc_int(const int a, const double z, const double lgam_a, const double* rk) {
+__device__ __forceinline__ double igamc_int(const int a, const double z, const double lgam_a, const double* rk) {
   if (!(z > 0.0)) return 1.0;
   if (z < (double)a) {
     double t = 1.0, s = 1.0;
@@ -595,25 +596,34 @@ __device__ double igamc_int(const int a, const double z, const double lgam_a, co
   return exp(-z + (double)(a - 1) * log(z) - lgam_a) * s;
 }
 
-// One inversion draw by a group of 16 lanes; pspec.py:50-62.  The reference tabulates the CDF on the
-// 1000-point grid, normalises it (cdf -= min; cdf /= max), de-duplicates and interpolates linearly
+// One inversion draw by a group of W = 16, 32 or 64 lanes of a wave; pspec.py:50-62.  The reference tabulates the CDF
+// on the 1000-point grid, normalises it (cdf -= min; cdf /= max), de-duplicates and interpolates linearly
 // at u.  The table is monotone, so min and max are its end points and the bracket
-// [first occurrence of the previous distinct value, first value >= u] is found by two 16-ary searches
-// (three rounds of one evaluation per lane each) instead of evaluating all 1000 points: ~13
-// incomplete-gamma sums per lane and channel instead of 1000 per channel by the whole block, and
-// the prior channels of a baseline are sampled side by side (16 groups per workgroup).
-// All 16 lanes of the group return the sample.
-template <class Pred>
-__device__ __forceinline__ int first_true16(const int n, Pred pred) {
+// [first occurrence of the previous distinct value, first value >= u] is found by W-ary searches
+// (one evaluation per lane and round) instead of evaluating all 1000 points, and
+// the prior channels of a baseline are sampled side by side (256 / W groups per workgroup).
+// All lanes of the group return the sample.
+// Every round is a dependent chain of a grid read, two divisions and a 31-term sum (about 1.5 us at T = 32), so the
+// rounds are what a draw costs: two for the end points + three per search x (up to) three searches + two for the
+// bracket's values it had been, 22 of k_draw's 30 us at config 2.  Now: the end points side by side on two lanes (1),
+// the search for the upper end of the bracket (3 at W = 16, 2 at W = 64), then ONE round in which the lanes evaluate
+// the table at hi, hi - 1, ..., hi - (W - 1): the previous distinct value, its first occurrence (where the run of equal
+// values below hi ends) and both bracket values come out of it by shuffles.  Only a run of equal values longer than the
+// group looked at (the flat ends of the table) and the u-outside-the-table cases take the searches of the general form.
+template <int W, class Pred>
+__device__ __forceinline__ int first_true_w(const int n, Pred pred) {
   // smallest i in [0, n) with pred(i), n if none; pred is monotone (false ... false true ... true)
-  const int j = threadIdx.x & 15, gsh = (threadIdx.x & 63) & ~15;
+  static_assert(W == 16 || W == 32 || W == 64, "group width");
+  constexpr int LW = (W == 16) ? 4 : (W == 32 ? 5 : 6);
+  const int j = threadIdx.x & (W - 1), gsh = (threadIdx.x & 63) & ~(W - 1);
+  const unsigned long long gmask = (W == 64) ? ~0ull : ((1ull << (W & 63)) - 1ull);
   int lo = 0, hi = n;                   // the answer is in [lo, hi]; hi < n is known to be true
   while (hi > lo) {
-    const int step = (hi - lo + 15) >> 4;
+    const int step = (hi - lo + W - 1) >> LW;
     const int idx = min(lo + (j + 1) * step - 1, hi - 1);
     const bool p = pred(idx);
-    const int m = __popc((unsigned)((__ballot(!p) >> gsh) & 0xFFFFull));     // leading false probes
-    if (m == 16) break;                 // every probe up to hi - 1 is false: the answer is hi
+    const int m = __popcll((__ballot(!p) >> gsh) & gmask);     // leading false probes
+    if (m == W) break;                  // every probe up to hi - 1 is false: the answer is hi
     const int nlo = lo + m * step;
     hi = min(lo + (m + 1) * step - 1, hi - 1);
     lo = nlo;
@@ -621,28 +631,59 @@ __device__ __forceinline__ int first_true16(const int n, Pred pred) {
   return hi;
 }
 
-__device__ double inversion_draw(const int alpha, const double lgam, const double beta, const double u,
-                                 const double* __restrict__ xg, const int ngrid, const double* rk) {
-  const double mn = igamc_int(alpha, beta / xg[0], lgam, rk);                    // cdf.min()
-  const double mx = igamc_int(alpha, beta / xg[ngrid - 1], lgam, rk) - mn;       // (cdf - min).max()
+// the general form: every case of the reference, by searches alone
+template <int W, class XG>
+__device__ __forceinline__ double inversion_draw_general(const int alpha, const double lgam, const double beta, const double u,
+                                         const XG xg, const int ngrid, const double* rk,
+                                         const double mn, const double mx, int hi) {
   auto cval = [&](const int i) { return (igamc_int(alpha, beta / xg[i], lgam, rk) - mn) / mx; };
-  // searchsorted(unique, u, 'left') in original indexing = number of table values < u
-  int hi = first_true16(ngrid, [&](const int i) { return !(cval(i) < u); });
   if (hi >= ngrid) {                    // u above the table: last two distinct values
     const double top = cval(ngrid - 1);
-    hi = first_true16(ngrid, [&](const int i) { return !(cval(i) < top); });
+    hi = first_true_w<W>(ngrid, [&](const int i) { return !(cval(i) < top); });
   }
   int lo;
   if (hi == 0) {                        // u at/below the first value: first two distinct values
     const double bot = cval(0);
-    hi = first_true16(ngrid, [&](const int i) { return !(cval(i) <= bot); });
+    hi = first_true_w<W>(ngrid, [&](const int i) { return !(cval(i) <= bot); });
     lo = 0;
     if (hi >= ngrid) return xg[0];      // degenerate table (all equal): the reference would give NaN
   } else {
     const double below = cval(hi - 1);  // previous distinct value; its first occurrence:
-    lo = first_true16(ngrid, [&](const int i) { return !(cval(i) < below); });
+    lo = first_true_w<W>(ngrid, [&](const int i) { return !(cval(i) < below); });
   }
   const double clo = cval(lo), chi = cval(hi), xlo = xg[lo], xhi = xg[hi];
+  const double slope = (xhi - xlo) / (chi - clo);
+  return slope * (u - clo) + xlo;
+}
+
+// XG: pointer type of the grid row (staging the slice's rows in LDS first was tried: the copy and its barrier cost more
+// than the searches' reads, which hit in L2 -- config 2: 30.3 against 24.9 us)
+template <int W, class XG>
+__device__ __forceinline__ double inversion_draw(const int alpha, const double lgam, const double beta, const double u,
+                                 const XG xg, const int ngrid, const double* rk) {
+  const int j = threadIdx.x & (W - 1), gsh = (threadIdx.x & 63) & ~(W - 1);
+  const unsigned long long gmask = (W == 64) ? ~0ull : ((1ull << (W & 63)) - 1ull);
+  // cdf.min() on the even lanes, cdf[-1] on the odd ones
+  const double e = igamc_int(alpha, beta / xg[(j & 1) ? ngrid - 1 : 0], lgam, rk);
+  const double mn = __shfl(e, gsh, 64);
+  const double mx = __shfl(e, gsh + 1, 64) - mn;                                 // (cdf - min).max()
+  auto cval = [&](const int i) { return (igamc_int(alpha, beta / xg[i], lgam, rk) - mn) / mx; };
+  // searchsorted(unique, u, 'left') in original indexing = number of table values < u
+  const int hi = first_true_w<W>(ngrid, [&](const int i) { return !(cval(i) < u); });
+  if (hi >= ngrid || hi == 0) return inversion_draw_general<W, XG>(alpha, lgam, beta, u, xg, ngrid, rk, mn, mx, hi);
+  // lane j: the table at hi - j
+  const int pj = max(hi - j, 0);
+  const double cv = cval(pj);
+  const double chi = __shfl(cv, gsh, 64), below = __shfl(cv, gsh + 1, 64);      // below: the previous distinct value
+  // its first occurrence: the run of lanes 1, 2, ... that hold a value >= below (the table is monotone: == below)
+  const bool ge = (j >= 1) && (hi - j >= 0) && !(cv < below);
+  const unsigned long long bits = ((__ballot(ge) >> gsh) & gmask) >> 1;         // bit j - 1: lane j
+  const int run = (int)__builtin_ctzll(~bits);                                  // (bit W - 1 of bits is clear)
+  if (run == W - 1 && hi - run > 0)     // equal values as far down as the group looked: the general search
+    return inversion_draw_general<W, XG>(alpha, lgam, beta, u, xg, ngrid, rk, mn, mx, hi);
+  const int lo = hi - run;
+  const double clo = __shfl(cv, gsh + run, 64);
+  const double xlo = xg[lo], xhi = xg[hi];
   const double slope = (xhi - xlo) / (chi - clo);
   return slope * (u - clo) + xlo;
 }
@@ -707,12 +748,20 @@ __global__ __launch_bounds__(256) void k_draw(const DrawArgs A) {
   }
   __syncthreads();
   const int np = pcount;
-  for (int i = tid >> 4; i < np; i += 16) {            // one prior channel per group of 16 lanes
-    const int k = plist[i], row = pmap[k];
-    const double v = inversion_draw(A.T, A.lgam_T, beta[k], A.uni[k], A.xgrid + (long)row * A.ngrid,
-                                    A.ngrid, rk);
-    if ((tid & 15) == 0) ps_out[k] = v;
-  }
+  // one prior channel per group of 64, 32 or 16 lanes: the widest that takes them all at once (wider groups need
+  // fewer search rounds); any width gives the same sample
+  auto draw_w = [&](auto wc) {
+    constexpr int W = decltype(wc)::value;
+    for (int i = tid / W; i < np; i += 256 / W) {
+      const int k = plist[i], row = pmap[k];
+      const double v = inversion_draw<W, const double*>(A.T, A.lgam_T, beta[k], A.uni[k],
+                                                        A.xgrid + (long)row * A.ngrid, A.ngrid, rk);
+      if ((tid & (W - 1)) == 0) ps_out[k] = v;
+    }
+  };
+  if (np <= 4) draw_w(std::integral_constant<int, 64>{});
+  else if (np <= 8) draw_w(std::integral_constant<int, 32>{});
+  else draw_w(std::integral_constant<int, 16>{});
   __syncthreads();
   // second ln-posterior term, the next 1 / a: sixteen lanes per group of 16 channels, a fixed shuffle tree each
   for (int sb = sb0 + (tid >> 4); sb < sb1; sb += 16) {
@@ -751,10 +800,25 @@ __global__ void k_inv_test(const int alpha, const double lgam, const double* __r
   const int i = blockIdx.x;
   for (int k = threadIdx.x; k < HPX_RK_MAX; k += 256) rk_s[k] = 1.0 / (double)(k > 0 ? k : 1);
   __syncthreads();
-  if (threadIdx.x < 16) {
-    const double v = inversion_draw(alpha, lgam, beta[i], u[i], xgrid + (long)i * ngrid, ngrid,
-                                    alpha <= HPX_RK_MAX ? rk_s : nullptr);
-    if (threadIdx.x == 0) out[i] = v;
+  // the three group widths, one wave each; they must agree to the bit (NaN otherwise)
+  __shared__ double res[3];
+  const double* rk = alpha <= HPX_RK_MAX ? rk_s : nullptr;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (wave == 0 && lane < 16) {
+    const double v = inversion_draw<16, const double*>(alpha, lgam, beta[i], u[i], xgrid + (long)i * ngrid, ngrid, rk);
+    if (lane == 0) res[0] = v;
+  } else if (wave == 1 && lane < 32) {
+    const double v = inversion_draw<32, const double*>(alpha, lgam, beta[i], u[i], xgrid + (long)i * ngrid, ngrid, rk);
+    if (lane == 0) res[1] = v;
+  } else if (wave == 2) {
+    const double v = inversion_draw<64, const double*>(alpha, lgam, beta[i], u[i], xgrid + (long)i * ngrid, ngrid, rk);
+    if (lane == 0) res[2] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const bool same = __double_as_longlong(res[0]) == __double_as_longlong(res[1]) &&
+                      __double_as_longlong(res[0]) == __double_as_longlong(res[2]);
+    out[i] = same ? res[0] : __longlong_as_double(0x7ff8000000000000ll);
   }
 }
 // lnpart[b][0] = sum_t r_t^H Ninv_{b,t} r_t with the masked residual r [b][NP][TP] and the units' planar Ninv
