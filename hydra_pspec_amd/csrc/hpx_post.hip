@@ -605,11 +605,13 @@ __device__ __forceinline__ double igamc_int(const int a, const double z, const d
 // All lanes of the group return the sample.
 // Every round is a dependent chain of a grid read, two divisions and a 31-term sum (about 1.5 us at T = 32), so the
 // rounds are what a draw costs: two for the end points + three per search x (up to) three searches + two for the
-// bracket's values it had been, 22 of k_draw's 30 us at config 2.  Now: the end points side by side on two lanes (1),
-// the search for the upper end of the bracket (3 at W = 16, 2 at W = 64), then ONE round in which the lanes evaluate
-// the table at hi, hi - 1, ..., hi - (W - 1): the previous distinct value, its first occurrence (where the run of equal
-// values below hi ends) and both bracket values come out of it by shuffles.  Only a run of equal values longer than the
-// group looked at (the flat ends of the table) and the u-outside-the-table cases take the searches of the general form.
+// bracket's values it had been, 22 of k_draw's 30 us at config 2.  Now, at W = 64 and the reference's 1000 points, TWO:
+// the end points ride on the first level of the search (63 probes + the first point), and the last round evaluates the
+// table at hi, hi - 1, ..., hi - (W - 1) for the upper bound hi of the remaining bracket: its top lanes finish the search,
+// and the previous distinct value, its first occurrence (where the run of equal values below the answer ends) and both
+// bracket values come out of the same round by shuffles.  (W = 32: three rounds, W = 16: four.)  Only a run of equal
+// values longer than the group looked at (the flat ends of the table) and the u-outside-the-table cases take the
+// searches of the general form.
 template <int W, class Pred>
 __device__ __forceinline__ int first_true_w(const int n, Pred pred) {
   // smallest i in [0, n) with pred(i), n if none; pred is monotone (false ... false true ... true)
@@ -661,29 +663,56 @@ __device__ __forceinline__ double inversion_draw_general(const int alpha, const 
 template <int W, class XG>
 __device__ __forceinline__ double inversion_draw(const int alpha, const double lgam, const double beta, const double u,
                                  const XG xg, const int ngrid, const double* rk) {
+  constexpr int LW = (W == 16) ? 4 : (W == 32 ? 5 : 6);
   const int j = threadIdx.x & (W - 1), gsh = (threadIdx.x & 63) & ~(W - 1);
   const unsigned long long gmask = (W == 64) ? ~0ull : ((1ull << (W & 63)) - 1ull);
-  // cdf.min() on the even lanes, cdf[-1] on the odd ones
-  const double e = igamc_int(alpha, beta / xg[(j & 1) ? ngrid - 1 : 0], lgam, rk);
-  const double mn = __shfl(e, gsh, 64);
-  const double mx = __shfl(e, gsh + 1, 64) - mn;                                 // (cdf - min).max()
-  auto cval = [&](const int i) { return (igamc_int(alpha, beta / xg[i], lgam, rk) - mn) / mx; };
+  auto raw = [&](const int i) { return igamc_int(alpha, beta / xg[i], lgam, rk); };
+  // ---- round 1: the end points AND the first level of the search.  Lanes 0 .. W-2 probe every step1-th point (the
+  // last of them is the table's last point: cdf[-1]), lane W-1 the first point (cdf.min()).
+  const int step1 = (ngrid + W - 2) / (W - 1);
+  const int idx1 = (j == W - 1) ? 0 : min((j + 1) * step1 - 1, ngrid - 1);
+  const double e1 = raw(idx1);
+  const double mn = __shfl(e1, gsh + W - 1, 64);
+  const double mx = __shfl(e1, gsh + W - 2, 64) - mn;                            // (cdf - min).max()
+  auto cval = [&](const int i) { return (raw(i) - mn) / mx; };
   // searchsorted(unique, u, 'left') in original indexing = number of table values < u
-  const int hi = first_true_w<W>(ngrid, [&](const int i) { return !(cval(i) < u); });
-  if (hi >= ngrid || hi == 0) return inversion_draw_general<W, XG>(alpha, lgam, beta, u, xg, ngrid, rk, mn, mx, hi);
-  // lane j: the table at hi - j
-  const int pj = max(hi - j, 0);
-  const double cv = cval(pj);
-  const double chi = __shfl(cv, gsh, 64), below = __shfl(cv, gsh + 1, 64);      // below: the previous distinct value
-  // its first occurrence: the run of lanes 1, 2, ... that hold a value >= below (the table is monotone: == below)
-  const bool ge = (j >= 1) && (hi - j >= 0) && !(cv < below);
-  const unsigned long long bits = ((__ballot(ge) >> gsh) & gmask) >> 1;         // bit j - 1: lane j
-  const int run = (int)__builtin_ctzll(~bits);                                  // (bit W - 1 of bits is clear)
-  if (run == W - 1 && hi - run > 0)     // equal values as far down as the group looked: the general search
+  const bool f1 = (j < W - 1) && (((e1 - mn) / mx) < u);
+  const int m1 = __popcll((__ballot(f1) >> gsh) & gmask);                        // leading false probes
+  if (m1 == W - 1) return inversion_draw_general<W, XG>(alpha, lgam, beta, u, xg, ngrid, rk, mn, mx, ngrid);
+  int lo = m1 * step1, hi = min((m1 + 1) * step1 - 1, ngrid - 1);                // the answer is in [lo, hi]; hi is true
+  // ---- further W-ary rounds until the last round can take the rest of the bracket along (W = 64: 15 points, as
+  // the lanes of the last round look at hi, hi - 1, ..., hi - 63; narrower groups search to the end)
+  constexpr int NARROW = (W == 64) ? 15 : 0;
+  while (hi - lo > NARROW) {
+    const int step = (hi - lo + W - 1) >> LW;
+    const int idx = min(lo + (j + 1) * step - 1, hi - 1);
+    const bool f = cval(idx) < u;
+    const int m = __popcll((__ballot(f) >> gsh) & gmask);
+    if (m == W) { lo = hi; break; }     // every probe up to hi - 1 is false: the answer is hi
+    const int nlo = lo + m * step;
+    hi = min(lo + (m + 1) * step - 1, hi - 1);
+    lo = nlo;
+  }
+  // ---- last round.  Lane j: the table at hi - j.  The lanes 0 .. hi - lo finish the search (the first true one from
+  // the top is hi itself); the lanes below give the previous distinct value, its first occurrence (where the run of
+  // equal values ends) and both bracket values by shuffles.
+  const int span = hi - lo;
+  const double cv = cval(max(hi - j, 0));
+  const bool tr = (j <= span) && !(cv < u);
+  const int mt = __popcll((__ballot(tr) >> gsh) & gmask);                        // true probes: lanes 0 .. mt - 1
+  const int sh = mt - 1;                                                         // lane of the answer
+  hi -= sh;
+  if (mt == 0 || hi == 0) return inversion_draw_general<W, XG>(alpha, lgam, beta, u, xg, ngrid, rk, mn, mx, mt == 0 ? ngrid : 0);
+  const double chi = __shfl(cv, gsh + sh, 64), below = __shfl(cv, gsh + sh + 1, 64);   // below: the previous distinct value
+  // its first occurrence: the run of lanes sh + 1, sh + 2, ... that hold a value >= below (monotone table: == below)
+  const bool ge = (j > sh) && (hi + sh - j >= 0) && !(cv < below);
+  const unsigned long long bits = (((__ballot(ge) >> gsh) & gmask) >> 1) >> sh;  // bit i: lane sh + 1 + i
+  const int run = (int)__builtin_ctzll(~bits);                                   // (the top bit of bits is clear)
+  if (run == W - 1 - sh && hi - run > 0)  // equal values as far down as the group looked: the general search
     return inversion_draw_general<W, XG>(alpha, lgam, beta, u, xg, ngrid, rk, mn, mx, hi);
-  const int lo = hi - run;
-  const double clo = __shfl(cv, gsh + run, 64);
-  const double xlo = xg[lo], xhi = xg[hi];
+  const int lo2 = hi - run;
+  const double clo = __shfl(cv, gsh + sh + run, 64);
+  const double xlo = xg[lo2], xhi = xg[hi];
   const double slope = (xhi - xlo) / (chi - clo);
   return slope * (u - clo) + xlo;
 }
@@ -714,7 +743,7 @@ struct DrawArgs {
 // write-back, serialised between the CUs of an XCD -- 34 us for a 10 us kernel when it was tried).  Either way the
 // result does not depend on the number of slices.
 __global__ __launch_bounds__(256) void k_draw(const DrawArgs A) {
-  extern __shared__ double dyn[];     // N ints: the channels with a prior
+  extern __shared__ double dyn[];     // the channels with a prior: N ints (channel), N ints (grid row), N doubles (beta)
   __shared__ int pcount;
   __shared__ double rk_s[HPX_RK_MAX];
   __shared__ double part[256];        // the slice's sums over groups of 16 channels
@@ -724,27 +753,37 @@ __global__ __launch_bounds__(256) void k_draw(const DrawArgs A) {
   const int k0 = sb0 * 16, k1 = min(N, sb1 * 16);
   for (int k = tid; k < HPX_RK_MAX; k += 256) rk_s[k] = 1.0 / (double)(k > 0 ? k : 1);
   const double* rk = (A.T <= HPX_RK_MAX) ? rk_s : nullptr;
-  // beta_k = N sum_t |z_kt|^2 from the partial sums of the residual kernel (one slot per block of a baseline
-  // there), added in slot order
-  double* beta = A.beta + (long)b * N;
-  for (int k = k0 + tid; k < k1; k += 256) {
-    double sum = 0.0;
-    for (int j = 0; j < A.npart; ++j) sum += A.bpart[((long)b * HPX_NPART + j) * N + k];
-    beta[k] = (double)N * sum;
-  }
   if (tid == 0) pcount = 0;
   __syncthreads();
+  double* beta = A.beta + (long)b * N;
   const double* bm = A.any_flags ? A.betam + (long)b * N : beta;
   const int32_t* pmap = A.pmap + (A.prior_shared ? 0 : (long)b * N);
   double* ps_out = A.ps_out + (long)b * A.ps_bstride;
-  // channels without a prior: x = beta * invgamma.ppf(U, a=T-1)   (pspec.py:125)
-  // channels with a prior: truncated draw with shape alpha+1 = T   (pspec.py:121-123).
-  // They are collected first (a scan of pmap by one thread per channel would be N dependent
-  // global loads); each draw depends only on its own channel, so their order is immaterial.
-  int* plist = reinterpret_cast<int*>(dyn);
+  // One pass over the slice's channels, everything a channel needs requested together (the prior map and the
+  // inverse-gamma variate do not wait for the sums):
+  //   beta_k = N sum_t |z_kt|^2 from the partial sums of the residual kernel (one slot per block of a baseline
+  //   there), added in slot order;
+  //   channels without a prior: x = beta * invgamma.ppf(U, a=T-1)   (pspec.py:125);
+  //   channels with a prior: truncated draw with shape alpha+1 = T   (pspec.py:121-123) -- collected (channel, grid
+  //   row, beta) in LDS, drawn below by groups of lanes; each draw depends only on its own channel, so their order
+  //   is immaterial.
+  int* plist = reinterpret_cast<int*>(dyn);           // [N] channel, [N] grid row, then [N] doubles: beta
+  int* prow = plist + N;
+  double* pbeta = dyn + N;
   for (int k = k0 + tid; k < k1; k += 256) {
-    if (pmap[k] < 0) ps_out[k] = A.igy[k] * beta[k];
-    else plist[atomicAdd(&pcount, 1)] = k;
+    const int pm = pmap[k];
+    const double y = A.igy[k];
+    double sum = 0.0;
+    for (int j = 0; j < A.npart; ++j) sum += A.bpart[((long)b * HPX_NPART + j) * N + k];
+    const double bk = (double)N * sum;
+    beta[k] = bk;
+    if (pm < 0) ps_out[k] = y * bk;
+    else {
+      const int slot = atomicAdd(&pcount, 1);
+      plist[slot] = k;
+      prow[slot] = pm;
+      pbeta[slot] = bk;
+    }
   }
   __syncthreads();
   const int np = pcount;
@@ -753,8 +792,8 @@ __global__ __launch_bounds__(256) void k_draw(const DrawArgs A) {
   auto draw_w = [&](auto wc) {
     constexpr int W = decltype(wc)::value;
     for (int i = tid / W; i < np; i += 256 / W) {
-      const int k = plist[i], row = pmap[k];
-      const double v = inversion_draw<W, const double*>(A.T, A.lgam_T, beta[k], A.uni[k],
+      const int k = plist[i], row = prow[i];
+      const double v = inversion_draw<W, const double*>(A.T, A.lgam_T, pbeta[i], A.uni[k],
                                                         A.xgrid + (long)row * A.ngrid, A.ngrid, rk);
       if ((tid & (W - 1)) == 0) ps_out[k] = v;
     }
@@ -975,7 +1014,7 @@ int hpx_post_solve(hpx_plan* p, int it_abs, const IterOut& O, hipStream_t st) {
   D.lnhist = nslice > 1 ? p->lnhist + (long)it_abs * nbl * ((N + 15) / 16 + 1) : nullptr;
   D.lnpost_out = nslice > 1 ? nullptr : O.lnpost_out;      // (several slices: k_lnpost_combine at the end of the run)
   D.lnpost_pitch = O.lnpost_pitch;
-  hipLaunchKernelGGL(k_draw, dim3(nslice, nbl), dim3(256), (size_t)N * sizeof(int) + 8, st, D);
+  hipLaunchKernelGGL(k_draw, dim3(nslice, nbl), dim3(256), (size_t)N * 16, st, D);      // (the prior channels' list)
   HPX_HIP(hipGetLastError());
   HPX_TRY(hpx_mark(p, st));
   return HPX_OK;

@@ -125,6 +125,43 @@ def test_invgamma_inversion_golden(T, golden):
         assert np.max(np.abs(out.cpu().numpy() / want[sel] - 1)) < 1e-10
 
 
+def test_invgamma_inversion_flat_ends_and_widths(T, monkeypatch):
+    """The draw's short cuts (bracket from one round of neighbouring table values; 16 / 32 / 64 lanes per draw) against
+    the searches of the general form: tables with long runs of equal values at both ends (the CDF saturates over most
+    of a wide grid), u from 1e-300 to 1 - 1e-13 (within a few ulp of 1 the computed table is no longer monotone where it
+    saturates, and which of the equal-looking points a search lands on is its own business).  The kernel returns NaN unless the three group widths agree to the
+    bit -- a run of equal values between 16 and 63 points long takes the short cut at one width and the general
+    searches at another.  Where u is inside the table's resolved part the value is the oracle's (pspec.py:11-64)."""
+    from hydra_pspec_amd import hpx
+    from oracle import pspec_ref
+    rng = np.random.default_rng(11)
+    us = [1e-300, 1e-17, 1e-9, 1e-3, 0.25, 0.5, 0.9, 1 - 1e-9, 1 - 1e-13]
+    cases = []
+    for a in (2, 8, 32):
+        for _ in range(6):
+            b = 10.0 ** rng.uniform(-3, 3)
+            lo = b / a * 10.0 ** rng.uniform(-5, -0.3)      # (beta / x from far above the shape to far below it:
+            hi = b / a * 10.0 ** rng.uniform(0.5, 6)        # the CDF rises inside the grid, flat on both sides)
+            cases += [(a, b, lo, hi, u) for u in us]
+    for a in (2, 8, 32):
+        sel = [c for c in cases if c[0] == a]
+        beta = np.array([c[1] for c in sel])
+        u = np.array([c[4] for c in sel])
+        xg = np.stack([np.logspace(np.log10(c[2]), np.log10(c[3]), 1000) for c in sel])
+        out = T.zeros(len(sel), dtype=T.float64, device="cuda")
+        db, du, dx = _dev(T, beta, T.float64), _dev(T, u, T.float64), _dev(T, xg, T.float64)
+        hpx.check(hpx.lib().hpx_invgamma_inversion(len(sel), a, hpx.ptr(db), hpx.ptr(du), hpx.ptr(dx), 1000,
+                                                   hpx.ptr(out), None))
+        got = out.cpu().numpy()
+        assert np.isfinite(got).all(), [c for c, g in zip(sel, got) if not np.isfinite(g)]   # (NaN: the widths disagree)
+        for g, (_, b, lo, hi, uu) in zip(got, sel):
+            assert lo * (1 - 1e-12) <= g <= hi * (1 + 1e-12)
+            if 1e-3 <= uu <= 0.9:
+                monkeypatch.setattr(np.random, "uniform", lambda: uu)
+                want = float(pspec_ref.inversion_sample_invgamma(a, b, lo, hi))
+                assert g == pytest.approx(want, rel=1e-8)
+
+
 def test_inversion_sample_invgamma_api(T, golden):
     from hydra_pspec_amd import pspec
     for a, b, lo, hi, seed, v, u_after in golden("small")["F3_cases"][::5]:
