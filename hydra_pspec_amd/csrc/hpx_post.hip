@@ -1014,7 +1014,10 @@ int hpx_post_solve(hpx_plan* p, int it_abs, const IterOut& O, hipStream_t st) {
   D.lnhist = nslice > 1 ? p->lnhist + (long)it_abs * nbl * ((N + 15) / 16 + 1) : nullptr;
   D.lnpost_out = nslice > 1 ? nullptr : O.lnpost_out;      // (several slices: k_lnpost_combine at the end of the run)
   D.lnpost_pitch = O.lnpost_pitch;
-  hipLaunchKernelGGL(k_draw, dim3(nslice, nbl), dim3(256), (size_t)N * 16, st, D);      // (the prior channels' list)
+  const size_t draw_lds = (size_t)N * 16;                   // the prior channels' list (channel, grid row, beta)
+  static hpx_lds_limit draw_limit;                          // (with the kernel's static 6 KB beyond 64 KB from N = 3700 on)
+  if (draw_lds > 48 * 1024) HPX_TRY(draw_limit.ensure(reinterpret_cast<const void*>(&k_draw), draw_lds));
+  hipLaunchKernelGGL(k_draw, dim3(nslice, nbl), dim3(256), draw_lds, st, D);
   HPX_HIP(hipGetLastError());
   HPX_TRY(hpx_mark(p, st));
   return HPX_OK;

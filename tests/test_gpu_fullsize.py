@@ -26,6 +26,18 @@ def test_batch_independence_and_determinism(N, frac):
     assert np.array_equal(one["signal_ps"][0], big["signal_ps"][17])
 
 
+def test_largest_channel_count_of_the_fused_kernels():
+    """N = 4096 (the largest in-LDS transform; k_draw's channel list is then 64 KB of dynamic LDS on top of its static
+    6 KB, beyond the default limit): two baselines, 2 iterations on the structured solve, finite, reproducible, and
+    baseline 1 alone == inside the pair."""
+    d, a = _run(2, 4096, T=8, M=4, niter=2, solver="auto")
+    _, again = _run(2, 4096, T=8, M=4, niter=2, solver="auto")
+    assert np.isfinite(a["signal_ps"]).all() and (a["signal_ps"] > 0).all() and np.isfinite(a["ln_post"]).all()
+    assert np.array_equal(a["signal_ps"], again["signal_ps"])
+    _, one = _run(1, 4096, T=8, M=4, niter=2, k0=1, solver="auto")
+    assert np.array_equal(one["signal_ps"][0], a["signal_ps"][1])
+
+
 @pytest.mark.parametrize("N,frac,solver", [(256, 0.0, "dense"), (512, 0.0, "dense"), (512, 0.0, "auto"),
                                            (1024, 0.15, "dense"), (1024, 0.15, "auto")])
 def test_short_chain_vs_oracle(N, frac, solver):
