@@ -153,7 +153,6 @@ __global__ __launch_bounds__(256) void k_resid(const ResArgs A) {
 // chi^2 total) in slot blockIdx.x; k_draw adds the slots in a fixed order.
 __global__ __launch_bounds__(256) void k_fft_resid(const ResArgs A) {
   extern __shared__ double fl[];
-  __shared__ double red[4];
   const int N = A.N, M = A.M, T = A.T, TP = A.TP, tcs = A.tcs, TC = 1 << tcs, logN = A.logN;
   // column groups of one baseline on one XCD (they share cache lines of X, D and the outputs);
   // workgroup ids go round-robin over the 8 XCDs
@@ -204,8 +203,11 @@ __global__ __launch_bounds__(256) void k_fft_resid(const ResArgs A) {
           const double sg = (k & 1) ? -1.0 : 1.0;
           fre[e] = zr[u] * sg;
           fim[e] = zi[u] * sg;
-          double v = zr[u] * zr[u] + zi[u] * zi[u];       // sum over this block's time columns
-          for (int o = TC >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+          // sum over this block's time columns: groups of eight first, then the groups -- a block of 16 columns leaves
+          // what two blocks of 8 leave once k_draw has added their slots in pairs (the launcher takes 8 instead of 16
+          // columns per block for batches that would not fill the CUs: a baseline's chain must not depend on that)
+          double v = zr[u] * zr[u] + zi[u] * zi[u];
+          for (int o = 1; o < TC; o <<= 1) v += __shfl_xor(v, o, 64);
           if (tc == 0) bp[k] = v;
         }
       }
@@ -385,8 +387,28 @@ __global__ __launch_bounds__(256) void k_fft_resid(const ResArgs A) {
       q[1] = lfi[e];
     }
   }
-  const double total = block_sum(acc, red);
-  if (tid == 0) A.lnpart[(long)b * HPX_NPART + cg] = total;
+  // chi^2 total of the block, again per group of eight time columns first (a lane's column is tid & (TC - 1) in both
+  // branches above; with TC = 16 bit 3 of the lane tells the group): the lanes of a group of eight, the groups of a
+  // wave that belong to the same eight columns, the waves ((w0 + w1) + (w2 + w3)), then columns 0-7 + columns 8-15
+  __shared__ double red2[8];
+  double v = acc;
+  v += __shfl_xor(v, 1, 64);
+  v += __shfl_xor(v, 2, 64);
+  v += __shfl_xor(v, 4, 64);
+  const bool second = (TC == 16) && (tid & 8);
+  double w0 = second ? 0.0 : v, w1 = second ? v : 0.0;
+#pragma unroll
+  for (int o = 8; o < 64; o <<= 1) {
+    w0 += __shfl_xor(w0, o, 64);
+    w1 += __shfl_xor(w1, o, 64);
+  }
+  if ((tid & 63) == 0) {
+    red2[tid >> 6] = w0;
+    red2[4 + (tid >> 6)] = w1;
+  }
+  __syncthreads();
+  if (tid == 0)
+    A.lnpart[(long)b * HPX_NPART + cg] = ((red2[0] + red2[1]) + (red2[2] + red2[3])) + ((red2[4] + red2[5]) + (red2[6] + red2[7]));
 }
 
 // The same for channel counts without an in-LDS FFT (N not a power of two, e.g. the 120 channels of
@@ -723,7 +745,7 @@ __device__ __forceinline__ double inversion_draw(const int alpha, const double l
 struct DrawArgs {
   const double *bpart, *lnpart, *betam, *uni, *igy, *xgrid, *ps_forced;
   double *beta, *lnp1;
-  int npart;
+  int npart, pair_slots;             // pair_slots: the residual kernel's slots hold eight time columns each (see k_fft_resid)
   const int32_t* pmap;
   double *ia, *ps_cur, *ps_out;
   long ps_bstride, forced_bstride;   // strides between baselines in ps_out / ps_forced
@@ -774,7 +796,12 @@ __global__ __launch_bounds__(256) void k_draw(const DrawArgs A) {
     const int pm = pmap[k];
     const double y = A.igy[k];
     double sum = 0.0;
-    for (int j = 0; j < A.npart; ++j) sum += A.bpart[((long)b * HPX_NPART + j) * N + k];
+    if (A.pair_slots) {               // (slots of eight time columns: two of them are what a slot of sixteen holds)
+      for (int j = 0; j < A.npart; j += 2)
+        sum += A.bpart[((long)b * HPX_NPART + j) * N + k] + (j + 1 < A.npart ? A.bpart[((long)b * HPX_NPART + j + 1) * N + k] : 0.0);
+    } else {
+      for (int j = 0; j < A.npart; ++j) sum += A.bpart[((long)b * HPX_NPART + j) * N + k];
+    }
     const double bk = (double)N * sum;
     beta[k] = bk;
     if (pm < 0) ps_out[k] = y * bk;
@@ -820,7 +847,12 @@ __global__ __launch_bounds__(256) void k_draw(const DrawArgs A) {
   __syncthreads();
   if (tid != 0) return;
   double tot = 0.0;                  // chi^2 total of the residual kernel's partial sums, in slot order
-  for (int j = 0; j < A.npart; ++j) tot += A.lnpart[(long)b * HPX_NPART + j];
+  if (A.pair_slots) {
+    for (int j = 0; j < A.npart; j += 2)
+      tot += A.lnpart[(long)b * HPX_NPART + j] + (j + 1 < A.npart ? A.lnpart[(long)b * HPX_NPART + j + 1] : 0.0);
+  } else {
+    for (int j = 0; j < A.npart; ++j) tot += A.lnpart[(long)b * HPX_NPART + j];
+  }
   if (gridDim.x == 1) {
     const double lnp = -tot - lnpost_blocks(part, nsub);     // -> ln posterior
     A.lnp1[b] = lnp;
@@ -927,14 +959,23 @@ int hpx_post_solve(hpx_plan* p, int it_abs, const IterOut& O, hipStream_t st) {
 #ifndef HPX_FR_ELEMS
 #define HPX_FR_ELEMS 4096      // complex elements of the signal block a workgroup of k_fft_resid holds in LDS
 #endif
-  int npart = 1, TC = HPX_FR_ELEMS / NP;
+  int npart = 1, TC = HPX_FR_ELEMS / NP, pair_slots = 0;
   if (TC > 16) TC = 16;
+  // a batch whose blocks of 16 columns would not reach every CU takes blocks of 8 (config 2: 128 -> 256 workgroups,
+  // 23.8 -> 18.9 us); the sums the blocks leave are formed per group of eight columns either way, so a baseline's
+  // results do not depend on the batch it is in
+  {
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    if (TC == 16 && M <= 16 && (long)nbl * (TP / 16) < (long)cus) TC = 8;
+  }
   const bool pow2 = N == NP && (N & (N - 1)) == 0 && N >= 32 && N <= 4096;
   const bool generic_post = p->dense_noise || p->per_time;      // modes only the two-kernel form implements
   if (pow2 && hpx_dft_use_fft && TC >= HPX_FUSE_TC && TP / TC <= HPX_NPART && !generic_post) {   // fewer columns per block: two kernels win
     while ((1 << R.logN) < N) ++R.logN;
     while ((1 << R.tcs) < TC) ++R.tcs;
     npart = TP / TC;
+    pair_slots = (TC == 8);
     // s = U z, residual, chi^2, |z|^2 sums in one pass (k_fft_resid); the two event marks
     // book it under "transform"
     const size_t lds = ((size_t)N * TC * 2 + N + (size_t)2 * M * TC + (size_t)2 * M * (256 / TC)) * sizeof(double);
@@ -1001,7 +1042,7 @@ int hpx_post_solve(hpx_plan* p, int it_abs, const IterOut& O, hipStream_t st) {
   HPX_TRY(hpx_mark(p, st));
   DrawArgs D;
   D.beta = p->beta; D.betam = p->betam; D.lnp1 = p->lnp1;
-  D.bpart = p->bpart; D.lnpart = p->lnpart; D.npart = npart;
+  D.bpart = p->bpart; D.lnpart = p->lnpart; D.npart = npart; D.pair_slots = pair_slots;
   D.uni = p->uni + (long)it_abs * N; D.igy = p->igy + (long)it_abs * N;
   D.xgrid = p->xgrid; D.pmap = p->pmap;
   D.ps_forced = O.ps_forced; D.forced_bstride = O.forced_bstride;
