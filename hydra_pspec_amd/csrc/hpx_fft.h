@@ -9,7 +9,7 @@ namespace {
 // base + m (N >> (s + R)), m = 0 .. 2^R - 1, only interact with each other over these stages,
 // so one LDS round trip and one barrier serve R stages (N = 512: three passes instead of nine).
 // Same butterflies, twiddles and (bit-reversed) output order as the unfused stages.
-template <int R, int SIGN>
+template <int R, int SIGN, int NTH = 256>
 __device__ __forceinline__ void fft_pass(double* __restrict__ fre, double* __restrict__ fim,
                                          const double* __restrict__ tw, const int N, const int h,
                                          const int logN, const int s, const int tcs,
@@ -18,7 +18,7 @@ __device__ __forceinline__ void fft_pass(double* __restrict__ fre, double* __res
   const int lq = logN - s - R;                 // log2 of the spacing between the E elements
   const int Hq = 1 << lq;
   const int ngroups = (N >> R) << tcs;
-  for (int gidx = tid; gidx < ngroups; gidx += 256) {
+  for (int gidx = tid; gidx < ngroups; gidx += NTH) {      // NTH: threads of the workgroup
     const int tc = gidx & ((1 << tcs) - 1), gi = gidx >> tcs;
     const int j = gi & (Hq - 1), blk = gi >> lq;
     const int base = (((blk << R) << lq) + j) << tcs;

@@ -151,7 +151,9 @@ __global__ __launch_bounds__(256) void k_resid(const ResArgs A) {
 // model, residual, chi^2 and the optional sample write-back for those columns, so s never goes
 // to HBM and back.  Blocks of one baseline leave their partial sums (|z|^2 per channel, the
 // chi^2 total) in slot blockIdx.x; k_draw adds the slots in a fixed order.
-__global__ __launch_bounds__(256) void k_fft_resid(const ResArgs A) {
+template <int NTH>
+__global__ __launch_bounds__(NTH, NTH / 128) void k_fft_resid(const ResArgs A) {
+  constexpr int NW = NTH / 64;                       // waves
   extern __shared__ double fl[];
   const int N = A.N, M = A.M, T = A.T, TP = A.TP, tcs = A.tcs, TC = 1 << tcs, logN = A.logN;
   // column groups of one baseline on one XCD (they share cache lines of X, D and the outputs);
@@ -167,11 +169,11 @@ __global__ __launch_bounds__(256) void k_fft_resid(const ResArgs A) {
   double* lfi = lfr + (M << tcs);
   const double* xre = A.Xre + (long)b * A.npad * TP;
   const double* xim = A.Xim + (long)b * A.npad * TP;
-  for (int j = tid; j < h; j += 256) {
+  for (int j = tid; j < h; j += NTH) {
     tw[j] = A.twre[(long)(h + 1) * N + h + j];
     tw[h + j] = A.twim[(long)(h + 1) * N + h + j];
   }
-  for (int e = tid; e < (M << tcs); e += 256) {
+  for (int e = tid; e < (M << tcs); e += NTH) {
     const int m = e >> tcs, tc = e & (TC - 1);
     lfr[e] = xre[(long)(N + m) * TP + c0 + tc];
     lfi[e] = xim[(long)(N + m) * TP + c0 + tc];
@@ -180,13 +182,13 @@ __global__ __launch_bounds__(256) void k_fft_resid(const ResArgs A) {
   // loads in batches of 16 per thread, all in flight before the first use (one element at a time
   // every iteration waits out a memory round trip); N * TC is a multiple of 256
   {
-    constexpr int UB = 16;
+    constexpr int UB = 4096 / NTH;
     const int total = N << tcs;
-    for (int e0 = tid; e0 < total; e0 += 256 * UB) {
+    for (int e0 = tid; e0 < total; e0 += NTH * UB) {
       double zr[UB], zi[UB];
 #pragma unroll
       for (int u = 0; u < UB; ++u) {
-        const int e = min(e0 + 256 * u, total - 1), k = e >> tcs, tc = e & (TC - 1);
+        const int e = min(e0 + NTH * u, total - 1), k = e >> tcs, tc = e & (TC - 1);
 #if HPX_FR_NT & 1
         zr[u] = __builtin_nontemporal_load(&xre[(long)k * TP + c0 + tc]);
         zi[u] = __builtin_nontemporal_load(&xim[(long)k * TP + c0 + tc]);
@@ -197,7 +199,7 @@ __global__ __launch_bounds__(256) void k_fft_resid(const ResArgs A) {
       }
 #pragma unroll
       for (int u = 0; u < UB; ++u) {
-        const int e = e0 + 256 * u;
+        const int e = e0 + NTH * u;
         if (e < total) {                                  // uniform over the workgroup
           const int k = e >> tcs, tc = e & (TC - 1);
           const double sg = (k & 1) ? -1.0 : 1.0;
@@ -216,14 +218,14 @@ __global__ __launch_bounds__(256) void k_fft_resid(const ResArgs A) {
   int s = 0;
   for (; s + 3 <= logN; s += 3) {
     __syncthreads();
-    fft_pass<3, 1>(fre, fim, tw, N, h, logN, s, tcs, tid);
+    fft_pass<3, 1, NTH>(fre, fim, tw, N, h, logN, s, tcs, tid);
   }
   if (logN - s == 2) {
     __syncthreads();
-    fft_pass<2, 1>(fre, fim, tw, N, h, logN, s, tcs, tid);
+    fft_pass<2, 1, NTH>(fre, fim, tw, N, h, logN, s, tcs, tid);
   } else if (logN - s == 1) {
     __syncthreads();
-    fft_pass<1, 1>(fre, fim, tw, N, h, logN, s, tcs, tid);
+    fft_pass<1, 1, NTH>(fre, fim, tw, N, h, logN, s, tcs, tid);
   }
   __syncthreads();
   const double* dre = A.Dre + (long)b * A.NP * TP;
@@ -253,7 +255,7 @@ __global__ __launch_bounds__(256) void k_fft_resid(const ResArgs A) {
     // undone by the LDS read of s instead.  The global operands of the next tile are requested
     // before the current one is worked on (two workgroups per CU: nothing else hides them).
     const int ntile = N >> 4;
-    const int tlast = wave + 4 * ((ntile - 1 - wave) >> 2);       // this wave's last tile
+    const int tlast = wave + NW * ((ntile - 1 - wave) / NW);      // this wave's last tile
     const bool tvalid = (li < TC) && (t < T);
     double nfr[4], nfi[4], ndr[4], ndi[4], nnv[4], nw[4];
 #if HPX_FR_NT & 2
@@ -281,14 +283,14 @@ __global__ __launch_bounds__(256) void k_fft_resid(const ResArgs A) {
     }                                                                                 \
   }
     if (wave < ntile) HPX_FR_LOAD(wave)
-    for (int xt = wave; xt < ntile; xt += 4) {
+    for (int xt = wave; xt < ntile; xt += NW) {
       const int x0 = xt << 4;
       double cfr[4], cfi[4], cdr[4], cdi[4], cnv[4], cw[4];
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         cfr[q] = nfr[q]; cfi[q] = nfi[q]; cdr[q] = ndr[q]; cdi[q] = ndi[q]; cnv[q] = nnv[q]; cw[q] = nw[q];
       }
-      HPX_FR_LOAD(min(xt + 4, tlast))                 // branch-free: re-read at the end
+      HPX_FR_LOAD(min(xt + NW, tlast))                // branch-free: re-read at the end
       d4 mr = {0., 0., 0., 0.}, mi = {0., 0., 0., 0.};
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {                // A[channel x0 + li][m = 4 ks + g] = F[x][m]
@@ -332,11 +334,11 @@ __global__ __launch_bounds__(256) void k_fft_resid(const ResArgs A) {
     // the round's channels are staged in LDS first (TC threads share a channel: from global
     // memory each of them would fetch the same 2 M values again)
     double* sfr = lfi + (M << tcs);                   // [256 / TC][M]
-    double* sfi = sfr + (256 >> tcs) * M;
-    const int xper = 256 >> tcs;
-    for (int e0 = 0; e0 < (N << tcs); e0 += 256) {
+    double* sfi = sfr + (NTH >> tcs) * M;
+    const int xper = NTH >> tcs;
+    for (int e0 = 0; e0 < (N << tcs); e0 += NTH) {
       __syncthreads();
-      for (int q = tid; q < xper * M; q += 256) {
+      for (int q = tid; q < xper * M; q += NTH) {
         const int xi = q / M, m = q - xi * M;
         const int xx = (int)(__brev((unsigned)((e0 >> tcs) + xi)) >> (32 - logN));
         sfr[q] = fmr[(long)xx * M + m];
@@ -379,7 +381,7 @@ __global__ __launch_bounds__(256) void k_fft_resid(const ResArgs A) {
     }
   }
   if (A.fg_out) {
-    for (int e = tid; e < (M << tcs); e += 256) {
+    for (int e = tid; e < (M << tcs); e += NTH) {
       const int m = e >> tcs, t = c0 + (e & (TC - 1));
       if (t >= T) continue;
       double* q = A.fg_out + (long)b * A.fg_bstride + ((long)t * M + m) * 2;
@@ -390,7 +392,7 @@ __global__ __launch_bounds__(256) void k_fft_resid(const ResArgs A) {
   // chi^2 total of the block, again per group of eight time columns first (a lane's column is tid & (TC - 1) in both
   // branches above; with TC = 16 bit 3 of the lane tells the group): the lanes of a group of eight, the groups of a
   // wave that belong to the same eight columns, the waves ((w0 + w1) + (w2 + w3)), then columns 0-7 + columns 8-15
-  __shared__ double red2[8];
+  __shared__ double red2[2 * NW];
   double v = acc;
   v += __shfl_xor(v, 1, 64);
   v += __shfl_xor(v, 2, 64);
@@ -404,11 +406,17 @@ __global__ __launch_bounds__(256) void k_fft_resid(const ResArgs A) {
   }
   if ((tid & 63) == 0) {
     red2[tid >> 6] = w0;
-    red2[4 + (tid >> 6)] = w1;
+    red2[NW + (tid >> 6)] = w1;
   }
   __syncthreads();
-  if (tid == 0)
-    A.lnpart[(long)b * HPX_NPART + cg] = ((red2[0] + red2[1]) + (red2[2] + red2[3])) + ((red2[4] + red2[5]) + (red2[6] + red2[7]));
+  if (tid == 0) {                    // (the waves in pairs, the pairs in order)
+    double t0 = 0.0, t1 = 0.0;
+    for (int w = 0; w < NW; w += 2) {
+      t0 += red2[w] + red2[w + 1];
+      t1 += red2[NW + w] + red2[NW + w + 1];
+    }
+    A.lnpart[(long)b * HPX_NPART + cg] = t0 + t1;
+  }
 }
 
 // The same for channel counts without an in-LDS FFT (N not a power of two, e.g. the 120 channels of
@@ -956,6 +964,11 @@ int hpx_post_solve(hpx_plan* p, int it_abs, const IterOut& O, hipStream_t st) {
   R.flags_t = p->per_time ? p->flags_t : nullptr;
   R.ninv_t = p->per_time ? p->ninv_t : nullptr;
   // time columns per block of the fused kernel: 64 KiB of LDS for the signal, as k_fft
+#ifndef HPX_FR_THREADS
+// threads of a workgroup of k_fft_resid: 256.  512 (twice the waves per CU to hide the tile operands' latency) leaves 128
+// registers a lane: 44 spilled, config 3 0.37 against 0.27 ms, config 2 22.7 against 18.6 us
+#define HPX_FR_THREADS 256
+#endif
 #ifndef HPX_FR_ELEMS
 #define HPX_FR_ELEMS 4096      // complex elements of the signal block a workgroup of k_fft_resid holds in LDS
 #endif
@@ -978,11 +991,12 @@ int hpx_post_solve(hpx_plan* p, int it_abs, const IterOut& O, hipStream_t st) {
     pair_slots = (TC == 8);
     // s = U z, residual, chi^2, |z|^2 sums in one pass (k_fft_resid); the two event marks
     // book it under "transform"
-    const size_t lds = ((size_t)N * TC * 2 + N + (size_t)2 * M * TC + (size_t)2 * M * (256 / TC)) * sizeof(double);
+    // (the mode rows' staging area behind the amplitudes only where the model term is not on the matrix pipe)
+    const size_t lds = ((size_t)N * TC * 2 + N + (size_t)2 * M * TC + (M > 16 ? (size_t)2 * M * (HPX_FR_THREADS / TC) : 0)) * sizeof(double);
     static hpx_lds_limit limit;
-    HPX_TRY(limit.ensure(reinterpret_cast<const void*>(&k_fft_resid), lds));
+    HPX_TRY(limit.ensure(reinterpret_cast<const void*>(&k_fft_resid<HPX_FR_THREADS>), lds));
     R.nbl = nbl; R.npart = npart;
-    hipLaunchKernelGGL(k_fft_resid, dim3(((nbl + 7) / 8) * 8 * npart), dim3(256), lds, st, R);
+    hipLaunchKernelGGL(k_fft_resid<HPX_FR_THREADS>, dim3(((nbl + 7) / 8) * 8 * npart), dim3(HPX_FR_THREADS), lds, st, R);
     HPX_HIP(hipGetLastError());
     HPX_TRY(hpx_mark(p, st));
   } else if (HPX_DFT_RESID && NP <= 256 && M <= 16 && hpx_dft_use_fft && !generic_post) {
