@@ -465,9 +465,31 @@ extern "C" int hpx_gibbs_run(hpx_plan* p, const double* ps0, int iter0, int nite
   const RunArgs A = {ps0, ps_forced, ps_out, lnpost_out, cr_out, fg_out, chisq_out, ps_last,
                      iter0, niter, thin < 1 ? 1 : thin, (hipStream_t)stream};
   HPX_TRY(run_check(p, A, "hpx_gibbs_run"));
+  // a run that continues from the plan's own bandpowers keeps a copy of them while the split factor may be taken: the
+  // run is repeated from there should the form's hand-off time out
+  const bool may_split = p->allow_split && p->split_retry && !p->per_time && p->solver == HPX_SOLVER_DENSE &&
+                         hpx_factor_split_parts(p->nbl, p->npad, p->ld) > 0;
+  if (may_split && !ps0) {
+    if (!p->ps_start) HPX_TRY(dev_alloc(p, &p->ps_start, (size_t)p->nbl * p->N));
+    HPX_HIP(hipMemcpyAsync(p->ps_start, p->ps_cur, (size_t)p->nbl * p->N * sizeof(double), hipMemcpyDeviceToDevice, A.st));
+  }
   HPX_TRY(run_begin(p, A));
   for (int it = 0; it < niter; ++it) HPX_TRY(run_iteration(p, A, it));
-  return finish_run(p, iter0, niter, lnpost_out, niter, ps_last, A.st);
+  int rc = finish_run(p, iter0, niter, lnpost_out, niter, ps_last, A.st);
+  if (rc == HPX_ETIMEOUT && may_split) {
+    // The parts of a system did not run side by side (the launcher's books cover this process only: another process
+    // on the GPU).  Nothing of the run is kept: the plan leaves the form for good and the run is repeated on the
+    // one-workgroup kernel -- the chain a batch too large to split would have given (tests/test_gpu_split.py).
+    p->allow_split = 0;
+    if (p->child) p->child->allow_split = 0;
+    p->split_fallbacks += 1;
+    RunArgs B = A;
+    if (!ps0) B.ps0 = p->ps_start;
+    HPX_TRY(run_begin(p, B));
+    for (int it = 0; it < niter; ++it) HPX_TRY(run_iteration(p, B, it));
+    rc = finish_run(p, iter0, niter, lnpost_out, niter, ps_last, A.st);
+  }
+  return rc;
 }
 
 extern "C" int hpx_gibbs_step_general(hpx_plan* p, const double* shp, int iter0, double* ps_out,

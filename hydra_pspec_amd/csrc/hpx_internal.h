@@ -84,6 +84,9 @@ struct hpx_plan {
   double *P2Tre, *P2Tim;   // [TP/16 tiles][NP columns][16 rows]: P2 by row tile (shared by the baselines)
   int solver;   // HPX_SOLVER_DENSE / HPX_SOLVER_FLAT / HPX_SOLVER_LOWRANK (hpx_plan_set_solver)
   int allow_split;  // HPX_OPT_FACTOR_SPLIT of this plan: small batches may take the split factor (default 1)
+  int split_retry;  // HPX_OPT_SPLIT_RETRY: a run whose split factor timed out is repeated once without the form (default 1)
+  int split_fallbacks;   // how often that happened
+  double* ps_start; // [nbl][N] the bandpowers a run continued from (kept for that repeat; allocated on first use)
   // HPX_SOLVER_LOWRANK: flagged channels per baseline, the small Schur system and its solution
   int lr_fmax, lr_npad;
   int32_t *lr_flist, *lr_fcount;

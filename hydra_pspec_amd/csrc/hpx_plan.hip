@@ -66,6 +66,7 @@ int hpx_plan_create_impl(hpx_plan** out, int nbl, int T, int N, int M, int extra
   p->lgam_T = lgamma((double)T);
   p->ev_used = 0;
   p->allow_split = 1;
+  p->split_retry = 1;
   const size_t nb = nbl, lsz = (size_t)p->npad * p->ld, xsz = (size_t)p->npad * p->TP,
                ssz = (size_t)p->NP * p->TP, rsz = (size_t)p->NP * p->ncolR;
   int rc = HPX_OK;
@@ -330,6 +331,10 @@ extern "C" int hpx_set_option(hpx_plan* p, int key, int value) {
       if (p->child) p->child->allow_split = p->allow_split;
       return HPX_OK;
     }
+    if (key == HPX_OPT_SPLIT_RETRY) {
+      p->split_retry = value != 0;
+      return HPX_OK;
+    }
     hpx_set_error("hpx_set_option: key %d is not a plan option", key);
     return HPX_EINVAL;
   }
@@ -339,6 +344,18 @@ extern "C" int hpx_set_option(hpx_plan* p, int key, int value) {
   else if (key == HPX_OPT_EIGH_INNER_SWEEPS || key == HPX_OPT_EIGH_TRACE) rc = hpx_eigh_set_option(key, value);
   if (rc != HPX_OK) hpx_set_error("hpx_set_option: unknown key %d or bad value %d", key, value);
   return rc;
+}
+
+extern "C" int hpx_get_option(const hpx_plan* p, int key, int* value) {
+  HPX_REQUIRE(p && value, "hpx_get_option: null argument");
+  if (key == HPX_OPT_FACTOR_SPLIT) *value = p->allow_split;
+  else if (key == HPX_OPT_SPLIT_RETRY) *value = p->split_retry;
+  else if (key == HPX_OPT_SPLIT_FALLBACKS) *value = p->split_fallbacks;
+  else {
+    hpx_set_error("hpx_get_option: key %d is not a plan option", key);
+    return HPX_EINVAL;
+  }
+  return HPX_OK;
 }
 
 extern "C" int hpx_plan_set_profiling(hpx_plan* p, int on) {

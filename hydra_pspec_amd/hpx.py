@@ -16,6 +16,7 @@ _LIB_PATH = Path(os.environ.get("HPX_LIB_PATH") or Path(__file__).resolve().pare
 
 HPX_OK, HPX_EINVAL, HPX_EHIP, HPX_ENOTPD, HPX_ETIMEOUT = 0, -1, -2, -3, -4
 OPT_FACTOR_SPLIT, OPT_SPLIT_HEAVY, OPT_SPLIT_SPIN_LIMIT, OPT_EIGH_INNER_SWEEPS, OPT_EIGH_TRACE = 1, 2, 3, 4, 5
+OPT_SPLIT_RETRY, OPT_SPLIT_FALLBACKS = 6, 7
 INFO_TIMEOUT = 0x40000000
 NSTAGE = 6
 SOLVER_DENSE, SOLVER_FLAT, SOLVER_LOWRANK, SOLVER_LOWRANK_DIRECT = 0, 1, 2, 3
@@ -43,6 +44,7 @@ SIGNATURES = {
     "hpx_gibbs_step_general": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "hpx_plan_info": (_i, [_vp, _vp]),
     "hpx_set_option": (_i, [_vp, _i, _i]),
+    "hpx_get_option": (_i, [_vp, _i, _vp]),
     "hpx_plan_set_profiling": (_i, [_vp, _i]),
     "hpx_plan_set_solver": (_i, [_vp, _i]),
     "hpx_plan_stage_ms": (_i, [_vp, _vp]),
@@ -102,7 +104,8 @@ def last_error():
 
 class HpxTimeout(RuntimeError):
     """HPX_ETIMEOUT: a hand-off between the workgroups of a split factorisation timed out -- the GPU is shared with
-    another process running the same form (set OPT_FACTOR_SPLIT to 0), not a property of the data."""
+    another process running the same form (set OPT_FACTOR_SPLIT to 0), not a property of the data.  hpx_gibbs_run
+    repeats such a run once without the form (OPT_SPLIT_RETRY) before it would report this."""
 
 
 def check(rc, what=""):
@@ -121,6 +124,13 @@ def check(rc, what=""):
 def set_option(key, value, plan=None):
     """hpx_set_option: library-wide (plan=None) or for one plan (OPT_* keys)."""
     check(lib().hpx_set_option(plan.handle if plan is not None else None, int(key), int(value)), "hpx_set_option")
+
+
+def get_option(key, plan):
+    """hpx_get_option: the current value of a plan option (OPT_FACTOR_SPLIT, OPT_SPLIT_RETRY, OPT_SPLIT_FALLBACKS)."""
+    v = C.c_int(0)
+    check(lib().hpx_get_option(plan.handle, int(key), C.byref(v)), "hpx_get_option")
+    return v.value
 
 
 def require_gpu():

@@ -217,7 +217,13 @@ int hpx_plan_info(hpx_plan* p, int32_t* info_host);
 #define HPX_OPT_SPLIT_SPIN_LIMIT 3
 #define HPX_OPT_EIGH_INNER_SWEEPS 4
 #define HPX_OPT_EIGH_TRACE 5
+#define HPX_OPT_SPLIT_RETRY 6       /* plan; default 1: hpx_gibbs_run repeats a run whose split factor timed out, once, on the
+                                     * one-workgroup kernel (the plan's HPX_OPT_FACTOR_SPLIT is 0 from then on) instead of
+                                     * returning HPX_ETIMEOUT */
+#define HPX_OPT_SPLIT_FALLBACKS 7   /* plan, read-only (hpx_get_option): how often that happened */
 int hpx_set_option(hpx_plan* p, int key, int value);
+/* The current value of a plan option (HPX_OPT_FACTOR_SPLIT, HPX_OPT_SPLIT_RETRY, HPX_OPT_SPLIT_FALLBACKS). */
+int hpx_get_option(const hpx_plan* plan, int key, int* value);
 
 /* Solver of the per-iteration linear system.  HPX_SOLVER_DENSE (default): batched Cholesky of
  * the (N+M) system (k_factor / k_backsolve), any diagonal Ninv and flags.  HPX_SOLVER_FLAT: for

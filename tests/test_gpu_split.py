@@ -94,9 +94,11 @@ def test_more_concurrent_plans_than_the_device_holds():
 
 def test_a_handoff_timeout_has_its_own_error():
     """A spin that gives up is reported as HPX_ETIMEOUT / hpx.HpxTimeout with bit 30 of the baseline's info word --
-    not as a non-positive pivot (FloatingPointError).  Forced by letting every spin give up after one poll."""
+    not as a non-positive pivot (FloatingPointError).  Forced by letting every spin give up after one poll, with the
+    automatic repeat (HPX_OPT_SPLIT_RETRY) switched off."""
     from hydra_pspec_amd import hpx
     gb, ps0 = _batch(8, 256, 3, 4)
+    hpx.set_option(hpx.OPT_SPLIT_RETRY, 0, plan=gb.plan)
     hpx.set_option(hpx.OPT_SPLIT_SPIN_LIMIT, 1)
     try:
         with pytest.raises(hpx.HpxTimeout, match="timed out"):
@@ -112,6 +114,50 @@ def test_a_handoff_timeout_has_its_own_error():
     b = _chain(gb, ps0, 4)
     gb.close()
     assert np.isfinite(a[0]).all() and np.array_equal(a[0], b[0])
+
+
+def test_a_timed_out_run_is_repeated_without_the_split_form():
+    """Default (HPX_OPT_SPLIT_RETRY = 1): hpx_gibbs_run repeats a run whose split factor timed out on the one-workgroup
+    kernel and the plan leaves the form for good -- the caller gets the chain of allow_split=False, bit for bit, for a
+    run started from given bandpowers and for one that continues from the plan's own; the fall-back is counted."""
+    from hydra_pspec_amd import hpx
+    niter = 3
+    gb, ps0 = _batch(8, 256, 3, 2 * niter, allow_split=False)
+    want1 = _chain(gb, ps0, niter)
+    out = gb.run(niter)                                    # continues from the plan's bandpowers
+    want2 = out["signal_ps"].cpu().numpy()
+    gb.close()
+    # (a) the first run times out
+    gb, ps0 = _batch(8, 256, 3, 2 * niter)
+    assert hpx.get_option(hpx.OPT_FACTOR_SPLIT, gb.plan) == 1 and hpx.get_option(hpx.OPT_SPLIT_FALLBACKS, gb.plan) == 0
+    hpx.set_option(hpx.OPT_SPLIT_SPIN_LIMIT, 1)
+    try:
+        got1 = _chain(gb, ps0, niter)
+    finally:
+        hpx.set_option(hpx.OPT_SPLIT_SPIN_LIMIT, 0)
+    assert hpx.get_option(hpx.OPT_FACTOR_SPLIT, gb.plan) == 0 and hpx.get_option(hpx.OPT_SPLIT_FALLBACKS, gb.plan) == 1
+    assert np.array_equal(got1[0], want1[0]) and np.array_equal(got1[1], want1[1])
+    got2 = gb.run(niter)["signal_ps"].cpu().numpy()
+    assert np.array_equal(got2, want2)
+    gb.close()
+    # (b) the continuing run times out: it is repeated from the bandpowers it started from -- the same as switching the
+    # form off by hand between the two runs
+    gb, ps0 = _batch(8, 256, 3, 2 * niter)
+    first = _chain(gb, ps0, niter)
+    hpx.set_option(hpx.OPT_FACTOR_SPLIT, 0, plan=gb.plan)
+    want = gb.run(niter)["signal_ps"].cpu().numpy()
+    gb.close()
+    gb, ps0 = _batch(8, 256, 3, 2 * niter)
+    again = _chain(gb, ps0, niter)
+    assert np.array_equal(first[0], again[0])
+    hpx.set_option(hpx.OPT_SPLIT_SPIN_LIMIT, 1)
+    try:
+        cont = gb.run(niter)["signal_ps"].cpu().numpy()
+    finally:
+        hpx.set_option(hpx.OPT_SPLIT_SPIN_LIMIT, 0)
+    assert hpx.get_option(hpx.OPT_SPLIT_FALLBACKS, gb.plan) == 1
+    assert np.array_equal(cont, want)
+    gb.close()
 
 
 def test_agent_scope_handoff_protocol():
