@@ -146,7 +146,7 @@ def cpu_baseline_multiproc(N, T, M, flag_frac, niter=8, max_procs=None):
 
 
 DENSE_STEP_SOURCES = ("hpx_factor.hip", "hpx_factor_wide.hip", "hpx_factor_split.hip", "hpx_factor_tiles.h",
-                      "hpx_backsolve.hip", "hpx_plan.hip", "hpx_setup.hip", "hpx_chain.hip", "hpx_post.hip", "hpx_woodbury.hip", "hpx_chain.h",
+                      "hpx_backsolve.hip", "hpx_backsolve_lds.hip", "hpx_plan.hip", "hpx_setup.hip", "hpx_chain.hip", "hpx_post.hip", "hpx_woodbury.hip", "hpx_chain.h",
                       "hpx_transform.hip", "hpx_internal.h", "hpx_fft.h", "Makefile")
 
 

@@ -1012,6 +1012,7 @@ int hpx_launch_backsolve(int nbl, int npad, int TP, int ld, const double* L, con
                          const double* Wim, double* Xre, double* Xim, hipStream_t st) {
 #ifndef HPX_BACKSOLVE_OLD
   if (hpx_backsolve_reg_ok(npad, TP)) return hpx_launch_backsolve_reg(nbl, npad, TP, ld, L, Wre, Wim, Xre, Xim, st);
+  if (hpx_backsolve_x_ok(npad, TP)) return hpx_launch_backsolve_x(nbl, npad, ld, L, Wre, Wim, Xre, Xim, st);
 #endif
   hipLaunchKernelGGL(k_backsolve, dim3(nbl), dim3(256), 0, st, L, Wre, Wim, Xre, Xim, npad, TP, ld);
   HPX_HIP(hipGetLastError());

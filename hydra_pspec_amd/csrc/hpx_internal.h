@@ -357,6 +357,10 @@ int hpx_launch_backsolve(int nbl, int npad, int TP, int ld, const double* L, con
                          const double* Wim, double* Xre, double* Xim, hipStream_t st);
 // the register-resident form (hpx_backsolve.hip): small orders, up to 32 right-hand sides
 int hpx_backsolve_reg_ok(int npad, int TP);
+// hpx_backsolve_lds.hip: X through LDS, L three chunks ahead (TP = 32, orders beyond the register form)
+int hpx_backsolve_x_ok(int npad, int TP);
+int hpx_launch_backsolve_x(int nbl, int npad, int ld, const double* L, const double* Wre, const double* Wim, double* Xre,
+                           double* Xim, hipStream_t st);
 int hpx_launch_backsolve_reg(int nbl, int npad, int TP, int ld, const double* L, const double* Wre, const double* Wim,
                              double* Xre, double* Xim, hipStream_t st);
 // out[b][x][c] = scale * sum_k W[x][k] in[b][k][c] (W = fop or conj(fop)), optional

@@ -969,6 +969,9 @@ int hpx_post_solve(hpx_plan* p, int it_abs, const IterOut& O, hipStream_t st) {
 // registers a lane: 44 spilled, config 3 0.37 against 0.27 ms, config 2 22.7 against 18.6 us
 #define HPX_FR_THREADS 256
 #endif
+#ifndef HPX_FR_HALVE
+#define HPX_FR_HALVE 1      // 0: never take 8-column blocks for small batches (A/B, tests)
+#endif
 #ifndef HPX_FR_ELEMS
 #define HPX_FR_ELEMS 4096      // complex elements of the signal block a workgroup of k_fft_resid holds in LDS
 #endif
@@ -980,7 +983,7 @@ int hpx_post_solve(hpx_plan* p, int it_abs, const IterOut& O, hipStream_t st) {
   {
     int dev = 0, cus = 0;
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    if (TC == 16 && M <= 16 && (long)nbl * (TP / 16) < (long)cus) TC = 8;
+    if (HPX_FR_HALVE && TC == 16 && M <= 16 && (long)nbl * (TP / 16) < (long)cus) TC = 8;
   }
   const bool pow2 = N == NP && (N & (N - 1)) == 0 && N >= 32 && N <= 4096;
   const bool generic_post = p->dense_noise || p->per_time;      // modes only the two-kernel form implements

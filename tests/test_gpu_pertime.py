@@ -34,8 +34,11 @@ def test_identical_per_time_inputs_reproduce_the_standard_chain():
     nt = np.broadcast_to(d["ninv_diag"][:, None, :], (nbl, T, N)).copy()
     pt = pspec.gibbs_sample_with_fg_batched(d["vis"], flt, d["fgmodes"], nt, d["ps_prior"], ps_initial=d["ps0"],
                                             Niter=5, seed=3, keep=("signal_cr", "fg_amps", "chisq"))
-    assert np.max(np.abs(pt["signal_ps"] / std["signal_ps"] - 1)) < 1e-10
-    assert relerr(pt["signal_cr"], std["signal_cr"]) < 1e-10 and relerr(pt["fg_amps"], std["fg_amps"]) < 1e-10
+    # (the two modes add the same terms in different orders -- their first draws differ by ~3e-15 -- and a prior channel's
+    # bandpower takes that through the solve of the next iteration: 5e-12, 2e-10, 1.3e-9, 1.5e-9 over these five)
+    dev = np.abs(pt["signal_ps"] / std["signal_ps"] - 1)
+    assert dev[:, 0].max() < 1e-13 and dev.max() < 2e-8
+    assert relerr(pt["signal_cr"], std["signal_cr"]) < 2e-8 and relerr(pt["fg_amps"], std["fg_amps"]) < 1e-10
     assert relerr(pt["chisq"], std["chisq"]) < 1e-8 and np.allclose(pt["ln_post"], std["ln_post"], rtol=1e-10)
 
 
