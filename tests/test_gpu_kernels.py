@@ -230,6 +230,33 @@ def test_assemble_K(T, Tn, N, M, frac):
     gb.close()
 
 
+def test_zpotrs_beyond_the_register_form(T):
+    """Orders 273 .. 1050 with 17 .. 32 right-hand sides (TP = 32): the back substitution of
+    csrc/hpx_backsolve_lds.hip (eight waves, the solution rows through an LDS ring, hand-counted operand waits) --
+    tile counts around the super-block boundaries of 8 tiles (128 columns), one to several groups of four chunks per
+    pass, a top super-block of one tile (C3's 33) and of eight, against numpy."""
+    from hydra_pspec_amd import hpx
+    rng = np.random.default_rng(2024)
+    sizes = [273, 288, 300, 383, 384, 385, 400, 496, 512, 513, 524, 528, 529, 640, 777, 1040, 1050]
+    worst = 0.0
+    for i, n in enumerate(sizes):
+        nrhs = [32, 17, 24, 31][i % 4]
+        nb = 1 + i % 3
+        A = _hpd(rng, nb, n, cond=1e3)
+        A = 0.5 * (A + np.conj(np.swapaxes(A, 1, 2)))
+        B = rng.standard_normal((nb, n, nrhs)) + 1j * rng.standard_normal((nb, n, nrhs))
+        dA, dB = _dev(T, A, T.complex128), _dev(T, B, T.complex128)
+        dX = T.zeros_like(dB)
+        info = T.zeros(nb, dtype=T.int32, device="cuda")
+        hpx.check(hpx.lib().hpx_zpotrs_batched(nb, n, nrhs, hpx.ptr(dA), hpx.ptr(dB), hpx.ptr(dX),
+                                               hpx.ptr(info), None))
+        assert not info.cpu().numpy().any(), (n, nrhs)
+        err = relerr(dX.cpu().numpy(), np.linalg.solve(A, B))
+        worst = max(worst, err)
+        assert err < 1e-10, (n, nrhs, err)
+    print(f"large orders: worst relative error {worst:.2e} over {len(sizes)} orders")
+
+
 def test_zpotrs_size_sweep(T):
     """Every order 1..70 and a few around the 16 / 32 block boundaries further up, with 1..40 right-hand
     sides: exercises the 16-wide last block column, single-tile groups, 2+2 / 3 groupings and the
