@@ -151,7 +151,14 @@ __global__ __launch_bounds__(256) void k_resid(const ResArgs A) {
 // model, residual, chi^2 and the optional sample write-back for those columns, so s never goes
 // to HBM and back.  Blocks of one baseline leave their partial sums (|z|^2 per channel, the
 // chi^2 total) in slot blockIdx.x; k_draw adds the slots in a fixed order.
-template <int NTH>
+// SPLIT8 (blocks of 8 time columns when that is the block size of the channel count, N >= 512): the model term's
+// MFMA tile is 16 channels x 16 columns and eight of them were padding -- half the matrix-pipe time, and half the
+// lanes idle in the element-wise part behind it.  Here the columns 8 .. 15 carry the IMAGINARY parts of the amplitudes:
+// with B = [Re f | Im f] one MFMA chain gives F_re [Re f | Im f] and a second F_im [Re f | Im f] (two MFMAs per k-step
+// instead of four); a swap of the lane halves (DPP row_ror:8) brings the partner's second product over, and lane
+// (t, g) then holds Re of the model term, lane (t + 8, g) Im.  The residual is finished one COMPONENT per lane: every
+// lane loads one of (Re d, Im d), reads one of (Re s, Im s) and adds its square to chi^2.
+template <int NTH, bool SPLIT8>
 __global__ __launch_bounds__(NTH, NTH / 128) void k_fft_resid(const ResArgs A) {
   constexpr int NW = NTH / 64;                       // waves
   extern __shared__ double fl[];
@@ -235,7 +242,90 @@ __global__ __launch_bounds__(NTH, NTH / 128) void k_fft_resid(const ResArgs A) {
   const double* ninv = A.ninv + (long)b * N;
   const uint8_t* fl8 = A.flags + (long)b * N;
   double acc = 0.0;
-  if (M <= 16) {
+  if (SPLIT8 && M <= 16) {
+    const int wave = tid >> 6, lane = tid & 63, li = lane & 15, g = lane >> 4;
+    const bool hi = li >= 8;                          // this lane's component: Re (li < 8) or Im
+    const int tc = li & 7, t = c0 + tc;
+    double bb[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {                  // B[m = 4 ks + g][col = li] = Re f[m][tc] | Im f[m][tc]
+      const int m = 4 * ks + g;
+      bb[ks] = (m < M) ? (hi ? lfi : lfr)[(m << tcs) + tc] : 0.0;
+    }
+    const int ntile = N >> 4;
+    const int tlast = wave + NW * ((ntile - 1 - wave) / NW);
+    const bool tvalid = t < T;
+    const double* dsel = hi ? dim_ : dre;             // the lane's component of the data ...
+    const double* ssel = hi ? fim : fre;              // ... and of the signal (LDS)
+    double nfr[4], nfi[4], nd[4], nnv[4], nw[4];
+#define HPX_FR_LOAD8(xt_)                                                             \
+  {                                                                                   \
+    const int x0_ = (xt_) << 4;                                                       \
+    _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {                                \
+      const int m = 4 * ks + g;                                                       \
+      const long fo_ = (long)(x0_ + li) * M + min(m, M - 1);                          \
+      const double fr_ = fmr[fo_], fi_ = fmi[fo_];                                    \
+      nfr[ks] = (m < M) ? fr_ : 0.0;                                                  \
+      nfi[ks] = (m < M) ? fi_ : 0.0;                                                  \
+    }                                                                                 \
+    _Pragma("unroll") for (int v = 0; v < 4; ++v) {                                   \
+      const int x_ = x0_ + HPX_ACC_ROW(g, v);                                         \
+      nd[v] = dsel[(long)x_ * TP + (tvalid ? t : 0)];                                 \
+      nnv[v] = ninv[x_];                                                              \
+      nw[v] = fl8[x_] ? 1.0 : 0.0;                                                    \
+    }                                                                                 \
+  }
+    if (wave < ntile) HPX_FR_LOAD8(wave)
+    for (int xt = wave; xt < ntile; xt += NW) {
+      const int x0 = xt << 4;
+      double cfr[4], cfi[4], cd[4], cnv[4], cw[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        cfr[q] = nfr[q]; cfi[q] = nfi[q]; cd[q] = nd[q]; cnv[q] = nnv[q]; cw[q] = nw[q];
+      }
+      HPX_FR_LOAD8(min(xt + NW, tlast))               // branch-free: re-read at the end
+      d4 d1 = {0., 0., 0., 0.}, d2 = {0., 0., 0., 0.};
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {                // A[channel x0 + li][m = 4 ks + g] = F[x][m]
+        if (4 * ks >= M) break;
+        d1 = mfma64(cfr[ks], bb[ks], d1);             // F_re [Re f | Im f]
+        d2 = mfma64(cfi[ks], bb[ks], d2);             // F_im [Re f | Im f]
+      }
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        // the partner lane's F_im product: Re (F f) = F_re Re f - F_im Im f,  Im (F f) = F_re Im f + F_im Re f
+        const long long raw = __double_as_longlong(d2[v]);
+        const int lo_ = __builtin_amdgcn_mov_dpp((int)(raw & 0xffffffffll), 0x128, 0xf, 0xf, false);     // row_ror:8
+        const int hi_ = __builtin_amdgcn_mov_dpp((int)(raw >> 32), 0x128, 0xf, 0xf, false);
+        const double other = __longlong_as_double(((long long)hi_ << 32) | (unsigned int)lo_);
+        const double mdl = hi ? d1[v] + other : d1[v] - other;
+        const int x = x0 + HPX_ACC_ROW(g, v);
+        const int pidx = (int)(__brev((unsigned)x) >> (32 - logN));
+        const long o = (long)x * TP + t;
+        double* gsel = hi ? A.Gim : A.Gre;
+        if (t >= T) {
+          if (A.any_flags) gsel[(long)b * A.NP * TP + o] = 0.0;
+          continue;
+        }
+        const double sc = (x & 1) ? -A.isn : A.isn;
+        const double sv = ssel[(pidx << tcs) + tc] * sc;
+        const double r = cd[v] - (sv + mdl);
+        const double w = cw[v];
+        const double c2 = (r * r) * cnv[v];           // this component's share of the channel's chi^2 term
+        acc += w * c2;
+        if (A.any_flags) gsel[(long)b * A.NP * TP + o] = w * sv;
+        if (A.cr_out) A.cr_out[(long)b * A.cr_bstride + ((long)t * N + x) * 2 + (hi ? 1 : 0)] = sv;
+        if (A.chisq_out) {                            // (rarely kept: the two components meet for it)
+          const long long rc = __double_as_longlong(c2);
+          const int cl = __builtin_amdgcn_mov_dpp((int)(rc & 0xffffffffll), 0x128, 0xf, 0xf, false);
+          const int ch = __builtin_amdgcn_mov_dpp((int)(rc >> 32), 0x128, 0xf, 0xf, false);
+          const double c2o = __longlong_as_double(((long long)ch << 32) | (unsigned int)cl);
+          if (!hi) A.chisq_out[(long)b * A.chisq_bstride + (long)t * N + x] = c2 + c2o;
+        }
+      }
+    }
+#undef HPX_FR_LOAD8
+  } else if (M <= 16) {
     // Model term F f on the matrix pipe: tiles of 16 channels x the block's time columns, K =
     // the (padded) mode index.  The accumulator lane (li, g) then holds channels x0 + g + 4v,
     // column tc = li: the residual is finished from there with a handful of vector ops per
@@ -969,6 +1059,9 @@ int hpx_post_solve(hpx_plan* p, int it_abs, const IterOut& O, hipStream_t st) {
 // registers a lane: 44 spilled, config 3 0.37 against 0.27 ms, config 2 22.7 against 18.6 us
 #define HPX_FR_THREADS 256
 #endif
+#ifndef HPX_FR_SPLIT8
+#define HPX_FR_SPLIT8 1     // 0: the four-MFMA form at every block size (A/B)
+#endif
 #ifndef HPX_FR_HALVE
 #define HPX_FR_HALVE 1      // 0: never take 8-column blocks for small batches (A/B, tests)
 #endif
@@ -997,9 +1090,17 @@ int hpx_post_solve(hpx_plan* p, int it_abs, const IterOut& O, hipStream_t st) {
     // (the mode rows' staging area behind the amplitudes only where the model term is not on the matrix pipe)
     const size_t lds = ((size_t)N * TC * 2 + N + (size_t)2 * M * TC + (M > 16 ? (size_t)2 * M * (HPX_FR_THREADS / TC) : 0)) * sizeof(double);
     static hpx_lds_limit limit;
-    HPX_TRY(limit.ensure(reinterpret_cast<const void*>(&k_fft_resid<HPX_FR_THREADS>), lds));
     R.nbl = nbl; R.npart = npart;
-    hipLaunchKernelGGL(k_fft_resid<HPX_FR_THREADS>, dim3(((nbl + 7) / 8) * 8 * npart), dim3(HPX_FR_THREADS), lds, st, R);
+    // (blocks of 8 columns because the channel count leaves no other choice: the component-per-lane form; where 16
+    // would fit and 8 is taken for a small batch, the sums must come out as a block of 16 leaves them: the other form)
+    if (HPX_FR_SPLIT8 && TC == 8 && HPX_FR_ELEMS / NP == 8 && M <= 16) {
+      HPX_TRY(limit.ensure(reinterpret_cast<const void*>(&k_fft_resid<HPX_FR_THREADS, true>), lds));
+      hipLaunchKernelGGL((k_fft_resid<HPX_FR_THREADS, true>), dim3(((nbl + 7) / 8) * 8 * npart), dim3(HPX_FR_THREADS), lds, st, R);
+    } else {
+      static hpx_lds_limit limit2;
+      HPX_TRY(limit2.ensure(reinterpret_cast<const void*>(&k_fft_resid<HPX_FR_THREADS, false>), lds));
+      hipLaunchKernelGGL((k_fft_resid<HPX_FR_THREADS, false>), dim3(((nbl + 7) / 8) * 8 * npart), dim3(HPX_FR_THREADS), lds, st, R);
+    }
     HPX_HIP(hipGetLastError());
     HPX_TRY(hpx_mark(p, st));
   } else if (HPX_DFT_RESID && NP <= 256 && M <= 16 && hpx_dft_use_fft && !generic_post) {
