@@ -3,6 +3,8 @@ not need a full-size reference chain, plus one short oracle comparison per shape
 import numpy as np
 import pytest
 
+from conftest import relerr
+
 pytestmark = pytest.mark.gpu
 
 
@@ -24,6 +26,26 @@ def test_batch_independence_and_determinism(N, frac):
     assert np.array_equal(big["ln_post"], again["ln_post"])
     _, one = _run(1, N, frac=frac, niter=3, k0=17, solver="dense")
     assert np.array_equal(one["signal_ps"][0], big["signal_ps"][17])
+
+
+@pytest.mark.parametrize("T,M,frac", [(20, 5, 0.1), (32, 12, 0.0)])
+def test_kept_outputs_at_512_channels_vs_oracle(T, M, frac):
+    """(Ntimes, Nfreq, Nmodes) = (20, 512, 5) with flags -- a ragged last block of time columns, few modes -- and the C3
+    shape, every output kept, 2 iterations against the exact-solve oracle: the component-per-lane form of the fused
+    transform + residual kernel (masked-signal and sample write-back split over the lane halves, the per-element chi^2
+    put together again) and the LDS-ring back substitution (Ntimes 17 .. 32: 32 right-hand-side columns)."""
+    from hydra_pspec_amd import pspec, synthetic
+    from oracle import pspec_ref
+    N = 512
+    d = synthetic.make_baselines(N, T, M, k0=3, nbl=1, flag_frac=frac, dense=True)
+    out = pspec.gibbs_sample_with_fg_batched(d["vis"], d["flags"], d["fgmodes"], d["Ninv"], d["ps_prior"],
+                                             S_initial=d["S_initial"], Niter=2, seed=d["seed"],
+                                             keep=("signal_cr", "fg_amps", "chisq"), solver="dense")
+    ref = pspec_ref.gibbs_sample_with_fg(d["vis"][0], d["flags"][0], d["S_initial"], d["fgmodes"], d["Ninv"],
+                                         d["ps_prior"], Niter=2, seed=d["seed"], solver="direct")
+    assert np.max(np.abs(out["signal_ps"][0] / ref[2] - 1)) < 1e-6
+    assert relerr(out["signal_cr"][0], ref[0]) < 1e-6 and relerr(out["fg_amps"][0], ref[3]) < 1e-6
+    assert relerr(out["chisq"][0], ref[4]) < 1e-6 and np.allclose(out["ln_post"][0], ref[5], rtol=1e-6)
 
 
 def test_largest_channel_count_of_the_fused_kernels():
