@@ -158,7 +158,21 @@ __global__ __launch_bounds__(256) void k_resid(const ResArgs A) {
 // instead of four); a swap of the lane halves (DPP row_ror:8) brings the partner's second product over, and lane
 // (t, g) then holds Re of the model term, lane (t + 8, g) Im.  The residual is finished one COMPONENT per lane: every
 // lane loads one of (Re d, Im d), reads one of (Re s, Im s) and adds its square to chi^2.
-template <int NTH, bool SPLIT8>
+typedef __attribute__((address_space(3))) double lds_f64_t;
+#ifdef HPX_FR_TRACE
+__device__ unsigned long long hpx_fr_trace[8 * 4 * 16];
+#define FR_TR(id_)                                                                               \
+  if (blockIdx.x < 8) {                                                                          \
+    unsigned long long t_;                                                                       \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory");                \
+    if ((threadIdx.x & 63) == 0) hpx_fr_trace[(blockIdx.x * 4 + (threadIdx.x >> 6)) * 16 + (id_)] = t_; \
+  }
+#else
+#define FR_TR(id_)
+#endif
+// OPT (the SPLIT8 form): bit 0 the batch has flags (the masked signal is written), bit 1 samples / chi^2 are kept this
+// iteration -- compile-time, so that the tile loop of the common iteration carries neither the stores nor their tests
+template <int NTH, bool SPLIT8, int OPT>
 __global__ __launch_bounds__(NTH, NTH / 128) void k_fft_resid(const ResArgs A) {
   constexpr int NW = NTH / 64;                       // waves
   extern __shared__ double fl[];
@@ -176,6 +190,25 @@ __global__ __launch_bounds__(NTH, NTH / 128) void k_fft_resid(const ResArgs A) {
   double* lfi = lfr + (M << tcs);
   const double* xre = A.Xre + (long)b * A.npad * TP;
   const double* xim = A.Xim + (long)b * A.npad * TP;
+  double* bp = A.bpart + ((long)b * HPX_NPART + cg) * N;
+  FR_TR(0)
+  // The block of the solution first: 16 loads per thread and array, all in flight before anything waits (the block is
+  // at most 4096 elements: one batch); the twiddles and the amplitudes are requested behind them (in front of them
+  // measures the same: 0.217 ms either way at config 3).
+  constexpr int UB = 4096 / NTH;
+  const int total = N << tcs;
+  double zr[UB], zi[UB];
+#pragma unroll
+  for (int u = 0; u < UB; ++u) {
+    const int e = min(tid + NTH * u, total - 1), k = e >> tcs, tc = e & (TC - 1);
+#if HPX_FR_NT & 1
+    zr[u] = __builtin_nontemporal_load(&xre[(long)k * TP + c0 + tc]);
+    zi[u] = __builtin_nontemporal_load(&xim[(long)k * TP + c0 + tc]);
+#else
+    zr[u] = xre[(long)k * TP + c0 + tc];
+    zi[u] = xim[(long)k * TP + c0 + tc];
+#endif
+  }
   for (int j = tid; j < h; j += NTH) {
     tw[j] = A.twre[(long)(h + 1) * N + h + j];
     tw[h + j] = A.twim[(long)(h + 1) * N + h + j];
@@ -185,46 +218,33 @@ __global__ __launch_bounds__(NTH, NTH / 128) void k_fft_resid(const ResArgs A) {
     lfr[e] = xre[(long)(N + m) * TP + c0 + tc];
     lfi[e] = xim[(long)(N + m) * TP + c0 + tc];
   }
-  double* bp = A.bpart + ((long)b * HPX_NPART + cg) * N;
-  // loads in batches of 16 per thread, all in flight before the first use (one element at a time
-  // every iteration waits out a memory round trip); N * TC is a multiple of 256
-  {
-    constexpr int UB = 4096 / NTH;
-    const int total = N << tcs;
-    for (int e0 = tid; e0 < total; e0 += NTH * UB) {
-      double zr[UB], zi[UB];
 #pragma unroll
-      for (int u = 0; u < UB; ++u) {
-        const int e = min(e0 + NTH * u, total - 1), k = e >> tcs, tc = e & (TC - 1);
-#if HPX_FR_NT & 1
-        zr[u] = __builtin_nontemporal_load(&xre[(long)k * TP + c0 + tc]);
-        zi[u] = __builtin_nontemporal_load(&xim[(long)k * TP + c0 + tc]);
-#else
-        zr[u] = xre[(long)k * TP + c0 + tc];
-        zi[u] = xim[(long)k * TP + c0 + tc];
-#endif
+  for (int u = 0; u < UB; ++u) {
+    const int e = tid + NTH * u;
+    if (e < total) {                                      // uniform over the workgroup
+      const int k = e >> tcs, tc = e & (TC - 1);
+      const double sg = (k & 1) ? -1.0 : 1.0;
+      fre[e] = zr[u] * sg;
+      fim[e] = zi[u] * sg;
+      // sum over this block's time columns: groups of eight first, then the groups -- a block of 16 columns leaves
+      // what two blocks of 8 leave once k_draw has added their slots in pairs (the launcher takes 8 instead of 16
+      // columns per block for batches that would not fill the CUs: a baseline's chain must not depend on that)
+      double v = zr[u] * zr[u] + zi[u] * zi[u];
+      if (tcs == 3) {                                     // (constant distances: no trip through the LDS crossbar's queue per step)
+        v += __shfl_xor(v, 1, 64);
+        v += __shfl_xor(v, 2, 64);
+        v += __shfl_xor(v, 4, 64);
+      } else {
+        for (int o = 1; o < TC; o <<= 1) v += __shfl_xor(v, o, 64);
       }
-#pragma unroll
-      for (int u = 0; u < UB; ++u) {
-        const int e = e0 + NTH * u;
-        if (e < total) {                                  // uniform over the workgroup
-          const int k = e >> tcs, tc = e & (TC - 1);
-          const double sg = (k & 1) ? -1.0 : 1.0;
-          fre[e] = zr[u] * sg;
-          fim[e] = zi[u] * sg;
-          // sum over this block's time columns: groups of eight first, then the groups -- a block of 16 columns leaves
-          // what two blocks of 8 leave once k_draw has added their slots in pairs (the launcher takes 8 instead of 16
-          // columns per block for batches that would not fill the CUs: a baseline's chain must not depend on that)
-          double v = zr[u] * zr[u] + zi[u] * zi[u];
-          for (int o = 1; o < TC; o <<= 1) v += __shfl_xor(v, o, 64);
-          if (tc == 0) bp[k] = v;
-        }
-      }
+      if (tc == 0) bp[k] = v;
     }
   }
+  FR_TR(1)
   int s = 0;
   for (; s + 3 <= logN; s += 3) {
     __syncthreads();
+    FR_TR(2 + s / 3)
     fft_pass<3, 1, NTH>(fre, fim, tw, N, h, logN, s, tcs, tid);
   }
   if (logN - s == 2) {
@@ -235,6 +255,7 @@ __global__ __launch_bounds__(NTH, NTH / 128) void k_fft_resid(const ResArgs A) {
     fft_pass<1, 1, NTH>(fre, fim, tw, N, h, logN, s, tcs, tid);
   }
   __syncthreads();
+  FR_TR(6)
   const double* dre = A.Dre + (long)b * A.NP * TP;
   const double* dim_ = A.Dim + (long)b * A.NP * TP;
   const double* fmr = A.Fre + (A.fg_shared ? 0 : (long)b * N * M);
@@ -243,9 +264,11 @@ __global__ __launch_bounds__(NTH, NTH / 128) void k_fft_resid(const ResArgs A) {
   const uint8_t* fl8 = A.flags + (long)b * N;
   double acc = 0.0;
   if (SPLIT8 && M <= 16) {
+    constexpr bool FL = (OPT & 1) != 0, KEEP = (OPT & 2) != 0;
     const int wave = tid >> 6, lane = tid & 63, li = lane & 15, g = lane >> 4;
     const bool hi = li >= 8;                          // this lane's component: Re (li < 8) or Im
     const int tc = li & 7, t = c0 + tc;
+    const bool tvalid = t < T;
     double bb[4];
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {                  // B[m = 4 ks + g][col = li] = Re f[m][tc] | Im f[m][tc]
@@ -254,25 +277,45 @@ __global__ __launch_bounds__(NTH, NTH / 128) void k_fft_resid(const ResArgs A) {
     }
     const int ntile = N >> 4;
     const int tlast = wave + NW * ((ntile - 1 - wave) / NW);
-    const bool tvalid = t < T;
-    const double* dsel = hi ? dim_ : dre;             // the lane's component of the data ...
-    const double* ssel = hi ? fim : fre;              // ... and of the signal (LDS)
+    // Everything a tile reads, as (wave-uniform base of the tile) + (32-bit lane offset in bytes, fixed over the
+    // tiles): one offset register per stream instead of a 64-bit address per load and tile.
+    const char* fr_b = reinterpret_cast<const char*>(fmr);
+    const char* fi_b = reinterpret_cast<const char*>(fmi);
+    const char* d_b = reinterpret_cast<const char*>(hi ? dim_ : dre);      // the lane's component of the data
+    const char* nv_b = reinterpret_cast<const char*>(ninv);
+    const lds_f64_t* ssel = (const lds_f64_t*)(hi ? fim : fre);            // ... and of the signal (LDS)
+    unsigned fo[4], dof[4], sof[4];
+    bool mok[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const int m = 4 * ks + g;
+      mok[ks] = m < M;
+      fo[ks] = 8u * (unsigned)(li * M + min(m, M - 1));                    // (clamped load, then the select: no branch)
+    }
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const int r = HPX_ACC_ROW(g, v);
+      dof[v] = 8u * (unsigned)(r * TP + (tvalid ? t : 0));
+      sof[v] = (unsigned)r;                                                // channel within the tile
+    }
+    const double sc = (g & 1) ? -A.isn : A.isn;       // (x & 1 = g & 1: the tile starts at a multiple of 16, rows g + 4 v)
     double nfr[4], nfi[4], nd[4], nnv[4], nw[4];
 #define HPX_FR_LOAD8(xt_)                                                             \
   {                                                                                   \
     const int x0_ = (xt_) << 4;                                                       \
+    const char* fa_ = fr_b + (long)x0_ * M * 8;                                       \
+    const char* fb_ = fi_b + (long)x0_ * M * 8;                                       \
+    const char* da_ = d_b + (long)x0_ * TP * 8;                                       \
     _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {                                \
-      const int m = 4 * ks + g;                                                       \
-      const long fo_ = (long)(x0_ + li) * M + min(m, M - 1);                          \
-      const double fr_ = fmr[fo_], fi_ = fmi[fo_];                                    \
-      nfr[ks] = (m < M) ? fr_ : 0.0;                                                  \
-      nfi[ks] = (m < M) ? fi_ : 0.0;                                                  \
+      const double fr_ = *reinterpret_cast<const double*>(fa_ + fo[ks]);              \
+      const double fi_ = *reinterpret_cast<const double*>(fb_ + fo[ks]);              \
+      nfr[ks] = mok[ks] ? fr_ : 0.0;                                                  \
+      nfi[ks] = mok[ks] ? fi_ : 0.0;                                                  \
     }                                                                                 \
     _Pragma("unroll") for (int v = 0; v < 4; ++v) {                                   \
-      const int x_ = x0_ + HPX_ACC_ROW(g, v);                                         \
-      nd[v] = dsel[(long)x_ * TP + (tvalid ? t : 0)];                                 \
-      nnv[v] = ninv[x_];                                                              \
-      nw[v] = fl8[x_] ? 1.0 : 0.0;                                                    \
+      nd[v] = *reinterpret_cast<const double*>(da_ + dof[v]);                         \
+      nnv[v] = *reinterpret_cast<const double*>(nv_b + 8u * (unsigned)(x0_ + sof[v])); \
+      nw[v] = fl8[x0_ + sof[v]] ? 1.0 : 0.0;                                          \
     }                                                                                 \
   }
     if (wave < ntile) HPX_FR_LOAD8(wave)
@@ -291,6 +334,7 @@ __global__ __launch_bounds__(NTH, NTH / 128) void k_fft_resid(const ResArgs A) {
         d1 = mfma64(cfr[ks], bb[ks], d1);             // F_re [Re f | Im f]
         d2 = mfma64(cfi[ks], bb[ks], d2);             // F_im [Re f | Im f]
       }
+      double mdl[4];
 #pragma unroll
       for (int v = 0; v < 4; ++v) {
         // the partner lane's F_im product: Re (F f) = F_re Re f - F_im Im f,  Im (F f) = F_re Im f + F_im Re f
@@ -298,30 +342,34 @@ __global__ __launch_bounds__(NTH, NTH / 128) void k_fft_resid(const ResArgs A) {
         const int lo_ = __builtin_amdgcn_mov_dpp((int)(raw & 0xffffffffll), 0x128, 0xf, 0xf, false);     // row_ror:8
         const int hi_ = __builtin_amdgcn_mov_dpp((int)(raw >> 32), 0x128, 0xf, 0xf, false);
         const double other = __longlong_as_double(((long long)hi_ << 32) | (unsigned int)lo_);
-        const double mdl = hi ? d1[v] + other : d1[v] - other;
-        const int x = x0 + HPX_ACC_ROW(g, v);
-        const int pidx = (int)(__brev((unsigned)x) >> (32 - logN));
-        const long o = (long)x * TP + t;
-        double* gsel = hi ? A.Gim : A.Gre;
-        if (t >= T) {
-          if (A.any_flags) gsel[(long)b * A.NP * TP + o] = 0.0;
-          continue;
+        mdl[v] = hi ? d1[v] + other : d1[v] - other;
+      }
+      double* gsel = (hi ? A.Gim : A.Gre) + (long)b * A.NP * TP;
+      if (tvalid) {
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          const int x = x0 + HPX_ACC_ROW(g, v);
+          const int pidx = (int)(__brev((unsigned)x) >> (32 - logN));
+          const double sv = ssel[(pidx << tcs) + tc] * sc;
+          const double r = cd[v] - (sv + mdl[v]);
+          const double w = cw[v];
+          const double c2 = (r * r) * cnv[v];         // this component's share of the channel's chi^2 term
+          acc += w * c2;
+          if (FL) gsel[(long)x * TP + t] = w * sv;
+          if (KEEP) {
+            if (A.cr_out) A.cr_out[(long)b * A.cr_bstride + ((long)t * N + x) * 2 + (hi ? 1 : 0)] = sv;
+            if (A.chisq_out) {                        // (the two components meet for it)
+              const long long rc = __double_as_longlong(c2);
+              const int cl = __builtin_amdgcn_mov_dpp((int)(rc & 0xffffffffll), 0x128, 0xf, 0xf, false);
+              const int ch = __builtin_amdgcn_mov_dpp((int)(rc >> 32), 0x128, 0xf, 0xf, false);
+              const double c2o = __longlong_as_double(((long long)ch << 32) | (unsigned int)cl);
+              if (!hi) A.chisq_out[(long)b * A.chisq_bstride + (long)t * N + x] = c2 + c2o;
+            }
+          }
         }
-        const double sc = (x & 1) ? -A.isn : A.isn;
-        const double sv = ssel[(pidx << tcs) + tc] * sc;
-        const double r = cd[v] - (sv + mdl);
-        const double w = cw[v];
-        const double c2 = (r * r) * cnv[v];           // this component's share of the channel's chi^2 term
-        acc += w * c2;
-        if (A.any_flags) gsel[(long)b * A.NP * TP + o] = w * sv;
-        if (A.cr_out) A.cr_out[(long)b * A.cr_bstride + ((long)t * N + x) * 2 + (hi ? 1 : 0)] = sv;
-        if (A.chisq_out) {                            // (rarely kept: the two components meet for it)
-          const long long rc = __double_as_longlong(c2);
-          const int cl = __builtin_amdgcn_mov_dpp((int)(rc & 0xffffffffll), 0x128, 0xf, 0xf, false);
-          const int ch = __builtin_amdgcn_mov_dpp((int)(rc >> 32), 0x128, 0xf, 0xf, false);
-          const double c2o = __longlong_as_double(((long long)ch << 32) | (unsigned int)cl);
-          if (!hi) A.chisq_out[(long)b * A.chisq_bstride + (long)t * N + x] = c2 + c2o;
-        }
+      } else if (FL) {                                // a padding column: the masked signal is zero there
+#pragma unroll
+        for (int v = 0; v < 4; ++v) gsel[(long)(x0 + HPX_ACC_ROW(g, v)) * TP + t] = 0.0;
       }
     }
 #undef HPX_FR_LOAD8
@@ -479,6 +527,7 @@ __global__ __launch_bounds__(NTH, NTH / 128) void k_fft_resid(const ResArgs A) {
       q[1] = lfi[e];
     }
   }
+  FR_TR(7)
   // chi^2 total of the block, again per group of eight time columns first (a lane's column is tid & (TC - 1) in both
   // branches above; with TC = 16 bit 3 of the lane tells the group): the lanes of a group of eight, the groups of a
   // wave that belong to the same eight columns, the waves ((w0 + w1) + (w2 + w3)), then columns 0-7 + columns 8-15
@@ -507,7 +556,13 @@ __global__ __launch_bounds__(NTH, NTH / 128) void k_fft_resid(const ResArgs A) {
     }
     A.lnpart[(long)b * HPX_NPART + cg] = t0 + t1;
   }
+  FR_TR(8)
 }
+#ifdef HPX_FR_TRACE
+extern "C" int hpx_debug_fr_trace(unsigned long long* host) {
+  return hipMemcpyFromSymbol(host, HIP_SYMBOL(hpx_fr_trace), sizeof(unsigned long long) * 8 * 4 * 16) == hipSuccess ? 0 : -2;
+}
+#endif
 
 // The same for channel counts without an in-LDS FFT (N not a power of two, e.g. the 120 channels of
 // the reference's test data) and small enough for the dense transform to be cheap (NP <= 256): s = U z
@@ -1089,18 +1144,26 @@ int hpx_post_solve(hpx_plan* p, int it_abs, const IterOut& O, hipStream_t st) {
     // book it under "transform"
     // (the mode rows' staging area behind the amplitudes only where the model term is not on the matrix pipe)
     const size_t lds = ((size_t)N * TC * 2 + N + (size_t)2 * M * TC + (M > 16 ? (size_t)2 * M * (HPX_FR_THREADS / TC) : 0)) * sizeof(double);
-    static hpx_lds_limit limit;
     R.nbl = nbl; R.npart = npart;
     // (blocks of 8 columns because the channel count leaves no other choice: the component-per-lane form; where 16
     // would fit and 8 is taken for a small batch, the sums must come out as a block of 16 leaves them: the other form)
+    const dim3 grid(((nbl + 7) / 8) * 8 * npart), block(HPX_FR_THREADS);
+#define HPX_FR_GO(SP_, OPT_)                                                                                    \
+  {                                                                                                             \
+    static hpx_lds_limit lim_;                                                                                  \
+    HPX_TRY(lim_.ensure(reinterpret_cast<const void*>(&k_fft_resid<HPX_FR_THREADS, SP_, OPT_>), lds));          \
+    hipLaunchKernelGGL((k_fft_resid<HPX_FR_THREADS, SP_, OPT_>), grid, block, lds, st, R);                      \
+  }
     if (HPX_FR_SPLIT8 && TC == 8 && HPX_FR_ELEMS / NP == 8 && M <= 16) {
-      HPX_TRY(limit.ensure(reinterpret_cast<const void*>(&k_fft_resid<HPX_FR_THREADS, true>), lds));
-      hipLaunchKernelGGL((k_fft_resid<HPX_FR_THREADS, true>), dim3(((nbl + 7) / 8) * 8 * npart), dim3(HPX_FR_THREADS), lds, st, R);
+      const int opt = (p->any_flags ? 1 : 0) | ((R.cr_out || R.chisq_out) ? 2 : 0);
+      if (opt == 0) HPX_FR_GO(true, 0)
+      else if (opt == 1) HPX_FR_GO(true, 1)
+      else if (opt == 2) HPX_FR_GO(true, 2)
+      else HPX_FR_GO(true, 3)
     } else {
-      static hpx_lds_limit limit2;
-      HPX_TRY(limit2.ensure(reinterpret_cast<const void*>(&k_fft_resid<HPX_FR_THREADS, false>), lds));
-      hipLaunchKernelGGL((k_fft_resid<HPX_FR_THREADS, false>), dim3(((nbl + 7) / 8) * 8 * npart), dim3(HPX_FR_THREADS), lds, st, R);
+      HPX_FR_GO(false, 0)
     }
+#undef HPX_FR_GO
     HPX_HIP(hipGetLastError());
     HPX_TRY(hpx_mark(p, st));
   } else if (HPX_DFT_RESID && NP <= 256 && M <= 16 && hpx_dft_use_fft && !generic_post) {
