@@ -387,6 +387,7 @@ __global__ __launch_bounds__(NTH, NTH / 128) void k_fft_resid(const ResArgs A) {
       bfr[ks] = ok ? lfr[(m << tcs) + li] : 0.0;
       bfi[ks] = ok ? lfi[(m << tcs) + li] : 0.0;
     }
+    constexpr bool FL = (OPT & 1) != 0, KEEP = (OPT & 2) != 0;      // (as in the form above)
     const int t = c0 + li;
     // Tiles run over channels in NATURAL order, so that everything in global memory (data, mode
     // rows, noise, outputs) is touched with unit stride; the bit reversal of the FFT output is
@@ -395,29 +396,46 @@ __global__ __launch_bounds__(NTH, NTH / 128) void k_fft_resid(const ResArgs A) {
     const int ntile = N >> 4;
     const int tlast = wave + NW * ((ntile - 1 - wave) / NW);      // this wave's last tile
     const bool tvalid = (li < TC) && (t < T);
+    // (wave-uniform base of the tile) + (32-bit lane offset in bytes, fixed over the tiles)
+    const char* fr_b = reinterpret_cast<const char*>(fmr);
+    const char* fi_b = reinterpret_cast<const char*>(fmi);
+    const char* dr_b = reinterpret_cast<const char*>(dre);
+    const char* di_b = reinterpret_cast<const char*>(dim_);
+    const char* nv_b = reinterpret_cast<const char*>(ninv);
+    unsigned fo[4], dof[4], sof[4];
+    bool mok[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const int m = 4 * ks + g;
+      mok[ks] = m < M;
+      fo[ks] = 8u * (unsigned)(li * M + min(m, M - 1));
+    }
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const int r = HPX_ACC_ROW(g, v);
+      dof[v] = 8u * (unsigned)(r * TP + (tvalid ? t : 0));
+      sof[v] = (unsigned)r;
+    }
+    const double sc = (g & 1) ? -A.isn : A.isn;       // (x & 1 = g & 1: rows g + 4 v of a tile that starts at a multiple of 16)
     double nfr[4], nfi[4], ndr[4], ndi[4], nnv[4], nw[4];
-#if HPX_FR_NT & 2
-#define HPX_FR_LDD(p_, o_) __builtin_nontemporal_load(&(p_)[o_])
-#else
-#define HPX_FR_LDD(p_, o_) (p_)[o_]
-#endif
 #define HPX_FR_LOAD(xt_)                                                              \
   {                                                                                   \
     const int x0_ = (xt_) << 4;                                                       \
+    const char* fa_ = fr_b + (long)x0_ * M * 8;                                       \
+    const char* fb_ = fi_b + (long)x0_ * M * 8;                                       \
+    const char* da_ = dr_b + (long)x0_ * TP * 8;                                      \
+    const char* db_ = di_b + (long)x0_ * TP * 8;                                      \
     _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {                                \
-      const int m = 4 * ks + g;                  /* unconditional (clamped) load, then the  */ \
-      const long fo_ = (long)(x0_ + li) * M + min(m, M - 1);      /* select: no branch      */ \
-      const double fr_ = fmr[fo_], fi_ = fmi[fo_];                                    \
-      nfr[ks] = (m < M) ? fr_ : 0.0;                                                  \
-      nfi[ks] = (m < M) ? fi_ : 0.0;                                                  \
+      const double fr_ = *reinterpret_cast<const double*>(fa_ + fo[ks]);              \
+      const double fi_ = *reinterpret_cast<const double*>(fb_ + fo[ks]);              \
+      nfr[ks] = mok[ks] ? fr_ : 0.0;                                                  \
+      nfi[ks] = mok[ks] ? fi_ : 0.0;                                                  \
     }                                                                                 \
     _Pragma("unroll") for (int v = 0; v < 4; ++v) {                                   \
-      const int x_ = x0_ + HPX_ACC_ROW(g, v);                                         \
-      const long o_ = (long)x_ * TP + (tvalid ? t : 0);                               \
-      ndr[v] = HPX_FR_LDD(dre, o_);                                                   \
-      ndi[v] = HPX_FR_LDD(dim_, o_);                                                  \
-      nnv[v] = ninv[x_];                                                              \
-      nw[v] = fl8[x_] ? 1.0 : 0.0;                                                    \
+      ndr[v] = *reinterpret_cast<const double*>(da_ + dof[v]);                        \
+      ndi[v] = *reinterpret_cast<const double*>(db_ + dof[v]);                        \
+      nnv[v] = *reinterpret_cast<const double*>(nv_b + 8u * (unsigned)(x0_ + sof[v])); \
+      nw[v] = fl8[x0_ + sof[v]] ? 1.0 : 0.0;                                          \
     }                                                                                 \
   }
     if (wave < ntile) HPX_FR_LOAD(wave)
@@ -438,32 +456,37 @@ __global__ __launch_bounds__(NTH, NTH / 128) void k_fft_resid(const ResArgs A) {
         mi = mfma64(cfr[ks], bfi[ks], mi);
         mi = mfma64(cfi[ks], bfr[ks], mi);
       }
-      if (li >= TC) continue;
+      if (tvalid) {
 #pragma unroll
-      for (int v = 0; v < 4; ++v) {
-        const int x = x0 + HPX_ACC_ROW(g, v);
-        const int pidx = (int)(__brev((unsigned)x) >> (32 - logN));
-        const long o = (long)x * TP + t;
-        if (t >= T) {
-          if (A.any_flags) { A.Gre[(long)b * A.NP * TP + o] = 0.0; A.Gim[(long)b * A.NP * TP + o] = 0.0; }
-          continue;
+        for (int v = 0; v < 4; ++v) {
+          const int x = x0 + HPX_ACC_ROW(g, v);
+          const int pidx = (int)(__brev((unsigned)x) >> (32 - logN));
+          const double sr = fre[(pidx << tcs) + li] * sc, si = fim[(pidx << tcs) + li] * sc;
+          const double rr = cdr[v] - (sr + mr[v]), ri = cdi[v] - (si + mi[v]);
+          const double w = cw[v];
+          const double c2 = (rr * rr + ri * ri) * cnv[v];
+          acc += w * c2;
+          if (FL) {
+            const long o = (long)b * A.NP * TP + (long)x * TP + t;
+            A.Gre[o] = w * sr;
+            A.Gim[o] = w * si;
+          }
+          if (KEEP) {
+            if (A.cr_out) {
+              double* q = A.cr_out + (long)b * A.cr_bstride + ((long)t * N + x) * 2;
+              q[0] = sr;
+              q[1] = si;
+            }
+            if (A.chisq_out) A.chisq_out[(long)b * A.chisq_bstride + (long)t * N + x] = c2;
+          }
         }
-        const double sc = (x & 1) ? -A.isn : A.isn;
-        const double sr = fre[(pidx << tcs) + li] * sc, si = fim[(pidx << tcs) + li] * sc;
-        const double rr = cdr[v] - (sr + mr[v]), ri = cdi[v] - (si + mi[v]);
-        const double w = cw[v];
-        const double c2 = (rr * rr + ri * ri) * cnv[v];
-        acc += w * c2;
-        if (A.any_flags) {
-          A.Gre[(long)b * A.NP * TP + o] = w * sr;
-          A.Gim[(long)b * A.NP * TP + o] = w * si;
+      } else if (FL && li < TC) {                     // a padding column: the masked signal is zero there
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          const long o = (long)b * A.NP * TP + (long)(x0 + HPX_ACC_ROW(g, v)) * TP + t;
+          A.Gre[o] = 0.0;
+          A.Gim[o] = 0.0;
         }
-        if (A.cr_out) {
-          double* q = A.cr_out + (long)b * A.cr_bstride + ((long)t * N + x) * 2;
-          q[0] = sr;
-          q[1] = si;
-        }
-        if (A.chisq_out) A.chisq_out[(long)b * A.chisq_bstride + (long)t * N + x] = c2;
       }
     }
 #undef HPX_FR_LOAD
@@ -1161,7 +1184,11 @@ int hpx_post_solve(hpx_plan* p, int it_abs, const IterOut& O, hipStream_t st) {
       else if (opt == 2) HPX_FR_GO(true, 2)
       else HPX_FR_GO(true, 3)
     } else {
-      HPX_FR_GO(false, 0)
+      const int opt = (p->any_flags ? 1 : 0) | ((R.cr_out || R.chisq_out) ? 2 : 0);
+      if (opt == 0) HPX_FR_GO(false, 0)
+      else if (opt == 1) HPX_FR_GO(false, 1)
+      else if (opt == 2) HPX_FR_GO(false, 2)
+      else HPX_FR_GO(false, 3)
     }
 #undef HPX_FR_GO
     HPX_HIP(hipGetLastError());
