@@ -128,7 +128,7 @@ line $O/bench_c3.log $O/${TAG}_bench_c3.json; echo "C3 done"
 head -12 $O/${TAG}_kernel_stats_c3.csv | cut -c1-160
 python3 -c "
 import json
-for c in ('c3','c5','c2','n4','dpss','oqe','fgmodes','fgmodes_order512','c3_dense_noise_flagged','c3_dense_noise','pertime_dense_noise','2ranks_one_gpu','6ranks_one_gpu'):
+for c in ('c3','c5','c2','n4','dpss','oqe','fgmodes','fgmodes_order512','c3_dense_noise_flagged','c3_dense_noise','pertime_dense_noise','2ranks_one_gpu','4ranks_one_gpu'):
     try:
         d=json.load(open('$O/${TAG}_bench_%s.json'%c)); r=d['roofline']
         print(c, 'value %.4g %s ms/step %.3f roofline %s %.4g frac %.3f n_gpus %d' % (d['value'], d['unit'], d['ms_per_step'], r['unit'], r['achieved'], r['frac'], d['n_gpus']), {k: round(v,3) for k,v in d.get('stage_ms_per_step',{}).items()}, 'cpu', d.get('cpu_baseline',{}).get('value'), 'dev', d.get('pk_max_rel_dev_vs_cpu', d.get('max_rel_dev_vs_cpu')))
