@@ -231,7 +231,7 @@ def test_assemble_K(T, Tn, N, M, frac):
 
 
 def test_zpotrs_beyond_the_register_form(T):
-    """Orders 273 .. 1050 with 17 .. 32 right-hand sides (TP = 32): the back substitution of
+    """Orders 273 .. 1050 with 17 .. 32 right-hand sides (32 columns) and with 1 .. 16 (16 columns): the back substitution of
     csrc/hpx_backsolve_lds.hip (eight waves, the solution rows through an LDS ring, hand-counted operand waits) --
     tile counts around the super-block boundaries of 8 tiles (128 columns), one to several groups of four chunks per
     pass, a top super-block of one tile (C3's 33) and of eight, against numpy."""
@@ -240,7 +240,7 @@ def test_zpotrs_beyond_the_register_form(T):
     sizes = [273, 288, 300, 383, 384, 385, 400, 496, 512, 513, 524, 528, 529, 640, 777, 1040, 1050]
     worst = 0.0
     for i, n in enumerate(sizes):
-        nrhs = [32, 17, 24, 31][i % 4]
+        nrhs = [32, 17, 1, 24, 16, 31, 9][i % 7]
         nb = 1 + i % 3
         A = _hpd(rng, nb, n, cond=1e3)
         A = 0.5 * (A + np.conj(np.swapaxes(A, 1, 2)))
