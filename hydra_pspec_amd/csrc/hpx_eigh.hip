@@ -201,6 +201,9 @@ __global__ __launch_bounds__(256, 2) void k_hj_step(double* __restrict__ wre, do
         const double off = Ga[0][0][e] * Ga[0][0][e] + Ga[0][1][e] * Ga[0][1][e];
         const double dd = Ga[0][0][r * (M + 1)] * Ga[0][0][c * (M + 1)];
         m = fmax(m, (dd > 0.0) ? off / dd : (off > 0.0 ? 1.0 : 0.0));
+        // fmax drops a NaN and the comparisons above turn one into 0: a non-finite Gram entry must not read as
+        // "orthogonal already" (+inf has the largest bit pattern of all non-negative doubles: it wins the atomicMax)
+        if (!(off <= 1.7e308) || !(fabs(dd) <= 1.7e308)) m = __builtin_inf();
       }
     }
     for (int o = 32; o > 0; o >>= 1) m = fmax(m, __shfl_xor(m, o, 64));
@@ -243,7 +246,8 @@ __global__ __launch_bounds__(256, 2) void k_hj_step(double* __restrict__ wre, do
             const double iac = hj_rsqrt(ac2);                      // 1 / |c|
             const double tau = (bq - a) * 0.5 * iac;
             const double h2 = 1.0 + tau * tau;
-            const double t = ((tau >= 0.0) ? 1.0 : -1.0) * hj_rcp(fabs(tau) + h2 * hj_rsqrt(h2));
+            // (tau^2 overflowing makes h2 = inf and rsq(inf) * inf a NaN: the rotation angle is 0 there)
+            const double t = (h2 <= 1.7e308) ? ((tau >= 0.0) ? 1.0 : -1.0) * hj_rcp(fabs(tau) + h2 * hj_rsqrt(h2)) : 0.0;
             cs = hj_rsqrt(1.0 + t * t);
             sn = t * cs;
             cp = cr * iac;
@@ -485,7 +489,14 @@ int hpx_eigh_psd_planar(int nb, int n, double* gr, const double* gi, double* vr,
     HPX_HIP(hipMemcpyAsync(hm.data(), meas, (size_t)nb * sizeof(double), hipMemcpyDeviceToHost, st));
     HPX_HIP(hipStreamSynchronize(st));
     worst = 0.0;
-    for (int b = 0; b < nb; ++b) worst = hm[b] > worst ? hm[b] : worst;
+    for (int b = 0; b < nb; ++b)
+      if (!(hm[b] <= worst)) worst = hm[b];
+    if (!std::isfinite(worst)) {
+      if (sweeps_out) *sweeps_out = -1;
+      hpx_set_error("hpx_eigh_psd_planar: non-finite Gram matrix at sweep %d (order %d): the input holds NaN / inf or "
+                    "overflows", sweeps, n);
+      return HPX_EINVAL;
+    }
     if (trace) fprintf(stderr, "hpx_eigh: sweep %d  max |G_ij|^2 / (G_ii G_jj) before its rotations = %.3e\n", sweeps, worst);
     // the measure was taken BEFORE this sweep's rotations, and the convergence is quadratic by then (measured:
     // 3e-7 -> 8e-13 -> 1e-25): below 1e-10 the sweep just done leaves the columns orthogonal to rounding

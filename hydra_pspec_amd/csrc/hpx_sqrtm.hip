@@ -219,8 +219,9 @@ int ns_iterate(const int nc, const int n, const double* ab, NsWork& K, const dou
     HPX_HIP(hipMemcpyAsync(herr.data(), K.err, (size_t)nc * sizeof(double), hipMemcpyDeviceToHost, st));
     HPX_HIP(hipStreamSynchronize(st));
     double worst = 0.0;
-    for (int b = 0; b < nc; ++b) worst = herr[b] > worst ? herr[b] : worst;
-    if (!(worst == worst)) {
+    for (int b = 0; b < nc; ++b)
+      if (!(herr[b] <= worst)) worst = herr[b];       // (written so that a NaN residual is kept, not dropped)
+    if (!std::isfinite(worst)) {
       hpx_set_error("hpx_sqrtm_hpd_batched: the iteration diverged (a matrix is not positive definite?)");
       return HPX_EINVAL;
     }

@@ -75,6 +75,17 @@ def build_parser():
                         "as soon as one sample is flagged, which is what the reference driver does (:524-541)")
     p.add_argument("--outputs", type=str, default="all",
                    help="'all' (the six reference files) or 'ps' (dps-eor.npy and ln-post.npy only)")
+    p.add_argument("--thin", type=int, default=1,
+                   help="keep every K-th iteration of the large histories (gcr-eor.npy, fg-amps.npy, chisq.npy: rows "
+                        "0, K, 2K, ...); dps-eor.npy and ln-post.npy always hold every iteration.  --write_Niter must be "
+                        "a multiple of K")
+    p.add_argument("--host_mem_gb", type=float, default=None,
+                   help="budget for the two pinned staging buffers of the output drain (default: half of MemAvailable); "
+                        "a run whose chunks do not fit stops BEFORE sampling, with the numbers")
+    p.add_argument("--fsync", action="store_true",
+                   help="force every flush to disk (data, then the header) before the next one: checkpoints survive "
+                        "a power loss, not only a crash of the process")
+    p.add_argument("--write_workers", type=int, default=4, help="file-writing threads of the output drain")
     p.add_argument("--dry_run", action="store_true",
                    help="everything but the sampling (no GPU touched): inputs, rank blocks, output tree, "
                         "checkpoint files (zeros) and timings -- exercises the multi-rank plumbing")
@@ -114,8 +125,7 @@ def any_time_unflagged(w):
 
 def _parent_start_ticks():
     """Start time of the parent process (clock ticks since boot, /proc/<ppid>/stat field 22): with its pid it names
-    ONE launch -- the ranks of a launch are children of one agent (torchrun) or one spawning process, a later launch
-    has another parent or another start time."""
+    ONE launch of plain `RANK=.. WORLD_SIZE=..` processes started by one shell."""
     try:
         with open(f"/proc/{os.getppid()}/stat") as f:
             return f.read().rsplit(")", 1)[1].split()[19]
@@ -124,14 +134,24 @@ def _parent_start_ticks():
 
 
 def launch_token():
-    """What the ranks of ONE launch have in common (and an earlier launch does not): names the files they
-    meet through.  torchrun exports TORCHELASTIC_RUN_ID / MASTER_PORT (both repeat from launch to launch: the parent's
-    pid and start time are appended); plain `RANK=.. WORLD_SIZE=..` launches of one parent share its pid."""
-    tail = f"pp{os.getppid()}-{_parent_start_ticks()}"
-    for k in ("HYDRA_PSPEC_RUN_ID", "TORCHELASTIC_RUN_ID", "MASTER_PORT"):
-        if os.environ.get(k):
-            return f"{k.lower()}-{os.environ[k]}-{tail}"
-    return tail
+    """What the ranks of ONE launch have in common: names the marker file they meet through.  Nothing node-local goes
+    into it when the launcher hands out an id, so that ranks on several nodes (torchrun --nnodes > 1, srun) sharing a
+    file system compute the same name: HYDRA_PSPEC_RUN_ID as given; otherwise torchrun's rendezvous (MASTER_ADDR,
+    MASTER_PORT, TORCHELASTIC_RUN_ID, restart count).  Those repeat from launch to launch: a marker left behind by a
+    launch that was killed is told apart by its age (START_SKEW) and rank 0's nonce, see main().  Only a launch with
+    neither (ranks started by hand from one shell) falls back to the parent's pid and start time."""
+    env = os.environ
+    if env.get("HYDRA_PSPEC_RUN_ID"):
+        return f"run-{env['HYDRA_PSPEC_RUN_ID']}"
+    if env.get("TORCHELASTIC_RUN_ID") or env.get("MASTER_PORT"):
+        return "rdzv-" + "-".join(str(env.get(k, "")) for k in ("MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID",
+                                                                 "TORCHELASTIC_RESTART_COUNT")).replace("/", "_")
+    return f"pp{os.getppid()}-{_parent_start_ticks()}"
+
+
+# how much earlier than this rank rank 0 may have started (launchers start ranks within seconds of each other; a marker
+# older than that belongs to another launch)
+START_SKEW = float(os.environ.get("HYDRA_PSPEC_START_SKEW", "120"))
 
 
 def write_json_atomic(path, obj):
@@ -155,6 +175,18 @@ def wait_for_file(path, newer_than, timeout=900.0, what="", nonce=None):
             pass
         time.sleep(0.05)
     raise SystemExit(f"rank synchronisation timed out waiting for {what or path}")
+
+
+def _mem_available():
+    """MemAvailable of /proc/meminfo in bytes (the host memory a run may still take)."""
+    try:
+        with open("/proc/meminfo") as f:
+            for line in f:
+                if line.startswith("MemAvailable:"):
+                    return int(line.split()[1]) * 1024
+    except OSError:
+        pass
+    return 16e9
 
 
 def load_aux(path, file_name, bl_str):
@@ -329,11 +361,10 @@ def main(argv=None):
         if world > 1:
             write_json_atomic(marker, {"created": time.time(), "old_args": old_args, "nonce": nonce})
     else:
-        met = wait_for_file(marker, t_launch - 300.0, what="rank 0 to prepare the output tree")
-        # A marker of an earlier launch with the same token (one shell starting the ranks by hand, twice) may still
-        # lie there for the instant before rank 0 removes it: read again a moment later and take what is there then
-        time.sleep(0.3)
-        met = wait_for_file(marker, t_launch - 300.0, what="rank 0 to prepare the output tree")
+        # only a marker written after this launch began counts (rank 0 removes the marker of a finished or failed launch
+        # on its way out, see below; one left by a KILLED launch is older than this rank's start minus the skew unless
+        # the relaunch came within START_SKEW seconds -- give such relaunches a fresh HYDRA_PSPEC_RUN_ID)
+        met = wait_for_file(marker, t_launch - START_SKEW, what="rank 0 to prepare the output tree")
         old_args, nonce = met["old_args"], met.get("nonce")
 
     # ---- sampling -----------------------------------------------------------------------
@@ -347,11 +378,18 @@ def main(argv=None):
             except OSError:
                 pass
         raise
+    finally:
+        if rank == 0 and world > 1:     # also when this launch failed: no marker outlives its launch
+            try:
+                os.remove(marker)
+            except FileNotFoundError:
+                pass
 
 
 def sample_and_write(args, rank, world, local_rank, results, marker, nonce, old_args, env):
     """Everything after the output tree exists: the chains, the periodic writes, the merged timings."""
-    from hydra_pspec_amd import pspec, utils
+    import shutil
+    from hydra_pspec_amd import drain, pspec
     (vis, flags_any, flags_pt, fg, ninv, ninv_dense, ps_prior, ps0, S_general, antpairs, nbl, nbl_all, N, T, t_load,
      t_start, t_launch) = (env[k] for k in ("vis", "flags_any", "flags_pt", "fg", "ninv", "ninv_dense", "ps_prior",
                                             "ps0", "S_general", "antpairs", "nbl", "nbl_all", "N", "T", "t_load",
@@ -366,48 +404,72 @@ def sample_and_write(args, rank, world, local_rank, results, marker, nonce, old_
         raise SystemExit("mixing Fourier-form and general sigcov0 across baselines is not supported")
     Niter = 1 if args.map_estimate else int(args.Niter)
     chunk = max(1, int(args.write_Niter))
-    names = {"signal_ps": "dps-eor.npy", "ln_post": "ln-post.npy"}
-    if all_out:
-        names.update(signal_cr="gcr-eor.npy", fg_amps="fg-amps.npy", chisq="chisq.npy")
+    thin = max(1, int(args.thin))
+    if thin > 1 and chunk % thin:
+        raise SystemExit(f"--write_Niter {chunk} must be a multiple of --thin {thin}")
+    names = ["signal_ps", "ln_post"] + (["signal_cr", "fg_amps", "chisq"] if all_out else [])
+    bdirs = [results / f"{ap[0]}-{ap[1]}" for ap in antpairs]
+    M = int(fg.shape[-1])
+
+    # ---- what the run will write and stage, BEFORE anything is sampled (SURVEY 7.3 "output volume": at C3, --outputs
+    # all without thinning is 537 GB of gcr-eor.npy) ------------------------------------------------------------------
+    disk_b, stage_b = drain.estimate_bytes(names, nbl, T, N, M, Niter, min(chunk, Niter), thin)
+    budget = args.host_mem_gb * 1e9 if args.host_mem_gb else 0.5 * _mem_available()
+    try:
+        free_disk = shutil.disk_usage(results).free
+    except OSError:
+        free_disk = None
+    if rank == 0 and (args.verbose or 2 * stage_b > 0.25 * budget):
+        print(f"outputs of this rank: {disk_b / 1e9:.2f} GB on disk ({len(names)} histories x {nbl} baselines x {Niter} "
+              f"iterations, thin {thin}); staged per flush: {stage_b / 1e9:.2f} GB on the device and twice that in pinned "
+              f"host memory (budget {budget / 1e9:.1f} GB)", flush=True)
+    hint = ("choose --outputs ps, a larger --thin or a smaller --write_Niter" if all_out
+            else "choose a smaller --write_Niter")
+    if 2 * stage_b > budget:
+        raise SystemExit(f"the output drain would need 2 x {stage_b / 1e9:.2f} GB of pinned host memory per flush "
+                         f"(--write_Niter {chunk}, --thin {thin}, --outputs {args.outputs}) against a budget of "
+                         f"{budget / 1e9:.1f} GB (--host_mem_gb): {hint}")
+    if free_disk is not None and disk_b > free_disk:
+        raise SystemExit(f"the run would write {disk_b / 1e9:.2f} GB into {results} which has {free_disk / 1e9:.2f} GB "
+                         f"free: {hint}")
 
     # --resume: continue from the checkpoints in the output tree.  They must come from the same
     # inputs and seed (args.json); baselines caught mid-write at different iterations are rolled
     # back to the earliest one (the chain is deterministic, nothing is lost but time).
-    iter0, hist = 0, None
+    iter0 = 0
     if args.resume and (args.map_estimate or S_general is not None):
         raise SystemExit("--resume is not available with --map_estimate or a sigcov0 that is not of the form "
                          "Fop^H diag(p) Fop: such a run cannot be continued from its bandpowers")
     if args.resume:
         if old_args is None:
             raise SystemExit(f"--resume: no args.json of an earlier run in {results}")
-        run_only = {"Niter", "resume", "clobber", "verbose", "write_Niter", "Nproc", "config", "outputs"}
-        diff = sorted(k for k in vars(args) if k not in run_only and old_args.get(k) != getattr(args, k))
+        run_only = {"Niter", "resume", "clobber", "verbose", "write_Niter", "Nproc", "config", "outputs", "host_mem_gb",
+                    "fsync", "write_workers"}
+        diff = sorted(k for k in vars(args) if k not in run_only and old_args.get(k, build_parser().get_default(k))
+                      != getattr(args, k))
         if diff:
             raise SystemExit("--resume: the earlier run in " + str(results) + " used different "
                              + ", ".join(f"{k} ({old_args.get(k)!r} != {getattr(args, k)!r})" for k in diff)
                              + ": refusing to splice two different chains")
-        previous = []
-        for ap in antpairs:
-            bdir = results / f"{ap[0]}-{ap[1]}"
-            missing = [n for n in names.values() if not (bdir / n).exists()]
+        k_done = None
+        for bdir in bdirs:
+            missing = [drain.HISTORY_FILES[k] for k in names if not (bdir / drain.HISTORY_FILES[k]).exists()]
             if missing:
                 raise SystemExit(f"--resume: {bdir} has no {', '.join(missing)} (an earlier run with --outputs ps "
                                  "cannot be continued with --outputs all)")
-            previous.append({k: np.load(bdir / n) for k, n in names.items()})
-        k_done = min(len(pv[k]) for pv in previous for k in names) if previous else 0
+            kb = drain.checkpoint_rows(bdir, names, thin)
+            k_done = kb if k_done is None else min(k_done, kb)
+        k_done = k_done or 0
         if k_done >= Niter:
             raise SystemExit(f"--resume: the chains in {results} already hold {k_done} iterations (--Niter {Niter}): "
                              "nothing to do")
         if k_done > 0:
             iter0 = k_done
-            hist = {k: [np.stack([pv[k][:k_done] for pv in previous])] for k in names}
-            ps0 = hist["signal_ps"][0][:, -1].copy()
+            ps0 = np.stack([np.load(bdir / "dps-eor.npy", mmap_mode="r")[k_done - 1] for bdir in bdirs])
         elif rank == 0:
             print("--resume: the checkpoints hold no iteration yet; starting at 0", flush=True)
     if rank == 0:
         write_json_atomic(results / "args.json", vars(args))
-    if hist is None:
-        hist = {k: [] for k in names}
 
     Ninv_arg = ninv if ninv_dense is None else ninv_dense
     gb = None
@@ -418,61 +480,52 @@ def sample_and_write(args, rank, world, local_rank, results, marker, nonce, old_
         # than devices) could starve each other's co-operating workgroups (hpx.h, HPX_OPT_FACTOR_SPLIT).
         gb = pspec.make_batch(vis, flags_any if flags_pt is None else flags_pt, fg, Ninv_arg, ps_prior, Niter,
                               seed=args.seed, map_estimate=args.map_estimate, allow_split=(world == 1))
-    fop = utils.fourier_operator(N)
-    write_times, ant_strs = [0.0] * nbl, [f"{ap[0]}_{ap[1]}" for ap in antpairs]
-
-    def write_all(done, periodic):
-        """The per-baseline files with everything sampled so far (reference pspec.py:625-653:
-        every write_Niter iterations and at the end).  Each file is replaced atomically, so a crash
-        leaves either the previous checkpoint or the new one, never a torn file."""
-        full = {k: (v[0] if len(v) == 1 else np.concatenate(v, axis=1)) for k, v in hist.items()}
-        for k in full:
-            hist[k] = [full[k]]
-        for b, ap in enumerate(antpairs):
-            bdir = results / f"{ap[0]}-{ap[1]}"
-            bdir.mkdir(parents=True, exist_ok=True)
-            tw = time.perf_counter()
-            arrays = {names[k]: full[k][b] for k in names}
-            if all_out:
-                S_last = pspec.covariance_from_pspec(full["signal_ps"][b, -1] / N ** 2, fop)
-                # rows [:done] of the current (N,N) covariance on a periodic write, the full matrix
-                # on the final one (the reference's slicing quirk, pspec.py:630 vs :648)
-                arrays["cov-eor.npy"] = S_last[:done] if periodic else S_last
-            for fn, arr in arrays.items():
-                tmp = bdir / (fn + ".tmp.npy")
-                np.save(tmp, arr)
-                os.replace(tmp, bdir / fn)
-            write_times[b] += time.perf_counter() - tw
+        free_dev = torch.cuda.mem_get_info()[0]
+        if 2 * stage_b > free_dev:          # the chunk being sampled + the one being copied
+            gb.close()
+            raise SystemExit(f"two chunks of outputs ({2 * stage_b / 1e9:.2f} GB) do not fit the {free_dev / 1e9:.1f} GB "
+                             f"left on the device: {hint}")
+    out_drain = drain.ChainDrain(torch, bdirs, names, T, N, M, min(chunk, Niter), thin=thin, all_out=all_out,
+                                 use_gpu=gb is not None, fsync=args.fsync, workers=args.write_workers)
+    out_drain.start(iter0)
+    t_setup = time.perf_counter() - t0
 
     done = iter0
     if gb is not None:
         gb.iter_done = iter0
     t_process = 0.0
-    shapes = {"signal_ps": (N,), "ln_post": (), "signal_cr": (T, N), "fg_amps": (T, args.Nfgmodes), "chisq": (T, N)}
+    shapes = {"signal_ps": (N,), "ln_post": (), "signal_cr": (T, N), "fg_amps": (T, M), "chisq": (T, N)}
+    failed = True
     try:
         while done < Niter:
             n = min(chunk - done % chunk, Niter - done)
             tp = time.perf_counter()
             if gb is None:            # --dry_run: files of the right shapes, no sampling
-                out = {k: torch.zeros((nbl, n) + shapes[k], dtype=torch.complex128 if k in ("signal_cr", "fg_amps")
-                                      else torch.float64) for k in names}
+                out = {k: torch.zeros((nbl, -(-n // thin) if k in drain.THINNED else n) + shapes[k],
+                                      dtype=torch.complex128 if k in ("signal_cr", "fg_amps") else torch.float64)
+                       for k in names}
             elif done == 0 and S_general is not None:
                 shp0 = np.stack([pspec.sqrt_cov_delay_basis(S_general[b]) for b in range(nbl)])
-                out = gb.run(n, shp0=shp0, keep=keep)
+                out = gb.run(n, shp0=shp0, keep=keep, thin=thin)
             else:
-                out = gb.run(n, ps0=ps0 if done == iter0 else None, keep=keep)
-            for k in names:
-                hist[k].append(out[k].cpu().numpy())
-            t_process += time.perf_counter() - tp
+                out = gb.run(n, ps0=ps0 if done == iter0 else None, keep=keep, thin=thin)
             done += n
-            if done % chunk == 0 or done == Niter:
-                write_all(done, periodic=(done % chunk == 0))
+            # the chunk is complete on the device: its copy and its files proceed behind the next chunk's sampling
+            out_drain.submit(out, n, done, periodic=(done % chunk == 0))
+            del out
+            t_process += time.perf_counter() - tp
             if args.verbose and rank == 0:
                 print(f"iteration {done}/{Niter}: {nbl * n / (time.perf_counter() - tp):.1f} baseline*iter/s", flush=True)
+        failed = False
     finally:
-        if gb is not None:
-            gb.close()
-    _ = t0
+        t_tail = time.perf_counter()
+        try:
+            out_drain.close(abort=failed)       # (complete chunks still reach the disk when the sampler failed)
+        finally:
+            if gb is not None:
+                gb.close()
+        t_tail = time.perf_counter() - t_tail
+    write_times, ant_strs = out_drain.write_times, [f"{ap[0]}_{ap[1]}" for ap in antpairs]
 
     # every rank's write times reach rank 0 (the reference gathers them, run-hydra-pspec.py:557, and writes
     # one timings.json, :570-581): per-rank files, merged and removed by rank 0
@@ -483,17 +536,12 @@ def sample_and_write(args, rank, world, local_rank, results, marker, nonce, old_
         t_bar = time.perf_counter()
         write_data = [{k: mine[k] for k in ("rank", "ant_pairs", "write_times")}]
         for r in range(1, world):
-            other = wait_for_file(results / f".timings-{r}.json", t_launch - 300.0, what=f"rank {r} to finish",
+            other = wait_for_file(results / f".timings-{r}.json", t_launch - START_SKEW, what=f"rank {r} to finish",
                                   nonce=nonce)
             if "failed" in other:
                 raise SystemExit(f"rank {r} stopped: {other['failed']}")
             write_data.append({k: other[k] for k in ("rank", "ant_pairs", "write_times")})
             os.remove(results / f".timings-{r}.json")
-        if world > 1:
-            try:
-                os.remove(marker)
-            except FileNotFoundError:
-                pass
         t_bar = time.perf_counter() - t_bar
         total = time.perf_counter() - t_start
         timings = {"num_ranks": world, "num_baselines": int(nbl_all),
@@ -501,6 +549,15 @@ def sample_and_write(args, rank, world, local_rank, results, marker, nonce, old_
                                      "barrier": t_bar, "total": total},
                    "write_data": write_data}
         write_json_atomic(results / "timings.json", timings)
+        # beyond the reference's keys (kept out of timings.json, whose key set is the reference's): where the rest of
+        # `total` went and what the drain did
+        write_json_atomic(results / "drain.json", {
+            "setup_s": t_setup, "drain_tail_s": t_tail, "bytes_written": int(out_drain.bytes_written),
+            "writer_file_s": out_drain.t_files, "writer_copy_wait_s": out_drain.t_copy_wait,
+            "sampler_backpressure_s": out_drain.t_backpressure, "write_workers": out_drain.workers,
+            "fsync": bool(args.fsync), "thin": thin, "write_Niter": chunk, "iter0": iter0, "Niter": Niter,
+            "baselines_this_rank": int(nbl),
+            "baseline_iter_per_s_process": (nbl * (Niter - iter0) / t_process) if t_process > 0 else None})
         ru = getrusage(RUSAGE_SELF)
         with open(results / "resources.json", "w") as f:
             json.dump({"ru_maxrss": ru.ru_maxrss, "ru_utime": ru.ru_utime, "ru_stime": ru.ru_stime}, f, indent=2)

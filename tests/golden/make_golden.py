@@ -3,7 +3,7 @@
 
 Run in the build container only (needs /root/reference):
 
-    python tests/golden/make_golden.py [--only small,steps,chain_synth,chain_testdata,chain_fullsize,steps_dense]
+    python tests/golden/make_golden.py [--only small,steps,chain_synth,chain_testdata,chain_fullsize,steps_dense,chain_long [--case c3,c3f,c5f]]
 
 The reference is imported unmodified; its two I/O-only dependencies that are
 absent here (pyuvdata, astropy -- used by file loaders, never by the Gibbs path)
@@ -384,9 +384,38 @@ def gen_chain_fullsize(hp):
     print("chain_fullsize.npz", len(out), "arrays")
 
 
+LONG_CASES = {"c3": (512, 0.0, 40, 200), "c3f": (512, 0.15, 41, 100), "c5f": (1024, 0.15, 42, 30)}
+
+
+def gen_chain_long(hp, cases):
+    """The reference AND its exact-solve control, free-running, long enough for SURVEY 8c's T2 gates at
+    BASELINE.json's channel counts: 200 iterations at (32, 512, 12) without flags, 100 with 15 % flags,
+    30 at (32, 1024, 12) with 15 % flags.  Same inputs as chain_fullsize.npz (same k0), one file per case
+    (chain_long_<tag>.npz) so that the cases can be produced by separate processes."""
+    from hydra_pspec_amd import synthetic
+    for tag in cases:
+        N, frac, k0, niter = LONG_CASES[tag]
+        T, M = 32, 12
+        d = synthetic.make_baselines(N, T, M, k0=k0, flag_frac=frac)
+        vis, fl = d["vis"][0], d["flags"][0]
+        out = dict(vis=vis, flags=fl, fgmodes=d["fgmodes"], ninv_diag=np.diag(d["Ninv"]).real.copy(),
+                   prior=d["ps_prior"], ps0=d["ps0"], seed=np.array(d["seed"]))
+        r = run_chain(hp, vis, fl, d["S_initial"], d["fgmodes"], d["Ninv"], d["ps_prior"], niter, d["seed"])
+        cr, _, ps, fg, chi, lp, _ = r
+        sel = sorted({0, 1, niter // 2, niter - 1})
+        out.update(ref_ps=ps, ref_lnpost=lp, sel=np.array(sel), ref_fg_sel=fg[sel],
+                   ref_cr_sel=cr[sel].astype(np.complex128), ref_chisq_sel=chi[sel])
+        with exact_solver():
+            r = run_chain(hp, vis, fl, d["S_initial"], d["fgmodes"], d["Ninv"], d["ps_prior"], niter, d["seed"])
+        out.update(exact_ps=r[2], exact_lnpost=r[5])
+        np.savez_compressed(HERE / f"chain_long_{tag}.npz", **out)
+        print(f"chain_long_{tag}.npz", len(out), "arrays")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="small,steps,chain_synth,chain_testdata")
+    ap.add_argument("--case", default="c3,c3f,c5f", help="cases of chain_long")
     args = ap.parse_args()
     hp = import_reference()
     todo = args.only.split(",")
@@ -402,6 +431,8 @@ def main():
         gen_chain_fullsize(hp)
     if "steps_dense" in todo:
         gen_steps_dense(hp)
+    if "chain_long" in todo:
+        gen_chain_long(hp, args.case.split(","))
 
 
 if __name__ == "__main__":

@@ -172,16 +172,31 @@ def test_driver_periodic_checkpoints_and_resume_guard(tmp_path, monkeypatch):
     # crash after the second chunk: the third gb.run raises
     real_run, calls = pspec.GibbsBatch.run, []
 
+    seen_mid_run = []
+
     def dying_run(self, niter, **kw):
         calls.append(niter)
         if len(calls) == 3:
+            # MID-RUN: the sampler is still "busy" (here: polling) while the drain's writer thread brings the first two
+            # chunks to disk behind it; whatever np.load sees at any instant is a valid array of complete iterations
+            import time
+            t_end = time.time() + 20
+            while time.time() < t_end:
+                a = np.load(tmp_path / "part" / "0-1" / "dps-eor.npy")
+                assert a.ndim == 2 and a.shape[1] == 32 and a.shape[0] in (0, 2, 4)
+                seen_mid_run.append(a.shape[0])
+                if a.shape[0] == 4:
+                    break
+                time.sleep(0.01)
             raise RuntimeError("simulated crash")
         return real_run(self, niter, **kw)
     monkeypatch.setattr(pspec.GibbsBatch, "run", dying_run)
     with pytest.raises(RuntimeError, match="simulated crash"):
         drv.main(common + ["--seed", "5", "--Niter", "6", "--dirname", "part"])
     monkeypatch.setattr(pspec.GibbsBatch, "run", real_run)
-    assert calls == [2, 2, 2]
+    assert calls == [2, 2, 2] and seen_mid_run[-1] == 4
+    full_ps = np.load(tmp_path / "full" / "0-1" / "dps-eor.npy")
+    assert np.array_equal(np.load(tmp_path / "part" / "0-1" / "dps-eor.npy"), full_ps[:4])
     for k in (1, 2):
         assert np.load(tmp_path / "part" / f"0-{k}" / "dps-eor.npy").shape == (4, 32)
         assert np.load(tmp_path / "part" / f"0-{k}" / "cov-eor.npy").shape == (4, 32)     # rows [:done], periodic write
@@ -253,6 +268,83 @@ def test_driver_per_time_flags(tmp_path):
         got = np.load(tmp_path / "pt" / f"0-{b + 1}" / "dps-eor.npy")
         assert np.array_equal(got, want["signal_ps"][b])
         assert not np.array_equal(got, np.load(tmp_path / "any" / f"0-{b + 1}" / "dps-eor.npy"))
+
+
+def test_npy_appender_keeps_a_valid_file_at_every_instant(tmp_path):
+    """hydra_pspec_amd/npy_append.py: rows appended flush by flush, the header's shape rewritten in place AFTER the data;
+    numpy.load reads the complete prefix whatever state the tail is in; a resume cuts back to a row count and goes on;
+    a file written by numpy.save is continued in place (numpy pads its headers) -- never a rewrite of the history."""
+    import os
+    from hydra_pspec_amd.npy_append import NpyAppender, read_header
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal((7, 3, 4)) + 1j * rng.standard_normal((7, 3, 4))
+    fn = tmp_path / "a.npy"
+    f = NpyAppender(fn, (3, 4), np.complex128).start()
+    assert np.load(fn).shape == (0, 3, 4)
+    ino = os.stat(fn).st_ino
+    f.append(x[:2])
+    assert np.array_equal(np.load(fn), x[:2])
+    # a torn flush: data beyond the header's row count (the next flush's rows, partially written) are ignored
+    with open(fn, "ab") as raw:
+        raw.write(b"\x01" * 100)
+    assert np.array_equal(np.load(fn), x[:2])
+    f.append(x[2:5])
+    assert np.array_equal(np.load(fn), x[:5]) and os.stat(fn).st_ino == ino          # same file: appended, not replaced
+    g = NpyAppender(fn, (3, 4), np.complex128).start(keep_rows=3)                     # resume at 3 iterations
+    assert np.array_equal(np.load(fn), x[:3]) and os.path.getsize(fn) == read_header(fn)[2] + 3 * 12 * 16
+    g.append(x[3:])
+    assert np.array_equal(np.load(fn), x)
+    with pytest.raises(ValueError):
+        g.append(x[:, :2])
+    np.save(tmp_path / "b.npy", x[:, 0, 0].real.copy())                               # numpy's own writer
+    h = NpyAppender(tmp_path / "b.npy", (), np.float64).start(keep_rows=4)
+    h.append(np.array([7.0, 8.0]))
+    assert np.array_equal(np.load(tmp_path / "b.npy"), np.r_[x[:4, 0, 0].real, 7.0, 8.0])
+    with pytest.raises(ValueError):
+        NpyAppender(tmp_path / "b.npy", (), np.float64).start(keep_rows=9)
+
+
+def test_circulant_cov_is_the_fourier_form():
+    """drain.circulant_cov = Fop^H diag(p) Fop (reference pspec.py:313-322) for even and odd channel counts."""
+    from hydra_pspec_amd import drain, utils
+    for N in (8, 9, 120):
+        p = np.random.default_rng(N).uniform(0.1, 2.0, N)
+        F = utils.fourier_operator(N)
+        assert np.abs(drain.circulant_cov(p) - F.conj().T @ np.diag(p) @ F).max() < 1e-11 * N
+
+
+def test_driver_drain_thin_budget_and_append_only(tmp_path, capsys):
+    """The driver's output side without a GPU (--dry_run): --thin K keeps every K-th iteration of the three large
+    histories and every iteration of dps-eor / ln-post; history files are appended to (same inode across flushes and
+    across a --resume), never rewritten; a run whose staged chunks exceed the host budget stops BEFORE sampling with the
+    numbers; --write_Niter must be a multiple of --thin."""
+    import os
+    drv = _driver()
+    common = ["--synthetic", "3,4,32", "--Nfgmodes", "3", "--seed", "4", "--out_dir", str(tmp_path), "--dry_run",
+              "--write_Niter", "4", "--thin", "2", "--dirname", "t"]
+    assert drv.main(common + ["--Niter", "8"]) == 0
+    res = tmp_path / "dryrun-t"
+    for k in (1, 2, 3):
+        assert np.load(res / f"0-{k}" / "dps-eor.npy").shape == (8, 32)
+        assert np.load(res / f"0-{k}" / "ln-post.npy").shape == (8,)
+        assert np.load(res / f"0-{k}" / "gcr-eor.npy").shape == (4, 4, 32)
+        assert np.load(res / f"0-{k}" / "fg-amps.npy").shape == (4, 4, 3)
+        assert np.load(res / f"0-{k}" / "chisq.npy").shape == (4, 4, 32)
+        assert np.load(res / f"0-{k}" / "cov-eor.npy").shape == (8, 32)           # periodic write: rows [:done]
+    ino = os.stat(res / "0-2" / "gcr-eor.npy").st_ino
+    assert drv.main(common + ["--Niter", "14", "--resume"]) == 0
+    assert os.stat(res / "0-2" / "gcr-eor.npy").st_ino == ino
+    assert np.load(res / "0-2" / "gcr-eor.npy").shape == (7, 4, 32) and np.load(res / "0-2" / "dps-eor.npy").shape == (14, 32)
+    assert np.load(res / "0-2" / "cov-eor.npy").shape == (32, 32)                 # final write (14 % 4 != 0): full matrix
+    d = json.loads((res / "drain.json").read_text())
+    assert d["iter0"] == 8 and d["bytes_written"] == 3 * (6 * (32 * 8 + 8) + 3 * (4 * 32 * 16 + 4 * 3 * 16 + 4 * 32 * 8))
+    with pytest.raises(SystemExit, match="thin"):
+        drv.main(common + ["--Niter", "20", "--resume", "--thin", "4"])           # another thinning: another run
+    with pytest.raises(SystemExit, match="pinned host memory"):
+        drv.main(common + ["--Niter", "8", "--dirname", "big", "--host_mem_gb", "1e-6"])
+    assert not (tmp_path / "dryrun-big" / "0-1").exists()                         # stopped before anything was written
+    with pytest.raises(SystemExit, match="multiple"):
+        drv.main(common + ["--Niter", "8", "--dirname", "odd", "--write_Niter", "3"])
 
 
 def _spawn_ranks(world, argv, env_extra=None, cwd=None):

@@ -134,3 +134,24 @@ def test_cov_eig_modes_more_times_than_channels():
         lam, U = lam[::-1][:nm], U[:, ::-1][:, :nm]
         assert np.max(np.abs(evals[b] / lam - 1)) < 1e-9
         assert np.max(1 - np.abs(np.sum(U.conj() * got[b], axis=0))) < 1e-9
+
+
+@pytest.mark.gpu
+def test_zheev_psd_refuses_non_finite_input():
+    """A NaN in the input reaches the Gram blocks: the convergence measure must not read it as "orthogonal already"
+    (fmax and the host's max both drop NaN): HPX_EINVAL, sweeps -1."""
+    import ctypes
+    import torch
+    from hydra_pspec_amd import hpx
+    n0, nb = 144, 2
+    rng = np.random.default_rng(1)
+    q = rng.standard_normal((nb, n0, n0)) + 1j * rng.standard_normal((nb, n0, n0))
+    A = q @ np.conj(np.swapaxes(q, 1, 2)) / n0 + np.eye(n0)
+    A[1, 5, 5] = np.nan
+    n = hpx.lib().hpx_zheev_psd_order(n0)
+    dA = torch.from_numpy(np.ascontiguousarray(A)).cuda()
+    w = torch.empty((nb, n), dtype=torch.float64, device="cuda")
+    v = torch.empty((nb, n0, n), dtype=torch.complex128, device="cuda")
+    sw = ctypes.c_int(0)
+    rc = hpx.lib().hpx_zheev_psd_batched(nb, n0, hpx.ptr(dA), hpx.ptr(w), hpx.ptr(v), ctypes.byref(sw), None)
+    assert rc in (hpx.HPX_EINVAL, hpx.HPX_ENOTPD), rc     # (the Cholesky in front may refuse it first)

@@ -310,3 +310,25 @@ def test_sqrtm_hpd_on_device(T, n, flagged):
         sq, isq = sq.cpu().numpy(), isq.cpu().numpy()
         assert np.abs(sq @ sq - A).max() < 1e-11 * np.abs(A).max()
         assert np.abs(sq @ isq - np.eye(n)).max() < 1e-11
+
+
+@pytest.mark.parametrize("nb", [1, 3])
+def test_sqrtm_indefinite_input_is_refused(T, nb):
+    """A matrix that is not positive definite makes Newton-Schulz overflow to inf, then NaN: the library must say so
+    (HPX_EINVAL), also when it is the ONLY matrix of the call (a NaN residual used to be dropped by the max and read as
+    converged), and pspec.sqrtm_masked_device must raise the reference-side error instead of handing NaN roots to the
+    chain."""
+    from hydra_pspec_amd import hpx, pspec
+    n = 48
+    rng = np.random.default_rng(5)
+    q = rng.standard_normal((nb, n, n)) + 1j * rng.standard_normal((nb, n, n))
+    A = q @ np.conj(np.swapaxes(q, 1, 2)) / n + 0.5 * np.eye(n)
+    lam, V = np.linalg.eigh(A[-1])
+    lam[0] = -0.7 * lam[-1]                           # one clearly negative eigenvalue
+    A[-1] = (V * lam) @ V.conj().T
+    dA = T.from_numpy(np.ascontiguousarray(A)).cuda()
+    sq, isq = T.empty_like(dA), T.empty_like(dA)
+    rc = hpx.lib().hpx_sqrtm_hpd_batched(nb, n, hpx.ptr(dA), hpx.ptr(sq), hpx.ptr(isq), 1e-7, 60, None, None)
+    assert rc == hpx.HPX_EINVAL, rc
+    with pytest.raises(FloatingPointError, match="not positive definite"):
+        pspec.sqrtm_masked_device(T, A, np.ones((nb, n), bool), T.device("cuda", T.cuda.current_device()))
