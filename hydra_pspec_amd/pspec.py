@@ -17,6 +17,7 @@ flat-noise data, through the diagonal + rank-Nmodes structure of ``M``); ``s = U
 ``Nbl = 1`` drop-in special case.
 """
 import ctypes as C
+import os
 import time
 
 import numpy as np
@@ -53,7 +54,19 @@ def draw_tables(T, N, Niter, seed, reseed=True):
     if reseed:
         np.random.seed(seed)
     u = np.random.random_sample((Niter, N))
-    return u, 1.0 / scipy.special.gammainccinv(T - 1.0, u)
+    igy = np.empty_like(u)
+    # element-wise (same values however it is split); scipy's ufunc loop runs without the GIL: rows over a few threads
+    nthr = min(8, os.cpu_count() or 1, max(1, u.size // 65536))
+    if nthr > 1:
+        from concurrent.futures import ThreadPoolExecutor
+        cuts = np.linspace(0, Niter, nthr + 1).astype(int)
+        with ThreadPoolExecutor(nthr) as ex:
+            list(ex.map(lambda i: scipy.special.gammainccinv(T - 1.0, u[cuts[i]:cuts[i + 1]], out=igy[cuts[i]:cuts[i + 1]]),
+                        range(nthr)))
+    else:
+        scipy.special.gammainccinv(T - 1.0, u, out=igy)
+    np.divide(1.0, igy, out=igy)
+    return u, igy
 
 
 # ------------------------------------------------------------------ input checks

@@ -75,6 +75,9 @@ def build_parser():
                         "as soon as one sample is flagged, which is what the reference driver does (:524-541)")
     p.add_argument("--outputs", type=str, default="all",
                    help="'all' (the six reference files) or 'ps' (dps-eor.npy and ln-post.npy only)")
+    p.add_argument("--solver", type=str, default="auto", choices=["auto", "dense"],
+                   help="'auto': baselines whose unflagged channels share one noise variance take the structured exact "
+                        "solve, everything else the batched dense Cholesky; 'dense': the dense Cholesky for all")
     p.add_argument("--thin", type=int, default=1,
                    help="keep every K-th iteration of the large histories (gcr-eor.npy, fg-amps.npy, chisq.npy: rows "
                         "0, K, 2K, ...); dps-eor.npy and ln-post.npy always hold every iteration.  --write_Niter must be "
@@ -479,7 +482,7 @@ def sample_and_write(args, rank, world, local_rank, results, marker, nonce, old_
         # with another Nproc must continue the very same chain -- and ranks that share a GPU (rehearsals, more ranks
         # than devices) could starve each other's co-operating workgroups (hpx.h, HPX_OPT_FACTOR_SPLIT).
         gb = pspec.make_batch(vis, flags_any if flags_pt is None else flags_pt, fg, Ninv_arg, ps_prior, Niter,
-                              seed=args.seed, map_estimate=args.map_estimate, allow_split=(world == 1))
+                              seed=args.seed, map_estimate=args.map_estimate, allow_split=(world == 1), solver=args.solver)
         free_dev = torch.cuda.mem_get_info()[0]
         if 2 * stage_b > free_dev:          # the chunk being sampled + the one being copied
             gb.close()
