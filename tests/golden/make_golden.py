@@ -3,7 +3,7 @@
 
 Run in the build container only (needs /root/reference):
 
-    python tests/golden/make_golden.py [--only small,steps,chain_synth,chain_testdata,chain_fullsize,steps_dense,chain_long [--case c3,c3f,c5f]]
+    python tests/golden/make_golden.py [--only small,steps,chain_synth,chain_testdata,chain_fullsize,steps_dense,dpss_control,chain_long [--case c3,c3f,c5f]]
 
 The reference is imported unmodified; its two I/O-only dependencies that are
 absent here (pyuvdata, astropy -- used by file loaders, never by the Gibbs path)
@@ -384,6 +384,36 @@ def gen_chain_fullsize(hp):
     print("chain_fullsize.npz", len(out), "arrays")
 
 
+def gen_dpss_control(hp):
+    """D1 control (the device exact_solver() is for the chain): the reference's dpss_fit_modes on the F10 inputs of
+    small.npz with ITS optimiser call (dpss.py:86-92: scipy.optimize.minimize, L-BFGS-B, default tolerances) swapped
+    in-process for the same call with tight stopping tolerances -- what the reference converges to when it is allowed to
+    converge.  SURVEY 8(a) D1 gates the closed form against this at 1e-6 of max |c|."""
+    import scipy.optimize
+    g = dict(np.load(HERE / "small.npz"))
+    out = {}
+    orig = hp.dpss.minimize
+
+    def tight(fun, x0, method=None, bounds=None, **kw):
+        return scipy.optimize.minimize(fun, x0, method=method, bounds=bounds,
+                                       options={"ftol": 1e-15, "gtol": 1e-12, "maxiter": 100000, "maxfun": 10000000})
+    hp.dpss.minimize = tight
+    try:
+        for i in range(3):
+            nm, al, has_t = g[f"F10_{i}_par"]
+            taper = g[f"F10_{i}_taper"] if has_t else None
+            modes, amps = hp.dpss.dpss_fit_modes(g[f"F10_{i}_d"], g[f"F10_{i}_w"], g[f"F10_{i}_freqs"], g[f"F10_{i}_cov"],
+                                                 nmodes=int(nm), alpha=al, taper=taper)
+            assert np.array_equal(modes, g[f"F10_{i}_modes"])
+            out[f"F10_{i}_amps_tight"] = amps
+            print("dpss control", i, "max |tight - default| / max|c| =",
+                  np.max(np.abs(amps - g[f"F10_{i}_amps"])) / np.max(np.abs(amps)))
+    finally:
+        hp.dpss.minimize = orig
+    np.savez(HERE / "dpss_control.npz", **out)
+    print("dpss_control.npz", len(out), "arrays")
+
+
 LONG_CASES = {"c3": (512, 0.0, 40, 200), "c3f": (512, 0.15, 41, 100), "c5f": (1024, 0.15, 42, 30)}
 
 
@@ -431,6 +461,8 @@ def main():
         gen_chain_fullsize(hp)
     if "steps_dense" in todo:
         gen_steps_dense(hp)
+    if "dpss_control" in todo:
+        gen_dpss_control(hp)
     if "chain_long" in todo:
         gen_chain_long(hp, args.case.split(","))
 

@@ -29,6 +29,9 @@ def test_dpss_fit_modes_vs_reference(golden):
         assert _cost(amps, modes, d, w, cov, taper) <= _cost(g[f"F10_{i}_amps"], modes, d, w, cov, taper) * (1 + 1e-12)
         _, cf = dpss_ref.dpss_fit_closed_form(d, w, fr, cov, nmodes=int(nm), alpha=al, taper=taper)
         assert np.max(np.abs(amps - cf)) < 1e-9 * scale       # same minimiser as the CPU closed form
+        # SURVEY 8(a) D1's gate against the reference with its optimiser allowed to converge (dpss_control.npz)
+        tight = golden("dpss_control")[f"F10_{i}_amps_tight"]
+        assert np.max(np.abs(amps - tight)) < 1e-6 * scale
 
 
 def test_dpss_batched_matches_single_and_complex_cov():

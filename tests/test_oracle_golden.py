@@ -159,6 +159,13 @@ def test_dpss_fit(golden):
         assert np.max(np.abs(amps_cf - g[f"F10_{i}_amps"])) < 1e-4 * scale      # the optimiser's slack: measured 1.4e-6 .. 1.9e-5
         assert _dpss_cost(amps_cf, modes, *args[:2], args[3], taper) <= \
             _dpss_cost(g[f"F10_{i}_amps"], modes, *args[:2], args[3], taper) * (1 + 1e-12)
+        # the CONTROL (tests/golden/dpss_control.npz): the reference itself with its optimiser allowed to converge
+        # (ftol 1e-15, gtol 1e-12; make_golden.py gen_dpss_control) -- SURVEY 8(a) D1's gate, 1e-6 of max |c|
+        # (measured 2.3e-7 .. 8.8e-7: what L-BFGS-B's finite-difference gradients leave)
+        tight = golden("dpss_control")[f"F10_{i}_amps_tight"]
+        assert np.max(np.abs(amps_cf - tight)) < 1e-6 * scale
+        assert _dpss_cost(amps_cf, modes, *args[:2], args[3], taper) <= \
+            _dpss_cost(tight, modes, *args[:2], args[3], taper) * (1 + 1e-12)
 
 
 @pytest.mark.parametrize("s", [8, 16])
@@ -195,6 +202,31 @@ def test_chain_fullsize_c3_prefix(golden):
                                  g["c3_prior"], Niter=2, seed=int(g["c3_seed"]))
     assert np.max(np.abs(res[2] / g["c3_ps"][:2] - 1)) < 1e-7
     assert np.allclose(res[5], g["c3_lnpost"][:2], rtol=1e-8)
+
+
+@pytest.mark.parametrize("tag,its", [("c3", (100, 199)), ("c3f", (60,)), ("c5f", (29,))])
+def test_oracle_deep_in_the_long_reference_chains(golden, tag, its):
+    """The oracle against the reference DEEP in its long chains (tests/golden/chain_long_<tag>.npz): iteration k is one
+    oracle step from the reference's own bandpowers of iteration k - 1, with the global stream where the reference had
+    it (seeded, then k * Nfreqs uniforms consumed: one per channel per iteration) and the same CG solver."""
+    g = golden(f"chain_long_{tag}")
+    N = g["vis"].shape[1]
+    fop = R.fourier_operator(N)
+    for k in its:
+        S_prev = R.covariance_from_pspec(g["ref_ps"][k - 1] / N ** 2, fop)
+        np.random.seed(int(g["seed"]))
+        np.random.random_sample(k * N)
+        o = R.gibbs_step_fgmodes(g["vis"] * g["flags"], g["flags"], S_prev, g["fgmodes"], np.diag(g["ninv_diag"]),
+                                 g["prior"])
+        ref = g["ref_ps"][k]
+        live = ref > 1e-9 * np.median(ref)
+        assert np.max(np.abs(o[2] / ref - 1)[live]) < 1e-6, (tag, k)
+        # ln posterior: ~1e11 of cancellation with flags; and once a foreground-wedge channel has collapsed to ~1e-16
+        # of the median (channels next to the prior window do, after ~100 iterations) its 1/ps term is chaotic
+        if live.all():
+            assert o[5] == pytest.approx(g["ref_lnpost"][k], rel=2e-5)
+        if k == g["sel"][-1]:
+            assert relerr(o[3], g["ref_fg_sel"][-1]) < 1e-6
 
 
 def test_oqe_closed_forms_equal_the_loop_forms():
