@@ -177,13 +177,26 @@ def test_reference_long_chain_t2(golden, tag, solver):
     forced = pspec.gibbs_sample_with_fg_batched(*args, ps_forced=ref[None], **kw)
     free = pspec.gibbs_sample_with_fg_batched(*args, **kw)
     live = ref > 1e-9 * np.median(ref)
-    t1 = np.abs(forced["signal_ps"][0] / ref - 1)[live]
-    dev = np.abs(free["signal_ps"][0] / ref - 1)
     cdev = np.abs(ctl / ref - 1)
-    print(f"{tag} {solver}: T1 max {t1.max():.2e} | T2 ours median {np.median(dev):.2e} p99 {np.percentile(dev, 99):.2e} "
-          f"max {dev.max():.2e} first-50 max {dev[:50].max():.2e} | control median {np.median(cdev):.2e} "
+    # channels the reference itself keeps to 1e-6 against its exact-solve control over the whole chain: the hard gates
+    # apply there.  The others (foreground-wedge channels next to the prior window whose bandpower collapses to 1e-8 ..
+    # 1e-16 of the median: 3 of 512 in the unflagged chain) are chaotic in the reference too -- SURVEY 8c expects them --
+    # and are gated against the control instead.
+    stable = cdev.max(axis=0) < 1e-6
+    t1_all = np.where(live, np.abs(forced["signal_ps"][0] / ref - 1), 0.0)
+    dev = np.abs(free["signal_ps"][0] / ref - 1)
+    t1 = t1_all[:, stable]
+    wild = np.where(~stable)[0]
+    print(f"{tag} {solver}: {stable.sum()} / {stable.size} channels stable in the reference's own control (others: {wild})")
+    print(f"   T1 stable max {t1.max():.2e}, others max {t1_all[:, ~stable].max() if len(wild) else 0.0:.2e} | T2 ours median "
+          f"{np.median(dev):.2e} p99 {np.percentile(dev, 99):.2e} stable max {dev[:, stable].max():.2e} first-50 stable max "
+          f"{dev[:50, stable].max():.2e} max {dev.max():.2e} | control median {np.median(cdev):.2e} "
           f"p99 {np.percentile(cdev, 99):.2e} max {cdev.max():.2e} first-50 max {cdev[:50].max():.2e}")
+    assert stable.mean() > 0.97
     assert t1.max() < 1e-6
+    # one forced step on a chaotic channel: its error is the draw's sensitivity there, bounded by what the control shows
+    if len(wild):
+        assert t1_all[:, ~stable].max() < max(1e-6, cdev[:, ~stable].max())
     # ln posterior where every channel is live (a wedge channel that has collapsed to ~1e-16 of the median makes its
     # 1 / ps term chaotic -- in the reference against its own control as well)
     ok = live.all(axis=1)
@@ -192,8 +205,9 @@ def test_reference_long_chain_t2(golden, tag, solver):
     assert np.median(dev) < 1e-6
     assert np.percentile(dev, 99) < 20 * max(np.percentile(cdev, 99), 1e-9)
     assert np.median(dev) < 20 * max(np.median(cdev), 1e-9)
+    assert dev[:50, stable].max() < 1e-6
     if tag == "c3":
-        assert np.percentile(dev, 99) < 1e-6 and dev[:50].max() < 1e-6
+        assert np.percentile(dev, 99) < 1e-6 and dev[:, stable].max() < 1e-6
     # the constrained realisations themselves, teacher-forced, at iterations 0 and niter / 2 (thin = niter / 2)
     sel = g["sel"]
     assert sel[0] == 0 and sel[2] == niter // 2
