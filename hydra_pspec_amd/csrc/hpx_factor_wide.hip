@@ -346,10 +346,24 @@ __device__ HPX_INL void strip_passes(const WideCtx& X, const hpx_gen& G, const G
     d4 a1[8], a2[8], a3[8];
     if (active) {
       if (GEN && GLDS && rt * 16 < G.rmin && c0 + 128 <= G.rmin) {     // no vector-memory instruction on this path
+        // Rows BELOW the super-block: every tile is off the diagonal (r0 >= c0 + 128 > c0 + 16 ci), entry (r, c) is the
+        // circulant's element r - c = d0 + 16 (7 - ci) + 4 (3 - v) with ONE per-lane index d0 >= 1 and compile-time
+        // offsets.  Through tile_init_closed the compiler could not know that and laid out the diagonal form as well
+        // (masked lanes, fma with 1 / a) with 19 hoisted per-lane addresses kept in scratch: every tile's reload sat
+        // behind an s_waitcnt vmcnt(0) -- a drain of the last tail step's stores, the next row operand and the staged
+        // chunk, then seven more scratch round trips: the 4.4 - 6 us "group prologue" of the step trace
+        // (profiles/r05_trace_factor_wide_c3.txt).  The index hangs on an opaque copy of the lane: not hoisted.
+        const int d0 = rt * 16 - c0 - 124 + opaque(li) - opaque(g);
+        const auto qr = V.cre + d0;
+        const auto qi = V.cim + d0;
 #pragma unroll
         for (int ci = 0; ci < 8; ++ci) {
           d4 vr, vi;
-          tile_init_closed<GLDS>(V, rt * 16, c0 + 16 * ci, li, g, vr, vi);
+#pragma unroll
+          for (int v = 0; v < 4; ++v) {
+            vr[v] = qr[16 * (7 - ci) + 4 * (3 - v)];
+            vi[v] = qi[16 * (7 - ci) + 4 * (3 - v)];
+          }
           a1[ci] = -0.5 * vr;
           a2[ci] = -0.5 * vr;
           a3[ci] = vi;
@@ -359,13 +373,74 @@ __device__ HPX_INL void strip_passes(const WideCtx& X, const hpx_gen& G, const G
         // computed at the top of every group's body instead -- where the compiler moved them -- they cost every
         // group some 500 instructions and 50 spills)
         const int rt16 = opaque_s(rt * 16), c0o = opaque_s(c0), lio = opaque(li), go = opaque(g);
+        if (GEN && GLDS && G.ere != nullptr && rt16 >= G.rmin && c0o + 128 <= G.rmin) {
+          // A strip of EDGE tiles (foreground rows / padding / right-hand sides) against signal columns: tile_init's
+          // edge arithmetic, operation for operation (same bits), but laid out for the whole strip -- the three
+          // conditions (edge tiles present, right-hand-side row, omega term) are uniform over the strip's eight tiles and
+          // are taken ONCE, and every load lands in the accumulator register it ends up in: 128 loads in flight behind
+          // one wait (plus 64 for the omega term) instead of six dependent round trips per tile, 8 tiles in turn
+          // (12 - 14 us per super-block in the step trace, profiles/r06_trace_factor_wide_c3.txt).
+          // (uniform base + 32-bit lane offset + immediate: one address register for the strip, not one per load)
+          typedef const __attribute__((address_space(1))) char* gbytes;
+          const gbytes eu = (gbytes)(G.ere + HPX_EIDX(rt16, c0o, G.rmin));
+          const unsigned lb = 8u * (unsigned)(go * 32 + lio);
 #pragma unroll
-        for (int ci = 0; ci < 8; ++ci) {
-          d4 vr, vi;
-          tile_init<GEN, GLDS>(G, V, X.Lb, rt16, c0o + 16 * ci, X.npad, lio, go, vr, vi);
-          a1[ci] = -0.5 * vr;
-          a2[ci] = -0.5 * vr;
-          a3[ci] = vi;
+          for (int ci = 0; ci < 8; ++ci) {
+            const gbytes tb = eu + ci * 4096;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+              a1[ci][v] = *(const glb_f64*)(tb + lb + 1024 * v);
+              a3[ci][v] = *(const glb_f64*)(tb + lb + 1024 * v + 128);
+            }
+          }
+          if (rt16 >= X.npad) {
+            if (G.has_omega) {
+              const long pb = ((long)((rt16 - X.npad) >> 4) * G.NP + c0o) << 4;
+              const gbytes pru = (gbytes)(G.p2tre + pb), piu = (gbytes)(G.p2tim + pb);
+              const unsigned lp = 8u * (unsigned)(go * 16 + lio);
+              const auto ia = V.ia + c0o + go;
+#pragma unroll
+              for (int ci = 0; ci < 8; ++ci)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) a2[ci][v] = *(const glb_f64*)(pru + ci * 2048 + lp + 512 * v);
+              // (1 / a read tile by tile, right in front of its products: all 32 values at once do not fit beside the
+              // three accumulator sets, and what the compiler then spills are freshly LOADED values, each behind a full wait)
+              __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+              for (int ci = 0; ci < 8; ++ci) {
+#pragma unroll
+                for (int v = 0; v < 4; ++v) a1[ci][v] = fma(ia[16 * ci + 4 * v], a2[ci][v], a1[ci][v]);
+                __builtin_amdgcn_sched_barrier(0);
+              }
+#pragma unroll
+              for (int ci = 0; ci < 8; ++ci)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) a2[ci][v] = *(const glb_f64*)(piu + ci * 2048 + lp + 512 * v);
+              __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+              for (int ci = 0; ci < 8; ++ci) {
+#pragma unroll
+                for (int v = 0; v < 4; ++v) a3[ci][v] = fma(ia[16 * ci + 4 * v], a2[ci][v], a3[ci][v]);
+                __builtin_amdgcn_sched_barrier(0);
+              }
+            }
+#pragma unroll
+            for (int ci = 0; ci < 8; ++ci) a3[ci] = -a3[ci];
+          }
+#pragma unroll
+          for (int ci = 0; ci < 8; ++ci) {
+            a1[ci] = -0.5 * a1[ci];
+            a2[ci] = a1[ci];
+          }
+        } else {
+#pragma unroll
+          for (int ci = 0; ci < 8; ++ci) {
+            d4 vr, vi;
+            tile_init<GEN, GLDS>(G, V, X.Lb, rt16, c0o + 16 * ci, X.npad, lio, go, vr, vi);
+            a1[ci] = -0.5 * vr;
+            a2[ci] = -0.5 * vr;
+            a3[ci] = vi;
+          }
         }
         wait_compiler_loads();
       }

@@ -11,5 +11,5 @@ for f in hpx_factor hpx_factor_wide hpx_factor_split; do
 done
 wait
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $ROOT/tools/experiments/ab/libhpx_$name.so /tmp/_v_${name}_hpx_factor.o /tmp/_v_${name}_hpx_factor_wide.o /tmp/_v_${name}_hpx_factor_split.o \
-  $CS/hpx_backsolve.o $CS/hpx_transform.o $CS/hpx_plan.o $CS/hpx_setup.o $CS/hpx_chain.o $CS/hpx_post.o $CS/hpx_woodbury.o $CS/hpx_extra.o $CS/hpx_flat.o $CS/hpx_lowrank.o $CS/hpx_modes.o $CS/hpx_sqrtm.o $CS/hpx_eigh.o
+  $CS/hpx_backsolve.o $CS/hpx_backsolve_lds.o $CS/hpx_transform.o $CS/hpx_plan.o $CS/hpx_setup.o $CS/hpx_chain.o $CS/hpx_post.o $CS/hpx_woodbury.o $CS/hpx_extra.o $CS/hpx_flat.o $CS/hpx_lowrank.o $CS/hpx_modes.o $CS/hpx_sqrtm.o $CS/hpx_eigh.o
 echo built libhpx_$name.so
