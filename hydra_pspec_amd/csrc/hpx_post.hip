@@ -172,8 +172,10 @@ __device__ unsigned long long hpx_fr_trace[8 * 4 * 16];
 #endif
 // OPT (the SPLIT8 form): bit 0 the batch has flags (the masked signal is written), bit 1 samples / chi^2 are kept this
 // iteration -- compile-time, so that the tile loop of the common iteration carries neither the stores nor their tests
-template <int NTH, bool SPLIT8, int OPT>
-__global__ __launch_bounds__(NTH, NTH / 128) void k_fft_resid(const ResArgs A) {
+// ELEMS: complex elements of the signal block in LDS: 4096 (64 KB, two workgroups per CU) or, for 1024 channels, 8192 (128 KB:
+// eight time columns still fit ONE workgroup per CU, which then has 512 threads -- the same eight waves per CU)
+template <int NTH, bool SPLIT8, int OPT, int ELEMS = 4096>
+__global__ __launch_bounds__(NTH, (ELEMS > 4096) ? 1 : NTH / 128) void k_fft_resid(const ResArgs A) {
   constexpr int NW = NTH / 64;                       // waves
   extern __shared__ double fl[];
   const int N = A.N, M = A.M, T = A.T, TP = A.TP, tcs = A.tcs, TC = 1 << tcs, logN = A.logN;
@@ -195,7 +197,7 @@ __global__ __launch_bounds__(NTH, NTH / 128) void k_fft_resid(const ResArgs A) {
   // The block of the solution first: 16 loads per thread and array, all in flight before anything waits (the block is
   // at most 4096 elements: one batch); the twiddles and the amplitudes are requested behind them (in front of them
   // measures the same: 0.217 ms either way at config 3).
-  constexpr int UB = 4096 / NTH;
+  constexpr int UB = ELEMS / NTH;
   const int total = N << tcs;
   double zr[UB], zi[UB];
 #pragma unroll
@@ -1146,7 +1148,13 @@ int hpx_post_solve(hpx_plan* p, int it_abs, const IterOut& O, hipStream_t st) {
 #ifndef HPX_FR_ELEMS
 #define HPX_FR_ELEMS 4096      // complex elements of the signal block a workgroup of k_fft_resid holds in LDS
 #endif
-  int npart = 1, TC = HPX_FR_ELEMS / NP, pair_slots = 0;
+#ifndef HPX_FR_BIG
+#define HPX_FR_BIG 1           // 0: never the 8192-element block (A/B)
+#endif
+  // (1024 channels: a block of 8192 elements, 128 KB of LDS, one 512-thread workgroup per CU -- with 4096 only four time
+  // columns fit and the transform and the residual are two kernels with the signal through HBM between them)
+  const int fr_elems = (HPX_FR_BIG && NP == 1024 && HPX_FR_ELEMS == 4096) ? 8192 : HPX_FR_ELEMS;
+  int npart = 1, TC = fr_elems / NP, pair_slots = 0;
   if (TC > 16) TC = 16;
   // a batch whose blocks of 16 columns would not reach every CU takes blocks of 8 (config 2: 128 -> 256 workgroups,
   // 23.8 -> 18.9 us); the sums the blocks leave are formed per group of eight columns either way, so a baseline's
@@ -1166,18 +1174,25 @@ int hpx_post_solve(hpx_plan* p, int it_abs, const IterOut& O, hipStream_t st) {
     // s = U z, residual, chi^2, |z|^2 sums in one pass (k_fft_resid); the two event marks
     // book it under "transform"
     // (the mode rows' staging area behind the amplitudes only where the model term is not on the matrix pipe)
-    const size_t lds = ((size_t)N * TC * 2 + N + (size_t)2 * M * TC + (M > 16 ? (size_t)2 * M * (HPX_FR_THREADS / TC) : 0)) * sizeof(double);
     R.nbl = nbl; R.npart = npart;
     // (blocks of 8 columns because the channel count leaves no other choice: the component-per-lane form; where 16
     // would fit and 8 is taken for a small batch, the sums must come out as a block of 16 leaves them: the other form)
-    const dim3 grid(((nbl + 7) / 8) * 8 * npart), block(HPX_FR_THREADS);
+    const bool big = fr_elems > 4096;
+    const size_t lds = ((size_t)N * TC * 2 + N + (size_t)2 * M * TC + (M > 16 ? (size_t)2 * M * ((big ? 512 : HPX_FR_THREADS) / TC) : 0)) * sizeof(double);
+    const dim3 grid(((nbl + 7) / 8) * 8 * npart), block(big ? 512 : HPX_FR_THREADS);
 #define HPX_FR_GO(SP_, OPT_)                                                                                    \
   {                                                                                                             \
-    static hpx_lds_limit lim_;                                                                                  \
-    HPX_TRY(lim_.ensure(reinterpret_cast<const void*>(&k_fft_resid<HPX_FR_THREADS, SP_, OPT_>), lds));          \
-    hipLaunchKernelGGL((k_fft_resid<HPX_FR_THREADS, SP_, OPT_>), grid, block, lds, st, R);                      \
+    if (big) {                                                                                                  \
+      static hpx_lds_limit limb_;                                                                               \
+      HPX_TRY(limb_.ensure(reinterpret_cast<const void*>(&k_fft_resid<512, SP_, OPT_, 8192>), lds));            \
+      hipLaunchKernelGGL((k_fft_resid<512, SP_, OPT_, 8192>), grid, block, lds, st, R);                         \
+    } else {                                                                                                    \
+      static hpx_lds_limit lim_;                                                                                \
+      HPX_TRY(lim_.ensure(reinterpret_cast<const void*>(&k_fft_resid<HPX_FR_THREADS, SP_, OPT_>), lds));        \
+      hipLaunchKernelGGL((k_fft_resid<HPX_FR_THREADS, SP_, OPT_>), grid, block, lds, st, R);                    \
+    }                                                                                                           \
   }
-    if (HPX_FR_SPLIT8 && TC == 8 && HPX_FR_ELEMS / NP == 8 && M <= 16) {
+    if (HPX_FR_SPLIT8 && TC == 8 && fr_elems / NP == 8 && M <= 16) {
       const int opt = (p->any_flags ? 1 : 0) | ((R.cr_out || R.chisq_out) ? 2 : 0);
       if (opt == 0) HPX_FR_GO(true, 0)
       else if (opt == 1) HPX_FR_GO(true, 1)
