@@ -27,17 +27,8 @@
 
 #define HPX_INL __forceinline__
 
-#ifndef HPX_BS_DEPTH4
-#define HPX_BS_DEPTH4 1      // L operand sets of the t-split form at 18 .. 33 tile rows (four slots per wave)
-#endif
-#ifndef HPX_BS_REG_MAXCT
-// tile rows up to which the register-resident form is taken.  From 18 rows on (three to five slots per wave) it can
-// only run one t-tile per workgroup (-DHPX_BS_REG_MAXCT=33: the t-tiles of a baseline on one XCD, in step, the second
-// reader of L served by that XCD's L2): measured at C3 1.19 ms against 0.84 ms for k_backsolve of hpx_factor.hip -- one
-// 8-wave workgroup per CU walks 33 dependent steps with one step of operand prefetch and nothing beside it (round 5,
-// the last design tried for this kernel)
-#define HPX_BS_REG_MAXCT 17
-#endif
+// (The register-resident form beyond 17 tile rows -- one t-tile per workgroup, three to five slots per wave -- measured
+// 1.19 ms against 0.84 ms for k_backsolve at C3 and is not part of the product: tools/experiments/backsolve_reg33.patch.)
 
 namespace {
 
@@ -509,14 +500,14 @@ __global__ __launch_bounds__(512, 2) void k_backsolve_reg(const double* __restri
   double* Xre = Xre_all + (long)b * npad * TP;
   double* Xim = Xim_all + (long)b * npad * TP;
   const int TT = TP >> 4;
-  constexpr int DEPTH = (NS <= 2) ? (TSPLIT ? 3 : (NS == 2 && HPX_BS_M3(NS) ? HPX_BS_DEPTH2W : 2))
-                                  : ((TSPLIT && NS <= 4) ? HPX_BS_DEPTH4 : 1);   // operand sets the registers hold without spills
+  static_assert(NS <= 2, "the register-resident form is instantiated for at most 17 tile rows");
+  constexpr int DEPTH = TSPLIT ? 3 : (NS == 2 && HPX_BS_M3(NS) ? HPX_BS_DEPTH2W : 2);   // operand sets the registers hold without spills
   if (TSPLIT) {
     if constexpr (NS >= 1 && NS <= 2) bs_tile_pass_ul<NS, 3>(Lre, Wgre, Wgim, Xre, Xim, xs, npad, TP, tsel << 4, wave, lane);
     else bs_reg_pass<NS, 1, DEPTH, HPX_BS_M3(NS)>(Lre, Wgre, Wgim, Xre, Xim, xs, npad, TP, tsel << 4, wave, lane);
     return;
   }
-  constexpr int NTMAX = (NS >= 5) ? 1 : 2;      // accumulators + L operands within the register file
+  constexpr int NTMAX = 2;                      // accumulators + L operands within the register file
   for (int tp = 0; tp < TT; tp += NTMAX) {
     if (NTMAX == 2 && tp + 1 < TT) bs_reg_pass<NS, 2, DEPTH, HPX_BS_M3(NS)>(Lre, Wgre, Wgim, Xre, Xim, xs, npad, TP, tp << 4, wave, lane);
     else bs_reg_pass<NS, 1, DEPTH, HPX_BS_M3(NS)>(Lre, Wgre, Wgim, Xre, Xim, xs, npad, TP, tp << 4, wave, lane);
@@ -540,9 +531,8 @@ template <int NS>
 int launch_reg(int nbl, int npad, int TP, int ld, const double* L, const double* Wre, const double* Wim, double* Xre,
                double* Xim, hipStream_t st) {
   const int TT = TP >> 4;
-  // one workgroup per (baseline, t-tile): small batches (most CUs would be idle) and, from 18 tile rows on, every
-  // batch -- there a wave's accumulators for two t-tiles no longer fit its registers
-  if (TT >= 2 && (2 * nbl <= device_cus() || NS >= 3))
+  // one workgroup per (baseline, t-tile) for small batches (most CUs would be idle otherwise)
+  if (TT >= 2 && 2 * nbl <= device_cus())
     hipLaunchKernelGGL((k_backsolve_reg<NS, true>), dim3(8 * TT * ((nbl + 7) / 8)), dim3(512), 0, st, L, Wre, Wim, Xre,
                        Xim, npad, TP, ld, nbl);
   else
@@ -562,7 +552,7 @@ int launch_reg(int nbl, int npad, int TP, int ld, const double* L, const double*
 // baselines, 0.32 against 0.32 ms for 1024.
 int hpx_backsolve_reg_ok(int npad, int TP) {
   const int nct = npad >> 4;
-  return (nct <= 17 && TP <= 32) || (nct <= HPX_BS_REG_MAXCT && TP == 32);
+  return nct <= 17 && TP <= 32;
 }
 
 int hpx_launch_backsolve_reg(int nbl, int npad, int TP, int ld, const double* L, const double* Wre, const double* Wim,
@@ -573,11 +563,6 @@ int hpx_launch_backsolve_reg(int nbl, int npad, int TP, int ld, const double* L,
     case 0: return launch_reg<0>(nbl, npad, TP, ld, L, Wre, Wim, Xre, Xim, st);
     case 1: return launch_reg<1>(nbl, npad, TP, ld, L, Wre, Wim, Xre, Xim, st);
     case 2: return launch_reg<2>(nbl, npad, TP, ld, L, Wre, Wim, Xre, Xim, st);
-    case 3: return launch_reg<3>(nbl, npad, TP, ld, L, Wre, Wim, Xre, Xim, st);
-    // (four slots: the compiler's allocation of this instantiation spills 118 registers, the five-slot one none --
-    // the fifth slot's tiles lie beyond the matrix and are skipped by the guards)
-    case 4: return launch_reg<5>(nbl, npad, TP, ld, L, Wre, Wim, Xre, Xim, st);
-    case 5: return launch_reg<5>(nbl, npad, TP, ld, L, Wre, Wim, Xre, Xim, st);
     default: break;
   }
   hpx_set_error("hpx_launch_backsolve_reg: order %d not handled", npad);

@@ -1010,10 +1010,8 @@ extern "C" int hpx_factor_form(int nb, int n, int nrhs, int* parts) {
 
 int hpx_launch_backsolve(int nbl, int npad, int TP, int ld, const double* L, const double* Wre,
                          const double* Wim, double* Xre, double* Xim, hipStream_t st) {
-#ifndef HPX_BACKSOLVE_OLD
   if (hpx_backsolve_reg_ok(npad, TP)) return hpx_launch_backsolve_reg(nbl, npad, TP, ld, L, Wre, Wim, Xre, Xim, st);
   if (hpx_backsolve_x_ok(npad, TP)) return hpx_launch_backsolve_x(nbl, npad, ld, L, Wre, Wim, Xre, Xim, st);
-#endif
   hipLaunchKernelGGL(k_backsolve, dim3(nbl), dim3(256), 0, st, L, Wre, Wim, Xre, Xim, npad, TP, ld);
   HPX_HIP(hipGetLastError());
   return HPX_OK;

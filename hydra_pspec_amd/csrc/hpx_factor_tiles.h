@@ -469,11 +469,8 @@ __device__ HPX_INL bool elim16w(const WideCtx& X, const int tcol, const bool las
       const double r0 = __builtin_amdgcn_rcp(dkn);
       rinv = fma(r0, fma(-dkn, r0, 1.0), r0);
     }
-#ifndef HPX_E16_PROBE
-#define HPX_E16_PROBE 0        // timing-only knobs of tools/experiments/elim/elim16w_probe.hip: 1 no inverse, 2 no outputs
-#endif
     // ---- ... the inverse's update of the step before ...
-    if (k > 0 && !(HPX_E16_PROBE & 1)) {
+    if (k > 0) {
 #pragma unroll
       for (int v = 0; v < 4; ++v) {
         if (4 * v > k - 1) continue;                   // row k - 1 of the inverse is zero right of column k - 1
@@ -485,7 +482,7 @@ __device__ HPX_INL bool elim16w(const WideCtx& X, const int tcol, const bool las
       }
     }
     // ---- ... and row k of the inverse out (final since that update) and back in
-    if (li == k && !(HPX_E16_PROBE & 1)) {
+    if (li == k) {
 #pragma unroll
       for (int v = 0; v < 4; ++v) yrw[g * 4 + v] = (cplx){yr[v], yi[v]};
     }
@@ -509,7 +506,6 @@ __device__ HPX_INL bool elim16w(const WideCtx& X, const int tcol, const bool las
 #undef HPX_E16_FENCE
   __builtin_amdgcn_s_setprio(0);
   bool bad = false;
-  if (HPX_E16_PROBE & 2) return dr[0] + yr[1] < -1e300;
   const double pib = dgs[li];
   const double sv = rsqrt_nr(pib);
   double wr[4], wi[4], sq[4];
@@ -565,25 +561,4 @@ __device__ HPX_INL bool elim16w(const WideCtx& X, const int tcol, const bool las
 __device__ HPX_INL bool elim16w(const WideCtx& X, const int tcol, const bool last_tile, const d4 re, const d4 im) {
   return elim16w(X, tcol, last_tile, re, im, [] {});
 }
-// a tile handed over in LDS (Ein: re | im, row-major [r][c], written in front of a barrier) -> the lane's elements
-__device__ HPX_INL void ein_load(const WideCtx& X, d4& re, d4& im) {
-  const lds_f64* const Ein = (const lds_f64*)hpx_stage0;
-  const int lane = opaque(X.lane), li = lane & 15, g = lane >> 4;
-#pragma unroll
-  for (int v = 0; v < 4; ++v) {
-    re[v] = Ein[li * 16 + g + 4 * v];
-    im[v] = Ein[256 + li * 16 + g + 4 * v];
-  }
-}
-
-// what a wave that takes no part in elim16 executes beside it: the same barriers (16 steps, one after the loop, one
-// at the end)
-__device__ HPX_INL void elim16_idle() {
-#ifndef HPX_DBG_F_NOELIM
-  for (int k = 0; k < 16; ++k) lds_barrier();
-#endif
-  lds_barrier();
-  lds_barrier();
-}
-
 }  // namespace

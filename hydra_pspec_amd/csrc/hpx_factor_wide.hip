@@ -192,20 +192,10 @@ __device__ HPX_INL bool diag_factor(const WideCtx& X, const int ct0, d4 (&a1)[9]
     const int lane = opaque(X.lane), li = lane & 15, g = lane >> 4;
     const int rd_re = g * 32 + li + 16 * (g & 1), rd_im = g * 32 + li + 16 * (1 - (g & 1));
     // (1) the diagonal tile goes to the elimination: all 256 threads (elim16) -- the one-wave form that eliminates the
-    // tile where it lies (elim16w, HPX_ELIM_WAVE) measured no faster here: 4.13 against 4.08 ms per launch at C3
+    // tile where it lies (elim16w) measured no faster here: 4.13 against 4.08 ms per launch at C3
+    // (tools/experiments/elim/wide_elim_wave.patch)
     HPX_TR(X, 2, ct0 >> 3, i, 0);
     lds_barrier();                                        // Vs and the elimination's scratch are free
-#ifdef HPX_ELIM_WAVE
-    {
-      d4 er = {0., 0., 0., 0.}, ei = er;
-      bool mine = false;
-#pragma unroll
-      for (int s = 0; s < 9; ++s)
-        if (tr[s] == i && tc[s] == i) { er = a1[s]; ei = a2[s]; mine = true; }
-      if (mine) bad |= elim16w(X, ct0 + i, false, er, ei);
-      lds_barrier();
-    }
-#else
 #pragma unroll
     for (int s = 0; s < 9; ++s)
       if (tr[s] == i && tc[s] == i) {
@@ -217,7 +207,6 @@ __device__ HPX_INL bool diag_factor(const WideCtx& X, const int ct0, d4 (&a1)[9]
       }
     lds_barrier();
     bad |= elim16(X, ct0 + i, false);
-#endif
     HPX_TR(X, 2, ct0 >> 3, i, 1);
     // (2b) odd tile of a pair: W10 = -inv(L11) (L10 inv(L00))
     if ((i & 1) && X.wave == ((i >> 1) & 3)) {
@@ -631,18 +620,7 @@ __device__ HPX_INL bool narrow_column(const WideCtx& X, const hpx_gen& G, const 
     Xs[ib * 16 + q] = kr;                   // Ein: read back by this thread
     Xs[256 + ib * 16 + q] = ki;
   }
-#ifdef HPX_ELIM_WAVE
-  lds_barrier();
-  bool bad = false;
-  if (X.wave == 0) {
-    d4 er, ei;
-    ein_load(X, er, ei);
-    bad = elim16w(X, t, (t + 1 == X.nct), er, ei);
-  }
-  lds_barrier();
-#else
   bool bad = elim16(X, t, (t + 1 == X.nct));
-#endif
   // ---- odd tile of a pair: W10 = -inv(L11) L10 inv(L00), operands from global memory
   if ((t & 1) && X.wave == 0) {
     d4 tre = {0., 0., 0., 0.}, tim = tre;
