@@ -73,3 +73,14 @@ def test_under_torch_distributed_run_the_ranks_are_used_as_given():
     assert r.returncode == 0, r.stderr[-2000:]
     res = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
     assert res["n_gpus"] == 2 and res["blocks"] == [[0, 1024], [1024, 2048]] and len(set(res["pids"])) == 2
+
+
+def test_committed_dry_run_records_parse():
+    """Every profiles/r*_dry_run_8.json is the launcher's own record of an 8-rank dry run: eight distinct processes, the
+    reference's contiguous blocks over 8192 baselines (BASELINE.json config C4).  (An empty file was committed once.)"""
+    files = sorted((REPO / "profiles").glob("r*_dry_run_8.json"))
+    assert files, "no dry-run record under profiles/"
+    for f in files:
+        res = json.loads(f.read_text())
+        assert res["dry_run"] is True and res["n_gpus"] == 8 and res["baselines_total"] == 8192, f
+        assert res["blocks"] == [[1024 * r, 1024 * (r + 1)] for r in range(8)] and len(set(res["pids"])) == 8, f

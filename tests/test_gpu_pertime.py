@@ -40,6 +40,21 @@ def test_identical_per_time_inputs_reproduce_the_standard_chain():
     assert dev[:, 0].max() < 1e-13 and dev.max() < 2e-8
     assert relerr(pt["signal_cr"], std["signal_cr"]) < 2e-8 and relerr(pt["fg_amps"], std["fg_amps"]) < 1e-10
     assert relerr(pt["chisq"], std["chisq"]) < 1e-8 and np.allclose(pt["ln_post"], std["ln_post"], rtol=1e-10)
+    # The drift above is the chain's own amplification, bounded separately here: with the bandpowers of EVERY iteration
+    # forced to the standard chain's, each iteration of the two modes solves the same systems -- the solutions, chi^2,
+    # the amplitudes and the draw from them must then agree to rounding at every iteration, not only at the first
+    # (a regression in the per-time draw or back substitution shows here at 1e-12, not under a 2e-8 allowance)
+    forced = std["signal_ps"]
+    kw = dict(ps_initial=d["ps0"], Niter=5, seed=3, keep=("signal_cr", "fg_amps", "chisq"), ps_forced=forced)
+    std_f = pspec.gibbs_sample_with_fg_batched(d["vis"], d["flags"], d["fgmodes"], d["ninv_diag"], d["ps_prior"],
+                                               solver="dense", **kw)
+    pt_f = pspec.gibbs_sample_with_fg_batched(d["vis"], flt, d["fgmodes"], nt, d["ps_prior"], **kw)
+    assert np.array_equal(std_f["signal_ps"], std["signal_ps"])            # (forcing a chain onto itself changes nothing)
+    worst = {k: relerr(pt_f[k], std_f[k]) for k in ("signal_cr", "fg_amps", "chisq")}
+    worst["signal_ps"] = float(np.abs(pt_f["signal_ps"] / std_f["signal_ps"] - 1).max())
+    print("per-time vs standard, teacher-forced, every iteration:", {k: f"{v:.1e}" for k, v in worst.items()})
+    assert worst["signal_cr"] < 1e-11 and worst["fg_amps"] < 1e-12 and worst["chisq"] < 1e-10
+    assert worst["signal_ps"] < 1e-11
 
 
 def test_pertime_chain_vs_oracle():

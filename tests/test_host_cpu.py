@@ -260,3 +260,44 @@ def test_bench_traffic_guard_and_host_cores(tmp_path, monkeypatch):
     assert "source_hash" in committed and set(committed["source_hash_files"]) == set(bench.DENSE_STEP_SOURCES)
     usable, avail, quota = bench.host_cores()
     assert 1 <= usable <= avail and (quota is None or usable <= quota)
+
+
+def _asm_checker():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("check_asm_spills", REPO / "tools" / "check_asm_spills.py")
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_asm_load_checker_sees_a_use_before_the_wait():
+    """tools/check_asm_spills.py replays a kernel's instruction stream with the vmcnt rule (in-order retirement): a read or a
+    spill of a scalar-base load's destination in front of the wait that covers it is reported, the same after it is not."""
+    chk = _asm_checker()
+    ld = "\tglobal_load_dwordx2 v[10:11], v3, s[4:5] offset:128 nt"
+    other = "\tglobal_load_dwordx2 v[20:21], v3, s[4:5]"
+    ok = [ld, other, "\ts_waitcnt vmcnt(1)", "\tv_fma_f64 v[30:31], v[10:11], v[12:13], v[14:15]",
+          "\ts_waitcnt vmcnt(0)", "\tscratch_store_dwordx2 off, v[20:21], off offset:8"]
+    assert chk.check_kernel("ok", list(enumerate(ok, 1))) == 0
+    early_read = [ld, other, "\ts_waitcnt vmcnt(1)", "\tv_fma_f64 v[30:31], v[20:21], v[12:13], v[14:15]"]
+    assert chk.check_kernel("early read", list(enumerate(early_read, 1))) == 1
+    early_spill = [ld, "\tscratch_store_dwordx2 off, v[10:11], off offset:8", "\ts_waitcnt vmcnt(0)"]
+    assert chk.check_kernel("early spill", list(enumerate(early_spill, 1))) == 1
+    # in-order retirement: with two stores issued behind the load, vmcnt(2) covers the load, vmcnt(3) does not
+    tail = ["\tglobal_store_dwordx2 v3, v[40:41], s[6:7]", "\tglobal_store_dwordx2 v3, v[42:43], s[6:7]"]
+    use = "\tv_add_f64 v[0:1], v[10:11], v[10:11]"
+    assert chk.check_kernel("covered", list(enumerate([ld] + tail + ["\ts_waitcnt vmcnt(2)", use], 1))) == 0
+    assert chk.check_kernel("not covered", list(enumerate([ld] + tail + ["\ts_waitcnt vmcnt(3)", use], 1))) == 1
+
+
+@pytest.mark.parametrize("unit", ["hpx_backsolve_lds", "hpx_backsolve", "hpx_factor_wide"])
+def test_hand_counted_vmcnt_units_have_no_early_use(unit):
+    """Compile-only (hipcc cross-compiles gfx950 here): the units whose loops issue loads from asm statements and wait with
+    hand-counted vmcnt have no spill and no read of such a register before its wait (a compiler or flag change
+    would otherwise corrupt X silently)."""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, str(REPO / "tools" / "check_asm_spills.py"),
+                        str(REPO / "hydra_pspec_amd" / "csrc" / f"{unit}.hip")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:]
+    assert "scratch stores" in r.stdout
