@@ -2,7 +2,7 @@
 //
 // k_backsolve of hpx_factor.hip reads every tile of L once but re-reads the solution X once per 128-column
 // super-block and runs at two 4-wave workgroups per CU; at C3 it moved 3.9 GB per launch for 2.8 GB of
-// algorithmic traffic and took 0.85 ms (DESIGN.md sections 9.4, 10.9).  Here ONE workgroup of eight waves owns a
+// algorithmic traffic and took 0.85 ms (docs/HISTORY.md sections 9.4, 10.9).  Here ONE workgroup of eight waves owns a
 // baseline and keeps all of X -- (n/16) row tiles x the t-tiles of a pass, as f64 MFMA accumulators -- in its
 // registers, right-looking from the last tile row to the first:
 //

@@ -17,7 +17,7 @@
 //   3. replaces the 16 columns by W Q (MFMA again; second read of the columns from L2).
 // The columns are stored block-wise, [block][row][8 columns], planar: both passes read and write whole 64-byte rows
 // of a block, 256 contiguous bytes per k-step.  A sweep moves 2 n^2 x 16 B per matrix through HBM per step ... the
-// method is bandwidth-bound: 1024 matrices of order 512 take about a second.
+// method is bandwidth-bound: 1024 matrices of order 512 take about a second (docs/HISTORY.md section 11.9).
 #include "hpx_internal.h"
 #include "../../include/hpx.h"
 

@@ -33,7 +33,7 @@
 // The tile groups, the diagonal-block update and the elimination are out-of-line functions: each
 // gets a register allocation of its own (out-of-line functions get the full 256-VGPR budget).
 //
-// Cache policy (k_factor sits on the CUs' memory path): the row-tile (B) operand
+// Cache policy (k_factor sits on the CUs' memory path, docs/HISTORY.md section 9.3): the row-tile (B) operand
 // loads of the k-loops are non-temporal -- each tile is streamed once per block column by one wave, and
 // the hint keeps it from displacing the panel operand, which every wave of the workgroup re-reads
 // (4.63 -> 4.30 ms at C3).  The other streams were measured too and left cached; the variants tried and
@@ -231,7 +231,7 @@ __device__ HPX_INL void offdiag_group(double* __restrict__ Lre, double* __restri
 // ---- tile groups with the panel operand shared through LDS (HPX_PANEL_LDS) -------------------
 // k_factor is bound by what a CU can pull through its memory path (a workgroup alone on a CU
 // factors a baseline in 1.3 ms, two share the CU's bandwidth and take 2.3 ms for two; 8 waves on one
-// baseline are no faster than 4: round-2 measurements), and a third of that
+// baseline are no faster than 4: round-2 measurements, docs/HISTORY.md section 6), and a third of that
 // traffic is the 32 x c0 panel operand, which every wave fetches again for each of its tile groups
 // (L2 hit rate 0.24).  Here the four waves of the workgroup take their groups in rounds, sweep the
 // k range together in chunks of 16 columns, and the panel chunk (2 tiles x 16 columns = 8 KB) is
@@ -958,7 +958,7 @@ __global__ void k_unpack_x(const double* __restrict__ Xre, const double* __restr
 }  // namespace
 
 // Waves per workgroup: 4 (two workgroups per CU) or 8 (one per CU, the baseline's tile passes spread over
-// twice the waves; HPX_FACTOR_WAVES in the environment, read once -- see DESIGN.md section 6 for the
+// twice the waves; HPX_FACTOR_WAVES in the environment, read once -- see docs/HISTORY.md section 6 for the
 // measurements behind the default).
 template <bool GEN, bool GLDS>
 static int launch_factor_t(int nbl, size_t lds, int npad, int ld, double* L, double* Wre, double* Wim,
@@ -971,7 +971,7 @@ static int launch_factor_t(int nbl, size_t lds, int npad, int ld, double* L, dou
 }
 
 // Which form runs: the wide one (hpx_factor_wide.hip: 128-column super-blocks, LDS-staged panels) from HPX_WIDE_MIN
-// columns on, this file's 32-wide one below.  Measured on one MI355X, 1024 systems: order 1040
+// columns on, this file's 32-wide one below.  Measured on one MI355X, 1024 systems (docs/HISTORY.md section 11): order 1040
 // 24.7 against 27.9 ms, order 528 4.06 against 4.19 ms, order 272 1.05 against 0.99 ms, order 144 0.92 against 0.73 ms
 // -- the wide form pays from four super-blocks on.
 #ifndef HPX_WIDE_MIN

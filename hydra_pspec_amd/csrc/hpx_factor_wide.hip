@@ -1,7 +1,7 @@
 // Batched complex-Hermitian Cholesky, wide form: left-looking by SUPER-BLOCKS of 128 columns with the
 // panel operand of every k-loop staged ONCE per workgroup through LDS (LDS-DMA, global_load_lds).
 //
-// Why (DESIGN.md sections 9.3, 10.9, 10.10, 11): the 32-wide kernel of hpx_factor.hip re-reads every
+// Why (docs/HISTORY.md sections 9.3, 10.9, 10.10, 11): the 32-wide kernel of hpx_factor.hip re-reads every
 // element of L once per 32-wide block column to its right (12 MB per baseline at C3) and sits on the HBM
 // roof at that traffic.  With 128-wide block columns the row-tile operand is read n/128 instead of n/32
 // times, and the 128 x k panel operand, which every wave of the workgroup needs, is brought in once per

@@ -1,5 +1,5 @@
 // Dense noise covariance with flagged channels: the Woodbury correction of the unflagged-noise solve
-// (DESIGN.md section 10.3).
+// (docs/HISTORY.md section 10.3).
 #include "hpx_chain.h"
 
 namespace {

@@ -1,5 +1,5 @@
 """Lane-level numpy emulation of the 4x4-blocked Cholesky + inverse of a 16 x 16 Hermitian block on one wave
-(the index bookkeeping of the MFMA form sketched in DESIGN.md section 10.10): checks L L^H = D and W = L^-1."""
+(the index bookkeeping of the MFMA form sketched in docs/HISTORY.md section 10.10): checks L L^H = D and W = L^-1."""
 import numpy as np
 
 rng = np.random.default_rng(0)

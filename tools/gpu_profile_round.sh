@@ -3,13 +3,14 @@
 #   bench lines for C3 (with CPU baseline), C5, C2, N4, dpss, oqe and a 2-rank rehearsal; rocprofv3 kernel
 #   stats of the C3 / C5-auto / dpss / oqe benches; PMC passes (FETCH_SIZE, WRITE_SIZE, MFMA busy, L2 hits)
 #   of the C3 bench, one counter set per pass; the FETCH_SIZE calibration probe.
-# usage: tools/gpu_profile_round.sh <tag> [A|B|AB]     e.g. r04 A (bench lines, rehearsals), then r04 B (kernel
-# traces, PMC passes, the C3 line): two calls fit gpurun's 20-minute limit
+# usage: tools/gpu_profile_round.sh <tag> [A|B|C|ABC]  e.g. r06 A (bench lines, rehearsals), r06 B (rocprofv3 kernel
+# traces), r06 C (PMC passes -> profiles/pmc_traffic.json for the sources as they are, then the C3 line): each call fits
+# gpurun's 20-minute limit.  C goes LAST: the traffic figure is hash-guarded against the kernel sources.
 TAG=${1:-r04}
 export TMPDIR=/tmp
 R=$PWD; O=$R/gpurun_out/prof; mkdir -p $O
 line() { grep -o '{"metric.*' $1 > $2; }
-PART=${2:-AB}
+PART=${2:-ABC}
 if [[ $PART == *A* ]]; then
 # (the C3 line itself is taken LAST, after the PMC passes have re-stamped profiles/pmc_traffic.json for these sources)
 timeout -k 10 300 python3 bench.py --steps 5 --warmup 1 --config C5 --no-cpu-baseline > $O/bench_c5.log 2>&1 && line $O/bench_c5.log $O/${TAG}_bench_c5.json; echo "C5 done"
@@ -31,7 +32,7 @@ HPX_BENCH_DEVICE=0 HPX_BENCH_BACKEND=gloo timeout -k 10 400 python3 bench.py --g
 sleep 5
 HPX_BENCH_DEVICE=0 HPX_BENCH_BACKEND=gloo timeout -k 10 400 python3 bench.py --gpus 4 --nbl 128 --steps 10 --warmup 2 --no-cpu-baseline --no-full-length > $O/bench_4rank.log 2>&1 && line $O/bench_4rank.log $O/${TAG}_bench_4ranks_one_gpu.json; echo "4-rank rehearsal done"
 fi
-if [[ $PART != *B* ]]; then exit 0; fi
+if [[ $PART == *B* ]]; then
 kt() {   # kernel-trace stats: kt <name> <bench args...>
   local name=$1; shift
   cd /tmp
@@ -49,6 +50,9 @@ kt c2 --config C2 --steps 20 --warmup 2 --no-cpu-baseline --no-full-length
 kt dense_flagged --config C3 --noise dense --flag-frac 0.15 --steps 5 --warmup 1
 kt dpss --config dpss --steps 10 --warmup 2
 kt oqe --config oqe --steps 3 --warmup 1
+fi
+if [[ $PART != *C* ]]; then exit 0; fi
+rm -rf $O/pmc1 $O/pmc2 $O/pmc3 $O/pmc4 $O/calib
 i=0
 for set in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" "TCC_HIT_sum TCC_MISS_sum"; do
   i=$((i+1))
