@@ -347,6 +347,46 @@ def test_driver_drain_thin_budget_and_append_only(tmp_path, capsys):
         drv.main(common + ["--Niter", "8", "--dirname", "odd", "--write_Niter", "3"])
 
 
+def test_driver_drain_failure_stops_the_run(tmp_path, monkeypatch):
+    """A writer-thread failure (disk full, directory gone) must not be swallowed: the sampler stops at its next flush
+    with the writer's own exception, and what reached the disk before is still a valid prefix."""
+    from hydra_pspec_amd import npy_append
+    drv = _driver()
+    real, calls = npy_append.NpyAppender.append, []
+
+    def failing(self, rows):
+        calls.append(self.path)
+        if len(calls) > 6:                        # 3 baselines x 2 files of the first flush go through
+            raise OSError(28, "No space left on device (simulated)")
+        return real(self, rows)
+    monkeypatch.setattr(npy_append.NpyAppender, "append", failing)
+    with pytest.raises(OSError, match="simulated"):
+        drv.main(["--synthetic", "3,4,32", "--Nfgmodes", "3", "--seed", "4", "--out_dir", str(tmp_path), "--dry_run",
+                  "--write_Niter", "2", "--Niter", "8", "--outputs", "ps", "--dirname", "f"])
+    monkeypatch.setattr(npy_append.NpyAppender, "append", real)
+    for k in (1, 2, 3):
+        assert np.load(tmp_path / "dryrun-f" / f"0-{k}" / "dps-eor.npy").shape == (2, 32)
+    assert not (tmp_path / "dryrun-f" / "timings.json").exists()
+
+
+@pytest.mark.gpu
+def test_driver_thin_outputs_are_rows_of_the_full_run(tmp_path):
+    """--thin K on the GPU: gcr-eor / fg-amps / chisq hold iterations 0, K, 2K, ... of the unthinned run bit for bit,
+    dps-eor / ln-post every iteration; a --resume across a chunk boundary continues both kinds of file."""
+    drv = _driver()
+    common = ["--synthetic", "2,8,32", "--Nfgmodes", "4", "--ps_prior_lo", "0.1", "--ps_prior_hi", "2", "--seed", "5",
+              "--out_dir", str(tmp_path), "--write_Niter", "4"]
+    assert drv.main(common + ["--Niter", "12", "--dirname", "full"]) == 0
+    assert drv.main(common + ["--Niter", "8", "--dirname", "thin", "--thin", "2"]) == 0
+    assert drv.main(common + ["--Niter", "12", "--dirname", "thin", "--thin", "2", "--resume"]) == 0
+    for k in (1, 2):
+        full, thin = tmp_path / "full" / f"0-{k}", tmp_path / "thin" / f"0-{k}"
+        for f in ("dps-eor.npy", "ln-post.npy", "cov-eor.npy"):
+            assert np.array_equal(np.load(thin / f), np.load(full / f)), f
+        for f in ("gcr-eor.npy", "fg-amps.npy", "chisq.npy"):
+            assert np.array_equal(np.load(thin / f), np.load(full / f)[::2]), f
+
+
 def _spawn_ranks(world, argv, env_extra=None, cwd=None):
     """Launch the driver as `world` plain processes (RANK / WORLD_SIZE / LOCAL_RANK, one shared run id), the
     way a launcher without MPI would; returns their exit codes and outputs."""
