@@ -6,6 +6,14 @@
 
 namespace {
 
+// chi^2 of one element with the operation order WRITTEN OUT (explicit fma): the same bits whether or not the samples /
+// chi^2 of the iteration are kept or the batch has flags -- left to the compiler's contraction, instantiations that store
+// the scaled signal formed the residual from a rounded product, the others from a fused one (ln-posterior differing in
+// the last bit between a thinned and an unthinned run of the same chain)
+__device__ __forceinline__ double chi2_term(const double rr, const double ri, const double nv) {
+  return fma(ri, ri, rr * rr) * nv;
+}
+
 // lnpart[b][0] = sum_{x,t} Re( conj(r[x][t]) v[x][t] )  (r^H Ninv r summed over the times; v = Ninv r)
 __global__ __launch_bounds__(256) void k_quadform(const double* __restrict__ rre, const double* __restrict__ rim,
                                                   const long r_bs, const int ld_r, const double* __restrict__ vre,
@@ -104,8 +112,8 @@ __global__ __launch_bounds__(256) void k_resid(const ResArgs A) {
     const double rr = dre[o] - mr, ri = dim_[o] - mi;
     const long ot = ((long)b * T + t) * N + x;
     const double w = (A.flags_t ? A.flags_t[ot] : fl[x]) ? 1.0 : 0.0;
-    const double c2 = (rr * rr + ri * ri) * (A.ninv_t ? A.ninv_t[ot] : ninv[x]);
-    acc += w * c2;
+    const double c2 = chi2_term(rr, ri, A.ninv_t ? A.ninv_t[ot] : ninv[x]);
+    acc = fma(w, c2, acc);
     if (A.any_flags) {
       A.Gre[(long)b * A.NP * TP + o] = w * sr;
       A.Gim[(long)b * A.NP * TP + o] = w * si;
@@ -352,11 +360,12 @@ __global__ __launch_bounds__(NTH, (ELEMS > 4096) ? 1 : NTH / 128) void k_fft_res
         for (int v = 0; v < 4; ++v) {
           const int x = x0 + HPX_ACC_ROW(g, v);
           const int pidx = (int)(__brev((unsigned)x) >> (32 - logN));
-          const double sv = ssel[(pidx << tcs) + tc] * sc;
-          const double r = cd[v] - (sv + mdl[v]);
+          const double sraw = ssel[(pidx << tcs) + tc];
+          const double sv = sraw * sc;                // (for the outputs; the residual takes the fused form)
+          const double r = cd[v] - fma(sraw, sc, mdl[v]);
           const double w = cw[v];
           const double c2 = (r * r) * cnv[v];         // this component's share of the channel's chi^2 term
-          acc += w * c2;
+          acc = fma(w, c2, acc);
           if (FL) gsel[(long)x * TP + t] = w * sv;
           if (KEEP) {
             if (A.cr_out) A.cr_out[(long)b * A.cr_bstride + ((long)t * N + x) * 2 + (hi ? 1 : 0)] = sv;
@@ -463,11 +472,12 @@ __global__ __launch_bounds__(NTH, (ELEMS > 4096) ? 1 : NTH / 128) void k_fft_res
         for (int v = 0; v < 4; ++v) {
           const int x = x0 + HPX_ACC_ROW(g, v);
           const int pidx = (int)(__brev((unsigned)x) >> (32 - logN));
-          const double sr = fre[(pidx << tcs) + li] * sc, si = fim[(pidx << tcs) + li] * sc;
-          const double rr = cdr[v] - (sr + mr[v]), ri = cdi[v] - (si + mi[v]);
+          const double rawr = fre[(pidx << tcs) + li], rawi = fim[(pidx << tcs) + li];
+          const double sr = rawr * sc, si = rawi * sc;                 // (for the outputs)
+          const double rr = cdr[v] - fma(rawr, sc, mr[v]), ri = cdi[v] - fma(rawi, sc, mi[v]);
           const double w = cw[v];
-          const double c2 = (rr * rr + ri * ri) * cnv[v];
-          acc += w * c2;
+          const double c2 = chi2_term(rr, ri, cnv[v]);
+          acc = fma(w, c2, acc);
           if (FL) {
             const long o = (long)b * A.NP * TP + (long)x * TP + t;
             A.Gre[o] = w * sr;
@@ -529,8 +539,8 @@ __global__ __launch_bounds__(NTH, (ELEMS > 4096) ? 1 : NTH / 128) void k_fft_res
       }
       const double rr = dre[o] - mr, ri = dim_[o] - mi;
       const double w = fl8[x] ? 1.0 : 0.0;
-      const double c2 = (rr * rr + ri * ri) * ninv[x];
-      acc += w * c2;
+      const double c2 = chi2_term(rr, ri, ninv[x]);
+      acc = fma(w, c2, acc);
       if (A.any_flags) {
         A.Gre[(long)b * A.NP * TP + o] = w * sr;
         A.Gim[(long)b * A.NP * TP + o] = w * si;
@@ -687,11 +697,11 @@ __global__ __launch_bounds__(256) void k_dft_resid(const ResArgs A) {
           if (A.any_flags) { A.Gre[(long)b * NP * TP + o] = 0.0; A.Gim[(long)b * NP * TP + o] = 0.0; }
           continue;
         }
-        const double s_r = sr[v] * A.isn, s_i = si[v] * A.isn;
-        const double rr = dre[o] - (s_r + mr[v]), ri = dim_[o] - (s_i + mi[v]);
+        const double s_r = sr[v] * A.isn, s_i = si[v] * A.isn;       // (for the outputs)
+        const double rr = dre[o] - fma(sr[v], A.isn, mr[v]), ri = dim_[o] - fma(si[v], A.isn, mi[v]);
         const double w = cw[v];
-        const double c2 = (rr * rr + ri * ri) * cnv[v];
-        acc += w * c2;
+        const double c2 = chi2_term(rr, ri, cnv[v]);
+        acc = fma(w, c2, acc);
         if (A.any_flags) {
           A.Gre[(long)b * NP * TP + o] = w * s_r;
           A.Gim[(long)b * NP * TP + o] = w * s_i;
