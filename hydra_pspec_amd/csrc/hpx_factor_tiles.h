@@ -370,6 +370,31 @@ __device__ HPX_INL bool elim16(const WideCtx& X, const int tcol /* global tile c
   lds_barrier();
   return bad;
 }
+// lane K (of each group of 16 lanes) to all 16 lanes of its group: DPP row_newbcast (gfx90a+), two 32-bit moves
+template <int K>
+__device__ HPX_INL double bcast16(const double x) {
+  const long long raw = __double_as_longlong(x);
+  // (every lane has a source lane: no "old" value to initialise)
+  const int lo = __builtin_amdgcn_mov_dpp((int)(raw & 0xffffffffll), 0x150 + K, 0xf, 0xf, true);
+  const int hi = __builtin_amdgcn_mov_dpp((int)(raw >> 32), 0x150 + K, 0xf, 0xf, true);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+// one lane's value as a wave-uniform one (v_readlane_b32 on the two halves; `lane` a constant after unrolling)
+__device__ HPX_INL double lane_value(const double x, const int lane) {
+  const long long raw = __double_as_longlong(x);
+  const int lo = __builtin_amdgcn_readlane((int)(raw & 0xffffffffll), lane);
+  const int hi = __builtin_amdgcn_readlane((int)(raw >> 32), lane);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+// (k is a constant after the unrolling of the loops that call this: the switch folds to one case)
+__device__ HPX_INL double bcast16_of(const double x, const int k) {
+  switch (k) {
+    case 0: return bcast16<0>(x);   case 1: return bcast16<1>(x);   case 2: return bcast16<2>(x);   case 3: return bcast16<3>(x);
+    case 4: return bcast16<4>(x);   case 5: return bcast16<5>(x);   case 6: return bcast16<6>(x);   case 7: return bcast16<7>(x);
+    case 8: return bcast16<8>(x);   case 9: return bcast16<9>(x);   case 10: return bcast16<10>(x); case 11: return bcast16<11>(x);
+    case 12: return bcast16<12>(x); case 13: return bcast16<13>(x); case 14: return bcast16<14>(x); default: return bcast16<15>(x);
+  }
+}
 // ---- the same elimination on ONE wave with the tile in registers: lane (li, g) holds row li, columns g + 4 v -- the
 // accumulator layout of a D^T tile, so the wave that owns the diagonal tile eliminates it where it lies.  No
 // workgroup barrier inside (elim16 has eighteen, and spends most of its time in them): per step the pivot column
@@ -402,7 +427,11 @@ __device__ HPX_INL bool elim16w(const WideCtx& X, const int tcol, const bool las
   // path.  Off it, in the shadow of that round trip: (a) the next pivot's reciprocal -- every lane forms
   // d_{k+1,k+1} - l_{k+1,k} conj(D_{k+1,k}) itself, with the very operations its owner applies (same bits), from one
   // broadcast read of the column and of the diagonal entry before the step; (b) the inverse's updates, one step behind
-  // (row k of Y is published after the step k-1 update, read back by all lanes and used one step later).
+  // (row k of Y is final after the step k-1 update, broadcast to all lanes and used one step later).
+  // Round 6: only the COLUMN goes through LDS now.  Row k of the inverse sits in lane li = k of every group of 16 lanes,
+  // register v <-> column g + 4 v -- a DPP row broadcast (row_newbcast:k), no masked LDS write / read-back; the two
+  // single entries the next pivot needs come out of their lanes with v_readlane.  Stand-alone 3.69 -> 3.14 us
+  // (tools/experiments/elim/elim16w_probe.hip), k_factor_split at C2 0.142 -> 0.136 ms.  Same operations per element.
   lds_f64* const rawn = raw;       // [4 lane groups][16]: real parts of the columns 4 (k+1 >> 2) + g BEFORE step k
 #define HPX_E16_FENCE()                                   \
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  \
@@ -449,7 +478,6 @@ __device__ HPX_INL bool elim16w(const WideCtx& X, const int tcol, const bool las
       const int k1 = k + 1, kv1 = k1 >> 2, kg1 = k1 & 3;
       const bool below = li > k1;
       col[g * 16 + li] = (cplx){below ? dr[kv1] : 0.0, below ? di[kv1] : 0.0};
-      if (k1 < 15) rawn[g * 16 + li] = dr[(k1 + 1) >> 2];
       HPX_E16_FENCE();
       __builtin_amdgcn_sched_barrier(0);
       c = col[kg1 * 16 + li];
@@ -457,8 +485,11 @@ __device__ HPX_INL bool elim16w(const WideCtx& X, const int tcol, const bool las
       for (int v = 0; v < 4; ++v)
         if (4 * v + 3 > k1) cq[v] = col[kg1 * 16 + g + 4 * v];
       if (k1 < 15) {
-        cn = col[kg1 * 16 + k1 + 1];
-        dn = rawn[((k1 + 1) & 3) * 16 + k1 + 1];
+        // the two values the NEXT pivot needs are single entries: straight out of their lane's registers (v_readlane,
+        // wave-uniform), not through LDS -- D[k1+1][k1] (lane (k1+1, kg1), register kv1) and D[k1+1][k1+1] as it is now
+        cn.x = lane_value(dr[kv1], kg1 * 16 + k1 + 1);
+        cn.y = lane_value(di[kv1], kg1 * 16 + k1 + 1);
+        dn = lane_value(dr[(k1 + 1) >> 2], ((k1 + 1) & 3) * 16 + k1 + 1);
       }
       __builtin_amdgcn_sched_barrier(0);
       // ---- in the shadow of that round trip: the next pivot (the owner's own operations on D[k+1][k+1]) ...
@@ -481,18 +512,17 @@ __device__ HPX_INL bool elim16w(const WideCtx& X, const int tcol, const bool las
         asm volatile("" : "+v"(yr[v]), "+v"(yi[v]));
       }
     }
-    // ---- ... and row k of the inverse out (final since that update) and back in
-    if (li == k) {
-#pragma unroll
-      for (int v = 0; v < 4; ++v) yrw[g * 4 + v] = (cplx){yr[v], yi[v]};
-    }
-    HPX_E16_FENCE();
+    // ---- ... and row k of the inverse (final since that update) to every lane: the row's entries for the columns
+    // g + 4 v sit in lane li = k of the lane's own group of 16, register v -- a DPP row broadcast (row_newbcast:k), no LDS
+    // round trip and no masked write
 #pragma unroll
     for (int v = 0; v < 4; ++v)
-      if (4 * v <= k) sy[v] = yrw[g * 4 + v];
+      if (4 * v <= k) {
+        sy[v].x = bcast16_of(yr[v], k);
+        sy[v].y = bcast16_of(yi[v], k);
+      }
     plr = lr;
     plm = lm;
-    HPX_E16_FENCE();
     __builtin_amdgcn_sched_barrier(0);
   }
 #pragma unroll
